@@ -1,0 +1,192 @@
+"""ORACLE -- ctypes bindings of the CPU restatement (test infrastructure only).
+
+Only tests/, bench.py's ``cpu_baseline`` leg and ``__graft_entry__.smoke()`` may
+import this package; the product (rd_vio_amd) never does.
+
+PARITY UNPINNED: the reference ships no fixtures and is unbuildable here; see
+oracle/rdvio_oracle.h and DESIGN.md.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+STATE_SIZE = 16
+PREINT_SIZE = 506
+PREINT_T, PREINT_Q, PREINT_P, PREINT_V, PREINT_COV, PREINT_SIC, PREINT_JAC = 0, 1, 5, 8, 11, 236, 461
+
+
+def build(force=False):
+    """Compile liboracle.so with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+        for f in os.listdir(_HERE)
+        if f.endswith((".c", ".h"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _p(a, t=ctypes.c_double):
+    if a is None:
+        return None
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+# ---------------------------------------------------------------- lie algebra
+def expmap(w):
+    q = np.zeros(4)
+    lib().ro_expmap(_p(_f64(w)), _p(q))
+    return q
+
+
+def logmap(q):
+    w = np.zeros(3)
+    lib().ro_logmap(_p(_f64(q)), _p(w))
+    return w
+
+
+def right_jacobian(w):
+    J = np.zeros((3, 3))
+    lib().ro_right_jacobian_c(_p(_f64(w)), _p(J))
+    return J
+
+
+def tangent_frame(z):
+    T = np.zeros((3, 3))
+    lib().ro_tangent_frame(_p(_f64(z)), _p(T))
+    return T
+
+
+def quat_plus(q, d):
+    o = np.zeros(4)
+    lib().ro_quat_plus(_p(_f64(q)), _p(_f64(d)), _p(o))
+    return o
+
+
+# ---------------------------------------------------------------- estimation
+def preintegrate(imu, t_end, bg, ba, noise, jac=True, cov=True):
+    imu = _f64(imu).reshape(-1, 7)
+    out = np.zeros(PREINT_SIZE)
+    lib().ro_preintegrate.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_double] + [ctypes.c_void_p] * 3 + [
+        ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    ok = lib().ro_preintegrate(len(imu), imu.ctypes.data, float(t_end), _f64(bg).ctypes.data, _f64(ba).ctypes.data,
+                               _f64(noise).ctypes.data, int(jac), int(cov), out.ctypes.data)
+    return out if ok else None
+
+
+def preint_predict(pre, state_i):
+    sj = np.zeros(16)
+    lib().ro_preint_predict(_p(_f64(pre)), _p(_f64(state_i)), _p(sj))
+    return sj
+
+
+def reprojection_eval(tgt, ref, lm, tangent, z_ref, inv_depth, states, extr, W, jac=True):
+    tgt, ref, lm = _i32(tgt), _i32(ref), _i32(lm)
+    n = len(tgt)
+    tangent, z_ref, inv_depth, states, extr, W = map(_f64, (tangent, z_ref, inv_depth, states, extr, W))
+    r = np.zeros((n, 2))
+    Jt = np.zeros((n, 2, 6)) if jac else None
+    Jr = np.zeros((n, 2, 6)) if jac else None
+    Jd = np.zeros((n, 2)) if jac else None
+    lib().ro_reprojection_eval(ctypes.c_int(n), _p(tgt, ctypes.c_int32), _p(ref, ctypes.c_int32),
+                               _p(lm, ctypes.c_int32), _p(tangent), _p(z_ref), _p(inv_depth), _p(states),
+                               _p(extr), _p(W), _p(r), _p(Jt), _p(Jr), _p(Jd))
+    return r, Jt, Jr, Jd
+
+
+def rotation_prior_eval(q_tgt, q_ref, z_ref, tangent, extr, W):
+    r = np.zeros(2)
+    J = np.zeros((2, 3))
+    lib().ro_rotation_prior_eval(_p(_f64(q_tgt)), _p(_f64(q_ref)), _p(_f64(z_ref)), _p(_f64(tangent)),
+                                 _p(_f64(extr)), _p(_f64(W)), _p(r), _p(J))
+    return r, J
+
+
+def preintegration_eval(state_i, state_j, pre, bias_lin, extr, jac=True):
+    r = np.zeros(15)
+    Ji = np.zeros((15, 15)) if jac else None
+    Jj = np.zeros((15, 15)) if jac else None
+    lib().ro_preintegration_eval(_p(_f64(state_i)), _p(_f64(state_j)), _p(_f64(pre)), _p(_f64(bias_lin)),
+                                 _p(_f64(extr)), _p(r), _p(Ji), _p(Jj))
+    return r, Ji, Jj
+
+
+def marginalization_eval(states, lin, S, f, jac=True):
+    states = _f64(states).reshape(-1, 16)
+    n = len(states)
+    D = 15 * n
+    r = np.zeros(D)
+    J = np.zeros((D, D)) if jac else None
+    lib().ro_marginalization_eval(ctypes.c_int(n), _p(states), _p(_f64(lin)), _p(_f64(S)), _p(_f64(f)), _p(r), _p(J))
+    return r, J
+
+
+class _MargProblem(ctypes.Structure):
+    _fields_ = [
+        ("nframes", ctypes.c_int), ("states", ctypes.c_void_p), ("extr", ctypes.c_void_p),
+        ("sqrt_inv_cov", ctypes.c_void_p), ("np", ctypes.c_int), ("prior_frames", ctypes.c_void_p),
+        ("lin", ctypes.c_void_p), ("S", ctypes.c_void_p), ("f", ctypes.c_void_p), ("preint01", ctypes.c_void_p),
+        ("nfac", ctypes.c_int), ("tgt", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("lm", ctypes.c_void_p),
+        ("tangent", ctypes.c_void_p), ("nlm", ctypes.c_int), ("z_ref", ctypes.c_void_p),
+        ("inv_depth", ctypes.c_void_p),
+    ]
+
+
+def marginalize(states, extr, W, prior_frames, lin, S, f, preint01, tgt, ref, lm, tangent, z_ref, inv_depth):
+    """CeresMarginalizationFactor::marginalize(0); returns S, f, lin, Lambda, eta."""
+    states = _f64(states).reshape(-1, 16)
+    nfm = len(states)
+    keep = dict(states=states, extr=_f64(extr), W=_f64(W), pf=_i32(prior_frames), lin=_f64(lin), S=_f64(S),
+                f=_f64(f), pre=_f64(preint01) if preint01 is not None else None, tgt=_i32(tgt), ref=_i32(ref),
+                lm=_i32(lm), tangent=_f64(tangent), z_ref=_f64(z_ref), inv_depth=_f64(inv_depth))
+    pb = _MargProblem()
+    pb.nframes = nfm
+    pb.states = keep["states"].ctypes.data
+    pb.extr = keep["extr"].ctypes.data
+    pb.sqrt_inv_cov = keep["W"].ctypes.data
+    pb.np = len(keep["pf"])
+    pb.prior_frames = keep["pf"].ctypes.data
+    pb.lin = keep["lin"].ctypes.data
+    pb.S = keep["S"].ctypes.data
+    pb.f = keep["f"].ctypes.data
+    pb.preint01 = keep["pre"].ctypes.data if keep["pre"] is not None else None
+    pb.nfac = len(keep["tgt"])
+    pb.tgt = keep["tgt"].ctypes.data
+    pb.ref = keep["ref"].ctypes.data
+    pb.lm = keep["lm"].ctypes.data
+    pb.tangent = keep["tangent"].ctypes.data
+    pb.nlm = len(keep["inv_depth"])
+    pb.z_ref = keep["z_ref"].ctypes.data
+    pb.inv_depth = keep["inv_depth"].ctypes.data
+    R = 15 * (nfm - 1)
+    S_out = np.zeros((R, R))
+    f_out = np.zeros(R)
+    lin_out = np.zeros((nfm - 1, 16))
+    Lam = np.zeros((R, R))
+    eta = np.zeros(R)
+    lib().ro_marginalize(ctypes.byref(pb), _p(S_out), _p(f_out), _p(lin_out), _p(Lam), _p(eta))
+    return S_out, f_out, lin_out, Lam, eta

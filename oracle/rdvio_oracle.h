@@ -1,0 +1,114 @@
+/*
+ * ORACLE -- CPU restatement of rd_vio's hot path (test infrastructure only).
+ *
+ * This library is the CHECKER for the HIP path in rd_vio_amd/: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The
+ * product (librdvio_hip.so) never links, loads or falls back to it.
+ *
+ * PARITY UNPINNED: /root/reference has no tests, fixtures or golden vectors and
+ * cannot be compiled here (Eigen / Ceres / OpenCV / yaml-cpp absent), so this
+ * restatement is anchored on the reference's source text (cited per function)
+ * and on self-consistency checks in tests/ (finite differences, Schur-vs-dense
+ * identities, closed forms).  The OpenCV and Ceres arithmetic it restates
+ * (LK, CLAHE, pyramid, GFTT; dogleg/Schur) follows their published algorithms
+ * (unpinned versions: OpenCV 4.x, Ceres >= 2.1).
+ *
+ * Array layouts (shared with include/rdvio_hip.h):
+ *   frame state   double[16] : q(x,y,z,w) p(3) v(3) bg(3) ba(3)
+ *   extrinsics    double[14] : cam q_cs(4) p_cs(3), imu q_cs(4) p_cs(3)
+ *   preint        double[RO_PREINT_SIZE] : t, q(4), p(3), v(3), cov(225), sqrt_inv_cov(225),
+ *                                          dq_dbg(9) dp_dbg(9) dp_dba(9) dv_dbg(9) dv_dba(9)
+ *   error state   theta(0..2) p(3..5) v(6..8) bg(9..11) ba(12..14)   (estimation/state.h:11-18)
+ *   matrices are row-major.
+ */
+#ifndef RDVIO_ORACLE_H
+#define RDVIO_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RO_STATE_SIZE 16
+#define RO_ES_SIZE 15
+#define RO_PREINT_SIZE 506
+#define RO_PREINT_T 0
+#define RO_PREINT_Q 1
+#define RO_PREINT_P 5
+#define RO_PREINT_V 8
+#define RO_PREINT_COV 11
+#define RO_PREINT_SIC 236
+#define RO_PREINT_JAC 461
+
+/* ---- lie algebra helpers exposed for tests (lie_algebra.{h,cpp}) ---- */
+void ro_expmap(const double *w, double *q);
+void ro_logmap(const double *q, double *w);
+void ro_right_jacobian_c(const double *w, double *J);
+void ro_tangent_frame(const double *z, double *T /*3x3 row-major [b1 b2 z] columns*/);
+void ro_quat_plus(const double *q, const double *delta, double *out); /* quaternion_parameterization.h:11-17 */
+
+/* ---- A7: PreIntegrator (preintegrator.cpp:7-112) ---- */
+/* imu: n x 7 (t, w[3], a[3]); noise: cov_w, cov_a, cov_bg, cov_ba (4 x 9 row-major) */
+int ro_preintegrate(int n, const double *imu, double t_end, const double *bg, const double *ba,
+                    const double *noise, int compute_jacobian, int compute_covariance, double *preint);
+/* PreIntegrator::predict, preintegrator.cpp:102-112 */
+void ro_preint_predict(const double *preint, const double *state_i, double *state_j);
+
+/* ---- A8/A9: reprojection factor (ceres/reprojection_factor.h:12-121) ---- */
+/* For each factor k: r[2k..], Jt[12k..] (2x6: theta_tgt,p_tgt), Jr[12k..] (2x6: theta_ref,p_ref), Jd[2k..].
+ * J pointers may be NULL (residual only). */
+void ro_reprojection_eval(int nf, const int32_t *tgt, const int32_t *ref, const int32_t *lm,
+                          const double *tangent /*nf x 9*/, const double *z_ref /*nl x 3*/,
+                          const double *inv_depth /*nl*/, const double *states /*nframes x 16*/,
+                          const double *extr /*14*/, const double *sqrt_inv_cov /*4*/,
+                          double *r, double *Jt, double *Jr, double *Jd);
+
+/* ---- A10: rotation prior (ceres/rotation_factor.h:11-67) ---- */
+void ro_rotation_prior_eval(const double *q_tgt, const double *q_ref, const double *z_ref,
+                            const double *tangent, const double *extr, const double *sqrt_inv_cov,
+                            double *r /*2*/, double *J /*2x3*/);
+
+/* ---- A11: preintegration error factor (ceres/preintegration_factor.h:11-163) ---- */
+/* bias_lin = (bg_i0, ba_i0) linearisation biases; r[15], Ji[15x15], Jj[15x15] (tangent columns) */
+void ro_preintegration_eval(const double *state_i, const double *state_j, const double *preint,
+                            const double *bias_lin /*6*/, const double *extr,
+                            double *r, double *Ji, double *Jj);
+
+/* ---- A12: marginalisation prior Evaluate (ceres/marginalization_factor.h:27-72) ---- */
+/* np frames; lin = np x 16 linearisation states; S = D x D (D = 15 np); f = D.
+ * r[D], J[D x D] (tangent columns); J may be NULL */
+void ro_marginalization_eval(int np, const double *states /*np x 16, the prior's frames in order*/,
+                             const double *lin, const double *S, const double *f, double *r, double *J);
+
+/* ---- A13: CeresMarginalizationFactor::marginalize(0) (ceres/marginalization_factor.h:74-475) ---- */
+typedef struct {
+    int nframes;              /* frames in the map (victim = frame 0) */
+    const double *states;     /* nframes x 16 */
+    const double *extr;       /* 14 */
+    const double *sqrt_inv_cov; /* 4 */
+    /* current prior */
+    int np;                   /* frames covered by the prior */
+    const int32_t *prior_frames; /* np map-frame indices */
+    const double *lin;        /* np x 16 */
+    const double *S;          /* (15 np)^2 */
+    const double *f;          /* 15 np */
+    /* preintegration between map frames 0 and 1 (keyframe_preintegration of frame 1); NULL if nframes < 2 */
+    const double *preint01;
+    /* reprojection factors of victim-observed tracks (host-selected: marginalization_factor.h:233-380) */
+    int nfac;
+    const int32_t *tgt, *ref, *lm;
+    const double *tangent;
+    int nlm;
+    const double *z_ref;
+    const double *inv_depth;
+} ro_marg_problem;
+/* outputs: S_out ((15 (nframes-1))^2), f_out, lin_out ((nframes-1) x 16);
+ * optional Lambda_out / eta_out = reduced information matrix / vector before the eigen step */
+void ro_marginalize(const ro_marg_problem *pb, double *S_out, double *f_out, double *lin_out,
+                    double *Lambda_out, double *eta_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,191 @@
+"""Synthetic inputs of the shapes BASELINE.json names.
+
+Used by tests/ and bench.py only -- there is no EuRoC data in the container or on
+the GPU box, so every config runs on a seeded synthetic stream of the same
+shape.  Pure numpy; nothing here touches the oracle or the HIP library.
+"""
+import numpy as np
+
+GRAVITY = 9.80665
+
+# configs/euroc_sensor.yaml:48-50 (camera -> body) and :10-12 (imu -> body, identity)
+EUROC_EXTR = np.array([
+    -7.7071797555374275e-03, 1.0499323370587278e-02, 7.0175280029197162e-01, 7.1230146066895372e-01,
+    -0.0216401454975, -0.064676986768, 0.00981073058949,
+    0.0, 0.0, 0.0, 1.0,
+    0.0, 0.0, 0.0,
+])
+EUROC_K = np.array([[458.654, 0.0, 367.215], [0.0, 457.296, 248.375], [0.0, 0.0, 1.0]])
+# configs/euroc_sensor.yaml:14-29
+EUROC_NOISE = np.concatenate([
+    (np.eye(3) * 2.8791302399999997e-08).ravel(), (np.eye(3) * 4.0e-6).ravel(),
+    (np.eye(3) * 3.7608844899999997e-10).ravel(), (np.eye(3) * 9.0e-6).ravel()])
+
+
+def sqrt_inv_cov_from_K(K, sigma2=0.5):
+    """handler.cpp:117-119: frame->sqrt_inv_cov = K[0:2,0:2] / sqrt(cov)"""
+    return np.array([[K[0, 0] / np.sqrt(sigma2), 0.0], [0.0, K[1, 1] / np.sqrt(sigma2)]])
+
+
+# ------------------------------------------------------------------ small quaternion helpers (x,y,z,w)
+def q_mul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by + ay * bw + az * bx - ax * bz,
+                     aw * bz + az * bw + ax * by - ay * bx,
+                     aw * bw - ax * bx - ay * by - az * bz])
+
+
+def q_conj(q):
+    return np.array([-q[0], -q[1], -q[2], q[3]])
+
+
+def q_to_mat(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def q_exp(w):
+    n = np.linalg.norm(w)
+    if n == 0:
+        return np.array([0.0, 0.0, 0.0, 1.0])
+    return np.concatenate([np.sin(0.5 * n) * w / n, [np.cos(0.5 * n)]])
+
+
+def euler_to_q(roll, pitch, yaw):
+    qx = q_exp(np.array([roll, 0, 0]))
+    qy = q_exp(np.array([0, pitch, 0]))
+    qz = q_exp(np.array([0, 0, yaw]))
+    return q_mul(qz, q_mul(qy, qx))
+
+
+def tangent_frame(z):
+    """lie_algebra.cpp:47-56 + reprojection_factor.h:19-21, numpy twin used to build inputs."""
+    d = int(np.argmax(np.abs(z)))
+    e = np.zeros(3)
+    e[(d + 1) % 3] = 1.0
+    b1 = np.cross(z, e)
+    b1 /= np.linalg.norm(b1)
+    b2 = np.cross(z, b1)
+    b2 /= np.linalg.norm(b2)
+    return np.stack([b1, b2, z], axis=1)
+
+
+# ------------------------------------------------------------------ trajectory
+def traj_pose(t):
+    p = np.array([1.5 * np.sin(0.4 * t), 1.0 * np.sin(0.6 * t), 0.3 * np.sin(0.9 * t)])
+    q = euler_to_q(0.2 * np.sin(0.5 * t), 0.15 * np.sin(0.7 * t), 0.3 * np.sin(0.3 * t))
+    return q, p
+
+
+def traj_vel(t, h=1e-5):
+    return (traj_pose(t + h)[1] - traj_pose(t - h)[1]) / (2 * h)
+
+
+def traj_imu(t, h=1e-4):
+    """analytic-derivative IMU sample (body frame): gyro, specific force."""
+    q, _ = traj_pose(t)
+    qp, _ = traj_pose(t + h)
+    qm, _ = traj_pose(t - h)
+    dq = q_mul(q_conj(qm), qp)
+    w = 2.0 * dq[:3] / (2 * h)
+    acc_w = (traj_pose(t + h)[1] - 2 * traj_pose(t)[1] + traj_pose(t - h)[1]) / (h * h)
+    a = q_to_mat(q).T @ (acc_w - np.array([0, 0, -GRAVITY]))
+    return w, a
+
+
+def make_imu_segment(t0, t1, rate=200.0, rng=None, noise=True):
+    """IMU samples in [t0, t1) as n x 7 (t, w, a)."""
+    ts = np.arange(t0, t1 - 1e-9, 1.0 / rate)
+    out = np.zeros((len(ts), 7))
+    for i, t in enumerate(ts):
+        w, a = traj_imu(t)
+        if noise and rng is not None:
+            w = w + rng.normal(0, np.sqrt(2.8791302399999997e-08 * rate), 3)
+            a = a + rng.normal(0, np.sqrt(4.0e-6 * rate), 3)
+        out[i] = np.concatenate([[t], w, a])
+    return out
+
+
+# ------------------------------------------------------------------ BA problem
+def make_ba_problem(n_frames=9, n_landmarks=150, seed=648, K=EUROC_K, extr=EUROC_EXTR, pix_noise=0.5,
+                    state_noise=True, dt_frame=0.25, obs_prob=0.9, t0=1.0):
+    """A window of `n_frames` keyframes observing `n_landmarks` landmarks.
+
+    Returns a dict of plain arrays in the layouts of include/rdvio_hip.h:
+    states (n,16), extr (14), sqrt_inv_cov (2,2), z_ref (L,3), inv_depth (L), and the
+    factor list tgt/ref/lm (F) + tangent (F,9).  Landmarks are anchored in the first
+    frame that observes them (track.h first_keypoint); every other observation is a factor
+    (sliding_window_tracker.cpp:261-275).
+    """
+    rng = np.random.default_rng(seed)
+    qcs, pcs = extr[0:4], extr[4:7]
+    Rcs = q_to_mat(qcs)
+    states = np.zeros((n_frames, 16))
+    cams = []
+    for i in range(n_frames):
+        t = t0 + dt_frame * i
+        q, p = traj_pose(t)
+        states[i, 0:4] = q
+        states[i, 4:7] = p
+        states[i, 7:10] = traj_vel(t)
+        states[i, 10:13] = rng.normal(0, 1e-3, 3)
+        states[i, 13:16] = rng.normal(0, 1e-2, 3)
+        Rwc = q_to_mat(q) @ Rcs
+        pwc = p + q_to_mat(q) @ pcs
+        cams.append((Rwc, pwc))
+    w_img, h_img = 2 * K[0, 2], 2 * K[1, 2]
+    z_ref, inv_depth, tgt, ref, lm, tangent = [], [], [], [], [], []
+    l = 0
+    attempts = 0
+    while l < n_landmarks and attempts < 100 * n_landmarks:
+        attempts += 1
+        # sample a landmark in front of a random camera
+        c = rng.integers(0, n_frames)
+        Rwc, pwc = cams[c]
+        u = np.array([rng.uniform(30, w_img - 30), rng.uniform(30, h_img - 30)])
+        depth = 1.0 / rng.uniform(0.1, 1.0)
+        ray = np.array([(u[0] - K[0, 2]) / K[0, 0], (u[1] - K[1, 2]) / K[1, 1], 1.0])
+        X = pwc + Rwc @ (ray / np.linalg.norm(ray) * depth)
+        obs = []
+        for i, (R, p) in enumerate(cams):
+            y = R.T @ (X - p)
+            if y[2] < 0.2:
+                continue
+            px = np.array([K[0, 0] * y[0] / y[2] + K[0, 2], K[1, 1] * y[1] / y[2] + K[1, 2]])
+            if not (20 <= px[0] < w_img - 20 and 20 <= px[1] < h_img - 20):
+                continue
+            if rng.uniform() > obs_prob:
+                continue
+            px = px + rng.normal(0, pix_noise, 2)
+            b = np.array([(px[0] - K[0, 2]) / K[0, 0], (px[1] - K[1, 2]) / K[1, 1], 1.0])
+            obs.append((i, b / np.linalg.norm(b)))
+        if len(obs) < 2:
+            continue
+        a_frame, a_bearing = obs[0]
+        Ra, pa = cams[a_frame]
+        z_ref.append(a_bearing)
+        inv_depth.append(1.0 / np.linalg.norm(Ra.T @ (X - pa)))
+        for (i, b) in obs[1:]:
+            tgt.append(i)
+            ref.append(a_frame)
+            lm.append(l)
+            tangent.append(tangent_frame(b).ravel())
+        l += 1
+    out = dict(
+        states=states, extr=extr.copy(), sqrt_inv_cov=sqrt_inv_cov_from_K(K), K=K.copy(),
+        z_ref=np.array(z_ref), inv_depth=np.array(inv_depth),
+        tgt=np.array(tgt, dtype=np.int32), ref=np.array(ref, dtype=np.int32), lm=np.array(lm, dtype=np.int32),
+        tangent=np.array(tangent), states_true=states.copy(), inv_depth_true=np.array(inv_depth))
+    if state_noise:
+        # perturb what BA is supposed to recover
+        for i in range(1, n_frames):
+            out["states"][i, 0:4] = q_mul(states[i, 0:4], q_exp(rng.normal(0, 2e-3, 3)))
+            out["states"][i, 0:4] /= np.linalg.norm(out["states"][i, 0:4])
+            out["states"][i, 4:7] += rng.normal(0, 1e-2, 3)
+            out["states"][i, 7:10] += rng.normal(0, 1e-2, 3)
+        out["inv_depth"] = out["inv_depth"] * rng.uniform(0.9, 1.1, len(inv_depth))
+    return out
