@@ -1,0 +1,137 @@
+/*
+ * rdvio_hip.h -- C ABI of the MI355X (gfx950) implementation of rd_vio's data-parallel hot path.
+ *
+ * This is the drop-in boundary: plain C, POD pointers and sizes, int status
+ * returns (0 = ok), no exceptions, no torch/Eigen/OpenCV types.  It sits exactly at the two plugin
+ * seams the reference already has:
+ *
+ *   seam 1  abstract rdvio::Image            src/rdvio/include/rdvio/types.h:153-177
+ *           (sole implementation OpenCvImage, src/rdvio_extra/src/opencv_image.cpp:38-161)
+ *   seam 2  rdvio::Solver facade + factors   src/rdvio_estimation/include/rdvio/estimation/solver.h:15-70
+ *           MarginalizationFactor::marginalize   .../marginalization_factor.h:9-12
+ *           PreIntegrator                        .../preintegrator.h:10-47
+ *
+ * INTEGRATION.md shows the reference-side subclasses (HipImage : rdvio::Image, the Solver facade and
+ * the MarginalizationFactor subclass) a maintainer adds to bind these entry points.
+ *
+ * Conventions (same as the reference):
+ *   quaternion (x,y,z,w); frame state double[16] = q(4) p(3) v(3) bg(3) ba(3);
+ *   error state theta(0..2) p(3..5) v(6..8) bg(9..11) ba(12..14); matrices row-major;
+ *   extrinsics double[14] = camera q_cs(4) p_cs(3), imu q_cs(4) p_cs(3).
+ * Host entry points take host pointers and copy; *_dev entry points take device pointers (HBM-resident
+ * data, e.g. torch tensors' data_ptr()) and only enqueue work on the context's stream.
+ */
+#ifndef RDVIO_HIP_H
+#define RDVIO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDVIO_OK 0
+#define RDVIO_ERR_INVALID 1   /* bad argument / shape mismatch (checked on the host before any launch) */
+#define RDVIO_ERR_HIP 2       /* a HIP runtime call failed; see rdvio_hip_last_error() */
+#define RDVIO_ERR_CAPACITY 3  /* problem larger than the context was created for */
+
+#define RDVIO_MAX_LEVELS 4    /* OpenCvImage::level_num() == 3 -> levels 0..3 (opencv_image.h:19) */
+#define RDVIO_LK_WIN 21       /* Size(21,21), opencv_image.cpp:96 */
+#define RDVIO_PYR_BORDER 32
+#define RDVIO_STATE_SIZE 16
+#define RDVIO_ES_SIZE 15
+#define RDVIO_PREINT_SIZE 506 /* t, q(4), p(3), v(3), cov(225), sqrt_inv_cov(225), dq_dbg dp_dbg dp_dba dv_dbg dv_dba (5x9) */
+
+typedef struct rdvio_hip_ctx rdvio_hip_ctx;
+
+/* Padded pyramid arena of one frame (replaces the std::vector<cv::Mat> image_pyramid of
+ * OpenCvImage, opencv_image.h:40): level l of the u8 image at img_off[l] (bytes), row stride
+ * stride[l] pixels, `border` pixels of BORDER_REFLECT_101 around it; Scharr derivatives as
+ * interleaved int16 (dx,dy) at deriv_off[l] (int16 elements) with a zero border. */
+typedef struct {
+    int32_t levels;
+    int32_t border;
+    int32_t w[RDVIO_MAX_LEVELS], h[RDVIO_MAX_LEVELS], stride[RDVIO_MAX_LEVELS];
+    int64_t img_off[RDVIO_MAX_LEVELS], deriv_off[RDVIO_MAX_LEVELS];
+    int64_t img_bytes, deriv_elems;
+} rdvio_pyr_layout;
+
+/* ------------------------------------------------------------------ context */
+/* One context per process/stream (the reference's process-global state makes it one Odometry per
+ * process anyway).  `stream` is a hipStream_t to enqueue on (NULL = context-owned stream). */
+int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_width, int max_height, int max_features,
+                         int max_window, int max_factors, void *stream);
+void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx);
+const char *rdvio_hip_last_error(const rdvio_hip_ctx *ctx);
+int rdvio_hip_sync(rdvio_hip_ctx *ctx);
+int rdvio_hip_pyr_layout_init(int width, int height, int max_level, rdvio_pyr_layout *out);
+const char *rdvio_hip_version(void);
+
+/* ------------------------------------------------------------------ seam 1: rdvio::Image */
+/* Image::preprocess (types.h:160; opencv_image.cpp:156-161): CLAHE(clip, tiles) in place, then the
+ * 4-level pyramid with Scharr derivatives, into image slot `slot` (0/1: the tracker keeps exactly two
+ * consecutive frames alive, feature_tracker.cpp:94). */
+int rdvio_hip_image_preprocess(rdvio_hip_ctx *ctx, int slot, const uint8_t *gray, int width, int height,
+                               int stride, double clahe_clip, int tiles_x, int tiles_y);
+int rdvio_hip_image_preprocess_dev(rdvio_hip_ctx *ctx, int slot, const uint8_t *gray_dev, int width,
+                                   int height, int stride, double clahe_clip, int tiles_x, int tiles_y);
+/* copy a slot's arenas back (parity tests) */
+int rdvio_hip_image_download(rdvio_hip_ctx *ctx, int slot, uint8_t *pyr_img, int16_t *pyr_deriv);
+
+/* Image::track_keypoints (types.h:165-168; opencv_image.cpp:75-154): forward LK from the initial guess,
+ * 20-px border and rows/4 max-flow rejection, backward LK, 0.5-px forward-backward check.
+ * curr_xy / next_xy: n x 2 doubles (pixels); has_guess == 0 <=> the reference's empty next_keypoints.
+ * status[i] != 0 <=> survivor; next_xy is written only for survivors (opencv_image.cpp:148-153). */
+int rdvio_hip_track_keypoints(rdvio_hip_ctx *ctx, int slot_curr, int slot_next, int n, const double *curr_xy,
+                              double *next_xy, int has_guess, uint8_t *status);
+int rdvio_hip_track_keypoints_dev(rdvio_hip_ctx *ctx, int slot_curr, int slot_next, int n,
+                                  const double *curr_xy_dev, double *next_xy_dev, int has_guess,
+                                  uint8_t *status_dev);
+/* one cv::calcOpticalFlowPyrLK call (float points, OPTFLOW_USE_INITIAL_FLOW), exposed for unit parity */
+int rdvio_hip_lk_flow(rdvio_hip_ctx *ctx, int slot_prev, int slot_next, int n, const float *prev_xy,
+                      float *next_xy, uint8_t *status, int max_iter, double eps);
+
+/* Image::detect_keypoints (types.h:162-164; opencv_image.cpp:38-73): GFTT-Harris (quality 1e-3,
+ * minDistance 20, block 3, k 0.04) -> response order -> Poisson-disk thinning against the existing
+ * points at `min_distance` -> 20-px border.  keypoints: in/out n x 2 doubles with capacity rows. */
+int rdvio_hip_detect_keypoints(rdvio_hip_ctx *ctx, int slot, double *keypoints, int n_existing, int capacity,
+                               int max_points, double min_distance, int *n_out);
+/* Harris response map of level 0 of a slot (float, width*height) -- unit parity */
+int rdvio_hip_harris_response(rdvio_hip_ctx *ctx, int slot, float *resp);
+/* Image::release_image_buffer (types.h:170) */
+int rdvio_hip_image_release(rdvio_hip_ctx *ctx, int slot);
+
+/* ------------------------------------------------------------------ seam 2: estimation */
+/* PreIntegrator::integrate (preintegrator.cpp:78-95): imu = n x 7 (t, gyro, acc), noise = cov_w cov_a
+ * cov_bg cov_ba (4 x 9).  nseg independent segments in one launch: seg_off[nseg+1] sample offsets,
+ * t_end/bg/ba per segment.  out: nseg x RDVIO_PREINT_SIZE. */
+int rdvio_hip_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off, const double *imu,
+                           const double *t_end, const double *bg, const double *ba, const double *noise,
+                           int compute_jacobian, int compute_covariance, double *preint_out);
+
+/* Sliding-window BA problem in SoA form (what Solver::add_* assembles through pointers,
+ * solver.cpp:88-178; which factors enter: sliding_window_tracker.cpp:226-300). */
+typedef struct {
+    int32_t n_frames;           /* frames in the window (W+1 at BA time) */
+    int32_t n_landmarks;
+    int32_t n_factors;          /* reprojection factors */
+    const double *states;       /* n_frames x 16 */
+    const double *extr;         /* 14 */
+    const double *sqrt_inv_cov; /* 2 x 2 */
+    const double *z_ref;        /* n_landmarks x 3: bearing in the anchor frame */
+    const double *inv_depth;    /* n_landmarks */
+    const int32_t *tgt, *ref, *lm; /* n_factors: target frame, anchor frame, landmark */
+    const double *tangent;      /* n_factors x 9: [b1 b2 z_obs] (reprojection_factor.h:16-22) */
+} rdvio_ba_problem;
+
+/* CeresReprojectionErrorFactor::Evaluate for every factor (reprojection_factor.h:24-89).
+ * r: F x 2; Jt: F x 2 x 6 (theta_tgt, p_tgt); Jr: F x 2 x 6 (theta_ref, p_ref); Jd: F x 2.
+ * The J pointers may be NULL. */
+int rdvio_hip_reprojection_eval(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, double *r, double *Jt,
+                                double *Jr, double *Jd);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -190,3 +190,141 @@ def marginalize(states, extr, W, prior_frames, lin, S, f, preint01, tgt, ref, lm
     eta = np.zeros(R)
     lib().ro_marginalize(ctypes.byref(pb), _p(S_out), _p(f_out), _p(lin_out), _p(Lam), _p(eta))
     return S_out, f_out, lin_out, Lam, eta
+
+
+# ---------------------------------------------------------------- image side
+MAX_LEVELS = 4
+
+
+class PyrLayout(ctypes.Structure):
+    _fields_ = [
+        ("levels", ctypes.c_int32), ("border", ctypes.c_int32),
+        ("w", ctypes.c_int32 * MAX_LEVELS), ("h", ctypes.c_int32 * MAX_LEVELS),
+        ("stride", ctypes.c_int32 * MAX_LEVELS),
+        ("img_off", ctypes.c_int64 * MAX_LEVELS), ("deriv_off", ctypes.c_int64 * MAX_LEVELS),
+        ("img_bytes", ctypes.c_int64), ("deriv_elems", ctypes.c_int64),
+    ]
+
+
+def pyr_layout(w, h, max_level=3):
+    L = PyrLayout()
+    lib().ro_pyr_layout_init(int(w), int(h), int(max_level), ctypes.byref(L))
+    return L
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def clahe(img, clip=6.0, tiles_x=8, tiles_y=8):
+    img = _u8(img)
+    h, w = img.shape
+    out = np.zeros_like(img)
+    lib().ro_clahe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    lib().ro_clahe(img.ctypes.data, w, h, w, float(clip), tiles_x, tiles_y, out.ctypes.data, w)
+    return out
+
+
+def build_pyramid(img, max_level=3):
+    """buildOpticalFlowPyramid of an (already CLAHE'd) image -> (layout, img arena u8, deriv arena i16)"""
+    img = _u8(img)
+    h, w = img.shape
+    L = pyr_layout(w, h, max_level)
+    pi = np.zeros(L.img_bytes, dtype=np.uint8)
+    pd = np.zeros(L.deriv_elems, dtype=np.int16)
+    lib().ro_build_pyramid(ctypes.c_void_p(img.ctypes.data), w, h, w, ctypes.byref(L),
+                           ctypes.c_void_p(pi.ctypes.data), ctypes.c_void_p(pd.ctypes.data))
+    return L, pi, pd
+
+
+def preprocess(gray, clip=6.0, tiles_x=8, tiles_y=8, max_level=3):
+    """OpenCvImage::preprocess: CLAHE then pyramid + Scharr."""
+    gray = _u8(gray)
+    h, w = gray.shape
+    L = pyr_layout(w, h, max_level)
+    pi = np.zeros(L.img_bytes, dtype=np.uint8)
+    pd = np.zeros(L.deriv_elems, dtype=np.int16)
+    lib().ro_preprocess.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                    ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib().ro_preprocess(gray.ctypes.data, w, h, w, float(clip), tiles_x, tiles_y, ctypes.addressof(L),
+                        pi.ctypes.data, pd.ctypes.data)
+    return L, pi, pd
+
+
+def level_view(L, pi, lv, with_border=False):
+    """numpy view of pyramid level lv of an image arena."""
+    B, s = L.border, L.stride[lv]
+    rows = L.h[lv] + 2 * B
+    a = pi[L.img_off[lv]:L.img_off[lv] + s * rows].reshape(rows, s)
+    return a[:, :L.w[lv] + 2 * B] if with_border else a[B:B + L.h[lv], B:B + L.w[lv]]
+
+
+def deriv_view(L, pd, lv, with_border=False):
+    B, s = L.border, L.stride[lv]
+    rows = L.h[lv] + 2 * B
+    a = pd[L.deriv_off[lv]:L.deriv_off[lv] + s * rows * 2].reshape(rows, s, 2)
+    return a[:, :L.w[lv] + 2 * B] if with_border else a[B:B + L.h[lv], B:B + L.w[lv]]
+
+
+def lk_flow(L, prev_img, prev_deriv, next_img, prev_xy, next_xy, max_iter=30, eps=0.01):
+    prev_xy = np.ascontiguousarray(prev_xy, dtype=np.float32).reshape(-1, 2)
+    nxt = np.ascontiguousarray(next_xy, dtype=np.float32).reshape(-1, 2).copy()
+    n = len(prev_xy)
+    st = np.zeros(n, dtype=np.uint8)
+    lib().ro_lk_flow.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                          ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
+    lib().ro_lk_flow(ctypes.addressof(L), prev_img.ctypes.data, prev_deriv.ctypes.data, next_img.ctypes.data, n,
+                     prev_xy.ctypes.data, nxt.ctypes.data, st.ctypes.data, int(max_iter), float(eps))
+    return nxt, st
+
+
+def track_keypoints(L, cur, nxt, curr_pts, guess=None):
+    """OpenCvImage::track_keypoints; cur/nxt are (img arena, deriv arena).  Returns next (n,2) double, status."""
+    curr_pts = _f64(curr_pts).reshape(-1, 2)
+    n = len(curr_pts)
+    nx = _f64(guess).reshape(-1, 2).copy() if guess is not None else np.zeros((n, 2))
+    st = np.zeros(n, dtype=np.uint8)
+    lib().ro_track_keypoints.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                                  ctypes.c_int, ctypes.c_void_p]
+    lib().ro_track_keypoints(ctypes.addressof(L), cur[0].ctypes.data, cur[1].ctypes.data, nxt[0].ctypes.data,
+                             nxt[1].ctypes.data, n, curr_pts.ctypes.data, nx.ctypes.data,
+                             int(guess is not None), st.ctypes.data)
+    return nx, st
+
+
+def harris_response(img, k=0.04):
+    img = _u8(img)
+    h, w = img.shape
+    out = np.zeros((h, w), dtype=np.float32)
+    lib().ro_harris_response.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                         ctypes.c_void_p]
+    lib().ro_harris_response(img.ctypes.data, w, h, w, float(k), out.ctypes.data)
+    return out
+
+
+def good_features(img, max_corners, quality=1e-3, min_dist=20.0, k=0.04):
+    img = _u8(img)
+    h, w = img.shape
+    cap = max_corners if max_corners > 0 else w * h
+    xy = np.zeros((cap, 2), dtype=np.float32)
+    resp = np.zeros(cap, dtype=np.float32)
+    lib().ro_good_features.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p,
+                                       ctypes.c_void_p]
+    n = lib().ro_good_features(img.ctypes.data, w, h, w, int(max_corners), float(quality), float(min_dist), float(k),
+                               xy.ctypes.data, resp.ctypes.data)
+    return xy[:n].copy(), resp[:n].copy()
+
+
+def detect_keypoints(img, existing, max_corners, min_dist):
+    img = _u8(img)
+    h, w = img.shape
+    existing = _f64(existing).reshape(-1, 2)
+    buf = np.zeros((len(existing) + max_corners, 2))
+    buf[:len(existing)] = existing
+    lib().ro_detect_keypoints.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_double, ctypes.c_void_p, ctypes.c_int]
+    n = lib().ro_detect_keypoints(img.ctypes.data, w, h, w, int(max_corners), float(min_dist), buf.ctypes.data,
+                                  len(existing))
+    return buf[:n].copy()

@@ -108,6 +108,40 @@ typedef struct {
 void ro_marginalize(const ro_marg_problem *pb, double *S_out, double *f_out, double *lin_out,
                     double *Lambda_out, double *eta_out);
 
+/* ================= image side (rows A1-A3; OpenCV arithmetic restated, see ro_image.c) ================= */
+#define RO_MAX_LEVELS 4      /* level_num() == 3 -> levels 0..3, opencv_image.h:19 */
+#define RO_LK_WIN 21         /* Size(21,21), opencv_image.cpp:96 */
+#define RO_PYR_BORDER 32     /* >= winSize+1; OpenCV pads by winSize=21, the extra columns are never read */
+
+/* One padded arena per frame.  Level l of the u8 image lives at img_off[l] (bytes) with row stride
+ * stride[l] and a `border`-pixel frame (BORDER_REFLECT_101); derivatives are interleaved int16 (dx,dy)
+ * at deriv_off[l] (int16 elements), same stride in pixels, zero border (BORDER_CONSTANT). */
+typedef struct {
+    int32_t levels;
+    int32_t border;
+    int32_t w[RO_MAX_LEVELS], h[RO_MAX_LEVELS], stride[RO_MAX_LEVELS];
+    int64_t img_off[RO_MAX_LEVELS], deriv_off[RO_MAX_LEVELS];
+    int64_t img_bytes, deriv_elems;
+} ro_pyr_layout;
+
+void ro_pyr_layout_init(int w, int h, int max_level, ro_pyr_layout *L);
+void ro_clahe(const uint8_t *src, int w, int h, int src_stride, double clip_limit, int tiles_x, int tiles_y,
+              uint8_t *dst, int dst_stride);
+void ro_build_pyramid(const uint8_t *img, int w, int h, int img_stride, const ro_pyr_layout *L, uint8_t *pyr_img,
+                      int16_t *pyr_deriv);
+void ro_preprocess(const uint8_t *gray, int w, int h, int stride, double clip, int tiles_x, int tiles_y,
+                   const ro_pyr_layout *L, uint8_t *pyr_img, int16_t *pyr_deriv);
+void ro_lk_flow(const ro_pyr_layout *L, const uint8_t *prev_img, const int16_t *prev_deriv, const uint8_t *next_img,
+                int n, const float *prev_xy, float *next_xy, uint8_t *status, int max_iter, double eps);
+void ro_track_keypoints(const ro_pyr_layout *L, const uint8_t *cur_img, const int16_t *cur_deriv,
+                        const uint8_t *nxt_img, const int16_t *nxt_deriv, int n, const double *curr,
+                        double *next, int has_guess, uint8_t *status);
+void ro_harris_response(const uint8_t *img, int w, int h, int stride, double k, float *resp);
+int ro_good_features(const uint8_t *img, int w, int h, int stride, int max_corners, double quality, double min_dist,
+                     double k, float *out_xy, float *out_resp);
+int ro_detect_keypoints(const uint8_t *img, int w, int h, int stride, int max_corners, double min_dist_poisson,
+                        double *keypoints, int n_existing);
+
 #ifdef __cplusplus
 }
 #endif

@@ -445,7 +445,7 @@ void ro_marginalize(const ro_marg_problem *pb, double *S_out, double *f_out, dou
     /* (i) current prior: J^T J, J^T r (:107-161) */
     {
         int np = pb->np, D = 15 * np;
-        double *ps = (double *)malloc(sizeof(double) * 16 * np);
+        double *ps = (double *)calloc((size_t)16 * (np > 0 ? np : 1), sizeof(double));
         for (int i = 0; i < np; ++i) memcpy(ps + 16 * i, pb->states + 16 * pb->prior_frames[i], 16 * sizeof(double));
         double *r = (double *)malloc(sizeof(double) * D);
         double *J = (double *)malloc(sizeof(double) * D * D);

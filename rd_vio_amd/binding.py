@@ -1,0 +1,283 @@
+"""ctypes binding of librdvio_hip.so (include/rdvio_hip.h).  No compute happens in Python."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+STATE_SIZE = 16
+PREINT_SIZE = 506
+MAX_LEVELS = 4
+
+# every symbol include/rdvio_hip.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "rdvio_hip_version", "rdvio_hip_pyr_layout_init", "rdvio_hip_ctx_create", "rdvio_hip_ctx_destroy",
+    "rdvio_hip_last_error", "rdvio_hip_sync", "rdvio_hip_image_preprocess", "rdvio_hip_image_preprocess_dev",
+    "rdvio_hip_image_download", "rdvio_hip_track_keypoints", "rdvio_hip_track_keypoints_dev", "rdvio_hip_lk_flow",
+    "rdvio_hip_detect_keypoints", "rdvio_hip_harris_response", "rdvio_hip_image_release", "rdvio_hip_preintegrate",
+    "rdvio_hip_reprojection_eval",
+]
+
+
+class RdvioError(RuntimeError):
+    pass
+
+
+class PyrLayout(ctypes.Structure):
+    _fields_ = [
+        ("levels", ctypes.c_int32), ("border", ctypes.c_int32),
+        ("w", ctypes.c_int32 * MAX_LEVELS), ("h", ctypes.c_int32 * MAX_LEVELS),
+        ("stride", ctypes.c_int32 * MAX_LEVELS),
+        ("img_off", ctypes.c_int64 * MAX_LEVELS), ("deriv_off", ctypes.c_int64 * MAX_LEVELS),
+        ("img_bytes", ctypes.c_int64), ("deriv_elems", ctypes.c_int64),
+    ]
+
+
+class BaProblem(ctypes.Structure):
+    _fields_ = [
+        ("n_frames", ctypes.c_int32), ("n_landmarks", ctypes.c_int32), ("n_factors", ctypes.c_int32),
+        ("states", ctypes.c_void_p), ("extr", ctypes.c_void_p), ("sqrt_inv_cov", ctypes.c_void_p),
+        ("z_ref", ctypes.c_void_p), ("inv_depth", ctypes.c_void_p),
+        ("tgt", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("lm", ctypes.c_void_p), ("tangent", ctypes.c_void_p),
+    ]
+
+
+def lib_path():
+    return os.path.join(_HERE, "librdvio_hip.so")
+
+
+def load_library():
+    """Load librdvio_hip.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RdvioError(f"{path} not built: run `python -m rd_vio_amd.build` (or __graft_entry__.build())")
+    try:
+        # share torch's HIP runtime when torch is present in the process (same SONAME libamdhip64.so.7)
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the binding itself
+        pass
+    lib = ctypes.CDLL(path)
+    lib.rdvio_hip_version.restype = ctypes.c_char_p
+    lib.rdvio_hip_last_error.restype = ctypes.c_char_p
+    lib.rdvio_hip_last_error.argtypes = [ctypes.c_void_p]
+    lib.rdvio_hip_ctx_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)] + [ctypes.c_int] * 6 + [ctypes.c_void_p]
+    lib.rdvio_hip_ctx_destroy.argtypes = [ctypes.c_void_p]
+    lib.rdvio_hip_ctx_destroy.restype = None
+    lib.rdvio_hip_sync.argtypes = [ctypes.c_void_p]
+    lib.rdvio_hip_pyr_layout_init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(PyrLayout)]
+    img_args = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                ctypes.c_double, ctypes.c_int, ctypes.c_int]
+    lib.rdvio_hip_image_preprocess.argtypes = img_args
+    lib.rdvio_hip_image_preprocess_dev.argtypes = img_args
+    lib.rdvio_hip_image_download.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.rdvio_hip_image_release.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    trk = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+           ctypes.c_void_p]
+    lib.rdvio_hip_track_keypoints.argtypes = trk
+    lib.rdvio_hip_track_keypoints_dev.argtypes = trk
+    lib.rdvio_hip_lk_flow.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
+    lib.rdvio_hip_detect_keypoints.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                               ctypes.POINTER(ctypes.c_int)]
+    lib.rdvio_hip_harris_response.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.rdvio_hip_preintegrate.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6 + [
+        ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.rdvio_hip_reprojection_eval.argtypes = [ctypes.c_void_p, ctypes.POINTER(BaProblem)] + [ctypes.c_void_p] * 4
+    _LIB = lib
+    return lib
+
+
+def have_gpu():
+    """True if a HIP device is usable (counts devices only; does not initialise a context)."""
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return os.path.exists("/dev/kfd")
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Context:
+    """rdvio_hip_ctx: owns the device buffers; one per process/stream."""
+
+    def __init__(self, max_width=752, max_height=480, max_features=1024, max_window=16, max_factors=16384,
+                 device=0, stream=None):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        rc = self._lib.rdvio_hip_ctx_create(ctypes.byref(self._h), device, max_width, max_height, max_features,
+                                            max_window, max_factors, stream)
+        if rc != 0:
+            msg = self._lib.rdvio_hip_last_error(self._h).decode() if self._h else "no HIP device / bad arguments"
+            if self._h:
+                self._lib.rdvio_hip_ctx_destroy(self._h)
+                self._h = None
+            raise RdvioError(f"rdvio_hip_ctx_create failed ({rc}): {msg}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rdvio_hip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RdvioError(f"rdvio_hip error {rc}: {self._lib.rdvio_hip_last_error(self._h).decode()}")
+
+    def sync(self):
+        self._check(self._lib.rdvio_hip_sync(self._h))
+
+    # ---------------------------------------------------------------- seam 2: estimation
+    def preintegrate(self, segments, t_end, bg, ba, noise, jac=True, cov=True):
+        """PreIntegrator::integrate for a batch of segments (list of n_i x 7 arrays). -> (nseg, 506)"""
+        nseg = len(segments)
+        off = np.zeros(nseg + 1, dtype=np.int32)
+        for i, s in enumerate(segments):
+            off[i + 1] = off[i] + len(s)
+        imu = _f64(np.concatenate([np.asarray(s, dtype=np.float64).reshape(-1, 7) for s in segments], axis=0)) \
+            if off[-1] > 0 else np.zeros((1, 7))
+        t_end, bg, ba, noise = _f64(t_end).reshape(nseg), _f64(bg).reshape(nseg, 3), _f64(ba).reshape(nseg, 3), _f64(noise)
+        out = np.zeros((nseg, PREINT_SIZE))
+        self._check(self._lib.rdvio_hip_preintegrate(self._h, nseg, off.ctypes.data, imu.ctypes.data, t_end.ctypes.data,
+                                                     bg.ctypes.data, ba.ctypes.data, noise.ctypes.data, int(jac),
+                                                     int(cov), out.ctypes.data))
+        return out
+
+    def _ba_problem(self, pb):
+        keep = dict(states=_f64(pb["states"]), extr=_f64(pb["extr"]), W=_f64(pb["sqrt_inv_cov"]),
+                    z_ref=_f64(pb["z_ref"]), inv_depth=_f64(pb["inv_depth"]), tgt=_i32(pb["tgt"]), ref=_i32(pb["ref"]),
+                    lm=_i32(pb["lm"]), tangent=_f64(pb["tangent"]))
+        c = BaProblem()
+        c.n_frames = len(keep["states"].reshape(-1, 16))
+        c.n_landmarks = len(keep["inv_depth"])
+        c.n_factors = len(keep["tgt"])
+        c.states = keep["states"].ctypes.data
+        c.extr = keep["extr"].ctypes.data
+        c.sqrt_inv_cov = keep["W"].ctypes.data
+        c.z_ref = keep["z_ref"].ctypes.data
+        c.inv_depth = keep["inv_depth"].ctypes.data
+        c.tgt = keep["tgt"].ctypes.data
+        c.ref = keep["ref"].ctypes.data
+        c.lm = keep["lm"].ctypes.data
+        c.tangent = keep["tangent"].ctypes.data
+        return c, keep
+
+    def reprojection_eval(self, pb, jac=True):
+        """CeresReprojectionErrorFactor::Evaluate over all factors of a BA problem dict."""
+        c, keep = self._ba_problem(pb)
+        n = c.n_factors
+        r = np.zeros((n, 2))
+        Jt = np.zeros((n, 2, 6)) if jac else None
+        Jr = np.zeros((n, 2, 6)) if jac else None
+        Jd = np.zeros((n, 2)) if jac else None
+        self._check(self._lib.rdvio_hip_reprojection_eval(
+            self._h, ctypes.byref(c), r.ctypes.data, Jt.ctypes.data if jac else None,
+            Jr.ctypes.data if jac else None, Jd.ctypes.data if jac else None))
+        return r, Jt, Jr, Jd
+
+
+class HipImage:
+    """Mirror of rdvio::Image (types.h:153-177) / OpenCvImage on a context image slot."""
+
+    def __init__(self, ctx, slot, gray):
+        self.ctx = ctx
+        self.slot = int(slot)
+        self.image = np.ascontiguousarray(gray, dtype=np.uint8)
+        if self.image.ndim != 2:
+            raise RdvioError("HipImage expects a single-channel u8 image")
+        self.L = None
+
+    def width(self):
+        return self.image.shape[1]
+
+    def height(self):
+        return self.image.shape[0]
+
+    def level_num(self):
+        return 3
+
+    def preprocess(self, clip_limit=6.0, width=8, height=8):
+        """Image::preprocess(clipLimit, width, height) -- opencv_image.cpp:156-161"""
+        h, w = self.image.shape
+        c = self.ctx
+        c._check(c._lib.rdvio_hip_image_preprocess(c._h, self.slot, self.image.ctypes.data, w, h, w, float(clip_limit),
+                                                   int(width), int(height)))
+        self.L = PyrLayout()
+        c._lib.rdvio_hip_pyr_layout_init(w, h, MAX_LEVELS - 1, ctypes.byref(self.L))
+
+    def download(self):
+        """(pyr_img u8 arena, pyr_deriv int16 arena) -- test helper"""
+        c = self.ctx
+        pi = np.zeros(self.L.img_bytes, dtype=np.uint8)
+        pd = np.zeros(self.L.deriv_elems, dtype=np.int16)
+        c._check(c._lib.rdvio_hip_image_download(c._h, self.slot, pi.ctypes.data, pd.ctypes.data))
+        return pi, pd
+
+    def track_keypoints(self, next_image, curr_keypoints, next_keypoints=None):
+        """Image::track_keypoints(next_image, curr, next_inout, status) -- opencv_image.cpp:75-154.
+        Returns (next_keypoints (n,2) double, status (n,) u8)."""
+        c = self.ctx
+        curr = _f64(curr_keypoints).reshape(-1, 2)
+        n = len(curr)
+        has_guess = next_keypoints is not None and len(next_keypoints) > 0
+        nxt = _f64(next_keypoints).reshape(-1, 2).copy() if has_guess else np.zeros((n, 2))
+        st = np.zeros(n, dtype=np.uint8)
+        c._check(c._lib.rdvio_hip_track_keypoints(c._h, self.slot, next_image.slot, n, curr.ctypes.data,
+                                                  nxt.ctypes.data, int(has_guess), st.ctypes.data))
+        return nxt, st
+
+    def lk_flow(self, next_image, prev_xy, next_xy, max_iter=30, eps=0.01):
+        c = self.ctx
+        prev = np.ascontiguousarray(prev_xy, dtype=np.float32).reshape(-1, 2)
+        nxt = np.ascontiguousarray(next_xy, dtype=np.float32).reshape(-1, 2).copy()
+        st = np.zeros(len(prev), dtype=np.uint8)
+        c._check(c._lib.rdvio_hip_lk_flow(c._h, self.slot, next_image.slot, len(prev), prev.ctypes.data,
+                                          nxt.ctypes.data, st.ctypes.data, int(max_iter), float(eps)))
+        return nxt, st
+
+    def harris_response(self):
+        c = self.ctx
+        h, w = self.image.shape
+        out = np.zeros((h, w), dtype=np.float32)
+        c._check(c._lib.rdvio_hip_harris_response(c._h, self.slot, out.ctypes.data))
+        return out
+
+    def detect_keypoints(self, keypoints, max_points=1000, keypoint_distance=10.0):
+        """Image::detect_keypoints(keypoints_inout, max_points, distance) -- opencv_image.cpp:38-73"""
+        c = self.ctx
+        existing = _f64(keypoints).reshape(-1, 2)
+        cap = len(existing) + int(max_points)
+        buf = np.zeros((cap, 2))
+        buf[:len(existing)] = existing
+        n_out = ctypes.c_int(0)
+        c._check(c._lib.rdvio_hip_detect_keypoints(c._h, self.slot, buf.ctypes.data, len(existing), cap,
+                                                   int(max_points), float(keypoint_distance), ctypes.byref(n_out)))
+        return buf[:n_out.value].copy()
+
+    def release_image_buffer(self):
+        c = self.ctx
+        c._check(c._lib.rdvio_hip_image_release(c._h, self.slot))

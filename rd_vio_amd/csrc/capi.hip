@@ -1,0 +1,344 @@
+// C ABI of librdvio_hip.so (include/rdvio_hip.h): argument checking on the host, staging copies,
+// kernel launches.  There is NO CPU fallback: every entry point either runs the HIP kernels or fails.
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "ctx.hpp"
+#include "host_select.hpp"
+
+extern "C" {
+
+const char *rdvio_hip_version(void) { return "rdvio_hip 0.1 (gfx950)"; }
+
+int rdvio_hip_pyr_layout_init(int w, int h, int max_level, rdvio_pyr_layout *L) {
+    if (!L || w <= 0 || h <= 0 || max_level < 0) return RDVIO_ERR_INVALID;
+    memset(L, 0, sizeof *L);
+    L->border = RDVIO_PYR_BORDER;
+    int lw = w, lh = h;
+    int64_t ioff = 0, doff = 0;
+    for (int lv = 0; lv <= max_level && lv < RDVIO_MAX_LEVELS; ++lv) {
+        L->w[lv] = lw;
+        L->h[lv] = lh;
+        const int stride = (lw + 2 * L->border + 63) / 64 * 64;
+        L->stride[lv] = stride;
+        L->img_off[lv] = ioff;
+        L->deriv_off[lv] = doff;
+        const int64_t rows = lh + 2 * L->border;
+        ioff += (int64_t)stride * rows;
+        doff += (int64_t)stride * rows * 2;
+        L->levels = lv + 1;
+        // cv::buildOpticalFlowPyramid stops before a level that would not exceed the LK window
+        lw = (lw + 1) / 2;
+        lh = (lh + 1) / 2;
+        if (lw <= RDVIO_LK_WIN || lh <= RDVIO_LK_WIN) break;
+    }
+    L->img_bytes = ioff;
+    L->deriv_elems = doff;
+    return RDVIO_OK;
+}
+
+#define CTX_ALLOC(ptr, bytes)                                                                         \
+    do {                                                                                              \
+        hipError_t e__ = hipMalloc((void **)&(ptr), (bytes));                                         \
+        if (e__ != hipSuccess) {                                                                      \
+            rdvio_fail(ctx, RDVIO_ERR_HIP, "hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(e__)); \
+            *out = ctx;                                                                               \
+            return RDVIO_ERR_HIP;                                                                     \
+        }                                                                                             \
+    } while (0)
+
+int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, int max_feat, int max_window,
+                         int max_factors, void *stream) {
+    if (!out) return RDVIO_ERR_INVALID;
+    *out = nullptr;
+    if (max_w < 32 || max_h < 32 || max_feat <= 0 || max_window <= 0 || max_factors <= 0) return RDVIO_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RDVIO_ERR_HIP;  // fail loudly: no GPU, no product
+    if (device < 0 || device >= ndev) return RDVIO_ERR_INVALID;
+    rdvio_hip_ctx *ctx = new (std::nothrow) rdvio_hip_ctx();
+    if (!ctx) return RDVIO_ERR_HIP;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) {
+        delete ctx;
+        return RDVIO_ERR_HIP;
+    }
+    ctx->max_w = max_w;
+    ctx->max_h = max_h;
+    ctx->max_feat = max_feat;
+    ctx->max_window = max_window;
+    ctx->max_factors = max_factors;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return RDVIO_ERR_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    rdvio_hip_pyr_layout_init(max_w, max_h, RDVIO_MAX_LEVELS - 1, &ctx->maxL);
+    for (int s = 0; s < RDVIO_NUM_SLOTS; ++s) {
+        CTX_ALLOC(ctx->slots[s].pyr_img, (size_t)ctx->maxL.img_bytes);
+        CTX_ALLOC(ctx->slots[s].pyr_deriv, (size_t)ctx->maxL.deriv_elems * sizeof(int16_t));
+    }
+    CTX_ALLOC(ctx->gray, (size_t)max_w * max_h);
+    CTX_ALLOC(ctx->clahe_lut, (size_t)RDVIO_MAX_TILES * 256);
+    CTX_ALLOC(ctx->harris, (size_t)max_w * max_h * sizeof(float));
+    CTX_ALLOC(ctx->harris_scalars, 4 * sizeof(uint32_t));
+    ctx->harris_cand_cap = (max_w * max_h) / 4 + 1024;  // 3x3 strict local maxima cannot exceed 1/4 of the pixels
+    CTX_ALLOC(ctx->harris_cand, (size_t)ctx->harris_cand_cap * sizeof(HarrisCand));
+    CTX_ALLOC(ctx->lk_curr, (size_t)max_feat * 2 * sizeof(double));
+    CTX_ALLOC(ctx->lk_next, (size_t)max_feat * 2 * sizeof(double));
+    CTX_ALLOC(ctx->lk_prevf, (size_t)max_feat * 2 * sizeof(float));
+    CTX_ALLOC(ctx->lk_nextf, (size_t)max_feat * 2 * sizeof(float));
+    CTX_ALLOC(ctx->lk_status, (size_t)max_feat);
+    const int nfr = max_window + 2;
+    const int max_lm = max_factors;  // every factor could belong to its own landmark
+    CTX_ALLOC(ctx->ba_states, (size_t)nfr * 16 * sizeof(double));
+    CTX_ALLOC(ctx->ba_extr, 18 * sizeof(double));
+    CTX_ALLOC(ctx->ba_zref, (size_t)max_lm * 3 * sizeof(double));
+    CTX_ALLOC(ctx->ba_invd, (size_t)max_lm * sizeof(double));
+    CTX_ALLOC(ctx->ba_tangent, (size_t)max_factors * 9 * sizeof(double));
+    CTX_ALLOC(ctx->ba_idx, (size_t)max_factors * 3 * sizeof(int32_t));
+    CTX_ALLOC(ctx->ba_r, (size_t)max_factors * 2 * sizeof(double));
+    CTX_ALLOC(ctx->ba_Jt, (size_t)max_factors * 12 * sizeof(double));
+    CTX_ALLOC(ctx->ba_Jr, (size_t)max_factors * 12 * sizeof(double));
+    CTX_ALLOC(ctx->ba_Jd, (size_t)max_factors * 2 * sizeof(double));
+    ctx->pre_max_seg = nfr + 8;
+    ctx->pre_max_samples = ctx->pre_max_seg * 256;
+    CTX_ALLOC(ctx->pre_imu, (size_t)ctx->pre_max_samples * 7 * sizeof(double));
+    CTX_ALLOC(ctx->pre_par, ((size_t)ctx->pre_max_seg * 7 + 36) * sizeof(double));
+    CTX_ALLOC(ctx->pre_out, (size_t)ctx->pre_max_seg * RDVIO_PREINT_SIZE * sizeof(double));
+    CTX_ALLOC(ctx->pre_off, (size_t)(ctx->pre_max_seg + 1) * sizeof(int32_t));
+    ctx->pinned_bytes = std::max<size_t>((size_t)ctx->harris_cand_cap * sizeof(HarrisCand), 1 << 20);
+    if (hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+        rdvio_fail(ctx, RDVIO_ERR_HIP, "hipHostMalloc failed");
+        *out = ctx;
+        return RDVIO_ERR_HIP;
+    }
+    *out = ctx;
+    return RDVIO_OK;
+}
+
+void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int s = 0; s < RDVIO_NUM_SLOTS; ++s) {
+        (void)hipFree(ctx->slots[s].pyr_img);
+        (void)hipFree(ctx->slots[s].pyr_deriv);
+    }
+    void *bufs[] = {ctx->gray, ctx->clahe_lut, ctx->harris, ctx->harris_scalars, ctx->harris_cand, ctx->lk_curr,
+                    ctx->lk_next, ctx->lk_prevf, ctx->lk_nextf, ctx->lk_status, ctx->ba_states, ctx->ba_extr,
+                    ctx->ba_zref, ctx->ba_invd, ctx->ba_tangent, ctx->ba_idx, ctx->ba_r, ctx->ba_Jt, ctx->ba_Jr,
+                    ctx->ba_Jd, ctx->pre_imu, ctx->pre_par, ctx->pre_out, ctx->pre_off};
+    for (void *b : bufs) (void)hipFree(b);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *rdvio_hip_last_error(const rdvio_hip_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int rdvio_hip_sync(rdvio_hip_ctx *ctx) {
+    if (!ctx) return RDVIO_ERR_INVALID;
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return RDVIO_OK;
+}
+
+// ------------------------------------------------------------------------------------------ seam 1
+static int check_image_args(rdvio_hip_ctx *ctx, int slot, const void *gray, int w, int h, int stride, int tx, int ty) {
+    if (!ctx) return RDVIO_ERR_INVALID;
+    if (slot < 0 || slot >= RDVIO_NUM_SLOTS) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "slot %d out of range", slot);
+    if (!gray || w < 32 || h < 32 || stride < w) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "bad image %dx%d stride %d", w, h, stride);
+    if (w > ctx->max_w || h > ctx->max_h) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "image %dx%d exceeds context %dx%d", w, h, ctx->max_w, ctx->max_h);
+    if (tx <= 0 || ty <= 0 || tx * ty > RDVIO_MAX_TILES) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "bad CLAHE tile grid %dx%d", tx, ty);
+    return RDVIO_OK;
+}
+
+int rdvio_hip_image_preprocess_dev(rdvio_hip_ctx *ctx, int slot, const uint8_t *gray_dev, int w, int h, int stride,
+                                   double clip, int tiles_x, int tiles_y) {
+    if (int rc = check_image_args(ctx, slot, gray_dev, w, h, stride, tiles_x, tiles_y)) return rc;
+    return rdvio_launch_preprocess(ctx, slot, gray_dev, w, h, stride, clip, tiles_x, tiles_y);
+}
+
+int rdvio_hip_image_preprocess(rdvio_hip_ctx *ctx, int slot, const uint8_t *gray, int w, int h, int stride, double clip,
+                               int tiles_x, int tiles_y) {
+    if (int rc = check_image_args(ctx, slot, gray, w, h, stride, tiles_x, tiles_y)) return rc;
+    RDVIO_HIP_CHECK(ctx, hipMemcpy2DAsync(ctx->gray, w, gray, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+    return rdvio_launch_preprocess(ctx, slot, ctx->gray, w, h, w, clip, tiles_x, tiles_y);
+}
+
+int rdvio_hip_image_download(rdvio_hip_ctx *ctx, int slot, uint8_t *pyr_img, int16_t *pyr_deriv) {
+    if (!ctx || slot < 0 || slot >= RDVIO_NUM_SLOTS) return RDVIO_ERR_INVALID;
+    ImageSlot &S = ctx->slots[slot];
+    if (!S.valid) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "slot %d not preprocessed", slot);
+    if (pyr_img) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(pyr_img, S.pyr_img, (size_t)S.L.img_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (pyr_deriv)
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(pyr_deriv, S.pyr_deriv, (size_t)S.L.deriv_elems * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return RDVIO_OK;
+}
+
+int rdvio_hip_image_release(rdvio_hip_ctx *ctx, int slot) {
+    if (!ctx || slot < 0 || slot >= RDVIO_NUM_SLOTS) return RDVIO_ERR_INVALID;
+    ctx->slots[slot].valid = false;  // buffers are context-owned and reused by the next preprocess
+    return RDVIO_OK;
+}
+
+int rdvio_hip_track_keypoints_dev(rdvio_hip_ctx *ctx, int slot_curr, int slot_next, int n, const double *curr_dev,
+                                  double *next_dev, int has_guess, uint8_t *status_dev) {
+    if (!ctx || n < 0 || (n > 0 && (!curr_dev || !next_dev || !status_dev))) return RDVIO_ERR_INVALID;
+    return rdvio_launch_track(ctx, slot_curr, slot_next, n, curr_dev, next_dev, has_guess, status_dev);
+}
+
+int rdvio_hip_track_keypoints(rdvio_hip_ctx *ctx, int slot_curr, int slot_next, int n, const double *curr_xy,
+                              double *next_xy, int has_guess, uint8_t *status) {
+    if (!ctx || n < 0 || (n > 0 && (!curr_xy || !next_xy || !status))) return RDVIO_ERR_INVALID;
+    if (n > ctx->max_feat) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d features exceed context capacity %d", n, ctx->max_feat);
+    if (n == 0) return RDVIO_OK;
+    const size_t bytes = (size_t)n * 2 * sizeof(double);
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lk_curr, curr_xy, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lk_next, next_xy, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = rdvio_launch_track(ctx, slot_curr, slot_next, n, ctx->lk_curr, ctx->lk_next, has_guess, ctx->lk_status)) return rc;
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(next_xy, ctx->lk_next, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(status, ctx->lk_status, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return RDVIO_OK;
+}
+
+int rdvio_hip_lk_flow(rdvio_hip_ctx *ctx, int slot_prev, int slot_next, int n, const float *prev_xy, float *next_xy,
+                      uint8_t *status, int max_iter, double eps) {
+    if (!ctx || n < 0 || (n > 0 && (!prev_xy || !next_xy || !status))) return RDVIO_ERR_INVALID;
+    if (n > ctx->max_feat) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d features exceed context capacity %d", n, ctx->max_feat);
+    if (n == 0) return RDVIO_OK;
+    const size_t bytes = (size_t)n * 2 * sizeof(float);
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lk_prevf, prev_xy, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lk_nextf, next_xy, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = rdvio_launch_lk_flow(ctx, slot_prev, slot_next, n, ctx->lk_prevf, ctx->lk_nextf, ctx->lk_status, max_iter, eps)) return rc;
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(next_xy, ctx->lk_nextf, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(status, ctx->lk_status, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return RDVIO_OK;
+}
+
+int rdvio_hip_harris_response(rdvio_hip_ctx *ctx, int slot, float *resp) {
+    if (!ctx || !resp || slot < 0 || slot >= RDVIO_NUM_SLOTS) return RDVIO_ERR_INVALID;
+    ImageSlot &S = ctx->slots[slot];
+    if (!S.valid) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "slot %d not preprocessed", slot);
+    if (int rc = rdvio_launch_harris(ctx, slot)) return rc;
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(resp, ctx->harris, (size_t)S.w * S.h * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return RDVIO_OK;
+}
+
+int rdvio_hip_detect_keypoints(rdvio_hip_ctx *ctx, int slot, double *keypoints, int n_existing, int capacity,
+                               int max_points, double min_distance, int *n_out) {
+    if (!ctx || !keypoints || !n_out || slot < 0 || slot >= RDVIO_NUM_SLOTS || n_existing < 0 || max_points <= 0 ||
+        capacity < n_existing)
+        return RDVIO_ERR_INVALID;
+    ImageSlot &S = ctx->slots[slot];
+    if (!S.valid) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "slot %d not preprocessed", slot);
+    // GFTTDetector::create(max_points, 1.0e-3, 20, 3, true): opencv_image.cpp:184-188
+    if (int rc = rdvio_launch_harris(ctx, slot)) return rc;
+    if (int rc = rdvio_launch_harris_candidates(ctx, slot, 1.0e-3)) return rc;
+    uint32_t scalars[2];
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(scalars, ctx->harris_scalars, sizeof scalars, hipMemcpyDeviceToHost, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    int nc = (int)std::min<uint32_t>(scalars[1], (uint32_t)ctx->harris_cand_cap);
+    HarrisCand *cand = (HarrisCand *)ctx->pinned;
+    if (nc > 0) {
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(cand, ctx->harris_cand, (size_t)nc * sizeof(HarrisCand), hipMemcpyDeviceToHost, ctx->stream));
+        RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    int total = rdvio_host_select_keypoints(cand, nc, S.w, S.h, max_points, 20.0, min_distance, keypoints, n_existing, capacity);
+    if (total < 0) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "keypoint capacity %d too small", capacity);
+    *n_out = total;
+    return RDVIO_OK;
+}
+
+// ------------------------------------------------------------------------------------------ seam 2
+int rdvio_hip_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off, const double *imu, const double *t_end,
+                           const double *bg, const double *ba, const double *noise, int cj, int cc, double *out) {
+    if (!ctx || nseg < 0 || (nseg > 0 && (!seg_off || !imu || !t_end || !bg || !ba || !noise || !out))) return RDVIO_ERR_INVALID;
+    if (nseg == 0) return RDVIO_OK;
+    if (nseg > ctx->pre_max_seg) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d segments exceed capacity %d", nseg, ctx->pre_max_seg);
+    if (seg_off[0] != 0) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "seg_off[0] must be 0");
+    for (int i = 0; i < nseg; ++i)
+        if (seg_off[i + 1] < seg_off[i]) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "seg_off must be non-decreasing");
+    const int ns = seg_off[nseg];
+    if (ns > ctx->pre_max_samples) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d samples exceed capacity %d", ns, ctx->pre_max_samples);
+    double *par = (double *)ctx->pinned;
+    for (int i = 0; i < nseg; ++i) {
+        par[7 * i] = t_end[i];
+        for (int k = 0; k < 3; ++k) {
+            par[7 * i + 1 + k] = bg[3 * i + k];
+            par[7 * i + 4 + k] = ba[3 * i + k];
+        }
+    }
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pre_par, par, (size_t)nseg * 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pre_par + 7 * (size_t)ctx->pre_max_seg, noise, 36 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pre_off, seg_off, (size_t)(nseg + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (ns > 0) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pre_imu, imu, (size_t)ns * 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    // the pinned staging buffer is reused by later calls: finish the uploads that read it before returning
+    if (int rc = rdvio_launch_preintegrate(ctx, nseg, cj, cc)) return rc;
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(out, ctx->pre_out, (size_t)nseg * RDVIO_PREINT_SIZE * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return RDVIO_OK;
+}
+
+static int upload_ba_problem(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb) {
+    if (!pb || pb->n_frames <= 0 || pb->n_factors < 0 || pb->n_landmarks < 0) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "bad BA problem");
+    if (pb->n_frames > ctx->max_window + 2) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d frames exceed window capacity", pb->n_frames);
+    if (pb->n_factors > ctx->max_factors || pb->n_landmarks > ctx->max_factors)
+        return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d factors / %d landmarks exceed capacity %d", pb->n_factors, pb->n_landmarks, ctx->max_factors);
+    if (!pb->states || !pb->extr || !pb->sqrt_inv_cov) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null BA arrays");
+    if (pb->n_factors > 0 && (!pb->tgt || !pb->ref || !pb->lm || !pb->tangent || !pb->z_ref || !pb->inv_depth))
+        return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null BA factor arrays");
+    // shapes are checked on the host so a kernel can never index out of bounds
+    for (int k = 0; k < pb->n_factors; ++k) {
+        if (pb->tgt[k] < 0 || pb->tgt[k] >= pb->n_frames || pb->ref[k] < 0 || pb->ref[k] >= pb->n_frames || pb->lm[k] < 0 ||
+            pb->lm[k] >= pb->n_landmarks)
+            return rdvio_fail(ctx, RDVIO_ERR_INVALID, "factor %d indexes out of range", k);
+    }
+    hipStream_t st = ctx->stream;
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_states, pb->states, (size_t)pb->n_frames * 16 * sizeof(double), hipMemcpyHostToDevice, st));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_extr, pb->extr, 14 * sizeof(double), hipMemcpyHostToDevice, st));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_extr + 14, pb->sqrt_inv_cov, 4 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (pb->n_landmarks > 0) {
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_zref, pb->z_ref, (size_t)pb->n_landmarks * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_invd, pb->inv_depth, (size_t)pb->n_landmarks * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    if (pb->n_factors > 0) {
+        const size_t nb = (size_t)pb->n_factors * sizeof(int32_t);
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_idx, pb->tgt, nb, hipMemcpyHostToDevice, st));
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_idx + ctx->max_factors, pb->ref, nb, hipMemcpyHostToDevice, st));
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_idx + 2 * (size_t)ctx->max_factors, pb->lm, nb, hipMemcpyHostToDevice, st));
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_tangent, pb->tangent, (size_t)pb->n_factors * 9 * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    return RDVIO_OK;
+}
+
+int rdvio_hip_reprojection_eval(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, double *r, double *Jt, double *Jr,
+                                double *Jd) {
+    if (!ctx || !r) return RDVIO_ERR_INVALID;
+    if ((Jt || Jr || Jd) && !(Jt && Jr && Jd)) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "pass all of Jt/Jr/Jd or none");
+    if (int rc = upload_ba_problem(ctx, pb)) return rc;
+    const int nf = pb->n_factors;
+    if (nf == 0) return RDVIO_OK;
+    if (int rc = rdvio_launch_reprojection(ctx, nf, Jt != nullptr)) return rc;
+    hipStream_t st = ctx->stream;
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(r, ctx->ba_r, (size_t)nf * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (Jt) {
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(Jt, ctx->ba_Jt, (size_t)nf * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(Jr, ctx->ba_Jr, (size_t)nf * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(Jd, ctx->ba_Jd, (size_t)nf * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    return RDVIO_OK;
+}
+
+}  // extern "C"

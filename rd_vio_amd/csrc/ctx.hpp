@@ -1,0 +1,92 @@
+// Internal context of librdvio_hip.so (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/rdvio_hip.h"
+
+#define RDVIO_NUM_SLOTS 2
+#define RDVIO_MAX_TILES 256  // CLAHE tile grid (8x8 in configs/setting.yaml:17-19)
+
+struct ImageSlot {
+    uint8_t *pyr_img = nullptr;    // padded u8 arena (all levels)
+    int16_t *pyr_deriv = nullptr;  // padded int16x2 arena (all levels)
+    rdvio_pyr_layout L{};
+    int w = 0, h = 0;
+    bool valid = false;
+};
+
+struct HarrisCand {
+    float v;
+    int32_t idx;
+};
+
+struct rdvio_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int max_w = 0, max_h = 0, max_feat = 0, max_window = 0, max_factors = 0;
+    rdvio_pyr_layout maxL{};
+
+    ImageSlot slots[RDVIO_NUM_SLOTS];
+    uint8_t *gray = nullptr;       // staging for host-side uploads (max_w*max_h)
+    uint8_t *clahe_lut = nullptr;  // RDVIO_MAX_TILES x 256
+    float *harris = nullptr;       // max_w*max_h
+    uint32_t *harris_scalars = nullptr;  // [0] ordered-uint max, [1] candidate count
+    HarrisCand *harris_cand = nullptr;
+    int harris_cand_cap = 0;
+
+    // LK device buffers
+    double *lk_curr = nullptr, *lk_next = nullptr;
+    float *lk_prevf = nullptr, *lk_nextf = nullptr;
+    uint8_t *lk_status = nullptr;
+
+    // estimation device buffers
+    double *ba_states = nullptr, *ba_extr = nullptr, *ba_zref = nullptr, *ba_invd = nullptr, *ba_tangent = nullptr;
+    int32_t *ba_idx = nullptr;  // tgt | ref | lm, each max_factors
+    double *ba_r = nullptr, *ba_Jt = nullptr, *ba_Jr = nullptr, *ba_Jd = nullptr;
+    double *pre_imu = nullptr, *pre_par = nullptr, *pre_out = nullptr;
+    int32_t *pre_off = nullptr;
+    int pre_max_samples = 0, pre_max_seg = 0;
+
+    // pinned host staging
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+
+    char err[512] = {0};
+};
+
+inline int rdvio_fail(rdvio_hip_ctx *ctx, int code, const char *fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define RDVIO_HIP_CHECK(ctx, expr)                                                                     \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return rdvio_fail(ctx, RDVIO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                              __FILE__, __LINE__);                                                     \
+    } while (0)
+
+// kernel launchers (defined in the .hip files)
+int rdvio_launch_preprocess(rdvio_hip_ctx *ctx, int slot, const uint8_t *gray_dev, int w, int h, int stride,
+                            double clip, int tiles_x, int tiles_y);
+int rdvio_launch_track(rdvio_hip_ctx *ctx, int slot_curr, int slot_next, int n, const double *curr_dev,
+                       double *next_dev, int has_guess, uint8_t *status_dev);
+int rdvio_launch_lk_flow(rdvio_hip_ctx *ctx, int slot_prev, int slot_next, int n, const float *prev_dev,
+                         float *next_dev, uint8_t *status_dev, int max_iter, double eps);
+int rdvio_launch_harris(rdvio_hip_ctx *ctx, int slot);
+int rdvio_launch_harris_candidates(rdvio_hip_ctx *ctx, int slot, double quality);
+int rdvio_launch_reprojection(rdvio_hip_ctx *ctx, int nf, int with_jac);
+int rdvio_launch_preintegrate(rdvio_hip_ctx *ctx, int nseg, int cj, int cc);

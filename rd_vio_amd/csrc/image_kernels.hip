@@ -1,0 +1,327 @@
+// Image side of the feature tracker on gfx950: CLAHE, 4-level pyramid + Scharr derivatives, Harris.
+//
+// Replaces the OpenCV calls of OpenCvImage::preprocess / detect_keypoints
+// (/root/reference/src/rdvio_extra/src/opencv_image.cpp:156-161, :38-73, :179-188):
+// cv::CLAHE::apply, cv::buildOpticalFlowPyramid(win 21x21, maxLevel 3, withDerivatives),
+// cv::GFTTDetector (Harris, block 3, k 0.04).  All arithmetic is integer or a fixed sequence of
+// single-rounded float/double operations (this file is compiled with -ffp-contract=off), so results
+// are bit-identical to the CPU oracle regardless of how the work is split over lanes.
+//
+// Data layout: one padded arena per frame (rdvio_pyr_layout): u8 levels with a 32-px
+// BORDER_REFLECT_101 frame and 64-byte-multiple row strides (coalesced 64-lane row segments),
+// derivatives as interleaved int16 (dx,dy) so one dword load fetches both.
+#include "ctx.hpp"
+
+namespace {
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * (len - 1) - p;
+    return p;
+}
+__device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+// ---------------------------------------------------------------------------------------------
+// CLAHE pass 1: one workgroup per tile -> clipped histogram -> LUT (cv::CLAHE, 8-bit path).
+// HBM-bound on paper (1 B read per pixel) but tiny: 64 tiles x 5640 px for EuRoC.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void clahe_lut_kernel(const uint8_t *__restrict__ src, int w, int h, int stride,
+                                                       int tiles_x, int tw, int th, int clip, float lut_scale,
+                                                       uint8_t *__restrict__ lut) {
+    __shared__ int hist[256];
+    __shared__ int scan[256];
+    const int t = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    hist[t] = 0;
+    __syncthreads();
+    const int area = tw * th;
+    for (int i = t; i < area; i += 256) {
+        int y = i / tw, x = i - y * tw;
+        int sy = reflect101(ty * th + y, h), sx = reflect101(tx * tw + x, w);
+        atomicAdd(&hist[src[(size_t)sy * stride + sx]], 1);
+    }
+    __syncthreads();
+    int v = hist[t];
+    if (clip > 0) {
+        int excess = v > clip ? v - clip : 0;
+        if (v > clip) v = clip;
+        scan[t] = excess;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (t < s) scan[t] += scan[t + s];
+            __syncthreads();
+        }
+        int clipped = scan[0];
+        __syncthreads();
+        int batch = clipped / 256;
+        int residual = clipped - batch * 256;
+        v += batch;
+        if (residual != 0) {
+            int step = 256 / residual;
+            if (step < 1) step = 1;
+            if (t % step == 0 && t / step < residual) v++;
+        }
+    }
+    // inclusive prefix sum over the 256 bins
+    scan[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        int add = (t >= off) ? scan[t - off] : 0;
+        __syncthreads();
+        scan[t] += add;
+        __syncthreads();
+    }
+    float f = (float)scan[t] * lut_scale;
+    lut[tile * 256 + t] = sat_u8(__float2int_rn(f));
+}
+
+// CLAHE pass 2 for one pixel: bilinear blend of the four neighbouring tile LUTs.
+__device__ __forceinline__ uint8_t clahe_apply(const uint8_t *__restrict__ src, int stride, int x, int y,
+                                               const uint8_t *__restrict__ lut, int tiles_x, int tiles_y, float inv_tw,
+                                               float inv_th) {
+    float tyf = (float)y * inv_th - 0.5f;
+    int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+    float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+    ty1 = max(ty1, 0);
+    ty2 = min(ty2, tiles_y - 1);
+    float txf = (float)x * inv_tw - 0.5f;
+    int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+    float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+    tx1 = max(tx1, 0);
+    tx2 = min(tx2, tiles_x - 1);
+    int v = src[(size_t)y * stride + x];
+    float l11 = lut[(ty1 * tiles_x + tx1) * 256 + v];
+    float l12 = lut[(ty1 * tiles_x + tx2) * 256 + v];
+    float l21 = lut[(ty2 * tiles_x + tx1) * 256 + v];
+    float l22 = lut[(ty2 * tiles_x + tx2) * 256 + v];
+    float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+    return sat_u8(__float2int_rn(res));
+}
+
+// ---------------------------------------------------------------------------------------------
+// One pyramid level per launch: level value (CLAHE for level 0, pyrDown of level lv-1 otherwise)
+// for every pixel of the PADDED domain (interior + reflect-101 border), staged through an LDS tile
+// with a 1-px halo so the Scharr derivative of interior pixels comes from LDS.
+// Algorithmic traffic: level 0: 1 B read + 1 B write + 4 B deriv write per pixel;
+// level l>0: 1 B write + 4 B deriv write (+ L2-resident re-reads of level l-1).
+// ---------------------------------------------------------------------------------------------
+#define PT_W 32
+#define PT_H 8
+template <bool LEVEL0>
+__global__ __launch_bounds__(256) void pyr_level_kernel(rdvio_pyr_layout L, int lv, uint8_t *__restrict__ pyr_img,
+                                                       int16_t *__restrict__ pyr_deriv,
+                                                       const uint8_t *__restrict__ gray, int gray_stride,
+                                                       const uint8_t *__restrict__ lut, int tiles_x, int tiles_y,
+                                                       float inv_tw, float inv_th) {
+    __shared__ int tile[(PT_H + 2)][(PT_W + 2) + 1];
+    const int B = L.border, w = L.w[lv], h = L.h[lv], s = L.stride[lv];
+    const int bx0 = blockIdx.x * PT_W - B, by0 = blockIdx.y * PT_H - B;  // image coords of the tile origin
+    const uint8_t *prev = nullptr;
+    int ps = 0;
+    if (!LEVEL0) {
+        ps = L.stride[lv - 1];
+        prev = pyr_img + L.img_off[lv - 1] + (size_t)B * ps + B;  // interior origin of level lv-1 (border is valid)
+    }
+    for (int i = threadIdx.x; i < (PT_H + 2) * (PT_W + 2); i += 256) {
+        int ly = i / (PT_W + 2), lx = i - ly * (PT_W + 2);
+        int x = bx0 + lx - 1, y = by0 + ly - 1;
+        int val = 0;
+        if (x >= -B - 1 && x <= w + B && y >= -B - 1 && y <= h + B) {
+            int rx = reflect101(x, w), ry = reflect101(y, h);
+            if (LEVEL0) {
+                val = clahe_apply(gray, gray_stride, rx, ry, lut, tiles_x, tiles_y, inv_tw, inv_th);
+            } else {
+                // cv::pyrDown: separable [1 4 6 4 1], (sum + 128) >> 8; taps 2r-2..2r+2 fall inside level lv-1's border
+                int acc = 0;
+#pragma unroll
+                for (int j = -2; j <= 2; ++j) {
+                    const uint8_t *row = prev + (ptrdiff_t)(2 * ry + j) * ps + 2 * rx;
+                    int r = row[-2] + row[2] + 4 * (row[-1] + row[1]) + 6 * row[0];
+                    int kj = (j == 0) ? 6 : ((j == -1 || j == 1) ? 4 : 1);
+                    acc += kj * r;
+                }
+                val = (acc + 128) >> 8;
+            }
+        }
+        tile[ly][lx] = val;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % PT_W, ly = threadIdx.x / PT_W;
+    const int x = bx0 + lx, y = by0 + ly;
+    if (x >= w + B || y >= h + B) return;
+    uint8_t *img = pyr_img + L.img_off[lv];
+    img[(size_t)(y + B) * s + (x + B)] = (uint8_t)tile[ly + 1][lx + 1];
+    if (x >= 0 && x < w && y >= 0 && y < h) {
+        // calcScharrDeriv: dx = [3 10 3]^T x [-1 0 1], dy = [-1 0 1]^T x [3 10 3]
+        int p00 = tile[ly][lx], p01 = tile[ly][lx + 1], p02 = tile[ly][lx + 2];
+        int p10 = tile[ly + 1][lx], p12 = tile[ly + 1][lx + 2];
+        int p20 = tile[ly + 2][lx], p21 = tile[ly + 2][lx + 1], p22 = tile[ly + 2][lx + 2];
+        int dx = ((p02 + p22) * 3 + p12 * 10) - ((p00 + p20) * 3 + p10 * 10);
+        int dy = ((p20 - p00) + (p22 - p02)) * 3 + (p21 - p01) * 10;
+        short2 d;
+        d.x = (short)dx;
+        d.y = (short)dy;
+        short2 *der = reinterpret_cast<short2 *>(pyr_deriv + L.deriv_off[lv]);
+        der[(size_t)(y + B) * s + (x + B)] = d;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Harris response (cornerHarris block 3, Sobel 3, k) -- exact-integer formulation ("Image-side arithmetic").
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t float_to_ordered(float f) {
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_float(uint32_t o) {
+    uint32_t b = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(b);
+}
+
+__global__ __launch_bounds__(256) void harris_kernel(rdvio_pyr_layout L, const uint8_t *__restrict__ pyr_img, double k,
+                                                    float *__restrict__ resp, uint32_t *__restrict__ max_out) {
+    __shared__ int sdx[(PT_H + 2)][(PT_W + 2) + 1];
+    __shared__ int sdy[(PT_H + 2)][(PT_W + 2) + 1];
+    __shared__ uint32_t smax[4];
+    const int B = L.border, w = L.w[0], h = L.h[0], s = L.stride[0];
+    const uint8_t *img = pyr_img + L.img_off[0] + (size_t)B * s + B;
+    const int bx0 = blockIdx.x * PT_W, by0 = blockIdx.y * PT_H;
+    for (int i = threadIdx.x; i < (PT_H + 2) * (PT_W + 2); i += 256) {
+        int ly = i / (PT_W + 2), lx = i - ly * (PT_W + 2);
+        int x = bx0 + lx - 1, y = by0 + ly - 1;
+        int gx = 0, gy = 0;
+        if (x <= w && y <= h) {
+            // box filter border is REFLECT_101 on the (dx,dy) products -> Sobel at the reflected coordinate;
+            // the Sobel's own border pixels come from the arena's reflect-101 frame.
+            int rx = reflect101(x, w), ry = reflect101(y, h);
+            const uint8_t *r0 = img + (ptrdiff_t)(ry - 1) * s + rx;
+            const uint8_t *r1 = r0 + s, *r2 = r1 + s;
+            gx = (r0[1] + 2 * r1[1] + r2[1]) - (r0[-1] + 2 * r1[-1] + r2[-1]);
+            gy = (r2[-1] + 2 * r2[0] + r2[1]) - (r0[-1] + 2 * r0[0] + r0[1]);
+        }
+        sdx[ly][lx] = gx;
+        sdy[ly][lx] = gy;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % PT_W, ly = threadIdx.x / PT_W;
+    const int x = bx0 + lx, y = by0 + ly;
+    float r = -INFINITY;
+    if (x < w && y < h) {
+        int sxx = 0, sxy = 0, syy = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                int gx = sdx[ly + j][lx + i], gy = sdy[ly + j][lx + i];
+                sxx += gx * gx;
+                sxy += gx * gy;
+                syy += gy * gy;
+            }
+        const double sc = 1.0 / (4.0 * 3.0 * 255.0);
+        const double s2 = sc * sc;
+        double a = s2 * (double)sxx, b = s2 * (double)sxy, c = s2 * (double)syy;
+        r = (float)(a * c - b * b - k * (a + c) * (a + c));
+        resp[(size_t)y * w + x] = r;
+    }
+    // block max -> one atomic per block
+    uint32_t o = (x < w && y < h) ? float_to_ordered(r) : 0u;
+    for (int off = 32; off > 0; off >>= 1) o = max(o, (uint32_t)__shfl_xor((int)o, off));
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = o;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(max_out, max(max(smax[0], smax[1]), max(smax[2], smax[3])));
+}
+
+// goodFeaturesToTrack: threshold at quality*max (THRESH_TOZERO), 3x3 local maximum on the thresholded map,
+// rows/cols 1..n-2 only.  Survivors are appended unordered; the host sorts them by (value desc, index desc),
+// which is cv::greaterThanPtr's order, so the candidate ORDER is deterministic.
+__global__ __launch_bounds__(256) void harris_candidates_kernel(const float *__restrict__ resp, int w, int h,
+                                                               double quality, uint32_t *__restrict__ scalars,
+                                                               HarrisCand *__restrict__ cand, int cap) {
+    const int x = blockIdx.x * PT_W + threadIdx.x % PT_W, y = blockIdx.y * PT_H + threadIdx.x / PT_W;
+    if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) return;
+    const float maxv = ordered_to_float(scalars[0]);
+    const float thr = (float)((double)maxv * quality);
+    float v = resp[(size_t)y * w + x];
+    float tv = v > thr ? v : 0.f;
+    if (tv == 0.f) return;
+    float m = tv;
+#pragma unroll
+    for (int j = -1; j <= 1; ++j)
+#pragma unroll
+        for (int i = -1; i <= 1; ++i) {
+            float n = resp[(size_t)(y + j) * w + (x + i)];
+            n = n > thr ? n : 0.f;
+            m = fmaxf(m, n);
+        }
+    if (tv == m) {
+        uint32_t slot = atomicAdd(&scalars[1], 1u);
+        if ((int)slot < cap) {
+            cand[slot].v = tv;
+            cand[slot].idx = y * w + x;
+        }
+    }
+}
+
+}  // namespace
+
+int rdvio_launch_preprocess(rdvio_hip_ctx *ctx, int slot, const uint8_t *gray_dev, int w, int h, int stride,
+                            double clip_limit, int tiles_x, int tiles_y) {
+    ImageSlot &S = ctx->slots[slot];
+    if (S.w != w || S.h != h) {
+        rdvio_hip_pyr_layout_init(w, h, RDVIO_MAX_LEVELS - 1, &S.L);
+        // derivative borders are BORDER_CONSTANT(0) and never written by the kernels
+        RDVIO_HIP_CHECK(ctx, hipMemsetAsync(S.pyr_deriv, 0, (size_t)S.L.deriv_elems * sizeof(int16_t), ctx->stream));
+        S.w = w;
+        S.h = h;
+    }
+    // cv::CLAHE::apply tile geometry (pads right/bottom by reflect-101 to a tile multiple)
+    int ew = w, eh = h;
+    if (w % tiles_x != 0 || h % tiles_y != 0) {
+        ew = w + (tiles_x - (w % tiles_x));
+        eh = h + (tiles_y - (h % tiles_y));
+    }
+    const int tw = ew / tiles_x, th = eh / tiles_y;
+    const int area = tw * th;
+    const float lut_scale = (float)255 / (float)area;
+    int clip = 0;
+    if (clip_limit > 0.0) {
+        clip = (int)(clip_limit * area / 256);
+        if (clip < 1) clip = 1;
+    }
+    hipLaunchKernelGGL(clahe_lut_kernel, dim3(tiles_x * tiles_y), dim3(256), 0, ctx->stream, gray_dev, w, h, stride,
+                       tiles_x, tw, th, clip, lut_scale, ctx->clahe_lut);
+    const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
+    const int B = S.L.border;
+    for (int lv = 0; lv < S.L.levels; ++lv) {
+        dim3 grid((S.L.w[lv] + 2 * B + PT_W - 1) / PT_W, (S.L.h[lv] + 2 * B + PT_H - 1) / PT_H);
+        if (lv == 0)
+            hipLaunchKernelGGL(pyr_level_kernel<true>, grid, dim3(256), 0, ctx->stream, S.L, lv, S.pyr_img, S.pyr_deriv,
+                               gray_dev, stride, ctx->clahe_lut, tiles_x, tiles_y, inv_tw, inv_th);
+        else
+            hipLaunchKernelGGL(pyr_level_kernel<false>, grid, dim3(256), 0, ctx->stream, S.L, lv, S.pyr_img, S.pyr_deriv,
+                               nullptr, 0, nullptr, 0, 0, 0.f, 0.f);
+    }
+    RDVIO_HIP_CHECK(ctx, hipGetLastError());
+    S.valid = true;
+    return RDVIO_OK;
+}
+
+int rdvio_launch_harris(rdvio_hip_ctx *ctx, int slot) {
+    ImageSlot &S = ctx->slots[slot];
+    RDVIO_HIP_CHECK(ctx, hipMemsetAsync(ctx->harris_scalars, 0, 2 * sizeof(uint32_t), ctx->stream));
+    dim3 grid((S.w + PT_W - 1) / PT_W, (S.h + PT_H - 1) / PT_H);
+    hipLaunchKernelGGL(harris_kernel, grid, dim3(256), 0, ctx->stream, S.L, S.pyr_img, 0.04, ctx->harris,
+                       ctx->harris_scalars);
+    RDVIO_HIP_CHECK(ctx, hipGetLastError());
+    return RDVIO_OK;
+}
+
+int rdvio_launch_harris_candidates(rdvio_hip_ctx *ctx, int slot, double quality) {
+    ImageSlot &S = ctx->slots[slot];
+    dim3 grid((S.w + PT_W - 1) / PT_W, (S.h + PT_H - 1) / PT_H);
+    hipLaunchKernelGGL(harris_candidates_kernel, grid, dim3(256), 0, ctx->stream, ctx->harris, S.w, S.h, quality,
+                       ctx->harris_scalars, ctx->harris_cand, ctx->harris_cand_cap);
+    RDVIO_HIP_CHECK(ctx, hipGetLastError());
+    return RDVIO_OK;
+}

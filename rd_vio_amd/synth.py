@@ -189,3 +189,70 @@ def make_ba_problem(n_frames=9, n_landmarks=150, seed=648, K=EUROC_K, extr=EUROC
             out["states"][i, 7:10] += rng.normal(0, 1e-2, 3)
         out["inv_depth"] = out["inv_depth"] * rng.uniform(0.9, 1.1, len(inv_depth))
     return out
+
+
+# ------------------------------------------------------------------ synthetic imagery
+def _value_noise(xs, ys, rng_seed, cell):
+    """smooth value noise: random lattice values with smoothstep interpolation, evaluated at (xs, ys)."""
+    gx = xs / cell
+    gy = ys / cell
+    x0 = np.floor(gx).astype(np.int64)
+    y0 = np.floor(gy).astype(np.int64)
+    fx = gx - x0
+    fy = gy - y0
+    fx = fx * fx * (3 - 2 * fx)
+    fy = fy * fy * (3 - 2 * fy)
+
+    def lat(ix, iy):
+        # hash lattice coordinates -> [0,1)
+        hsh = (ix * 73856093) ^ (iy * 19349663) ^ (rng_seed * 83492791)
+        hsh = (hsh ^ (hsh >> 13)) * 1274126177
+        hsh = hsh ^ (hsh >> 16)
+        return (hsh & 0xFFFFFF) / float(0x1000000)
+
+    v00, v10 = lat(x0, y0), lat(x0 + 1, y0)
+    v01, v11 = lat(x0, y0 + 1), lat(x0 + 1, y0 + 1)
+    return (v00 * (1 - fx) + v10 * fx) * (1 - fy) + (v01 * (1 - fx) + v11 * fx) * fy
+
+
+def render_scene(w, h, offset=(0.0, 0.0), seed=648, n_blobs=None, rot=0.0):
+    """u8 image of a fixed planar 'world' texture sampled at pixel + offset (optionally rotated about
+    the image centre by `rot` rad): 3-octave value noise (mean 110, amplitude 40) + Gaussian blobs
+    (sigma in U[1.5,3], amplitude in U[60,200])."""
+    rng = np.random.default_rng(seed)
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
+    c, s = np.cos(rot), np.sin(rot)
+    X = c * (xs - cx) - s * (ys - cy) + cx + offset[0]
+    Y = s * (xs - cx) + c * (ys - cy) + cy + offset[1]
+    img = np.full((h, w), 110.0)
+    for o, cell in enumerate((64.0, 32.0, 16.0)):
+        img += (40.0 / (1.75 * (1 << o)) * 2.0) * (_value_noise(X, Y, seed + o, cell) - 0.5) * 2.0
+    if n_blobs is None:
+        n_blobs = max(50, w * h // 600)
+    bx = rng.uniform(-40, w + 40, n_blobs)
+    by = rng.uniform(-40, h + 40, n_blobs)
+    bs = rng.uniform(1.5, 3.0, n_blobs)
+    ba = rng.uniform(60, 200, n_blobs) * rng.choice([-0.5, 1.0], n_blobs)
+    for i in range(n_blobs):
+        r = int(4 * bs[i] + 2)
+        # bounding box of the blob in image coordinates (approximate for small rot/offset)
+        ux = bx[i] - offset[0]
+        uy = by[i] - offset[1]
+        x0, x1 = int(max(0, ux - r - 8)), int(min(w, ux + r + 9))
+        y0, y1 = int(max(0, uy - r - 8)), int(min(h, uy + r + 9))
+        if x0 >= x1 or y0 >= y1:
+            continue
+        d2 = (X[y0:y1, x0:x1] - bx[i]) ** 2 + (Y[y0:y1, x0:x1] - by[i]) ** 2
+        img[y0:y1, x0:x1] += ba[i] * np.exp(-d2 / (2 * bs[i] ** 2))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def jittered_grid(w, h, nx, ny, seed=648, margin=40):
+    """nx*ny feature points on a jittered grid inside the image (SURVEY.md 8d kernel-level LK input)."""
+    rng = np.random.default_rng(seed)
+    gx = np.linspace(margin, w - margin, nx)
+    gy = np.linspace(margin, h - margin, ny)
+    pts = np.stack(np.meshgrid(gx, gy), axis=-1).reshape(-1, 2)
+    pts += rng.uniform(-3, 3, pts.shape)
+    return pts

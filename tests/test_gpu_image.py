@@ -1,0 +1,143 @@
+"""GPU parity (MI355X): HIP image path vs the CPU oracle, bit-exact (integer / index work).
+All calls go through the C ABI (rd_vio_amd.binding -> librdvio_hip.so)."""
+import numpy as np
+import pytest
+
+import rd_vio_amd
+from rd_vio_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = rd_vio_amd.Context(max_width=1280, max_height=720, max_features=2048)
+    yield c
+    c.close()
+
+
+def _arena_equal(oracle, L, a, b, kind):
+    """compare only the bytes the layout defines (row padding beyond w+2B is unspecified)"""
+    for lv in range(L.levels):
+        va = (oracle.level_view if kind == "img" else oracle.deriv_view)(L, a, lv, with_border=True)
+        vb = (oracle.level_view if kind == "img" else oracle.deriv_view)(L, b, lv, with_border=True)
+        if not (va == vb).all():
+            bad = np.argwhere(va != vb)
+            return False, (lv, bad[:5].tolist(), int((va != vb).sum()))
+    return True, None
+
+
+@pytest.mark.parametrize("size,seed", [((752, 480), 1), ((1280, 720), 2), ((750, 477), 3), ((100, 90), 4)])
+def test_preprocess_bit_exact(ctx, oracle, size, seed):
+    w, h = size
+    img = synth.render_scene(w, h, seed=seed)
+    Lo, pi, pd = oracle.preprocess(img)
+    g = rd_vio_amd.HipImage(ctx, 0, img)
+    g.preprocess(6.0, 8, 8)
+    gi, gd = g.download()
+    ok, info = _arena_equal(oracle, Lo, pi, gi, "img")
+    assert ok, ("image arena mismatch", info)
+    ok, info = _arena_equal(oracle, Lo, pd, gd, "deriv")
+    assert ok, ("deriv arena mismatch", info)
+
+
+def test_preprocess_edge_images(ctx, oracle):
+    for img in (np.zeros((480, 752), np.uint8), np.full((480, 752), 255, np.uint8),
+                np.random.default_rng(0).integers(0, 256, (480, 752), dtype=np.uint8)):
+        Lo, pi, pd = oracle.preprocess(img)
+        g = rd_vio_amd.HipImage(ctx, 1, img)
+        g.preprocess(6.0, 8, 8)
+        gi, gd = g.download()
+        assert _arena_equal(oracle, Lo, pi, gi, "img")[0]
+        assert _arena_equal(oracle, Lo, pd, gd, "deriv")[0]
+
+
+def _pair(ctx, oracle, w, h, seed, offset, rot=0.0):
+    a = synth.render_scene(w, h, seed=seed)
+    b = synth.render_scene(w, h, seed=seed, offset=offset, rot=rot)
+    La, ia, da = oracle.preprocess(a)
+    Lb, ib, db = oracle.preprocess(b)
+    ga, gb = rd_vio_amd.HipImage(ctx, 0, a), rd_vio_amd.HipImage(ctx, 1, b)
+    ga.preprocess()
+    gb.preprocess()
+    return La, (ia, da), (ib, db), ga, gb
+
+
+@pytest.mark.parametrize("w,h,n,offset,rot", [
+    (752, 480, (15, 10), (3.3, -2.1), 0.0),
+    (752, 480, (20, 15), (-7.6, 5.2), 0.01),
+    (1280, 720, (40, 25), (2.2, 1.7), 0.004),
+])
+def test_track_keypoints_bit_exact(ctx, oracle, w, h, n, offset, rot):
+    L, A, B, ga, gb = _pair(ctx, oracle, w, h, 11, offset, rot)
+    pts = synth.jittered_grid(w, h, n[0], n[1])
+    rng = np.random.default_rng(5)
+    guess = pts - np.array(offset) + rng.uniform(-3, 3, pts.shape)
+    for g in (None, guess):
+        ref_next, ref_st = oracle.track_keypoints(L, A, B, pts, guess=g)
+        got_next, got_st = ga.track_keypoints(gb, pts, g)
+        assert (ref_st == got_st).all(), np.argwhere(ref_st != got_st)[:10]
+        assert ref_st.sum() > 0.7 * len(pts)
+        m = ref_st > 0
+        assert (ref_next[m] == got_next[m]).all()  # bit-exact positions
+        # non-survivors are left untouched (opencv_image.cpp:148-153)
+        expect = g if g is not None else np.zeros_like(pts)
+        assert (got_next[~m] == expect[~m]).all()
+
+
+def test_lk_flow_bit_exact_including_failures(ctx, oracle):
+    L, A, B, ga, gb = _pair(ctx, oracle, 752, 480, 12, (4.0, 3.0))
+    rng = np.random.default_rng(9)
+    pts = rng.uniform(-30, 790, (300, 2)).astype(np.float32)   # includes points outside the image
+    pts[:, 1] = rng.uniform(-30, 510, 300)
+    init = pts + rng.uniform(-5, 5, pts.shape).astype(np.float32)
+    ref_next, ref_st = oracle.lk_flow(L, A[0], A[1], B[0], pts, init)
+    got_next, got_st = ga.lk_flow(gb, pts, init)
+    assert (ref_st == got_st).all()
+    assert (ref_next == got_next).all()
+    assert 0 < ref_st.sum() < len(pts)
+
+
+def test_track_empty_and_flat(ctx, oracle):
+    flat = np.full((480, 752), 128, np.uint8)
+    g0, g1 = rd_vio_amd.HipImage(ctx, 0, flat), rd_vio_amd.HipImage(ctx, 1, flat)
+    g0.preprocess()
+    g1.preprocess()
+    nxt, st = g0.track_keypoints(g1, np.zeros((0, 2)))
+    assert len(st) == 0
+    nxt, st = g0.track_keypoints(g1, np.array([[100.0, 100.0], [300.0, 200.0]]))
+    assert (st == 0).all()
+
+
+@pytest.mark.parametrize("size,seed", [((752, 480), 21), ((1280, 720), 22)])
+def test_harris_and_detect_bit_exact(ctx, oracle, size, seed):
+    w, h = size
+    img = synth.render_scene(w, h, seed=seed)
+    Lo, pi, pd = oracle.preprocess(img)
+    lvl0 = np.ascontiguousarray(oracle.level_view(Lo, pi, 0))
+    g = rd_vio_amd.HipImage(ctx, 0, img)
+    g.preprocess()
+    ref = oracle.harris_response(lvl0)
+    got = g.harris_response()
+    assert (ref.view(np.uint32) == got.view(np.uint32)).all()
+    for existing in (np.zeros((0, 2)), oracle.detect_keypoints(lvl0, np.zeros((0, 2)), 40, 20.0)):
+        for maxp, dist in ((150, 10.0), (300, 20.0), (1000, 10.0)):
+            ref_kp = oracle.detect_keypoints(lvl0, existing, maxp, dist)
+            got_kp = g.detect_keypoints(existing, maxp, dist)
+            assert ref_kp.shape == got_kp.shape and (ref_kp == got_kp).all()
+            assert len(ref_kp) > len(existing)
+
+
+def test_capacity_and_argument_errors(ctx):
+    small = rd_vio_amd.Context(max_width=128, max_height=96, max_features=8)
+    img = synth.render_scene(752, 480, seed=1)
+    g = rd_vio_amd.HipImage(small, 0, img)
+    with pytest.raises(rd_vio_amd.RdvioError):
+        g.preprocess()  # image larger than the context
+    ok = rd_vio_amd.HipImage(small, 0, img[:96, :128])
+    ok.preprocess()
+    with pytest.raises(rd_vio_amd.RdvioError):
+        ok.track_keypoints(rd_vio_amd.HipImage(small, 1, img[:96, :128]), np.zeros((4, 2)) + 50)  # slot 1 never preprocessed
+    with pytest.raises(rd_vio_amd.RdvioError):
+        ok.track_keypoints(ok, np.zeros((9, 2)) + 50)  # more features than capacity
+    small.close()
