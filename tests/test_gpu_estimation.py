@@ -65,6 +65,10 @@ def test_preintegrate_parity(ctx, oracle, jac, cov):
             _close(got[i][461:], ref[461:], rtol=1e-10, what=f"seg{i} jac")
         if cov:
             _close(got[i][11:236], ref[11:236], rtol=1e-10, what=f"seg{i} cov")
+            if len(s) < 2:
+                # a single increment leaves the (p,v) covariance rank-deficient: cov.inverse() is garbage in the
+                # reference too (preintegrator.cpp:97-100), so there is nothing meaningful to compare
+                continue
             # sqrt_inv_cov: compare the information matrix it encodes (Cholesky of an inverse amplifies rounding)
             U, Ur = got[i][236:461].reshape(15, 15), ref[236:461].reshape(15, 15)
             _close(U.T @ U, Ur.T @ Ur, rtol=1e-7, what=f"seg{i} info")
