@@ -110,26 +110,65 @@ int rdvio_hip_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off,
                            const double *t_end, const double *bg, const double *ba, const double *noise,
                            int compute_jacobian, int compute_covariance, double *preint_out);
 
-/* Sliding-window BA problem in SoA form (what Solver::add_* assembles through pointers,
- * solver.cpp:88-178; which factors enter: sliding_window_tracker.cpp:226-300). */
+/* One Solver problem in SoA form: what Solver::add_frame_states / add_track_states / add_factor assemble
+ * through pointers (solver.cpp:88-178).  Which states and factors enter each solve is the caller's
+ * (host) decision, exactly as in sliding_window_tracker.cpp:101-125 (localize_newframe), :226-300
+ * (refine_window) and :349-444 (refine_subwindow).  The reference's "prior" factor flavours are the same
+ * factors with constant blocks: ReprojectionPriorFactor = reprojection factor whose anchor frame and
+ * landmark are fixed (reprojection_factor.h:99-121); PreIntegrationPriorFactor = frame i fixed
+ * (preintegration_factor.h:165-198).  Factors must be ordered by landmark (lm non-decreasing). */
 typedef struct {
-    int32_t n_frames;           /* frames in the window (W+1 at BA time) */
+    int32_t n_frames;
+    const double *states;          /* n_frames x 16 (initial values) */
+    const uint8_t *frame_fixed;    /* n_frames: 1 = constant block (FT_FIX_POSE|FT_FIX_MOTION, solver.cpp:92-113,
+                                      or a frame that is not a parameter of this solve) */
+    const double *extr;            /* 14 */
+    const double *sqrt_inv_cov;    /* 2 x 2 */
     int32_t n_landmarks;
-    int32_t n_factors;          /* reprojection factors */
-    const double *states;       /* n_frames x 16 */
-    const double *extr;         /* 14 */
-    const double *sqrt_inv_cov; /* 2 x 2 */
-    const double *z_ref;        /* n_landmarks x 3: bearing in the anchor frame */
-    const double *inv_depth;    /* n_landmarks */
-    const int32_t *tgt, *ref, *lm; /* n_factors: target frame, anchor frame, landmark */
-    const double *tangent;      /* n_factors x 9: [b1 b2 z_obs] (reprojection_factor.h:16-22) */
+    const double *z_ref;           /* n_landmarks x 3: bearing in the anchor frame */
+    const double *inv_depth;       /* n_landmarks (initial values) */
+    const uint8_t *lm_fixed;       /* n_landmarks: 1 = constant */
+    int32_t n_factors;             /* reprojection factors, CauchyLoss(1.0) (solver.cpp:116-132) */
+    const int32_t *tgt, *ref, *lm; /* target frame, anchor frame, landmark */
+    const double *tangent;         /* n_factors x 9: [b1 b2 z_obs] (reprojection_factor.h:16-22) */
+    int32_t n_rot;                 /* rotation priors, CauchyLoss(1.0) (solver.cpp:134-141; rotation_factor.h) */
+    const int32_t *rot_tgt, *rot_ref;
+    const double *rot_zref;        /* n_rot x 3 */
+    const double *rot_tangent;     /* n_rot x 9 */
+    int32_t n_preint;              /* preintegration factors, no loss (solver.cpp:143-170) */
+    const int32_t *pre_i, *pre_j;
+    const double *preint;          /* n_preint x RDVIO_PREINT_SIZE */
+    int32_t n_prior;               /* frames covered by the marginalisation prior (0 = none; solver.cpp:172-178) */
+    const int32_t *prior_frames;   /* n_prior frame indices */
+    const double *prior_lin;       /* n_prior x 16 linearisation states */
+    const double *prior_S;         /* (15 n_prior)^2 sqrt information */
+    const double *prior_f;         /* 15 n_prior */
 } rdvio_ba_problem;
+
+typedef struct {
+    int32_t iterations;            /* trust-region iterations (Ceres' iteration counter) */
+    int32_t successful_steps;
+    double initial_cost, final_cost;
+    int32_t termination;           /* 0 convergence, 1 iteration limit, 2 failure */
+} rdvio_ba_summary;
 
 /* CeresReprojectionErrorFactor::Evaluate for every factor (reprojection_factor.h:24-89).
  * r: F x 2; Jt: F x 2 x 6 (theta_tgt, p_tgt); Jr: F x 2 x 6 (theta_ref, p_ref); Jd: F x 2.
  * The J pointers may be NULL. */
 int rdvio_hip_reprojection_eval(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, double *r, double *Jt,
                                 double *Jr, double *Jd);
+
+/* Solver::solve (solver.cpp:180-194): ceres::Solve with TRUST_REGION/DOGLEG, SPARSE_SCHUR (landmarks
+ * eliminated), max_num_iterations = solver.iteration_limit.  The whole trust-region loop runs on the device.
+ * states_out (n_frames x 16) and inv_depth_out (n_landmarks) receive the optimised values (the reference
+ * updates Frame/Track members in place, solver.cpp:191). */
+int rdvio_hip_ba_solve(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, int max_iterations, double *states_out,
+                       double *inv_depth_out, rdvio_ba_summary *summary);
+/* Split form for HBM-resident operation: upload once, then (re)solve from the uploaded initial values
+ * without any host->device traffic; fetch copies the result back. */
+int rdvio_hip_ba_upload(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb);
+int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int max_iterations);
+int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, double *states_out, double *inv_depth_out, rdvio_ba_summary *summary);
 
 #ifdef __cplusplus
 }

@@ -328,3 +328,74 @@ def detect_keypoints(img, existing, max_corners, min_dist):
     n = lib().ro_detect_keypoints(img.ctypes.data, w, h, w, int(max_corners), float(min_dist), buf.ctypes.data,
                                   len(existing))
     return buf[:n].copy()
+
+
+# ---------------------------------------------------------------- solver (A14)
+class _BaProblem(ctypes.Structure):
+    _fields_ = [
+        ("n_frames", ctypes.c_int), ("frame_fixed", ctypes.c_void_p), ("extr", ctypes.c_void_p),
+        ("sqrt_inv_cov", ctypes.c_void_p), ("n_landmarks", ctypes.c_int), ("lm_fixed", ctypes.c_void_p),
+        ("z_ref", ctypes.c_void_p), ("n_factors", ctypes.c_int), ("tgt", ctypes.c_void_p), ("ref", ctypes.c_void_p),
+        ("lm", ctypes.c_void_p), ("tangent", ctypes.c_void_p), ("n_rot", ctypes.c_int), ("rot_tgt", ctypes.c_void_p),
+        ("rot_ref", ctypes.c_void_p), ("rot_zref", ctypes.c_void_p), ("rot_tangent", ctypes.c_void_p),
+        ("n_preint", ctypes.c_int), ("pre_i", ctypes.c_void_p), ("pre_j", ctypes.c_void_p),
+        ("preint", ctypes.c_void_p), ("np", ctypes.c_int), ("prior_frames", ctypes.c_void_p),
+        ("lin", ctypes.c_void_p), ("S", ctypes.c_void_p), ("f", ctypes.c_void_p),
+    ]
+
+
+class BaSummary(ctypes.Structure):
+    _fields_ = [("iterations", ctypes.c_int), ("successful_steps", ctypes.c_int), ("initial_cost", ctypes.c_double),
+                ("final_cost", ctypes.c_double), ("termination", ctypes.c_int)]
+
+
+def pack_ba_problem(pb, struct_cls=_BaProblem):
+    """dict -> (ctypes struct, keepalive).  Optional keys default to 'none'."""
+    n = len(_f64(pb["states"]).reshape(-1, 16))
+    nl = len(pb["inv_depth"])
+    k = dict(
+        frame_fixed=np.ascontiguousarray(pb.get("frame_fixed", np.zeros(n)), dtype=np.uint8),
+        extr=_f64(pb["extr"]), W=_f64(pb["sqrt_inv_cov"]),
+        lm_fixed=np.ascontiguousarray(pb.get("lm_fixed", np.zeros(nl)), dtype=np.uint8),
+        z_ref=_f64(pb["z_ref"]).reshape(-1, 3), tgt=_i32(pb["tgt"]), ref=_i32(pb["ref"]), lm=_i32(pb["lm"]),
+        tangent=_f64(pb["tangent"]).reshape(-1, 9),
+        rot_tgt=_i32(pb.get("rot_tgt", [])), rot_ref=_i32(pb.get("rot_ref", [])),
+        rot_zref=_f64(pb.get("rot_zref", np.zeros((0, 3)))), rot_tangent=_f64(pb.get("rot_tangent", np.zeros((0, 9)))),
+        pre_i=_i32(pb.get("pre_i", [])), pre_j=_i32(pb.get("pre_j", [])),
+        preint=_f64(pb.get("preint", np.zeros((0, PREINT_SIZE)))),
+        prior_frames=_i32(pb.get("prior_frames", [])), lin=_f64(pb.get("lin", np.zeros((0, 16)))),
+        S=_f64(pb.get("S", np.zeros((0, 0)))), f=_f64(pb.get("f", np.zeros(0))),
+    )
+    c = struct_cls()
+    c.n_frames = n
+    c.frame_fixed = k["frame_fixed"].ctypes.data
+    c.extr = k["extr"].ctypes.data
+    c.sqrt_inv_cov = k["W"].ctypes.data
+    c.n_landmarks = nl
+    c.lm_fixed = k["lm_fixed"].ctypes.data
+    c.z_ref = k["z_ref"].ctypes.data
+    c.n_factors = len(k["tgt"])
+    c.tgt, c.ref, c.lm = k["tgt"].ctypes.data, k["ref"].ctypes.data, k["lm"].ctypes.data
+    c.tangent = k["tangent"].ctypes.data
+    c.n_rot = len(k["rot_tgt"])
+    c.rot_tgt, c.rot_ref = k["rot_tgt"].ctypes.data, k["rot_ref"].ctypes.data
+    c.rot_zref, c.rot_tangent = k["rot_zref"].ctypes.data, k["rot_tangent"].ctypes.data
+    c.n_preint = len(k["pre_i"])
+    c.pre_i, c.pre_j = k["pre_i"].ctypes.data, k["pre_j"].ctypes.data
+    c.preint = k["preint"].ctypes.data
+    c.np = len(k["prior_frames"])
+    c.prior_frames = k["prior_frames"].ctypes.data
+    c.lin, c.S, c.f = k["lin"].ctypes.data, k["S"].ctypes.data, k["f"].ctypes.data
+    return c, k
+
+
+def ba_solve(pb, max_iterations=30):
+    """rdvio::Solver::solve on a problem dict -> (states, inv_depth, BaSummary)"""
+    c, keep = pack_ba_problem(pb)
+    states = _f64(pb["states"]).reshape(-1, 16).copy()
+    invd = _f64(pb["inv_depth"]).copy()
+    sm = BaSummary()
+    lib().ro_ba_solve.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib().ro_ba_solve(ctypes.addressof(c), int(max_iterations), states.ctypes.data, invd.ctypes.data,
+                      ctypes.addressof(sm))
+    return states, invd, sm

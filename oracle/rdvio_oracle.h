@@ -142,6 +142,48 @@ int ro_good_features(const uint8_t *img, int w, int h, int stride, int max_corne
 int ro_detect_keypoints(const uint8_t *img, int w, int h, int stride, int max_corners, double min_dist_poisson,
                         double *keypoints, int n_existing);
 
+/* ================= A14: the non-linear solve (Ceres restated, see ro_solver.c) ================= */
+#define RO_TERM_CONVERGENCE 0
+#define RO_TERM_NO_CONVERGENCE 1
+#define RO_TERM_FAILURE 2
+
+/* One Solver problem in SoA form (what Solver::add_* assemble through pointers, solver.cpp:88-178).
+ * "prior" factor flavours are expressed through the fixed flags: a ReprojectionPriorFactor is a
+ * reprojection factor whose anchor frame and landmark are fixed; a PreIntegrationPriorFactor has frame i fixed. */
+typedef struct {
+    int n_frames;
+    const uint8_t *frame_fixed;   /* 1 = constant (FT_FIX_POSE|FT_FIX_MOTION, or not a parameter of this solve) */
+    const double *extr;           /* 14 */
+    const double *sqrt_inv_cov;   /* 4 */
+    int n_landmarks;
+    const uint8_t *lm_fixed;      /* 1 = constant inverse depth */
+    const double *z_ref;          /* n_landmarks x 3 */
+    int n_factors;                /* reprojection factors (CauchyLoss) */
+    const int32_t *tgt, *ref, *lm;
+    const double *tangent;        /* n_factors x 9 */
+    int n_rot;                    /* rotation priors (CauchyLoss), ceres/rotation_factor.h */
+    const int32_t *rot_tgt, *rot_ref;
+    const double *rot_zref;       /* n_rot x 3 */
+    const double *rot_tangent;    /* n_rot x 9 */
+    int n_preint;                 /* preintegration factors (no loss) */
+    const int32_t *pre_i, *pre_j;
+    const double *preint;         /* n_preint x RO_PREINT_SIZE */
+    int np;                       /* marginalisation prior over np frames (0 = none) */
+    const int32_t *prior_frames;
+    const double *lin, *S, *f;
+} ro_ba_problem;
+
+typedef struct {
+    int iterations;        /* trust-region iterations performed (Ceres iteration counter) */
+    int successful_steps;
+    double initial_cost, final_cost;
+    int termination;
+} ro_ba_summary;
+
+/* states_io: n_frames x 16, inv_depth_io: n_landmarks; updated in place like Solver::solve (solver.cpp:191). */
+int ro_ba_solve(const ro_ba_problem *pb, int max_iterations, double *states_io, double *inv_depth_io,
+                ro_ba_summary *summary);
+
 #ifdef __cplusplus
 }
 #endif

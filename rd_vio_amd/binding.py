@@ -17,7 +17,8 @@ EXPORTS = [
     "rdvio_hip_last_error", "rdvio_hip_sync", "rdvio_hip_image_preprocess", "rdvio_hip_image_preprocess_dev",
     "rdvio_hip_image_download", "rdvio_hip_track_keypoints", "rdvio_hip_track_keypoints_dev", "rdvio_hip_lk_flow",
     "rdvio_hip_detect_keypoints", "rdvio_hip_harris_response", "rdvio_hip_image_release", "rdvio_hip_preintegrate",
-    "rdvio_hip_reprojection_eval",
+    "rdvio_hip_reprojection_eval", "rdvio_hip_ba_solve", "rdvio_hip_ba_upload", "rdvio_hip_ba_solve_resident",
+    "rdvio_hip_ba_fetch",
 ]
 
 
@@ -36,12 +37,26 @@ class PyrLayout(ctypes.Structure):
 
 
 class BaProblem(ctypes.Structure):
+    """rdvio_ba_problem (include/rdvio_hip.h)"""
     _fields_ = [
-        ("n_frames", ctypes.c_int32), ("n_landmarks", ctypes.c_int32), ("n_factors", ctypes.c_int32),
-        ("states", ctypes.c_void_p), ("extr", ctypes.c_void_p), ("sqrt_inv_cov", ctypes.c_void_p),
-        ("z_ref", ctypes.c_void_p), ("inv_depth", ctypes.c_void_p),
-        ("tgt", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("lm", ctypes.c_void_p), ("tangent", ctypes.c_void_p),
+        ("n_frames", ctypes.c_int32), ("states", ctypes.c_void_p), ("frame_fixed", ctypes.c_void_p),
+        ("extr", ctypes.c_void_p), ("sqrt_inv_cov", ctypes.c_void_p),
+        ("n_landmarks", ctypes.c_int32), ("z_ref", ctypes.c_void_p), ("inv_depth", ctypes.c_void_p),
+        ("lm_fixed", ctypes.c_void_p),
+        ("n_factors", ctypes.c_int32), ("tgt", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("lm", ctypes.c_void_p),
+        ("tangent", ctypes.c_void_p),
+        ("n_rot", ctypes.c_int32), ("rot_tgt", ctypes.c_void_p), ("rot_ref", ctypes.c_void_p),
+        ("rot_zref", ctypes.c_void_p), ("rot_tangent", ctypes.c_void_p),
+        ("n_preint", ctypes.c_int32), ("pre_i", ctypes.c_void_p), ("pre_j", ctypes.c_void_p),
+        ("preint", ctypes.c_void_p),
+        ("n_prior", ctypes.c_int32), ("prior_frames", ctypes.c_void_p), ("prior_lin", ctypes.c_void_p),
+        ("prior_S", ctypes.c_void_p), ("prior_f", ctypes.c_void_p),
     ]
+
+
+class BaSummary(ctypes.Structure):
+    _fields_ = [("iterations", ctypes.c_int32), ("successful_steps", ctypes.c_int32),
+                ("initial_cost", ctypes.c_double), ("final_cost", ctypes.c_double), ("termination", ctypes.c_int32)]
 
 
 def lib_path():
@@ -89,6 +104,11 @@ def load_library():
     lib.rdvio_hip_preintegrate.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6 + [
         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.rdvio_hip_reprojection_eval.argtypes = [ctypes.c_void_p, ctypes.POINTER(BaProblem)] + [ctypes.c_void_p] * 4
+    lib.rdvio_hip_ba_solve.argtypes = [ctypes.c_void_p, ctypes.POINTER(BaProblem), ctypes.c_int, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.POINTER(BaSummary)]
+    lib.rdvio_hip_ba_upload.argtypes = [ctypes.c_void_p, ctypes.POINTER(BaProblem)]
+    lib.rdvio_hip_ba_solve_resident.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.rdvio_hip_ba_fetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(BaSummary)]
     _LIB = lib
     return lib
 
@@ -168,23 +188,61 @@ class Context:
         return out
 
     def _ba_problem(self, pb):
-        keep = dict(states=_f64(pb["states"]), extr=_f64(pb["extr"]), W=_f64(pb["sqrt_inv_cov"]),
-                    z_ref=_f64(pb["z_ref"]), inv_depth=_f64(pb["inv_depth"]), tgt=_i32(pb["tgt"]), ref=_i32(pb["ref"]),
-                    lm=_i32(pb["lm"]), tangent=_f64(pb["tangent"]))
+        """problem dict -> rdvio_ba_problem (optional keys default to 'none')"""
+        states = _f64(pb["states"]).reshape(-1, 16)
+        n, nl = len(states), len(pb["inv_depth"])
+        u8 = lambda a: np.ascontiguousarray(a, dtype=np.uint8)  # noqa: E731
+        k = dict(
+            states=states, frame_fixed=u8(pb.get("frame_fixed", np.zeros(n))), extr=_f64(pb["extr"]),
+            W=_f64(pb["sqrt_inv_cov"]), z_ref=_f64(pb["z_ref"]).reshape(-1, 3), inv_depth=_f64(pb["inv_depth"]),
+            lm_fixed=u8(pb.get("lm_fixed", np.zeros(nl))), tgt=_i32(pb["tgt"]), ref=_i32(pb["ref"]), lm=_i32(pb["lm"]),
+            tangent=_f64(pb["tangent"]).reshape(-1, 9), rot_tgt=_i32(pb.get("rot_tgt", [])),
+            rot_ref=_i32(pb.get("rot_ref", [])), rot_zref=_f64(pb.get("rot_zref", np.zeros((0, 3)))),
+            rot_tangent=_f64(pb.get("rot_tangent", np.zeros((0, 9)))), pre_i=_i32(pb.get("pre_i", [])),
+            pre_j=_i32(pb.get("pre_j", [])), preint=_f64(pb.get("preint", np.zeros((0, PREINT_SIZE)))),
+            prior_frames=_i32(pb.get("prior_frames", [])), lin=_f64(pb.get("lin", np.zeros((0, 16)))),
+            S=_f64(pb.get("S", np.zeros((0, 0)))), f=_f64(pb.get("f", np.zeros(0))))
         c = BaProblem()
-        c.n_frames = len(keep["states"].reshape(-1, 16))
-        c.n_landmarks = len(keep["inv_depth"])
-        c.n_factors = len(keep["tgt"])
-        c.states = keep["states"].ctypes.data
-        c.extr = keep["extr"].ctypes.data
-        c.sqrt_inv_cov = keep["W"].ctypes.data
-        c.z_ref = keep["z_ref"].ctypes.data
-        c.inv_depth = keep["inv_depth"].ctypes.data
-        c.tgt = keep["tgt"].ctypes.data
-        c.ref = keep["ref"].ctypes.data
-        c.lm = keep["lm"].ctypes.data
-        c.tangent = keep["tangent"].ctypes.data
-        return c, keep
+        c.n_frames, c.n_landmarks, c.n_factors = n, nl, len(k["tgt"])
+        c.states, c.frame_fixed = k["states"].ctypes.data, k["frame_fixed"].ctypes.data
+        c.extr, c.sqrt_inv_cov = k["extr"].ctypes.data, k["W"].ctypes.data
+        c.z_ref, c.inv_depth, c.lm_fixed = k["z_ref"].ctypes.data, k["inv_depth"].ctypes.data, k["lm_fixed"].ctypes.data
+        c.tgt, c.ref, c.lm, c.tangent = (k["tgt"].ctypes.data, k["ref"].ctypes.data, k["lm"].ctypes.data,
+                                         k["tangent"].ctypes.data)
+        c.n_rot = len(k["rot_tgt"])
+        c.rot_tgt, c.rot_ref = k["rot_tgt"].ctypes.data, k["rot_ref"].ctypes.data
+        c.rot_zref, c.rot_tangent = k["rot_zref"].ctypes.data, k["rot_tangent"].ctypes.data
+        c.n_preint = len(k["pre_i"])
+        c.pre_i, c.pre_j, c.preint = k["pre_i"].ctypes.data, k["pre_j"].ctypes.data, k["preint"].ctypes.data
+        c.n_prior = len(k["prior_frames"])
+        c.prior_frames, c.prior_lin = k["prior_frames"].ctypes.data, k["lin"].ctypes.data
+        c.prior_S, c.prior_f = k["S"].ctypes.data, k["f"].ctypes.data
+        return c, k
+
+    def ba_solve(self, pb, max_iterations=30):
+        """Solver::solve on a problem dict -> (states, inv_depth, BaSummary)"""
+        c, keep = self._ba_problem(pb)
+        states = np.zeros((c.n_frames, 16))
+        invd = np.zeros(c.n_landmarks)
+        sm = BaSummary()
+        self._check(self._lib.rdvio_hip_ba_solve(self._h, ctypes.byref(c), int(max_iterations), states.ctypes.data,
+                                                 invd.ctypes.data, ctypes.byref(sm)))
+        return states, invd, sm
+
+    def ba_upload(self, pb):
+        c, keep = self._ba_problem(pb)
+        self._check(self._lib.rdvio_hip_ba_upload(self._h, ctypes.byref(c)))
+        self.sync()  # the source arrays may be freed by the caller after this returns
+        self._ba_shape = (c.n_frames, c.n_landmarks)
+
+    def ba_solve_resident(self, max_iterations=30):
+        self._check(self._lib.rdvio_hip_ba_solve_resident(self._h, int(max_iterations)))
+
+    def ba_fetch(self):
+        n, nl = self._ba_shape
+        states, invd, sm = np.zeros((n, 16)), np.zeros(nl), BaSummary()
+        self._check(self._lib.rdvio_hip_ba_fetch(self._h, states.ctypes.data, invd.ctypes.data, ctypes.byref(sm)))
+        return states, invd, sm
 
     def reprojection_eval(self, pb, jac=True):
         """CeresReprojectionErrorFactor::Evaluate over all factors of a BA problem dict."""

@@ -6,13 +6,9 @@
 //  * preintegrate_kernel       <- PreIntegrator::{reset,increment,integrate,compute_sqrt_inv_cov}
 //      /root/reference/src/rdvio_estimation/src/preintegrator.cpp:7-100
 #include "ctx.hpp"
-#include "dmath.hpp"
+#include "factors.hpp"
 
 namespace {
-
-enum { ST_Q = 0, ST_P = 4, ST_V = 7, ST_BG = 10, ST_BA = 13 };
-enum { ES_Q = 0, ES_P = 3, ES_V = 6, ES_BG = 9, ES_BA = 12 };
-enum { PRE_T = 0, PRE_Q = 1, PRE_P = 5, PRE_V = 8, PRE_COV = 11, PRE_SIC = 236, PRE_JAC = 461 };
 
 // One thread per factor.  Per factor: 2 int32 frame indices + landmark index, 72 B tangent, 24 B z_ref,
 // 8 B inverse depth read (poses are shared, L2/L1-resident); 16 B + 208 B written when r/J are materialised.
@@ -29,67 +25,24 @@ __global__ __launch_bounds__(256) void reprojection_eval_kernel(int nf, const in
                                                                double *__restrict__ Jd_out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nf) return;
-    const Q4 qcs = q_load(extr);
-    const V3 pcs = v3_load(extr + 4);
-    const double *st = states + 16 * tgt[k], *sr = states + 16 * ref[k];
-    const Q4 q_t = q_load(st + ST_Q), q_r = q_load(sr + ST_Q);
-    const V3 p_t = v3_load(st + ST_P), p_r = v3_load(sr + ST_P);
-    const M3 T = m3_load(tangent + 9 * (size_t)k);
     const int l = lm[k];
-    const V3 z_ref = v3_load(z_ref_all + 3 * (size_t)l);
-    const double rho = inv_depth_all[l];
-
-    const V3 y_ref = z_ref / rho;
-    const V3 y_rc = rot(qcs, y_ref) + pcs;
-    const V3 x = rot(q_r, y_rc) + p_r;
-    const V3 y_tc = rot_inv(q_t, x - p_t);
-    const V3 y_t = rot_inv(qcs, y_tc - pcs);
-    const M3 Tt = transpose(T);
-    const V3 u = Tt * y_t;
-    const double h0 = u.x / u.z, h1 = u.y / u.z;
-    const double w00 = W[0], w01 = W[1], w10 = W[2], w11 = W[3];
-    r_out[2 * (size_t)k] = w00 * h0 + w01 * h1;
-    r_out[2 * (size_t)k + 1] = w10 * h0 + w11 * h1;
-    if (!Jt_out) return;
-
-    // A = W dproj(u) T^T   (2x3), rows a0, a1
-    const double iz = 1.0 / u.z, iz2 = u.z * u.z;
-    const double d00 = iz, d02 = -u.x / iz2, d11 = iz, d12 = -u.y / iz2;
-    // WD (2x3)
-    const double wd[6] = {w00 * d00, w01 * d11, w00 * d02 + w01 * d12, w10 * d00, w11 * d11, w10 * d02 + w11 * d12};
-    double A[6], Bm[6], C[6], D[6];
+    double r[2], Jt[12], Jr[12], Jd[2];
+    if (Jt_out) {
+        reprojection_factor<true>(states + 16 * tgt[k], states + 16 * ref[k], tangent + 9 * (size_t)k,
+                                  z_ref_all + 3 * (size_t)l, inv_depth_all[l], extr, W, r, Jt, Jr, Jd);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            A[i * 3 + j] = wd[i * 3] * Tt.m[j] + wd[i * 3 + 1] * Tt.m[3 + j] + wd[i * 3 + 2] * Tt.m[6 + j];
-    const M3 RcsT = transpose(to_mat(qcs));
-    const M3 RtT = transpose(to_mat(q_t));
-    const M3 Rr = to_mat(q_r);
-#define MUL23(OUT, IN, M)                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 3; ++j) OUT[i * 3 + j] = \
-        IN[i * 3] * M.m[j] + IN[i * 3 + 1] * M.m[3 + j] + IN[i * 3 + 2] * M.m[6 + j];
-    MUL23(Bm, A, RcsT)   // dr/dy_tgt_center
-    MUL23(C, Bm, RtT)    // dr/dx
-    MUL23(D, C, Rr)      // dr/dy_ref_center
-    const M3 Ht = hat(y_tc), Hr = hat(y_rc);
-    double Mt[6], Mr[6];
-    MUL23(Mt, Bm, Ht)
-    MUL23(Mr, D, Hr)
-#undef MUL23
-    double *Jt = Jt_out + 12 * (size_t)k, *Jr = Jr_out + 12 * (size_t)k;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            Jt[i * 6 + j] = Mt[i * 3 + j];
-            Jt[i * 6 + 3 + j] = -C[i * 3 + j];
-            Jr[i * 6 + j] = -Mr[i * 3 + j];
-            Jr[i * 6 + 3 + j] = C[i * 3 + j];
+        for (int i = 0; i < 12; ++i) {
+            Jt_out[12 * (size_t)k + i] = Jt[i];
+            Jr_out[12 * (size_t)k + i] = Jr[i];
         }
-    const V3 t3 = to_mat(qcs) * y_ref;
-    Jd_out[2 * (size_t)k] = -(D[0] * t3.x + D[1] * t3.y + D[2] * t3.z) / rho;
-    Jd_out[2 * (size_t)k + 1] = -(D[3] * t3.x + D[4] * t3.y + D[5] * t3.z) / rho;
+        Jd_out[2 * (size_t)k] = Jd[0];
+        Jd_out[2 * (size_t)k + 1] = Jd[1];
+    } else {
+        reprojection_factor<false>(states + 16 * tgt[k], states + 16 * ref[k], tangent + 9 * (size_t)k,
+                                   z_ref_all + 3 * (size_t)l, inv_depth_all[l], extr, W, r, Jt, Jr, Jd);
+    }
+    r_out[2 * (size_t)k] = r[0];
+    r_out[2 * (size_t)k + 1] = r[1];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -113,6 +113,19 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
     CTX_ALLOC(ctx->pre_par, ((size_t)ctx->pre_max_seg * 7 + 36) * sizeof(double));
     CTX_ALLOC(ctx->pre_out, (size_t)ctx->pre_max_seg * RDVIO_PREINT_SIZE * sizeof(double));
     CTX_ALLOC(ctx->pre_off, (size_t)(ctx->pre_max_seg + 1) * sizeof(int32_t));
+    {
+        const size_t F = (size_t)max_factors, Lm = (size_t)max_factors, Nmax = 15 * (size_t)nfr, npre = (size_t)nfr + 8;
+        size_t bytes = (1 << 16) + F * 420 + Lm * (176 + 48 * (size_t)nfr) + Nmax * Nmax * 8 * 4 +
+                       npre * (RDVIO_PREINT_SIZE + 1400) * 8 + Nmax * 8 * 32;
+        bytes += bytes / 4;
+        ctx->ba_arena_bytes = ctx->ba_host_bytes = bytes;
+        CTX_ALLOC(ctx->ba_arena, bytes);
+        if (hipHostMalloc(&ctx->ba_host, bytes, hipHostMallocDefault) != hipSuccess) {
+            rdvio_fail(ctx, RDVIO_ERR_HIP, "hipHostMalloc(ba_host) failed");
+            *out = ctx;
+            return RDVIO_ERR_HIP;
+        }
+    }
     ctx->pinned_bytes = std::max<size_t>((size_t)ctx->harris_cand_cap * sizeof(HarrisCand), 1 << 20);
     if (hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
         rdvio_fail(ctx, RDVIO_ERR_HIP, "hipHostMalloc failed");
@@ -137,6 +150,8 @@ void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
                     ctx->ba_Jd, ctx->pre_imu, ctx->pre_par, ctx->pre_out, ctx->pre_off};
     for (void *b : bufs) (void)hipFree(b);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->ba_host) (void)hipHostFree(ctx->ba_host);
+    (void)hipFree(ctx->ba_arena);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

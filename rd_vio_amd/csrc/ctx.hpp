@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "../../include/rdvio_hip.h"
+#include "solver_ws.hpp"
 
 #define RDVIO_NUM_SLOTS 2
 #define RDVIO_MAX_TILES 256  // CLAHE tile grid (8x8 in configs/setting.yaml:17-19)
@@ -53,6 +54,13 @@ struct rdvio_hip_ctx {
     double *pre_imu = nullptr, *pre_par = nullptr, *pre_out = nullptr;
     int32_t *pre_off = nullptr;
     int pre_max_samples = 0, pre_max_seg = 0;
+
+    // BA solver: pinned input blob, device arena (inputs + scratch), workspace descriptor
+    void *ba_host = nullptr, *ba_arena = nullptr;
+    size_t ba_host_bytes = 0, ba_arena_bytes = 0;
+    SolverWs ba_ws{};
+    size_t ba_in_states_off = 0, ba_in_invd_off = 0, ba_in_bytes = 0;
+    bool ba_ready = false;
 
     // pinned host staging
     void *pinned = nullptr;

@@ -1,0 +1,196 @@
+// Device-side factor evaluation (FP64), shared by the stand-alone evaluation kernels and the solver.
+// Each function cites the reference code it follows (paths relative to /root/reference).
+#pragma once
+#include "dmath.hpp"
+
+enum { ST_Q = 0, ST_P = 4, ST_V = 7, ST_BG = 10, ST_BA = 13 };
+enum { ES_Q = 0, ES_P = 3, ES_V = 6, ES_BG = 9, ES_BA = 12 };
+enum { PRE_T = 0, PRE_Q = 1, PRE_P = 5, PRE_V = 8, PRE_COV = 11, PRE_SIC = 236, PRE_JAC = 461 };
+enum { EX_CQ = 0, EX_CP = 4, EX_IQ = 7, EX_IP = 11 };
+
+// QuaternionParameterization::Plus on a 16-double frame state
+// (src/rdvio_estimation/include/rdvio/estimation/ceres/quaternion_parameterization.h:11-17)
+DM void state_plus(const double *s, const double *d15, double *o) {
+    Q4 q = normalized(q_load(s) * expmap(v3_load(d15)));
+    q_store(o, q);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) o[4 + i] = s[4 + i] + d15[3 + i];
+}
+
+// CeresReprojectionErrorFactor::Evaluate
+// (src/rdvio_estimation/include/rdvio/estimation/ceres/reprojection_factor.h:24-89).
+// Jt/Jr: 2x6 row-major (theta, p) of the target / anchor frame, Jd: 2 (inverse depth).
+template <bool WITH_JAC>
+DM void reprojection_factor(const double *__restrict__ st, const double *__restrict__ sr, const double *__restrict__ T9,
+                            const double *__restrict__ zref3, double rho, const double *__restrict__ extr,
+                            const double *__restrict__ W, double *r, double *Jt, double *Jr, double *Jd) {
+    const Q4 qcs = q_load(extr + EX_CQ);
+    const V3 pcs = v3_load(extr + EX_CP);
+    const Q4 q_t = q_load(st + ST_Q), q_r = q_load(sr + ST_Q);
+    const V3 p_t = v3_load(st + ST_P), p_r = v3_load(sr + ST_P);
+    const M3 T = m3_load(T9);
+    const V3 z_ref = v3_load(zref3);
+    const V3 y_ref = z_ref / rho;
+    const V3 y_rc = rot(qcs, y_ref) + pcs;
+    const V3 x = rot(q_r, y_rc) + p_r;
+    const V3 y_tc = rot_inv(q_t, x - p_t);
+    const V3 y_t = rot_inv(qcs, y_tc - pcs);
+    const M3 Tt = transpose(T);
+    const V3 u = Tt * y_t;
+    const double h0 = u.x / u.z, h1 = u.y / u.z;
+    const double w00 = W[0], w01 = W[1], w10 = W[2], w11 = W[3];
+    r[0] = w00 * h0 + w01 * h1;
+    r[1] = w10 * h0 + w11 * h1;
+    if (!WITH_JAC) return;
+    const double iz = 1.0 / u.z, z2 = u.z * u.z;
+    const double d02 = -u.x / z2, d12 = -u.y / z2;
+    const double wd[6] = {w00 * iz, w01 * iz, w00 * d02 + w01 * d12, w10 * iz, w11 * iz, w10 * d02 + w11 * d12};
+    double A[6], Bm[6], C[6], D[6], Mt[6], Mr[6];
+#define RDVIO_MUL23(OUT, IN, MAT)                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 3; ++j) OUT[i * 3 + j] = \
+        IN[i * 3] * (MAT).m[j] + IN[i * 3 + 1] * (MAT).m[3 + j] + IN[i * 3 + 2] * (MAT).m[6 + j];
+    RDVIO_MUL23(A, wd, Tt)
+    const M3 Rcs = to_mat(qcs);
+    const M3 RcsT = transpose(Rcs);
+    const M3 RtT = transpose(to_mat(q_t));
+    const M3 Rr = to_mat(q_r);
+    RDVIO_MUL23(Bm, A, RcsT)  // dr/dy_tgt_center
+    RDVIO_MUL23(C, Bm, RtT)   // dr/dx
+    RDVIO_MUL23(D, C, Rr)     // dr/dy_ref_center
+    const M3 Ht = hat(y_tc), Hr = hat(y_rc);
+    RDVIO_MUL23(Mt, Bm, Ht)
+    RDVIO_MUL23(Mr, D, Hr)
+#undef RDVIO_MUL23
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Jt[i * 6 + j] = Mt[i * 3 + j];
+            Jt[i * 6 + 3 + j] = -C[i * 3 + j];
+            Jr[i * 6 + j] = -Mr[i * 3 + j];
+            Jr[i * 6 + 3 + j] = C[i * 3 + j];
+        }
+    const V3 t3 = Rcs * y_ref;
+    Jd[0] = -(D[0] * t3.x + D[1] * t3.y + D[2] * t3.z) / rho;
+    Jd[1] = -(D[3] * t3.x + D[4] * t3.y + D[5] * t3.z) / rho;
+}
+
+// CeresRotationPriorFactor::Evaluate (src/rdvio_estimation/include/rdvio/estimation/ceres/rotation_factor.h:22-58);
+// J: 2x3 row-major wrt theta of the target frame.
+template <bool WITH_JAC>
+DM void rotation_prior_factor(const double *q_tgt4, const double *q_ref4, const double *zref3, const double *T9,
+                              const double *extr, const double *W, double *r, double *J) {
+    const Q4 qcs = q_load(extr + EX_CQ);
+    const V3 pcs = v3_load(extr + EX_CP);
+    const Q4 q_t = q_load(q_tgt4), q_r = q_load(q_ref4);
+    const V3 z_rc = rot(qcs, v3_load(zref3)) + pcs;  // translation added to a bearing: reference quirk (:34)
+    const V3 z_tc = rot_inv(q_t, rot(q_r, z_rc));
+    const V3 z_t = rot_inv(qcs, z_tc - pcs);
+    const M3 Tt = transpose(m3_load(T9));
+    const V3 u = Tt * z_t;
+    const double h0 = u.x / u.z, h1 = u.y / u.z;
+    r[0] = W[0] * h0 + W[1] * h1;
+    r[1] = W[2] * h0 + W[3] * h1;
+    if (!WITH_JAC) return;
+    const double iz = 1.0 / u.z, z2 = u.z * u.z;
+    const double d02 = -u.x / z2, d12 = -u.y / z2;
+    const double wd[6] = {W[0] * iz, W[1] * iz, W[0] * d02 + W[1] * d12, W[2] * iz, W[3] * iz, W[2] * d02 + W[3] * d12};
+    const M3 RcsT = transpose(to_mat(qcs));
+    const M3 H = hat(z_tc);
+    double A[6], Bm[6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) A[i * 3 + j] = wd[i * 3] * Tt.m[j] + wd[i * 3 + 1] * Tt.m[3 + j] + wd[i * 3 + 2] * Tt.m[6 + j];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Bm[i * 3 + j] = A[i * 3] * RcsT.m[j] + A[i * 3 + 1] * RcsT.m[3 + j] + A[i * 3 + 2] * RcsT.m[6 + j];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) J[i * 3 + j] = Bm[i * 3] * H.m[j] + Bm[i * 3 + 1] * H.m[3 + j] + Bm[i * 3 + 2] * H.m[6 + j];
+}
+
+DM void blk3_set(double *M, int ld, int r0, int c0, const M3 &B, double s) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) M[(r0 + i) * ld + c0 + j] = s * B.m[i * 3 + j];
+}
+
+// CeresPreIntegrationErrorFactor::Evaluate, UNWHITENED part
+// (src/rdvio_estimation/include/rdvio/estimation/ceres/preintegration_factor.h:19-153):
+// e (15) and, if requested, the 15x15 blocks Gi, Gj (tangent columns; must be zero-initialised by the caller)
+// before the left multiplication by delta.sqrt_inv_cov (:155 and the per-block products).
+template <bool WITH_JAC>
+DM void preintegration_unwhitened(const double *si, const double *sj, const double *pre, const double *bias_lin,
+                                  const double *extr, double *e, double *Gi, double *Gj) {
+    const V3 g = v3(0, 0, -9.80665);
+    const Q4 q_ci = q_load(si + ST_Q), q_cj = q_load(sj + ST_Q);
+    const V3 p_ci = v3_load(si + ST_P), v_i = v3_load(si + ST_V), bg_i = v3_load(si + ST_BG), ba_i = v3_load(si + ST_BA);
+    const V3 p_cj = v3_load(sj + ST_P), v_j = v3_load(sj + ST_V), bg_j = v3_load(sj + ST_BG), ba_j = v3_load(sj + ST_BA);
+    const Q4 iq = q_load(extr + EX_IQ);
+    const V3 ip = v3_load(extr + EX_IP);
+    const Q4 q_i = q_ci * iq, q_j = q_cj * iq;
+    const V3 p_i = p_ci + rot(q_ci, ip), p_j = p_cj + rot(q_cj, ip);
+    const double dt = pre[PRE_T];
+    const Q4 dq = q_load(pre + PRE_Q);
+    const V3 dp = v3_load(pre + PRE_P), dv = v3_load(pre + PRE_V);
+    const M3 dq_dbg = m3_load(pre + PRE_JAC), dp_dbg = m3_load(pre + PRE_JAC + 9), dp_dba = m3_load(pre + PRE_JAC + 18),
+             dv_dbg = m3_load(pre + PRE_JAC + 27), dv_dba = m3_load(pre + PRE_JAC + 36);
+    const V3 dbg = bg_i - v3_load(bias_lin), dba = ba_i - v3_load(bias_lin + 3);
+
+    const V3 th = dq_dbg * dbg;
+    const Q4 corr = dq * expmap(th);
+    const V3 r_th = logmap(conj(corr) * conj(q_i) * q_j);
+    const V3 r_p = rot_inv(q_i, p_j - p_i - dt * v_i - (0.5 * dt * dt) * g) - (dp + dp_dbg * dbg + dp_dba * dba);
+    const V3 r_v = rot_inv(q_i, v_j - v_i - dt * g) - (dv + dv_dbg * dbg + dv_dba * dba);
+    v3_store(e + ES_Q, r_th);
+    v3_store(e + ES_P, r_p);
+    v3_store(e + ES_V, r_v);
+    v3_store(e + ES_BG, bg_j - bg_i);
+    v3_store(e + ES_BA, ba_j - ba_i);
+    if (!WITH_JAC) return;
+
+    const M3 Jrinv = inverse3(right_jacobian(r_th));
+    const M3 RjT = to_mat(conj(q_j)), Rci = to_mat(q_ci), RciT = transpose(Rci), Rcj = to_mat(q_cj);
+    const M3 RiT = to_mat(conj(q_i)), IqT = to_mat(conj(iq));
+    const M3 I3 = m3_identity();
+    // d/d theta_i
+    blk3_set(Gi, 15, ES_Q, ES_Q, Jrinv * (RjT * Rci), -1.0);
+    blk3_set(Gi, 15, ES_P, ES_Q, IqT * hat(RciT * (p_j - p_ci - dt * v_i - (0.5 * dt * dt) * g)), 1.0);
+    blk3_set(Gi, 15, ES_V, ES_Q, IqT * hat(RciT * (v_j - v_i - dt * g)), 1.0);
+    // d/d p_i, d/d v_i
+    blk3_set(Gi, 15, ES_P, ES_P, RiT, -1.0);
+    blk3_set(Gi, 15, ES_P, ES_V, RiT, -dt);
+    blk3_set(Gi, 15, ES_V, ES_V, RiT, -1.0);
+    // d/d bg_i
+    const M3 ERt = to_mat(conj(expmap(r_th)));
+    blk3_set(Gi, 15, ES_Q, ES_BG, ((Jrinv * ERt) * right_jacobian(th)) * dq_dbg, -1.0);
+    blk3_set(Gi, 15, ES_P, ES_BG, dp_dbg, -1.0);
+    blk3_set(Gi, 15, ES_V, ES_BG, dv_dbg, -1.0);
+    blk3_set(Gi, 15, ES_BG, ES_BG, I3, -1.0);
+    // d/d ba_i
+    blk3_set(Gi, 15, ES_P, ES_BA, dp_dba, -1.0);
+    blk3_set(Gi, 15, ES_V, ES_BA, dv_dba, -1.0);
+    blk3_set(Gi, 15, ES_BA, ES_BA, I3, -1.0);
+    // d/d theta_j, p_j, v_j, bg_j, ba_j
+    blk3_set(Gj, 15, ES_Q, ES_Q, Jrinv * IqT, 1.0);
+    blk3_set(Gj, 15, ES_P, ES_Q, (RiT * Rcj) * hat(ip), -1.0);
+    blk3_set(Gj, 15, ES_P, ES_P, RiT, 1.0);
+    blk3_set(Gj, 15, ES_V, ES_V, RiT, 1.0);
+    blk3_set(Gj, 15, ES_BG, ES_BG, I3, 1.0);
+    blk3_set(Gj, 15, ES_BA, ES_BA, I3, 1.0);
+}
+
+// CeresMarginalizationFactor::Evaluate, per-frame part
+// (src/rdvio_estimation/include/rdvio/estimation/ceres/marginalization_factor.h:29-52):
+// e15 = [log(q0^-1 q); p-p0; v-v0; bg-bg0; ba-ba0] and Jr(e_theta)^-1.
+DM void marginalization_frame_error(const double *s, const double *lin, double *e15, M3 *Jrinv) {
+    const V3 eth = logmap(conj(q_load(lin + ST_Q)) * q_load(s + ST_Q));
+    v3_store(e15, eth);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) e15[3 + i] = s[4 + i] - lin[4 + i];
+    if (Jrinv) *Jrinv = inverse3(right_jacobian(eth));
+}

@@ -1,0 +1,247 @@
+// Host side of rdvio_hip_ba_solve: validates the SoA problem, builds the graph index structures
+// (frame-pair factor lists, per-landmark factor ranges -- the SoA export of what refine_window assembles
+// through pointers, /root/reference/src/rdvio/src/sliding_window_tracker.cpp:226-300), packs everything into
+// one pinned blob, uploads it with a single copy and launches the persistent solver kernel.
+#include <algorithm>
+#include <vector>
+
+#include "ctx.hpp"
+#include "solver_ws.hpp"
+
+namespace {
+
+struct Packer {
+    uint8_t *base;
+    size_t cap, off = 0;
+    bool ok = true;
+    template <class Tp>
+    size_t put(const Tp *src, size_t n) {
+        off = (off + 15) & ~(size_t)15;
+        const size_t at = off, bytes = n * sizeof(Tp);
+        if (at + bytes > cap) {
+            ok = false;
+            return at;
+        }
+        if (n && src) memcpy(base + at, src, bytes);
+        off += bytes;
+        return at;
+    }
+    size_t reserve(size_t bytes) {
+        off = (off + 15) & ~(size_t)15;
+        const size_t at = off;
+        if (at + bytes > cap) ok = false;
+        off += bytes;
+        return at;
+    }
+};
+
+}  // namespace
+
+static int ba_prepare(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb) {
+    if (!pb) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null BA problem");
+    const int nfr = pb->n_frames, nl = pb->n_landmarks, nf = pb->n_factors, nrot = pb->n_rot, npre = pb->n_preint,
+              np = pb->n_prior;
+    if (nfr <= 0 || nl < 0 || nf < 0 || nrot < 0 || npre < 0 || np < 0) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "negative BA sizes");
+    if (nfr > ctx->max_window + 2) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d frames exceed window capacity %d", nfr, ctx->max_window + 2);
+    if (nf > ctx->max_factors || nl > ctx->max_factors || nrot > ctx->max_factors)
+        return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d factors / %d landmarks exceed capacity %d", nf, nl, ctx->max_factors);
+    if (npre > nfr + 8 || np > nfr) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "too many preintegration factors / prior frames");
+    if (!pb->states || !pb->frame_fixed || !pb->extr || !pb->sqrt_inv_cov) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null frame arrays");
+    if (nl > 0 && (!pb->z_ref || !pb->inv_depth || !pb->lm_fixed)) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null landmark arrays");
+    if (nf > 0 && (!pb->tgt || !pb->ref || !pb->lm || !pb->tangent)) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null factor arrays");
+    if (nrot > 0 && (!pb->rot_tgt || !pb->rot_ref || !pb->rot_zref || !pb->rot_tangent)) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null rotation-prior arrays");
+    if (npre > 0 && (!pb->pre_i || !pb->pre_j || !pb->preint)) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null preintegration arrays");
+    if (np > 0 && (!pb->prior_frames || !pb->prior_lin || !pb->prior_S || !pb->prior_f)) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null prior arrays");
+    // every index is range-checked here so that the kernel can never read out of bounds
+    for (int k = 0; k < nf; ++k) {
+        if (pb->tgt[k] < 0 || pb->tgt[k] >= nfr || pb->ref[k] < 0 || pb->ref[k] >= nfr || pb->lm[k] < 0 || pb->lm[k] >= nl)
+            return rdvio_fail(ctx, RDVIO_ERR_INVALID, "factor %d indexes out of range", k);
+        if (k > 0 && pb->lm[k] < pb->lm[k - 1]) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "factors must be ordered by landmark (factor %d)", k);
+    }
+    for (int k = 0; k < nrot; ++k)
+        if (pb->rot_tgt[k] < 0 || pb->rot_tgt[k] >= nfr || pb->rot_ref[k] < 0 || pb->rot_ref[k] >= nfr)
+            return rdvio_fail(ctx, RDVIO_ERR_INVALID, "rotation prior %d indexes out of range", k);
+    for (int k = 0; k < npre; ++k)
+        if (pb->pre_i[k] < 0 || pb->pre_i[k] >= nfr || pb->pre_j[k] < 0 || pb->pre_j[k] >= nfr)
+            return rdvio_fail(ctx, RDVIO_ERR_INVALID, "preintegration factor %d indexes out of range", k);
+    for (int i = 0; i < np; ++i)
+        if (pb->prior_frames[i] < 0 || pb->prior_frames[i] >= nfr) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "prior frame %d out of range", i);
+
+    // ---- graph index structures
+    std::vector<int32_t> fcol(nfr);
+    int nfree = 0;
+    for (int i = 0; i < nfr; ++i) fcol[i] = pb->frame_fixed[i] ? -1 : nfree++;
+    const int N = 15 * nfree, D = 15 * np;
+    const int npairs = nfree * (nfree + 1) / 2;
+    std::vector<int32_t> pair_fi(npairs), pair_fj(npairs), diag_pair(std::max(nfree, 1));
+    std::vector<int> pair_index((size_t)std::max(nfree * nfree, 1), -1);
+    {
+        int p = 0;
+        for (int i = 0; i < nfree; ++i)
+            for (int j = i; j < nfree; ++j) {
+                pair_fi[p] = i;
+                pair_fj[p] = j;
+                pair_index[(size_t)i * nfree + j] = p;
+                if (i == j) diag_pair[i] = p;
+                ++p;
+            }
+    }
+    std::vector<int32_t> pair_off(npairs + 1, 0);
+    auto visit = [&](auto &&emit) {
+        for (int k = 0; k < nf; ++k) {
+            const int ct = fcol[pb->tgt[k]], cr = fcol[pb->ref[k]];
+            if (ct >= 0) emit(pair_index[(size_t)ct * nfree + ct], k * 4 + 0);  // Jt^T Jt
+            if (cr >= 0) emit(pair_index[(size_t)cr * nfree + cr], k * 4 + 3);  // Jr^T Jr
+            if (ct >= 0 && cr >= 0 && ct != cr) {
+                if (ct < cr) emit(pair_index[(size_t)ct * nfree + cr], k * 4 + 2);  // rows Jt, cols Jr
+                else emit(pair_index[(size_t)cr * nfree + ct], k * 4 + 1);          // rows Jr, cols Jt
+            }
+        }
+    };
+    visit([&](int p, int) { pair_off[p + 1]++; });
+    for (int p = 0; p < npairs; ++p) pair_off[p + 1] += pair_off[p];
+    std::vector<int32_t> pair_item((size_t)std::max(pair_off[npairs], 1));
+    {
+        std::vector<int32_t> cur(pair_off.begin(), pair_off.end() - 1);
+        visit([&](int p, int item) { pair_item[cur[p]++] = item; });
+    }
+    std::vector<int32_t> lm_first(std::max(nl, 1), 0), lm_count(std::max(nl, 1), 0);
+    for (int k = 0; k < nf; ++k) {
+        if (lm_count[pb->lm[k]] == 0) lm_first[pb->lm[k]] = k;
+        lm_count[pb->lm[k]]++;
+    }
+    int n_lfree = 0;
+    for (int l = 0; l < nl; ++l)
+        if (lm_count[l] > 0 && !pb->lm_fixed[l]) n_lfree++;
+
+    // ---- pack inputs into the pinned blob (one H2D copy), then carve device scratch behind it
+    Packer P{(uint8_t *)ctx->ba_host, ctx->ba_host_bytes};
+    double extr18[18];
+    memcpy(extr18, pb->extr, 14 * sizeof(double));
+    memcpy(extr18 + 14, pb->sqrt_inv_cov, 4 * sizeof(double));
+    const size_t o_states = P.put(pb->states, (size_t)nfr * 16);
+    const size_t o_invd = P.put(pb->inv_depth, (size_t)nl);
+    const size_t o_lmfixed = P.put(pb->lm_fixed, (size_t)nl);
+    const size_t o_extr = P.put(extr18, 18);
+    const size_t o_zref = P.put(pb->z_ref, (size_t)nl * 3);
+    const size_t o_tgt = P.put(pb->tgt, (size_t)nf), o_ref = P.put(pb->ref, (size_t)nf), o_lm = P.put(pb->lm, (size_t)nf);
+    const size_t o_tan = P.put(pb->tangent, (size_t)nf * 9);
+    const size_t o_rt = P.put(pb->rot_tgt, (size_t)nrot), o_rr = P.put(pb->rot_ref, (size_t)nrot);
+    const size_t o_rz = P.put(pb->rot_zref, (size_t)nrot * 3), o_rtan = P.put(pb->rot_tangent, (size_t)nrot * 9);
+    const size_t o_pi = P.put(pb->pre_i, (size_t)npre), o_pj = P.put(pb->pre_j, (size_t)npre);
+    const size_t o_pre = P.put(pb->preint, (size_t)npre * RDVIO_PREINT_SIZE);
+    const size_t o_pf = P.put(pb->prior_frames, (size_t)np), o_lin = P.put(pb->prior_lin, (size_t)np * 16);
+    const size_t o_S = P.put(pb->prior_S, (size_t)D * D), o_f = P.put(pb->prior_f, (size_t)D);
+    const size_t o_fcol = P.put(fcol.data(), (size_t)nfr);
+    const size_t o_lmf = P.put(lm_first.data(), (size_t)nl), o_lmc = P.put(lm_count.data(), (size_t)nl);
+    const size_t o_pfi = P.put(pair_fi.data(), (size_t)npairs), o_pfj = P.put(pair_fj.data(), (size_t)npairs);
+    const size_t o_poff = P.put(pair_off.data(), (size_t)npairs + 1);
+    const size_t o_pitem = P.put(pair_item.data(), pair_item.size());
+    const size_t o_dp = P.put(diag_pair.data(), diag_pair.size());
+    if (!P.ok) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "BA problem does not fit the context's staging buffer");
+    const size_t in_bytes = P.off;
+
+    // scratch (device only): bump-allocate behind the inputs
+    Packer Sx{nullptr, ctx->ba_arena_bytes};
+    Sx.off = in_bytes;
+    auto dd = [&](size_t n) { return Sx.reserve(std::max<size_t>(n, 1) * sizeof(double)); };
+    const size_t s_x = dd((size_t)nfr * 16), s_xd = dd(nl), s_xc = dd((size_t)nfr * 16), s_xdc = dd(nl), s_user = dd((size_t)nfr * 16);
+    const size_t s_lfree = Sx.reserve(std::max(nl, 1));
+    const size_t s_rf = dd((size_t)nf * 2), s_Jt = dd((size_t)nf * 12), s_Jr = dd((size_t)nf * 12), s_Jd = dd((size_t)nf * 2);
+    const size_t s_rr = dd((size_t)nrot * 2), s_Jro = dd((size_t)nrot * 6);
+    const size_t s_ep = dd((size_t)npre * 15), s_G = dd((size_t)npre * 450), s_rp = dd((size_t)npre * 15), s_cp = dd((size_t)npre * 15), s_Jp = dd((size_t)npre * 450);
+    const size_t s_em = dd(D), s_rm = dd(D), s_cm = dd(D), s_Jri = dd((size_t)np * 9), s_Lam = dd((size_t)D * D), s_eta0 = dd(D), s_le = dd(D), s_Ex = dd(D);
+    const size_t s_H = dd((size_t)N * N), s_Sm = dd((size_t)N * N), s_g = dd(N), s_yp = dd(N);
+    const size_t s_lmm = dd(nl), s_lmg = dd(nl), s_lmw = dd(nl), s_A = dd((size_t)nl * 6 * nfree), s_yl = dd(nl);
+    const size_t s_sigp = dd(N), s_sigl = dd(nl), s_dgp = dd(N), s_dgl = dd(nl), s_grp = dd(N), s_grl = dd(nl), s_gnp = dd(N), s_gnl = dd(nl), s_tp = dd(N), s_tl = dd(nl);
+    const size_t s_sum = dd(8);
+    if (!Sx.ok) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "BA problem does not fit the context's device arena");
+
+    uint8_t *B = (uint8_t *)ctx->ba_arena;
+    SolverWs &w = ctx->ba_ws;
+    memset(&w, 0, sizeof w);
+    w.nfr = nfr; w.nl = nl; w.nf = nf; w.nrot = nrot; w.npre = npre; w.np = np; w.D = D; w.nfree = nfree; w.N = N;
+    w.npairs = npairs; w.n_lfree_hint = n_lfree;
+#define DP(off) ((double *)(B + (off)))
+#define IP(off) ((const int32_t *)(B + (off)))
+    w.lm_fixed = B + o_lmfixed;
+    w.extr = DP(o_extr); w.z_ref = DP(o_zref);
+    w.tgt = IP(o_tgt); w.ref = IP(o_ref); w.lm = IP(o_lm); w.tangent = DP(o_tan);
+    w.rot_tgt = IP(o_rt); w.rot_ref = IP(o_rr); w.rot_zref = DP(o_rz); w.rot_tangent = DP(o_rtan);
+    w.pre_i = IP(o_pi); w.pre_j = IP(o_pj); w.preint = DP(o_pre);
+    w.prior_frames = IP(o_pf); w.lin = DP(o_lin); w.S = DP(o_S); w.f = DP(o_f);
+    w.fcol = IP(o_fcol); w.lm_first = IP(o_lmf); w.lm_count = IP(o_lmc);
+    w.pair_fi = IP(o_pfi); w.pair_fj = IP(o_pfj); w.pair_off = IP(o_poff); w.pair_item = IP(o_pitem); w.diag_pair = IP(o_dp);
+    w.x = DP(s_x); w.xd = DP(s_xd); w.xc = DP(s_xc); w.xdc = DP(s_xdc); w.user = DP(s_user); w.lfree = B + s_lfree;
+    w.r_f = DP(s_rf); w.Jt = DP(s_Jt); w.Jr = DP(s_Jr); w.Jd = DP(s_Jd); w.r_r = DP(s_rr); w.Jro = DP(s_Jro);
+    w.e_p = DP(s_ep); w.G = DP(s_G); w.r_p = DP(s_rp); w.c_p = DP(s_cp); w.Jp = DP(s_Jp);
+    w.e_m = DP(s_em); w.r_m = DP(s_rm); w.c_m = DP(s_cm); w.Jri = DP(s_Jri); w.Lam = DP(s_Lam); w.eta0 = DP(s_eta0); w.le = DP(s_le); w.Ex = DP(s_Ex);
+    w.H = DP(s_H); w.Sm = DP(s_Sm); w.g = DP(s_g); w.yp = DP(s_yp);
+    w.lm_m = DP(s_lmm); w.lm_g = DP(s_lmg); w.lm_w = DP(s_lmw); w.A = DP(s_A); w.yl = DP(s_yl);
+    w.sig_p = DP(s_sigp); w.sig_l = DP(s_sigl); w.diag_p = DP(s_dgp); w.diag_l = DP(s_dgl); w.grad_p = DP(s_grp); w.grad_l = DP(s_grl);
+    w.gn_p = DP(s_gnp); w.gn_l = DP(s_gnl); w.tp = DP(s_tp); w.tl = DP(s_tl);
+    w.summary = DP(s_sum);
+#undef DP
+#undef IP
+    ctx->ba_in_states_off = o_states;
+    ctx->ba_in_invd_off = o_invd;
+    ctx->ba_in_bytes = in_bytes;
+    ctx->ba_ready = true;
+    return RDVIO_OK;
+}
+
+extern "C" {
+
+int rdvio_hip_ba_upload(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb) {
+    if (!ctx) return RDVIO_ERR_INVALID;
+    ctx->ba_ready = false;
+    // the pinned blob may still be in flight from a previous upload on this stream
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = ba_prepare(ctx, pb)) return rc;
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_arena, ctx->ba_host, ctx->ba_in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    return RDVIO_OK;
+}
+
+int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int max_iterations) {
+    if (!ctx) return RDVIO_ERR_INVALID;
+    if (!ctx->ba_ready) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "no BA problem uploaded");
+    if (max_iterations < 0) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "negative iteration limit");
+    SolverWs &w = ctx->ba_ws;
+    w.max_iter = max_iterations;
+    uint8_t *B = (uint8_t *)ctx->ba_arena;
+    // (re)start from the uploaded initial values: device-to-device, no host traffic
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(w.x, B + ctx->ba_in_states_off, (size_t)w.nfr * 16 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if (w.nl > 0)
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(w.xd, B + ctx->ba_in_invd_off, (size_t)w.nl * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    rdvio_launch_ba_solve(ctx->stream, w);
+    RDVIO_HIP_CHECK(ctx, hipGetLastError());
+    return RDVIO_OK;
+}
+
+int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, double *states_out, double *inv_depth_out, rdvio_ba_summary *summary) {
+    if (!ctx) return RDVIO_ERR_INVALID;
+    if (!ctx->ba_ready) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "no BA problem uploaded");
+    SolverWs &w = ctx->ba_ws;
+    double sum[8] = {0};
+    if (states_out) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(states_out, w.x, (size_t)w.nfr * 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (inv_depth_out && w.nl > 0) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(inv_depth_out, w.xd, (size_t)w.nl * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(sum, w.summary, sizeof sum, hipMemcpyDeviceToHost, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (summary) {
+        summary->iterations = (int32_t)sum[0];
+        summary->successful_steps = (int32_t)sum[1];
+        summary->initial_cost = sum[2];
+        summary->final_cost = sum[3];
+        summary->termination = (int32_t)sum[4];
+    }
+    return RDVIO_OK;
+}
+
+int rdvio_hip_ba_solve(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, int max_iterations, double *states_out,
+                       double *inv_depth_out, rdvio_ba_summary *summary) {
+    if (int rc = rdvio_hip_ba_upload(ctx, pb)) return rc;
+    if (int rc = rdvio_hip_ba_solve_resident(ctx, max_iterations)) return rc;
+    return rdvio_hip_ba_fetch(ctx, states_out, inv_depth_out, summary);
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+// Workspace descriptor of the persistent BA solver kernel (device pointers; passed by value).
+#pragma once
+#include <cstdint>
+
+#define RDVIO_SOLVER_THREADS 512
+
+struct SolverWs {
+    // ---- problem (read-only on the device)
+    int nfr, nl, nf, nrot, npre, np, D, nfree, N, npairs, max_iter, n_lfree_hint;
+    const uint8_t *lm_fixed;
+    const double *extr;  // 14 extrinsics + 4 sqrt_inv_cov
+    const double *z_ref;
+    const int32_t *tgt, *ref, *lm;
+    const double *tangent;
+    const int32_t *rot_tgt, *rot_ref;
+    const double *rot_zref, *rot_tangent;
+    const int32_t *pre_i, *pre_j;
+    const double *preint;
+    const int32_t *prior_frames;
+    const double *lin, *S, *f;
+    // graph index structures (built on the host with the problem: A16, sliding_window_tracker.cpp:226-300)
+    const int32_t *fcol;                 // frame -> free slot or -1
+    const int32_t *lm_first, *lm_count;  // factors of a landmark are contiguous
+    const int32_t *pair_fi, *pair_fj, *pair_off, *pair_item, *diag_pair;
+    // ---- state
+    double *x, *xd;                      // in/out: frame states, inverse depths
+    double *xc, *xdc, *user;
+    uint8_t *lfree;
+    // ---- stored linearisation
+    double *r_f, *Jt, *Jr, *Jd;
+    double *r_r, *Jro;
+    double *e_p, *G, *r_p, *c_p, *Jp;    // Jp: per factor [Ji 225 | Jj 225]
+    double *e_m, *r_m, *c_m, *Jri, *Lam, *eta0, *le, *Ex;
+    // ---- normal equations / step
+    double *H, *Sm, *g, *yp;
+    double *lm_m, *lm_g, *lm_w, *A, *yl;
+    double *sig_p, *sig_l, *diag_p, *diag_l, *grad_p, *grad_l, *gn_p, *gn_l, *tp, *tl;
+    double *summary;                     // iterations, successful steps, initial cost, final cost, termination
+};
+
+void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w);

@@ -97,8 +97,12 @@ def traj_imu(t, h=1e-4):
     return w, a
 
 
-def make_imu_segment(t0, t1, rate=200.0, rng=None, noise=True):
-    """IMU samples in [t0, t1) as n x 7 (t, w, a)."""
+TRUE_BG = np.array([1e-3, -2e-3, 5e-4])
+TRUE_BA = np.array([0.02, -0.01, 0.03])
+
+
+def make_imu_segment(t0, t1, rate=200.0, rng=None, noise=True, bg=None, ba=None):
+    """IMU samples in [t0, t1) as n x 7 (t, w, a); optional constant sensor biases are added."""
     ts = np.arange(t0, t1 - 1e-9, 1.0 / rate)
     out = np.zeros((len(ts), 7))
     for i, t in enumerate(ts):
@@ -106,6 +110,10 @@ def make_imu_segment(t0, t1, rate=200.0, rng=None, noise=True):
         if noise and rng is not None:
             w = w + rng.normal(0, np.sqrt(2.8791302399999997e-08 * rate), 3)
             a = a + rng.normal(0, np.sqrt(4.0e-6 * rate), 3)
+        if bg is not None:
+            w = w + bg
+        if ba is not None:
+            a = a + ba
         out[i] = np.concatenate([[t], w, a])
     return out
 
@@ -132,8 +140,8 @@ def make_ba_problem(n_frames=9, n_landmarks=150, seed=648, K=EUROC_K, extr=EUROC
         states[i, 0:4] = q
         states[i, 4:7] = p
         states[i, 7:10] = traj_vel(t)
-        states[i, 10:13] = rng.normal(0, 1e-3, 3)
-        states[i, 13:16] = rng.normal(0, 1e-2, 3)
+        states[i, 10:13] = TRUE_BG
+        states[i, 13:16] = TRUE_BA
         Rwc = q_to_mat(q) @ Rcs
         pwc = p + q_to_mat(q) @ pcs
         cams.append((Rwc, pwc))
@@ -187,6 +195,8 @@ def make_ba_problem(n_frames=9, n_landmarks=150, seed=648, K=EUROC_K, extr=EUROC
             out["states"][i, 0:4] /= np.linalg.norm(out["states"][i, 0:4])
             out["states"][i, 4:7] += rng.normal(0, 1e-2, 3)
             out["states"][i, 7:10] += rng.normal(0, 1e-2, 3)
+        out["states"][:, 10:13] += rng.normal(0, 1e-5, (n_frames, 3))
+        out["states"][:, 13:16] += rng.normal(0, 1e-4, (n_frames, 3))
         out["inv_depth"] = out["inv_depth"] * rng.uniform(0.9, 1.1, len(inv_depth))
     return out
 
@@ -256,3 +266,37 @@ def jittered_grid(w, h, nx, ny, seed=648, margin=40):
     pts = np.stack(np.meshgrid(gx, gy), axis=-1).reshape(-1, 2)
     pts += rng.uniform(-3, 3, pts.shape)
     return pts
+
+
+def make_window_problem(n_frames=9, n_landmarks=150, seed=648, with_prior=True, with_preint=True,
+                        preintegrate=None, **kw):
+    """make_ba_problem + what refine_window adds (sliding_window_tracker.cpp:226-300): a preintegration
+    factor between consecutive frames and a marginalisation prior over all frames but the newest
+    (marginalization_factor.h:14-31: frame 0 pose pinned with 1e15).  `preintegrate(imu, t_end, bg, ba)`
+    supplies the PreIntegrator (the oracle's or the HIP one) so this module stays independent of both."""
+    pb = make_ba_problem(n_frames=n_frames, n_landmarks=n_landmarks, seed=seed, **kw)
+    rng = np.random.default_rng(seed + 1)
+    dt_frame, t0 = kw.get("dt_frame", 0.25), kw.get("t0", 1.0)
+    if with_preint:
+        pre, pi, pj = [], [], []
+        for j in range(1, n_frames):
+            imu = make_imu_segment(t0 + dt_frame * (j - 1), t0 + dt_frame * j, rng=rng, bg=TRUE_BG, ba=TRUE_BA)
+            b = pb["states"][j - 1, 10:16]
+            pre.append(preintegrate(imu, t0 + dt_frame * j, b[:3], b[3:]))
+            pi.append(j - 1)
+            pj.append(j)
+        pb["preint"] = np.array(pre)
+        pb["pre_i"] = np.array(pi, dtype=np.int32)
+        pb["pre_j"] = np.array(pj, dtype=np.int32)
+    if with_prior:
+        npf = n_frames - 1
+        D = 15 * npf
+        S = np.zeros((D, D))
+        S[0:6, 0:6] = 1e15 * np.eye(6)
+        pb["prior_frames"] = np.arange(npf, dtype=np.int32)
+        pb["lin"] = pb["states"][:npf].copy()
+        pb["S"] = S
+        pb["f"] = np.zeros(D)
+    pb["frame_fixed"] = np.zeros(n_frames, dtype=np.uint8)
+    pb["lm_fixed"] = np.zeros(len(pb["inv_depth"]), dtype=np.uint8)
+    return pb

@@ -81,3 +81,71 @@ def test_preintegrate_parity(ctx, oracle, jac, cov):
 def test_preintegrate_empty_segment(ctx):
     out = ctx.preintegrate([np.zeros((0, 7))], [1.0], [np.zeros(3)], [np.zeros(3)], synth.EUROC_NOISE)
     assert out[0][0] == 0 and list(out[0][1:5]) == [0, 0, 0, 1] and (out[0][5:] == 0).all()
+
+
+def _oracle_pre(oracle):
+    return lambda imu, t, bg, ba: oracle.preintegrate(imu, t, bg, ba, synth.EUROC_NOISE)
+
+
+@pytest.mark.parametrize("nfr,nl,seed,kw", [
+    (9, 150, 648, {}),                                   # config 1/2: window 8, 150 features
+    (11, 300, 649, {}),                                  # config 3: window 10, 300 features
+    (9, 150, 650, dict(with_preint=False, fix2=True)),   # vision only (no IMU quirk): converges
+    (5, 40, 651, dict(with_prior=False, fix2=True)),     # no marginalisation prior
+])
+def test_ba_solve_parity(ctx, oracle, nfr, nl, seed, kw):
+    kw = dict(kw)
+    fix2 = kw.pop("fix2", False)
+    pb = synth.make_window_problem(nfr, nl, seed, preintegrate=_oracle_pre(oracle), **kw)
+    if fix2:
+        pb["frame_fixed"][:2] = 1
+    ref_s, ref_d, ref_sm = oracle.ba_solve(pb, 30)
+    got_s, got_d, got_sm = ctx.ba_solve(pb, 30)
+    assert got_sm.iterations == ref_sm.iterations and got_sm.successful_steps == ref_sm.successful_steps
+    assert got_sm.termination == ref_sm.termination
+    assert abs(got_sm.initial_cost - ref_sm.initial_cost) <= 1e-9 * abs(ref_sm.initial_cost)
+    assert abs(got_sm.final_cost - ref_sm.final_cost) <= 1e-7 * abs(ref_sm.final_cost)
+    # states: tolerance 1e-7 absolute (same accept/reject trajectory; FP64 summation order differs)
+    assert np.abs(got_s - ref_s).max() < 1e-7
+    assert np.abs(got_d - ref_d).max() < 1e-7
+    assert ref_sm.final_cost < ref_sm.initial_cost
+
+
+def test_ba_solve_localize_shape(ctx, oracle):
+    # localize_newframe (sliding_window_tracker.cpp:101-125): one free frame, a preintegration prior from the
+    # fixed previous frame, reprojection priors (anchor frames and landmarks constant)
+    pb = synth.make_window_problem(9, 150, 652, preintegrate=_oracle_pre(oracle), with_prior=False)
+    pb["frame_fixed"][:] = 1
+    pb["frame_fixed"][8] = 0
+    pb["lm_fixed"][:] = 1
+    keep = pb["tgt"] == 8
+    for k in ("tgt", "ref", "lm", "tangent"):
+        pb[k] = pb[k][keep]
+    pb["pre_i"], pb["pre_j"], pb["preint"] = pb["pre_i"][-1:], pb["pre_j"][-1:], pb["preint"][-1:]
+    ref_s, ref_d, ref_sm = oracle.ba_solve(pb, 30)
+    got_s, got_d, got_sm = ctx.ba_solve(pb, 30)
+    assert (got_sm.iterations, got_sm.successful_steps, got_sm.termination) == \
+        (ref_sm.iterations, ref_sm.successful_steps, ref_sm.termination)
+    assert np.abs(got_s - ref_s).max() < 1e-8
+    assert (got_s[:8] == pb["states"][:8]).all() and (got_d == pb["inv_depth"]).all()  # constants untouched
+
+
+def test_ba_solve_resident_is_repeatable(ctx, oracle):
+    pb = synth.make_window_problem(9, 150, 648, preintegrate=_oracle_pre(oracle))
+    ctx.ba_upload(pb)
+    out = []
+    for _ in range(2):
+        ctx.ba_solve_resident(30)
+        out.append(ctx.ba_fetch())
+    assert (out[0][0] == out[1][0]).all() and (out[0][1] == out[1][1]).all()  # bitwise reproducible
+    assert out[0][2].iterations == out[1][2].iterations
+
+
+def test_ba_solve_rejects_bad_problems(ctx, oracle):
+    pb = synth.make_window_problem(5, 20, 1, preintegrate=_oracle_pre(oracle))
+    bad = dict(pb, lm=pb["lm"][::-1].copy())
+    with pytest.raises(rd_vio_amd.RdvioError):
+        ctx.ba_solve(bad)  # factors not ordered by landmark
+    bad = dict(pb, pre_j=pb["pre_j"] + 100)
+    with pytest.raises(rd_vio_amd.RdvioError):
+        ctx.ba_solve(bad)
