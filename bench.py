@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of rd_vio's per-frame hot path on MI355X (BASELINE.json metric).
+
+A "step" is one camera frame of the hot path on a synthetic EuRoC-shaped stream (there is no EuRoC data on
+the box): CLAHE + 4-level pyramid + Scharr (A1) -> fused forward/backward pyramidal LK (A2) -> GFTT-Harris
+detection (A3) -> IMU preintegration of the frame segment and the W keyframe segments (A7) ->
+localize_newframe solve and refine_window solve (A8-A14), with every input resident in HBM before the timed
+region.  Multi-GPU = one independent replica (one stream) per GPU, no collective on the data path
+(SURVEY.md 8e); torch.distributed is used only for the barrier / max-over-ranks timing.
+
+Prints ONE JSON line (see the round contract): metric/value/unit + `roofline` (dominant kernel, measured with
+HIP events on the launch stream) + `cpu_baseline` (the CPU oracle timed on this box, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[1]: EuRoC V1_01_easy shape, 150 features, window 8
+    "euroc_v101": dict(width=752, height=480, features=150, window=8, landmarks=150, iters=30,
+                       name="EuRoC V1_01_easy-shaped synthetic stream 752x480, 150 features, window 8, LK + BA on GPU"),
+    # configs[4]: roofline run
+    "synthetic_720p": dict(width=1280, height=720, features=1000, window=16, landmarks=1000, iters=30,
+                           name="synthetic 1280x720 stream, 1000 features, window 16"),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_PEAK_TFLOPS = 78.6    # MI355X FP64 vector/matrix peak
+
+
+def lk_algorithmic_bytes(n):
+    """per feature.level.direction 22x22 B template + 22x22x4 B gradients + 22x22 B search patch
+    (LDS-staged, read once) = 2904 B; 4 levels x 2 directions; + 17 B of point I/O per feature."""
+    return n * 4 * 2 * (22 * 22 * (1 + 4 + 1)) + n * 17
+
+
+def preprocess_algorithmic_bytes(L):
+    """P0 (1 read + 1 write CLAHE) + sum_l P_l (1 read + 4 write deriv) + sum_{l>=1} P_l write."""
+    P = [L.w[i] * L.h[i] for i in range(L.levels)]
+    return 2 * P[0] + 5 * sum(P) + sum(P[1:])
+
+
+def build_workload(cfg, ctx, torch, dev, seed=648):
+    import rd_vio_amd
+    from rd_vio_amd import synth
+
+    w, h, nfeat, W = cfg["width"], cfg["height"], cfg["features"], cfg["window"]
+    wl = {}
+    # a short loop of frames: the same planar scene under a small per-frame motion
+    n_img = 4
+    offs = [(0.0, 0.0), (2.6, -1.4), (5.1, -2.9), (2.4, -1.2)]
+    frames = [synth.render_scene(w, h, seed=seed, offset=o, rot=0.002 * i) for i, o in enumerate(offs)]
+    wl["frames_host"] = frames
+    wl["frames"] = [torch.from_numpy(f).to(dev) for f in frames]
+    # features: what detect_keypoints finds on frame 0 (min distance as in configs/setting.yaml:12)
+    img0 = rd_vio_amd.HipImage(ctx, 1, frames[0])
+    img0.preprocess()
+    kp = img0.detect_keypoints(np.zeros((0, 2)), nfeat, 10.0)
+    if len(kp) < nfeat:  # top up from a jittered grid so the feature count matches the config
+        extra = synth.jittered_grid(w, h, 40, 25, seed=seed)[: nfeat - len(kp)]
+        kp = np.concatenate([kp, extra])
+    kp = kp[:nfeat]
+    wl["kp_host"] = kp
+    wl["curr"] = torch.from_numpy(kp.copy()).to(dev)
+    wl["next"] = torch.zeros_like(wl["curr"])
+    wl["status"] = torch.zeros(nfeat, dtype=torch.uint8, device=dev)
+    # IMU: one frame segment (no covariance: feature_tracker.cpp:82-84) + W keyframe segments with covariance and
+    # Jacobians (sliding_window_tracker.cpp:294)
+    rng = np.random.default_rng(seed + 1)
+    segs, par = [], []
+    segs.append(synth.make_imu_segment(1.0, 1.05, rng=rng, bg=synth.TRUE_BG, ba=synth.TRUE_BA))
+    par.append([1.05, *synth.TRUE_BG, *synth.TRUE_BA])
+    for j in range(W):
+        t0 = 1.0 + 0.25 * j
+        segs.append(synth.make_imu_segment(t0, t0 + 0.25, rng=rng, bg=synth.TRUE_BG, ba=synth.TRUE_BA))
+        par.append([t0 + 0.25, *synth.TRUE_BG, *synth.TRUE_BA])
+    off = np.zeros(len(segs) + 1, dtype=np.int32)
+    for i, s in enumerate(segs):
+        off[i + 1] = off[i] + len(s)
+    wl["imu_segs"], wl["imu_par"] = segs, np.array(par)
+    wl["imu"] = torch.from_numpy(np.concatenate(segs)).to(dev)
+    wl["imu_off"] = torch.from_numpy(off).to(dev)
+    wl["imu_par_dev"] = torch.from_numpy(np.array(par)).to(dev)
+    wl["noise"] = torch.from_numpy(synth.EUROC_NOISE.copy()).to(dev)
+    wl["pre_out"] = torch.zeros((len(segs), rd_vio_amd.PREINT_SIZE), dtype=torch.float64, device=dev)
+    # BA problems (preintegration through the HIP PreIntegrator, not the oracle)
+    gpu_pre = lambda imu, t, bg, ba: ctx.preintegrate([imu], [t], [bg], [ba], synth.EUROC_NOISE)[0]  # noqa: E731
+    K = synth.EUROC_K.copy()
+    if (w, h) != (752, 480):
+        K = np.array([[900.0, 0, w / 2.0], [0, 900.0, h / 2.0], [0, 0, 1.0]])
+    pb = synth.make_window_problem(W + 1, cfg["landmarks"], seed, preintegrate=gpu_pre, K=K)
+    wl["window_pb"] = pb
+    loc = dict(pb)
+    loc["frame_fixed"] = np.ones(W + 1, dtype=np.uint8)
+    loc["frame_fixed"][W] = 0
+    loc["lm_fixed"] = np.ones(len(pb["inv_depth"]), dtype=np.uint8)
+    keep = pb["tgt"] == W
+    for k in ("tgt", "ref", "lm", "tangent"):
+        loc[k] = pb[k][keep]
+    loc["pre_i"], loc["pre_j"], loc["preint"] = pb["pre_i"][-1:], pb["pre_j"][-1:], pb["preint"][-1:]
+    for k in ("prior_frames", "lin", "S", "f"):
+        loc.pop(k, None)
+    wl["localize_pb"] = loc
+    ctx.ba_upload(pb, slot=0)
+    ctx.ba_upload(loc, slot=1)
+    wl["L"] = img0.L
+    return wl
+
+
+def cpu_baseline(cfg, wl, budget_s=12.0, max_frames=400):
+    """The CPU oracle (single thread) on the same per-frame workload; bounded sample."""
+    import oracle
+    from rd_vio_amd import synth
+
+    oracle.build()
+    frames = wl["frames_host"]
+    kp = wl["kp_host"]
+    pyr = oracle.preprocess(frames[0])
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        img = frames[(n + 1) % len(frames)]
+        nxt = oracle.preprocess(img)
+        oracle.track_keypoints(pyr[0], (pyr[1], pyr[2]), (nxt[1], nxt[2]), kp)
+        lvl0 = np.ascontiguousarray(oracle.level_view(nxt[0], nxt[1], 0))
+        oracle.detect_keypoints(lvl0, np.zeros((0, 2)), cfg["features"], 10.0)
+        for i, s in enumerate(wl["imu_segs"]):
+            p = wl["imu_par"][i]
+            oracle.preintegrate(s, p[0], p[1:4], p[4:7], synth.EUROC_NOISE, jac=i > 0, cov=i > 0)
+        oracle.ba_solve(wl["localize_pb"], cfg["iters"])
+        oracle.ba_solve(wl["window_pb"], cfg["iters"])
+        pyr = nxt
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= max_frames:
+            break
+    return dict(value=n / el, unit="frames/s", cores=1, kind="port",
+                sample=f"{n} frames of the same synthetic stream through the CPU oracle (oracle/*.c, gcc -O2, 1 thread), "
+                       f"{el:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="euroc_v101", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from rd_vio_amd import build as rbuild
+    import rd_vio_amd
+
+    rbuild.build()
+    stream = torch.cuda.current_stream()
+    ctx = rd_vio_amd.Context(max_width=cfg["width"], max_height=cfg["height"], max_features=max(1024, cfg["features"]),
+                             max_window=cfg["window"], max_factors=20000, device=local_rank, stream=stream.cuda_stream)
+    wl = build_workload(cfg, ctx, torch, dev)
+    lib, h = ctx._lib, ctx._h
+    w, hh, nfeat, iters = cfg["width"], cfg["height"], cfg["features"], cfg["iters"]
+    nseg = len(wl["imu_segs"])
+    kp_buf = np.zeros((nfeat + nfeat, 2))
+    import ctypes
+
+    n_out = ctypes.c_int(0)
+    stage_names = ["preprocess", "lk_track", "detect", "preintegrate", "ba_localize", "ba_window"]
+
+    def step(k, ev=None):
+        cur, prv = k % 2, (k + 1) % 2
+        img = wl["frames"][k % len(wl["frames"])]
+        if ev: ev[0].record()
+        ctx._check(lib.rdvio_hip_image_preprocess_dev(h, cur, img.data_ptr(), w, hh, w, 6.0, 8, 8))
+        if ev: ev[1].record()
+        ctx._check(lib.rdvio_hip_track_keypoints_dev(h, prv, cur, nfeat, wl["curr"].data_ptr(), wl["next"].data_ptr(),
+                                                     0, wl["status"].data_ptr()))
+        if ev: ev[2].record()
+        ctx._check(lib.rdvio_hip_detect_keypoints(h, cur, kp_buf.ctypes.data, 0, len(kp_buf), nfeat, 10.0,
+                                                  ctypes.byref(n_out)))
+        if ev: ev[3].record()
+        # frame segment without covariance, keyframe segments with (two launches, as the reference's two call sites)
+        ctx._check(lib.rdvio_hip_preintegrate_dev(h, 1, wl["imu_off"].data_ptr(), wl["imu"].data_ptr(),
+                                                  wl["imu_par_dev"].data_ptr(), wl["noise"].data_ptr(), 0, 0,
+                                                  wl["pre_out"].data_ptr()))
+        ctx._check(lib.rdvio_hip_preintegrate_dev(h, nseg - 1, wl["imu_off"].data_ptr() + 4, wl["imu"].data_ptr(),
+                                                  wl["imu_par_dev"].data_ptr() + 56, wl["noise"].data_ptr(), 1, 1,
+                                                  wl["pre_out"].data_ptr() + 8 * rd_vio_amd.PREINT_SIZE))
+        if ev: ev[4].record()
+        ctx._check(lib.rdvio_hip_ba_solve_resident(h, 1, iters))
+        if ev: ev[5].record()
+        ctx._check(lib.rdvio_hip_ba_solve_resident(h, 0, iters))
+        if ev: ev[6].record()
+        # the frame's results are consumed by host logic before the next frame
+        ctx.sync()
+
+    # slot 1 holds frame 0 (build_workload); warm up
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k, evs[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    stage_ms = np.zeros(6)
+    for e in evs:
+        for i in range(6):
+            stage_ms[i] += e[i].elapsed_time(e[i + 1])
+    stage_ms /= args.steps
+    _, _, sm_win = ctx.ba_fetch(0)
+    _, _, sm_loc = ctx.ba_fetch(1)
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        stages = {n: round(float(v), 4) for n, v in zip(stage_names, stage_ms)}
+        dom = int(np.argmax(stage_ms))
+        lk_us = stage_ms[1] * 1e3
+        # roofline of the LK kernel (the image-side hot loop and the only single-kernel stage with an HBM roofline
+        # worth quoting); the solver is latency-bound FP64 and is reported in `stages_ms`
+        lk_bytes = lk_algorithmic_bytes(nfeat)
+        roof = dict(kernel="lk_track_kernel", bound="hbm", achieved=round(lk_bytes / (lk_us * 1e-6) / 1e9, 3),
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(lk_bytes / (lk_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 6),
+                    traffic=None, algorithmic_bytes=lk_bytes, avg_launch_us=round(float(lk_us), 2),
+                    dominant_stage=stage_names[dom])
+        out = {
+            "metric": "VIO frames/sec per GPU (hot path: LK tracker + sliding-window BA), synthetic EuRoC-shaped stream",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/int64 (image, LK) + f64 (estimation)", "data": "synthetic",
+            "config": {"workload": cfg["name"], "features": nfeat, "window": cfg["window"],
+                       "solver_iteration_limit": iters, "replicas": world,
+                       "ba_window": {"factors": int(len(wl["window_pb"]["tgt"])), "iterations": int(sm_win.iterations),
+                                     "successful_steps": int(sm_win.successful_steps)},
+                       "ba_localize": {"factors": int(len(wl["localize_pb"]["tgt"])), "iterations": int(sm_loc.iterations)}},
+            "stages_ms": stages,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, wl)
+            out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 2)
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -109,6 +109,11 @@ int rdvio_hip_image_release(rdvio_hip_ctx *ctx, int slot);
 int rdvio_hip_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off, const double *imu,
                            const double *t_end, const double *bg, const double *ba, const double *noise,
                            int compute_jacobian, int compute_covariance, double *preint_out);
+/* Same with every array resident in HBM: imu_dev (n x 7), par_dev (nseg x 7: t_end, bg, ba), noise_dev (36),
+ * seg_off_dev (nseg+1), out_dev (nseg x RDVIO_PREINT_SIZE).  Only enqueues the kernel. */
+int rdvio_hip_preintegrate_dev(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off_dev, const double *imu_dev,
+                               const double *par_dev, const double *noise_dev, int compute_jacobian,
+                               int compute_covariance, double *preint_out_dev);
 
 /* One Solver problem in SoA form: what Solver::add_frame_states / add_track_states / add_factor assemble
  * through pointers (solver.cpp:88-178).  Which states and factors enter each solve is the caller's
@@ -166,9 +171,11 @@ int rdvio_hip_ba_solve(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, int max_i
                        double *inv_depth_out, rdvio_ba_summary *summary);
 /* Split form for HBM-resident operation: upload once, then (re)solve from the uploaded initial values
  * without any host->device traffic; fetch copies the result back. */
-int rdvio_hip_ba_upload(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb);
-int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int max_iterations);
-int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, double *states_out, double *inv_depth_out, rdvio_ba_summary *summary);
+#define RDVIO_BA_SLOTS 2 /* e.g. slot 0 = window BA (refine_window), slot 1 = localize_newframe */
+int rdvio_hip_ba_upload(rdvio_hip_ctx *ctx, int slot, const rdvio_ba_problem *pb);
+int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int slot, int max_iterations);
+int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double *inv_depth_out,
+                       rdvio_ba_summary *summary);
 
 #ifdef __cplusplus
 }

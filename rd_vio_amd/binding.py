@@ -17,6 +17,7 @@ EXPORTS = [
     "rdvio_hip_last_error", "rdvio_hip_sync", "rdvio_hip_image_preprocess", "rdvio_hip_image_preprocess_dev",
     "rdvio_hip_image_download", "rdvio_hip_track_keypoints", "rdvio_hip_track_keypoints_dev", "rdvio_hip_lk_flow",
     "rdvio_hip_detect_keypoints", "rdvio_hip_harris_response", "rdvio_hip_image_release", "rdvio_hip_preintegrate",
+    "rdvio_hip_preintegrate_dev",
     "rdvio_hip_reprojection_eval", "rdvio_hip_ba_solve", "rdvio_hip_ba_upload", "rdvio_hip_ba_solve_resident",
     "rdvio_hip_ba_fetch",
 ]
@@ -106,9 +107,12 @@ def load_library():
     lib.rdvio_hip_reprojection_eval.argtypes = [ctypes.c_void_p, ctypes.POINTER(BaProblem)] + [ctypes.c_void_p] * 4
     lib.rdvio_hip_ba_solve.argtypes = [ctypes.c_void_p, ctypes.POINTER(BaProblem), ctypes.c_int, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.POINTER(BaSummary)]
-    lib.rdvio_hip_ba_upload.argtypes = [ctypes.c_void_p, ctypes.POINTER(BaProblem)]
-    lib.rdvio_hip_ba_solve_resident.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    lib.rdvio_hip_ba_fetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(BaSummary)]
+    lib.rdvio_hip_ba_upload.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(BaProblem)]
+    lib.rdvio_hip_ba_solve_resident.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    lib.rdvio_hip_ba_fetch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.POINTER(BaSummary)]
+    lib.rdvio_hip_preintegrate_dev.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [
+        ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     _LIB = lib
     return lib
 
@@ -229,19 +233,22 @@ class Context:
                                                  invd.ctypes.data, ctypes.byref(sm)))
         return states, invd, sm
 
-    def ba_upload(self, pb):
+    def ba_upload(self, pb, slot=0):
         c, keep = self._ba_problem(pb)
-        self._check(self._lib.rdvio_hip_ba_upload(self._h, ctypes.byref(c)))
+        self._check(self._lib.rdvio_hip_ba_upload(self._h, int(slot), ctypes.byref(c)))
         self.sync()  # the source arrays may be freed by the caller after this returns
-        self._ba_shape = (c.n_frames, c.n_landmarks)
+        if not hasattr(self, "_ba_shape"):
+            self._ba_shape = {}
+        self._ba_shape[int(slot)] = (c.n_frames, c.n_landmarks)
 
-    def ba_solve_resident(self, max_iterations=30):
-        self._check(self._lib.rdvio_hip_ba_solve_resident(self._h, int(max_iterations)))
+    def ba_solve_resident(self, max_iterations=30, slot=0):
+        self._check(self._lib.rdvio_hip_ba_solve_resident(self._h, int(slot), int(max_iterations)))
 
-    def ba_fetch(self):
-        n, nl = self._ba_shape
+    def ba_fetch(self, slot=0):
+        n, nl = self._ba_shape[int(slot)]
         states, invd, sm = np.zeros((n, 16)), np.zeros(nl), BaSummary()
-        self._check(self._lib.rdvio_hip_ba_fetch(self._h, states.ctypes.data, invd.ctypes.data, ctypes.byref(sm)))
+        self._check(self._lib.rdvio_hip_ba_fetch(self._h, int(slot), states.ctypes.data, invd.ctypes.data,
+                                                 ctypes.byref(sm)))
         return states, invd, sm
 
     def reprojection_eval(self, pb, jac=True):

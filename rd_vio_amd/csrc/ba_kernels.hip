@@ -335,10 +335,10 @@ int rdvio_launch_reprojection(rdvio_hip_ctx *ctx, int nf, int with_jac) {
     return RDVIO_OK;
 }
 
-int rdvio_launch_preintegrate(rdvio_hip_ctx *ctx, int nseg, int cj, int cc) {
+int rdvio_launch_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *off, const double *imu, const double *par,
+                              const double *noise, int cj, int cc, double *out) {
     if (nseg <= 0) return RDVIO_OK;
-    hipLaunchKernelGGL(preintegrate_kernel, dim3(nseg), dim3(64), 0, ctx->stream, nseg, ctx->pre_off, ctx->pre_imu,
-                       ctx->pre_par, ctx->pre_par + 7 * (size_t)ctx->pre_max_seg, cj, cc, ctx->pre_out);
+    hipLaunchKernelGGL(preintegrate_kernel, dim3(nseg), dim3(64), 0, ctx->stream, nseg, off, imu, par, noise, cj, cc, out);
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
     return RDVIO_OK;
 }

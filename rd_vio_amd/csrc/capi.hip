@@ -119,11 +119,13 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
                        npre * (RDVIO_PREINT_SIZE + 1400) * 8 + Nmax * 8 * 32;
         bytes += bytes / 4;
         ctx->ba_arena_bytes = ctx->ba_host_bytes = bytes;
-        CTX_ALLOC(ctx->ba_arena, bytes);
-        if (hipHostMalloc(&ctx->ba_host, bytes, hipHostMallocDefault) != hipSuccess) {
-            rdvio_fail(ctx, RDVIO_ERR_HIP, "hipHostMalloc(ba_host) failed");
-            *out = ctx;
-            return RDVIO_ERR_HIP;
+        for (int s = 0; s < RDVIO_BA_SLOTS; ++s) {
+            CTX_ALLOC(ctx->ba[s].arena, bytes);
+            if (hipHostMalloc(&ctx->ba[s].host, bytes, hipHostMallocDefault) != hipSuccess) {
+                rdvio_fail(ctx, RDVIO_ERR_HIP, "hipHostMalloc(ba host blob) failed");
+                *out = ctx;
+                return RDVIO_ERR_HIP;
+            }
         }
     }
     ctx->pinned_bytes = std::max<size_t>((size_t)ctx->harris_cand_cap * sizeof(HarrisCand), 1 << 20);
@@ -150,8 +152,10 @@ void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
                     ctx->ba_Jd, ctx->pre_imu, ctx->pre_par, ctx->pre_out, ctx->pre_off};
     for (void *b : bufs) (void)hipFree(b);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-    if (ctx->ba_host) (void)hipHostFree(ctx->ba_host);
-    (void)hipFree(ctx->ba_arena);
+    for (int s = 0; s < RDVIO_BA_SLOTS; ++s) {
+        if (ctx->ba[s].host) (void)hipHostFree(ctx->ba[s].host);
+        (void)hipFree(ctx->ba[s].arena);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -299,10 +303,18 @@ int rdvio_hip_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off,
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pre_off, seg_off, (size_t)(nseg + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     if (ns > 0) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pre_imu, imu, (size_t)ns * 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     // the pinned staging buffer is reused by later calls: finish the uploads that read it before returning
-    if (int rc = rdvio_launch_preintegrate(ctx, nseg, cj, cc)) return rc;
+    if (int rc = rdvio_launch_preintegrate(ctx, nseg, ctx->pre_off, ctx->pre_imu, ctx->pre_par,
+                                           ctx->pre_par + 7 * (size_t)ctx->pre_max_seg, cj, cc, ctx->pre_out))
+        return rc;
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(out, ctx->pre_out, (size_t)nseg * RDVIO_PREINT_SIZE * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return RDVIO_OK;
+}
+
+int rdvio_hip_preintegrate_dev(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off_dev, const double *imu_dev,
+                               const double *par_dev, const double *noise_dev, int cj, int cc, double *out_dev) {
+    if (!ctx || nseg < 0 || (nseg > 0 && (!seg_off_dev || !imu_dev || !par_dev || !noise_dev || !out_dev))) return RDVIO_ERR_INVALID;
+    return rdvio_launch_preintegrate(ctx, nseg, seg_off_dev, imu_dev, par_dev, noise_dev, cj, cc, out_dev);
 }
 
 static int upload_ba_problem(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb) {

@@ -56,11 +56,13 @@ struct rdvio_hip_ctx {
     int pre_max_samples = 0, pre_max_seg = 0;
 
     // BA solver: pinned input blob, device arena (inputs + scratch), workspace descriptor
-    void *ba_host = nullptr, *ba_arena = nullptr;
+    struct BaSlot {
+        void *host = nullptr, *arena = nullptr;
+        SolverWs ws{};
+        size_t in_states_off = 0, in_invd_off = 0, in_bytes = 0;
+        bool ready = false;
+    } ba[RDVIO_BA_SLOTS];
     size_t ba_host_bytes = 0, ba_arena_bytes = 0;
-    SolverWs ba_ws{};
-    size_t ba_in_states_off = 0, ba_in_invd_off = 0, ba_in_bytes = 0;
-    bool ba_ready = false;
 
     // pinned host staging
     void *pinned = nullptr;
@@ -97,4 +99,5 @@ int rdvio_launch_lk_flow(rdvio_hip_ctx *ctx, int slot_prev, int slot_next, int n
 int rdvio_launch_harris(rdvio_hip_ctx *ctx, int slot);
 int rdvio_launch_harris_candidates(rdvio_hip_ctx *ctx, int slot, double quality);
 int rdvio_launch_reprojection(rdvio_hip_ctx *ctx, int nf, int with_jac);
-int rdvio_launch_preintegrate(rdvio_hip_ctx *ctx, int nseg, int cj, int cc);
+int rdvio_launch_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *off, const double *imu, const double *par,
+                              const double *noise, int cj, int cc, double *out);

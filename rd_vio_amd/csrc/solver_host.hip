@@ -37,7 +37,7 @@ struct Packer {
 
 }  // namespace
 
-static int ba_prepare(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb) {
+static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvio_ba_problem *pb) {
     if (!pb) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null BA problem");
     const int nfr = pb->n_frames, nl = pb->n_landmarks, nf = pb->n_factors, nrot = pb->n_rot, npre = pb->n_preint,
               np = pb->n_prior;
@@ -115,7 +115,7 @@ static int ba_prepare(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb) {
         if (lm_count[l] > 0 && !pb->lm_fixed[l]) n_lfree++;
 
     // ---- pack inputs into the pinned blob (one H2D copy), then carve device scratch behind it
-    Packer P{(uint8_t *)ctx->ba_host, ctx->ba_host_bytes};
+    Packer P{(uint8_t *)slot.host, ctx->ba_host_bytes};
     double extr18[18];
     memcpy(extr18, pb->extr, 14 * sizeof(double));
     memcpy(extr18 + 14, pb->sqrt_inv_cov, 4 * sizeof(double));
@@ -157,8 +157,8 @@ static int ba_prepare(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb) {
     const size_t s_sum = dd(8);
     if (!Sx.ok) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "BA problem does not fit the context's device arena");
 
-    uint8_t *B = (uint8_t *)ctx->ba_arena;
-    SolverWs &w = ctx->ba_ws;
+    uint8_t *B = (uint8_t *)slot.arena;
+    SolverWs &w = slot.ws;
     memset(&w, 0, sizeof w);
     w.nfr = nfr; w.nl = nl; w.nf = nf; w.nrot = nrot; w.npre = npre; w.np = np; w.D = D; w.nfree = nfree; w.N = N;
     w.npairs = npairs; w.n_lfree_hint = n_lfree;
@@ -183,45 +183,50 @@ static int ba_prepare(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb) {
     w.summary = DP(s_sum);
 #undef DP
 #undef IP
-    ctx->ba_in_states_off = o_states;
-    ctx->ba_in_invd_off = o_invd;
-    ctx->ba_in_bytes = in_bytes;
-    ctx->ba_ready = true;
+    slot.in_states_off = o_states;
+    slot.in_invd_off = o_invd;
+    slot.in_bytes = in_bytes;
+    slot.ready = true;
     return RDVIO_OK;
 }
+
+static bool bad_slot(int slot) { return slot < 0 || slot >= RDVIO_BA_SLOTS; }
 
 extern "C" {
 
-int rdvio_hip_ba_upload(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb) {
-    if (!ctx) return RDVIO_ERR_INVALID;
-    ctx->ba_ready = false;
+int rdvio_hip_ba_upload(rdvio_hip_ctx *ctx, int slot, const rdvio_ba_problem *pb) {
+    if (!ctx || bad_slot(slot)) return RDVIO_ERR_INVALID;
+    rdvio_hip_ctx::BaSlot &S = ctx->ba[slot];
+    S.ready = false;
     // the pinned blob may still be in flight from a previous upload on this stream
     RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (int rc = ba_prepare(ctx, pb)) return rc;
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_arena, ctx->ba_host, ctx->ba_in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = ba_prepare(ctx, S, pb)) return rc;
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(S.arena, S.host, S.in_bytes, hipMemcpyHostToDevice, ctx->stream));
     return RDVIO_OK;
 }
 
-int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int max_iterations) {
-    if (!ctx) return RDVIO_ERR_INVALID;
-    if (!ctx->ba_ready) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "no BA problem uploaded");
+int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int slot, int max_iterations) {
+    if (!ctx || bad_slot(slot)) return RDVIO_ERR_INVALID;
+    rdvio_hip_ctx::BaSlot &S = ctx->ba[slot];
+    if (!S.ready) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "no BA problem uploaded in slot %d", slot);
     if (max_iterations < 0) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "negative iteration limit");
-    SolverWs &w = ctx->ba_ws;
+    SolverWs &w = S.ws;
     w.max_iter = max_iterations;
-    uint8_t *B = (uint8_t *)ctx->ba_arena;
+    uint8_t *B = (uint8_t *)S.arena;
     // (re)start from the uploaded initial values: device-to-device, no host traffic
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(w.x, B + ctx->ba_in_states_off, (size_t)w.nfr * 16 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(w.x, B + S.in_states_off, (size_t)w.nfr * 16 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     if (w.nl > 0)
-        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(w.xd, B + ctx->ba_in_invd_off, (size_t)w.nl * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(w.xd, B + S.in_invd_off, (size_t)w.nl * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     rdvio_launch_ba_solve(ctx->stream, w);
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
     return RDVIO_OK;
 }
 
-int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, double *states_out, double *inv_depth_out, rdvio_ba_summary *summary) {
-    if (!ctx) return RDVIO_ERR_INVALID;
-    if (!ctx->ba_ready) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "no BA problem uploaded");
-    SolverWs &w = ctx->ba_ws;
+int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double *inv_depth_out, rdvio_ba_summary *summary) {
+    if (!ctx || bad_slot(slot)) return RDVIO_ERR_INVALID;
+    rdvio_hip_ctx::BaSlot &S = ctx->ba[slot];
+    if (!S.ready) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "no BA problem uploaded in slot %d", slot);
+    SolverWs &w = S.ws;
     double sum[8] = {0};
     if (states_out) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(states_out, w.x, (size_t)w.nfr * 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (inv_depth_out && w.nl > 0) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(inv_depth_out, w.xd, (size_t)w.nl * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -239,9 +244,9 @@ int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, double *states_out, double *inv_depth
 
 int rdvio_hip_ba_solve(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, int max_iterations, double *states_out,
                        double *inv_depth_out, rdvio_ba_summary *summary) {
-    if (int rc = rdvio_hip_ba_upload(ctx, pb)) return rc;
-    if (int rc = rdvio_hip_ba_solve_resident(ctx, max_iterations)) return rc;
-    return rdvio_hip_ba_fetch(ctx, states_out, inv_depth_out, summary);
+    if (int rc = rdvio_hip_ba_upload(ctx, 0, pb)) return rc;
+    if (int rc = rdvio_hip_ba_solve_resident(ctx, 0, max_iterations)) return rc;
+    return rdvio_hip_ba_fetch(ctx, 0, states_out, inv_depth_out, summary);
 }
 
 }  // extern "C"
