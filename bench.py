@@ -175,7 +175,10 @@ def main():
     import rd_vio_amd
 
     rbuild.build()
-    stream = torch.cuda.current_stream()
+    # an explicit (non-default) stream: the context enqueues on it and torch.cuda.Event records on it, so the
+    # HIP events below bracket exactly the kernels of each stage
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     ctx = rd_vio_amd.Context(max_width=cfg["width"], max_height=cfg["height"], max_features=max(1024, cfg["features"]),
                              max_window=cfg["window"], max_factors=20000, device=local_rank, stream=stream.cuda_stream)
     wl = build_workload(cfg, ctx, torch, dev)
