@@ -177,6 +177,40 @@ int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int slot, int max_iterations
 int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double *inv_depth_out,
                        rdvio_ba_summary *summary);
 
+/* MarginalizationFactor::marginalize(0) (marginalization_factor.h:9-12; ceres/marginalization_factor.h:74-475;
+ * called by Map::marginalize_frame, map.cpp:50-62).  Frame 0 of `states` is the victim.  The caller passes the
+ * current prior, keyframe_preintegration of frame 1 (NULL if none), and the reprojection factors of every
+ * TT_VALID, keyframe-anchored track the victim observes (all of the track's non-anchor observations that are
+ * still in the window, :233-380), ordered by landmark. */
+typedef struct {
+    int32_t n_frames;              /* frames in the map (W+1) */
+    const double *states;          /* n_frames x 16 */
+    const double *extr;            /* 14 */
+    const double *sqrt_inv_cov;    /* 2 x 2 */
+    int32_t n_prior;               /* frames covered by the current prior */
+    const int32_t *prior_frames;
+    const double *prior_lin, *prior_S, *prior_f;
+    const double *preint01;        /* RDVIO_PREINT_SIZE or NULL */
+    int32_t n_landmarks;
+    const double *z_ref, *inv_depth;
+    int32_t n_factors;
+    const int32_t *tgt, *ref, *lm;
+    const double *tangent;
+} rdvio_marg_problem;
+
+/* Outputs: the new prior over frames 1..n_frames-1: S_out (R x R, R = 15 (n_frames-1)), f_out (R), lin_out
+ * ((n_frames-1) x 16 = the current states of the retained frames).  Lambda_out / eta_out (optional) are the
+ * reduced information matrix / vector before the sqrt step.  S_out is A sqrt factor: S^T S and S^T f equal the
+ * reference's (eigenvalues <= 1e-8 removed); S itself is only defined up to an orthogonal left factor, exactly
+ * like the reference's eigenvector-based factor.  force_eigen != 0 forces the literal eigendecomposition path;
+ * *used_fast_path reports whether the Cholesky path produced the factor. */
+int rdvio_hip_marginalize(rdvio_hip_ctx *ctx, const rdvio_marg_problem *pb, int force_eigen, double *S_out,
+                          double *f_out, double *lin_out, double *Lambda_out, double *eta_out, int *used_fast_path);
+int rdvio_hip_marginalize_upload(rdvio_hip_ctx *ctx, const rdvio_marg_problem *pb);
+int rdvio_hip_marginalize_resident(rdvio_hip_ctx *ctx, int force_eigen);
+int rdvio_hip_marginalize_fetch(rdvio_hip_ctx *ctx, double *S_out, double *f_out, double *lin_out,
+                                double *Lambda_out, double *eta_out, int *used_fast_path);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,8 @@ EXPORTS = [
     "rdvio_hip_detect_keypoints", "rdvio_hip_harris_response", "rdvio_hip_image_release", "rdvio_hip_preintegrate",
     "rdvio_hip_preintegrate_dev",
     "rdvio_hip_reprojection_eval", "rdvio_hip_ba_solve", "rdvio_hip_ba_upload", "rdvio_hip_ba_solve_resident",
-    "rdvio_hip_ba_fetch",
+    "rdvio_hip_ba_fetch", "rdvio_hip_marginalize", "rdvio_hip_marginalize_upload", "rdvio_hip_marginalize_resident",
+    "rdvio_hip_marginalize_fetch",
 ]
 
 
@@ -52,6 +53,18 @@ class BaProblem(ctypes.Structure):
         ("preint", ctypes.c_void_p),
         ("n_prior", ctypes.c_int32), ("prior_frames", ctypes.c_void_p), ("prior_lin", ctypes.c_void_p),
         ("prior_S", ctypes.c_void_p), ("prior_f", ctypes.c_void_p),
+    ]
+
+
+class MargProblem(ctypes.Structure):
+    """rdvio_marg_problem (include/rdvio_hip.h)"""
+    _fields_ = [
+        ("n_frames", ctypes.c_int32), ("states", ctypes.c_void_p), ("extr", ctypes.c_void_p),
+        ("sqrt_inv_cov", ctypes.c_void_p), ("n_prior", ctypes.c_int32), ("prior_frames", ctypes.c_void_p),
+        ("prior_lin", ctypes.c_void_p), ("prior_S", ctypes.c_void_p), ("prior_f", ctypes.c_void_p),
+        ("preint01", ctypes.c_void_p), ("n_landmarks", ctypes.c_int32), ("z_ref", ctypes.c_void_p),
+        ("inv_depth", ctypes.c_void_p), ("n_factors", ctypes.c_int32), ("tgt", ctypes.c_void_p),
+        ("ref", ctypes.c_void_p), ("lm", ctypes.c_void_p), ("tangent", ctypes.c_void_p),
     ]
 
 
@@ -111,6 +124,11 @@ def load_library():
     lib.rdvio_hip_ba_solve_resident.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.rdvio_hip_ba_fetch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.POINTER(BaSummary)]
+    lib.rdvio_hip_marginalize.argtypes = [ctypes.c_void_p, ctypes.POINTER(MargProblem), ctypes.c_int] + \
+        [ctypes.c_void_p] * 5 + [ctypes.POINTER(ctypes.c_int)]
+    lib.rdvio_hip_marginalize_upload.argtypes = [ctypes.c_void_p, ctypes.POINTER(MargProblem)]
+    lib.rdvio_hip_marginalize_resident.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.rdvio_hip_marginalize_fetch.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 5 + [ctypes.POINTER(ctypes.c_int)]
     lib.rdvio_hip_preintegrate_dev.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [
         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     _LIB = lib
@@ -250,6 +268,44 @@ class Context:
         self._check(self._lib.rdvio_hip_ba_fetch(self._h, int(slot), states.ctypes.data, invd.ctypes.data,
                                                  ctypes.byref(sm)))
         return states, invd, sm
+
+    def _marg_problem(self, states, extr, W, prior_frames, lin, S, f, preint01, tgt, ref, lm, tangent, z_ref, inv_depth):
+        k = dict(states=_f64(states).reshape(-1, 16), extr=_f64(extr), W=_f64(W), pf=_i32(prior_frames), lin=_f64(lin),
+                 S=_f64(S), f=_f64(f), pre=_f64(preint01) if preint01 is not None else None, tgt=_i32(tgt),
+                 ref=_i32(ref), lm=_i32(lm), tangent=_f64(tangent), z_ref=_f64(z_ref), inv_depth=_f64(inv_depth))
+        c = MargProblem()
+        c.n_frames = len(k["states"])
+        c.states, c.extr, c.sqrt_inv_cov = k["states"].ctypes.data, k["extr"].ctypes.data, k["W"].ctypes.data
+        c.n_prior = len(k["pf"])
+        c.prior_frames, c.prior_lin = k["pf"].ctypes.data, k["lin"].ctypes.data
+        c.prior_S, c.prior_f = k["S"].ctypes.data, k["f"].ctypes.data
+        c.preint01 = k["pre"].ctypes.data if k["pre"] is not None else None
+        c.n_landmarks = len(k["inv_depth"])
+        c.z_ref, c.inv_depth = k["z_ref"].ctypes.data, k["inv_depth"].ctypes.data
+        c.n_factors = len(k["tgt"])
+        c.tgt, c.ref, c.lm, c.tangent = k["tgt"].ctypes.data, k["ref"].ctypes.data, k["lm"].ctypes.data, k["tangent"].ctypes.data
+        return c, k
+
+    def marginalize(self, states, extr, W, prior_frames, lin, S, f, preint01, tgt, ref, lm, tangent, z_ref, inv_depth,
+                    force_eigen=False):
+        """MarginalizationFactor::marginalize(0) -> (S, f, lin, Lambda, eta, used_fast_path)"""
+        c, keep = self._marg_problem(states, extr, W, prior_frames, lin, S, f, preint01, tgt, ref, lm, tangent, z_ref,
+                                     inv_depth)
+        R = 15 * (c.n_frames - 1)
+        S_out, f_out, lin_out = np.zeros((R, R)), np.zeros(R), np.zeros((c.n_frames - 1, 16))
+        Lam, eta, fast = np.zeros((R, R)), np.zeros(R), ctypes.c_int(0)
+        self._check(self._lib.rdvio_hip_marginalize(self._h, ctypes.byref(c), int(force_eigen), S_out.ctypes.data,
+                                                    f_out.ctypes.data, lin_out.ctypes.data, Lam.ctypes.data,
+                                                    eta.ctypes.data, ctypes.byref(fast)))
+        return S_out, f_out, lin_out, Lam, eta, bool(fast.value)
+
+    def marginalize_upload(self, *args):
+        c, keep = self._marg_problem(*args)
+        self._check(self._lib.rdvio_hip_marginalize_upload(self._h, ctypes.byref(c)))
+        self.sync()
+
+    def marginalize_resident(self, force_eigen=False):
+        self._check(self._lib.rdvio_hip_marginalize_resident(self._h, int(force_eigen)))
 
     def reprojection_eval(self, pb, jac=True):
         """CeresReprojectionErrorFactor::Evaluate over all factors of a BA problem dict."""

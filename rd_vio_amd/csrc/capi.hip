@@ -128,6 +128,18 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
             }
         }
     }
+    {
+        const size_t F = (size_t)max_factors, Nmax = 15 * (size_t)nfr;
+        size_t bytes = (1 << 16) + F * 420 + F * (64 + 48 * (size_t)nfr) + Nmax * Nmax * 8 * 8;
+        bytes += bytes / 4;
+        ctx->marg_bytes = bytes;
+        CTX_ALLOC(ctx->marg_arena, bytes);
+        if (hipHostMalloc(&ctx->marg_host, bytes, hipHostMallocDefault) != hipSuccess) {
+            rdvio_fail(ctx, RDVIO_ERR_HIP, "hipHostMalloc(marg host blob) failed");
+            *out = ctx;
+            return RDVIO_ERR_HIP;
+        }
+    }
     ctx->pinned_bytes = std::max<size_t>((size_t)ctx->harris_cand_cap * sizeof(HarrisCand), 1 << 20);
     if (hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
         rdvio_fail(ctx, RDVIO_ERR_HIP, "hipHostMalloc failed");
@@ -152,6 +164,8 @@ void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
                     ctx->ba_Jd, ctx->pre_imu, ctx->pre_par, ctx->pre_out, ctx->pre_off};
     for (void *b : bufs) (void)hipFree(b);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->marg_host) (void)hipHostFree(ctx->marg_host);
+    (void)hipFree(ctx->marg_arena);
     for (int s = 0; s < RDVIO_BA_SLOTS; ++s) {
         if (ctx->ba[s].host) (void)hipHostFree(ctx->ba[s].host);
         (void)hipFree(ctx->ba[s].arena);

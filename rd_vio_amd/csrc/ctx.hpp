@@ -10,6 +10,7 @@
 
 #include "../../include/rdvio_hip.h"
 #include "solver_ws.hpp"
+#include "marg_ws.hpp"
 
 #define RDVIO_NUM_SLOTS 2
 #define RDVIO_MAX_TILES 256  // CLAHE tile grid (8x8 in configs/setting.yaml:17-19)
@@ -63,6 +64,11 @@ struct rdvio_hip_ctx {
         bool ready = false;
     } ba[RDVIO_BA_SLOTS];
     size_t ba_host_bytes = 0, ba_arena_bytes = 0;
+    // marginalisation
+    void *marg_host = nullptr, *marg_arena = nullptr;
+    size_t marg_bytes = 0, marg_in_bytes = 0;
+    MargWs marg_ws{};
+    bool marg_ready = false;
 
     // pinned host staging
     void *pinned = nullptr;

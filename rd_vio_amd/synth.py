@@ -300,3 +300,26 @@ def make_window_problem(n_frames=9, n_landmarks=150, seed=648, with_prior=True, 
     pb["frame_fixed"] = np.zeros(n_frames, dtype=np.uint8)
     pb["lm_fixed"] = np.zeros(len(pb["inv_depth"]), dtype=np.uint8)
     return pb
+
+
+def make_marg_inputs(pb, with_full_prior=False, seed=9):
+    """What Map::marginalize_frame(0) hands to marginalize() for a window problem: the current prior, the
+    preintegration between frames 0 and 1 and the reprojection factors of the tracks the victim (frame 0)
+    observes (marginalization_factor.h:233-380).  Returns the positional argument tuple shared by the oracle's and
+    the HIP binding's marginalize(): (states, extr, W, prior_frames, lin, S, f, preint01, tgt, ref, lm, tangent,
+    z_ref, inv_depth)."""
+    rng = np.random.default_rng(seed)
+    n = len(pb["states"])
+    npf = n - 1
+    D = 15 * npf
+    if with_full_prior:
+        S = np.linalg.qr(rng.normal(size=(D, D)) * 3.0)[1]
+        f = rng.normal(size=D)
+        lin = pb["states"][:npf].copy()
+        lin[:, 4:7] += rng.normal(0, 1e-3, (npf, 3))
+    else:
+        S, f, lin = pb["S"], pb["f"], pb["lin"]
+    seen = set(pb["lm"][(pb["tgt"] == 0) | (pb["ref"] == 0)].tolist())
+    keep = np.array([l in seen for l in pb["lm"]], dtype=bool)
+    return (pb["states"], pb["extr"], pb["sqrt_inv_cov"], np.arange(npf, dtype=np.int32), lin, S, f, pb["preint"][0],
+            pb["tgt"][keep], pb["ref"][keep], pb["lm"][keep], pb["tangent"][keep], pb["z_ref"], pb["inv_depth"])

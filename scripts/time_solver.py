@@ -1,0 +1,33 @@
+"""Developer timing aid: wall time of the resident BA solve for problem variants (GPU box only)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+import rd_vio_amd
+from rd_vio_amd import synth
+
+ctx = rd_vio_amd.Context(max_window=16, max_factors=20000)
+pre = lambda imu, t, bg, ba: ctx.preintegrate([imu], [t], [bg], [ba], synth.EUROC_NOISE)[0]
+
+
+def timeit(pb, iters, reps=20):
+    ctx.ba_upload(pb, 0)
+    ctx.ba_solve_resident(iters, 0); ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.ba_solve_resident(iters, 0)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / reps
+    _, _, sm = ctx.ba_fetch(0)
+    return dt * 1e6, sm.iterations, sm.successful_steps
+
+
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+for name, kw in (("full", {}), ("no_prior", dict(with_prior=False)), ("no_preint", dict(with_preint=False)),
+                 ("vision_only", dict(with_prior=False, with_preint=False))):
+    pb = synth.make_window_problem(W + 1, L, 648, preintegrate=pre, **kw)
+    if not kw.get("with_preint", True):
+        pb["frame_fixed"][:2] = 1
+    for iters in (0, 1, 5, 30):
+        us, it, ok = timeit(pb, iters)
+        print(f"{name:12s} F={len(pb['tgt'])} max_iter={iters:2d}: {us:9.1f} us  iterations={it} successful={ok}")

@@ -149,3 +149,62 @@ def test_ba_solve_rejects_bad_problems(ctx, oracle):
     bad = dict(pb, pre_j=pb["pre_j"] + 100)
     with pytest.raises(rd_vio_amd.RdvioError):
         ctx.ba_solve(bad)
+
+
+def _check_marg(oracle, args, got, lam_tol=1e-9):
+    S2, f2, lin2, Lam, eta, fast = got
+    So, fo, lino, Lamo, etao = oracle.marginalize(*args)
+    scale = np.abs(Lamo).max()
+    assert np.abs(Lam - Lamo).max() <= lam_tol * scale
+    assert np.abs(eta - etao).max() <= lam_tol * max(np.abs(etao).max(), 1.0)
+    assert (lin2 == lino).all()
+    # the sqrt factor is unique only up to an orthogonal left factor: compare what it encodes.
+    # Tolerance 1e-7 relative: the clamp at 1e-8 and sqrt/square round trip of entries up to ~1e10.
+    assert np.abs(S2.T @ S2 - So.T @ So).max() <= 1e-7 * scale
+    assert np.abs(S2.T @ f2 - So.T @ fo).max() <= 1e-6 * max(np.abs(etao).max(), 1.0)
+    return fast
+
+
+@pytest.mark.parametrize("nfr,nl,seed", [(9, 150, 648), (11, 300, 649), (5, 40, 3)])
+def test_marginalize_parity_initial_prior(ctx, oracle, nfr, nl, seed):
+    # first marginalisation: the prior is the 1e15 pin of frame 0 (marginalization_factor.h:27-31); most rows of the
+    # reduced information are structurally zero (no v/bias information on frames >= 2)
+    pb = synth.make_window_problem(nfr, nl, seed, preintegrate=_oracle_pre(oracle))
+    args = synth.make_marg_inputs(pb)
+    fast = _check_marg(oracle, args, ctx.marginalize(*args))
+    slow = _check_marg(oracle, args, ctx.marginalize(*args, force_eigen=True))
+    assert not slow  # the literal eigendecomposition path was exercised
+    assert isinstance(fast, bool)
+
+
+def test_marginalize_parity_dense_prior(ctx, oracle):
+    pb = synth.make_window_problem(9, 150, 650, preintegrate=_oracle_pre(oracle))
+    args = synth.make_marg_inputs(pb, with_full_prior=True)
+    fast = _check_marg(oracle, args, ctx.marginalize(*args))
+    assert fast  # full-rank information: the Cholesky path must have produced the factor
+    _check_marg(oracle, args, ctx.marginalize(*args, force_eigen=True))
+
+
+def test_marginalize_chain_feeds_solver(ctx, oracle):
+    # marginalise, then use the new prior in a window solve of the remaining frames: GPU prior vs oracle prior
+    pb = synth.make_window_problem(9, 150, 651, preintegrate=_oracle_pre(oracle))
+    args = synth.make_marg_inputs(pb)
+    S2, f2, lin2, *_ = ctx.marginalize(*args)
+    So, fo, lino, *_ = oracle.marginalize(*args)
+    keep = (pb["tgt"] != 0) & (pb["ref"] != 0)
+
+    def sub(S, f, lin):
+        q = dict(pb)
+        q["states"] = pb["states"][1:]
+        q["frame_fixed"] = pb["frame_fixed"][1:]
+        for k in ("tgt", "ref"):
+            q[k] = pb[k][keep] - 1
+        q["lm"], q["tangent"] = pb["lm"][keep], pb["tangent"][keep]
+        q["pre_i"], q["pre_j"], q["preint"] = pb["pre_i"][1:] - 1, pb["pre_j"][1:] - 1, pb["preint"][1:]
+        q["prior_frames"] = np.arange(8, dtype=np.int32)
+        q["S"], q["f"], q["lin"] = S, f, lin
+        return q
+    s_gpu, d_gpu, sm_gpu = ctx.ba_solve(sub(S2, f2, lin2), 10)
+    s_ref, d_ref, sm_ref = oracle.ba_solve(sub(So, fo, lino), 10)
+    assert abs(sm_gpu.initial_cost - sm_ref.initial_cost) <= 1e-6 * sm_ref.initial_cost
+    assert np.abs(s_gpu - s_ref).max() < 1e-5
