@@ -4,7 +4,8 @@
 A "step" is one camera frame of the hot path on a synthetic EuRoC-shaped stream (there is no EuRoC data on
 the box): CLAHE + 4-level pyramid + Scharr (A1) -> fused forward/backward pyramidal LK (A2) -> GFTT-Harris
 detection (A3) -> IMU preintegration of the frame segment and the W keyframe segments (A7) ->
-localize_newframe solve and refine_window solve (A8-A14), with every input resident in HBM before the timed
+localize_newframe solve, refine_window solve (A8-A14) and marginalisation of the oldest frame (A13), with every
+input resident in HBM before the timed
 region.  Multi-GPU = one independent replica (one stream) per GPU, no collective on the data path
 (SURVEY.md 8e); torch.distributed is used only for the barrier / max-over-ranks timing.
 
@@ -109,6 +110,8 @@ def build_workload(cfg, ctx, torch, dev, seed=648):
     wl["localize_pb"] = loc
     ctx.ba_upload(pb, slot=0)
     ctx.ba_upload(loc, slot=1)
+    wl["marg_args"] = synth.make_marg_inputs(pb)
+    ctx.marginalize_upload(*wl["marg_args"])
     wl["L"] = img0.L
     return wl
 
@@ -135,6 +138,7 @@ def cpu_baseline(cfg, wl, budget_s=12.0, max_frames=400):
             oracle.preintegrate(s, p[0], p[1:4], p[4:7], synth.EUROC_NOISE, jac=i > 0, cov=i > 0)
         oracle.ba_solve(wl["localize_pb"], cfg["iters"])
         oracle.ba_solve(wl["window_pb"], cfg["iters"])
+        oracle.marginalize(*wl["marg_args"])
         pyr = nxt
         n += 1
         el = time.perf_counter() - t0
@@ -157,19 +161,15 @@ def main():
 
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
+    from rd_vio_amd import replica
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # one process per GPU; "nccl" is RCCL on ROCm and is used for the barrier / max-over-ranks only
+    rank, local_rank, world, dist = replica.init_distributed("nccl", device_id=dev)
 
     from rd_vio_amd import build as rbuild
     import rd_vio_amd
@@ -189,7 +189,8 @@ def main():
     import ctypes
 
     n_out = ctypes.c_int(0)
-    stage_names = ["preprocess", "lk_track", "detect", "preintegrate", "ba_localize", "ba_window"]
+    stage_names = ["preprocess", "lk_track", "detect", "preintegrate", "ba_localize", "ba_window", "marginalize"]
+    NS = len(stage_names)
 
     def step(k, ev=None):
         cur, prv = k % 2, (k + 1) % 2
@@ -215,31 +216,20 @@ def main():
         if ev: ev[5].record()
         ctx._check(lib.rdvio_hip_ba_solve_resident(h, 0, iters))
         if ev: ev[6].record()
+        ctx._check(lib.rdvio_hip_marginalize_resident(h, 0))  # slide_window -> Map::marginalize_frame(0)
+        if ev: ev[7].record()
         # the frame's results are consumed by host logic before the next frame
         ctx.sync()
 
     # slot 1 holds frame 0 (build_workload); warm up
     for k in range(args.warmup):
         step(k)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k, evs[k])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    stage_ms = np.zeros(6)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(NS + 1)] for _ in range(args.steps)]
+    elapsed = replica.timed_region(lambda k: step(k, evs[k - args.warmup]), args.steps, sync=torch.cuda.synchronize,
+                                   dist=dist, device=dev, first_index=args.warmup)
+    stage_ms = np.zeros(NS)
     for e in evs:
-        for i in range(6):
+        for i in range(NS):
             stage_ms[i] += e[i].elapsed_time(e[i + 1])
     stage_ms /= args.steps
     _, _, sm_win = ctx.ba_fetch(0)
@@ -275,7 +265,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 2)
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 
