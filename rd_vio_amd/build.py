@@ -8,8 +8,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librdvio_hip.so")
 SOURCES = ["capi.hip", "image_kernels.hip", "lk_kernels.hip", "ba_kernels.hip", "solver_kernels.hip", "solver_host.hip", "marg_kernels.hip", "marg_host.hip",
            "host_select.cpp"]
-# -ffp-contract=off: the image/LK arithmetic must round exactly like the oracle (bit-exact feature indices).
-FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# No FMA contraction anywhere: the image / LK arithmetic must round exactly like the oracle (bit-exact feature
+# indices), and the FP64 estimation code relies on exact cancellations the reference (built without FMA) also has --
+# e.g. q0^-1 * q == identity at the linearisation point, which the 1e15 prior pin would otherwise amplify to 1e-2.
+CONTRACT = {}
 
 
 def needs_build():
@@ -24,12 +27,13 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = ["-DRDVIO_PROF"] if os.environ.get("RDVIO_PROF") else []  # diagnostic phase stamps (never timed builds)
     objs = []
     procs = []
     for s in SOURCES:
         o = os.path.join(CSRC, s.rsplit(".", 1)[0] + ".o")
         objs.append(o)
-        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc] + FLAGS + extra + [f"-ffp-contract={CONTRACT.get(s, 'off')}", "-x", "hip", "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -1,45 +1,144 @@
-// Workgroup-level building blocks shared by the solver and the marginalisation kernels: fixed-order block
-// reductions and the blocked (15-wide) Cholesky factorisation / solve.  T = threads per workgroup.
+// Workgroup-level FP64 building blocks shared by the solver and the marginalisation kernels (gfx950):
+//  * fixed-order block reductions (wave xor-shuffle + one LDS stage: 1 barrier per reduction, bitwise reproducible)
+//  * v_mfma_f64_16x16x4_f64 tile products for the three GEMM-shaped pieces (S^T S, A^T W A, Cholesky trailing update)
+//  * wave-per-row mat-vec with coalesced row reads
+//  * blocked (15-wide) Cholesky factorisation / solve with the diagonal block staged in LDS
+// T = threads per workgroup (multiple of 64).
 #pragma once
 #include "dmath.hpp"
 
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
 template <int T>
 struct BlockShared {
-    double red[T];
+    double red[2][4][T / 64];  // double-buffered partials for up to 4 simultaneous reductions
     double blk[15 * 16];
     double vec[16];
     int flag;
+    int red_phase;
 };
 
-template <int T>
-DM double block_sum(BlockShared<T> &sh, double v) {
-    const int t = threadIdx.x;
-    sh.red[t] = v;
+DM double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+DM double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+
+// Sum NV values over the workgroup; every thread receives the totals.  One __syncthreads per call: the partial
+// buffers alternate between two banks, so the next call cannot overwrite values another wave is still reading.
+template <int T, int NV>
+DM void block_sum_n(BlockShared<T> &sh, double (&v)[NV], int &phase) {
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double s = wave_sum(v[i]);
+        if (lane == 0) sh.red[phase][i][wave] = s;
+    }
     __syncthreads();
 #pragma unroll
-    for (int s = T / 2; s > 0; s >>= 1) {
-        if (t < s) sh.red[t] += sh.red[t + s];
-        __syncthreads();
+    for (int i = 0; i < NV; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < T / 64; ++q) s += sh.red[phase][i][q];
+        v[i] = s;
     }
-    const double r = sh.red[0];
-    __syncthreads();
-    return r;
+    phase ^= 1;
 }
 template <int T>
-DM double block_max(BlockShared<T> &sh, double v) {
-    const int t = threadIdx.x;
-    sh.red[t] = v;
-    __syncthreads();
-#pragma unroll
-    for (int s = T / 2; s > 0; s >>= 1) {
-        if (t < s) sh.red[t] = fmax(sh.red[t], sh.red[t + s]);
-        __syncthreads();
-    }
-    const double r = sh.red[0];
-    __syncthreads();
-    return r;
+DM double block_sum(BlockShared<T> &sh, double v, int &phase) {
+    double a[1] = {v};
+    block_sum_n<T, 1>(sh, a, phase);
+    return a[0];
 }
+template <int T>
+DM double block_max(BlockShared<T> &sh, double v, int &phase) {
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const double s = wave_max(v);
+    if (lane == 0) sh.red[phase][0][wave] = s;
+    __syncthreads();
+    double m = sh.red[phase][0][0];
+#pragma unroll
+    for (int q = 1; q < T / 64; ++q) m = fmax(m, sh.red[phase][0][q]);
+    phase ^= 1;
+    return m;
+}
+
+// One 16x16 output tile  C[m0.., n0..] = sum_k a(k, m) * w(k) * b(k, n)  on one wavefront with
+// v_mfma_f64_16x16x4_f64.  a(k, m) = Ap[k * sak + m * sam], b(k, n) = Bp[k * sbk + n * sbn]; w may be null.
+// Lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; result register r of lane l is
+// C[row = (l >> 4) + 4 r][col = l & 15].
+DM double4_t mfma_tile_f64(const double *__restrict__ Ap, long sak, long sam, const double *__restrict__ Bp, long sbk,
+                           long sbn, const double *__restrict__ w, int K, int m0, int n0, int M, int N) {
+    const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
+    const bool am = (m0 + i) < M, bn = (n0 + i) < N;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    const double *ap = Ap + (long)(m0 + i) * sam, *bp = Bp + (long)(n0 + i) * sbn;
+    int k0 = 0;
+    for (; k0 + 16 <= K; k0 += 16) {  // 4 MFMAs per trip: 8 independent loads in flight
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 4 * u + kk;
+            a[u] = am ? ap[(long)k * sak] : 0.0;
+            b[u] = bn ? bp[(long)k * sbk] : 0.0;
+            if (w) a[u] *= w[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+    for (; k0 < K; k0 += 4) {
+        const int k = k0 + kk;
+        double a = 0.0, b = 0.0;
+        if (k < K) {
+            a = am ? ap[(long)k * sak] : 0.0;
+            b = bn ? bp[(long)k * sbk] : 0.0;
+            if (w) a *= w[k];
+        }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// C (M x N, row-major, ld = ldc) = A^T diag(w) B with A: K x M, B: K x N row-major; tiles spread over the waves.
+// If `lower_only`, tiles strictly above the diagonal are skipped (symmetric result, M == N).
+template <int T>
+DM void block_gemm_tn(double *__restrict__ C, int ldc, const double *__restrict__ A, int lda, const double *__restrict__ B,
+                      int ldb, const double *__restrict__ w, int M, int N, int K, bool lower_only) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = T / 64;
+    const int tm = (M + 15) / 16, tn = (N + 15) / 16;
+    for (int tile = wave; tile < tm * tn; tile += nw) {
+        const int bi = tile / tn, bj = tile - bi * tn;
+        if (lower_only && bj > bi) continue;
+        const double4_t acc = mfma_tile_f64(A, lda, 1, B, ldb, 1, w, K, 16 * bi, 16 * bj, M, N);
+        const int col = 16 * bj + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * bi + (lane >> 4) + 4 * r;
+            if (row < M && col < N) C[(long)row * ldc + col] = acc[r];
+        }
+    }
+}
+
+// y[row] = sum_c Mx[row * ld + c] * x[c]  (+ add[row]) for row in [0, R): one wave per row, coalesced row reads.
+// Calls emit(row, value) on lane 0 of the owning wave.
+template <int T, class Emit>
+DM void block_matvec_rows(const double *__restrict__ Mx, int ld, int R, int C, const double *__restrict__ x, Emit emit) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = T / 64;
+    for (int row = wave; row < R; row += nw) {
+        double acc = 0.0;
+        for (int c = lane; c < C; c += 64) acc += Mx[(long)row * ld + c] * x[c];
+        acc = wave_sum(acc);
+        if (lane == 0) emit(row, acc);
+    }
+}
+
 // blocked (15-wide) in-place Cholesky of the N x N matrix M (lower triangle), N a multiple of 15.
+// Diagonal block: LDS, first wave.  Panel: one thread per row.  Trailing update: MFMA tiles.
 // Returns 0 on a non-positive / non-finite pivot.
 template <int T>
 DM int cholesky_blocked(BlockShared<T> &sh, double *M, int N) {
@@ -49,7 +148,6 @@ DM int cholesky_blocked(BlockShared<T> &sh, double *M, int N) {
     __syncthreads();
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = 15 * kb;
-        // (1) diagonal block: factor in LDS by the first wave
         for (int i = t; i < 225; i += T) sh.blk[(i / 15) * 16 + (i % 15)] = M[(size_t)(k0 + i / 15) * N + k0 + (i % 15)];
         __syncthreads();
         if (t < 64) {
@@ -65,7 +163,6 @@ DM int cholesky_blocked(BlockShared<T> &sh, double *M, int N) {
                 if (t > j && t < 15) sh.blk[t * 16 + j] /= d;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                // trailing update inside the block: entries (r, c), j < c <= r < 15
                 for (int e = t; e < 225; e += 64) {
                     const int r = e / 15, c = e - 15 * r;
                     if (c > j && r >= c) sh.blk[r * 16 + c] -= sh.blk[r * 16 + j] * sh.blk[c * 16 + j];
@@ -79,29 +176,39 @@ DM int cholesky_blocked(BlockShared<T> &sh, double *M, int N) {
             const int r = i / 15, c = i - 15 * r;
             if (c <= r) M[(size_t)(k0 + r) * N + k0 + c] = sh.blk[r * 16 + c];
         }
-        // (2) panel below: row i solves x L_kk^T = M[i, k0:k0+15]
+        // panel below: row i solves x L_kk^T = M[i, k0:k0+15]
         for (int i = k0 + 15 + t; i < N; i += T) {
             double x[15];
 #pragma unroll
             for (int c = 0; c < 15; ++c) {
                 double s = M[(size_t)i * N + k0 + c];
-                for (int q = 0; q < c; ++q) s -= x[q] * sh.blk[c * 16 + q];
+#pragma unroll
+                for (int q = 0; q < 15; ++q)
+                    if (q < c) s -= x[q] * sh.blk[c * 16 + q];
                 x[c] = s / sh.blk[c * 16 + c];
             }
 #pragma unroll
             for (int c = 0; c < 15; ++c) M[(size_t)i * N + k0 + c] = x[c];
         }
         __syncthreads();
-        // (3) trailing update of the lower triangle
+        // trailing update of the lower triangle: C[r][c] -= sum_q P[r][q] P[c][q], 16x16 MFMA tiles
         const int rem = N - (k0 + 15);
-        for (int e = t; e < rem * rem; e += T) {
-            const int r = e / rem, c = e - r * rem;
-            if (c > r) continue;
-            const double *Lr = M + (size_t)(k0 + 15 + r) * N + k0, *Lc = M + (size_t)(k0 + 15 + c) * N + k0;
-            double acc = 0.0;
+        if (rem > 0) {
+            const int wave = t >> 6, lane = t & 63, nw = T / 64;
+            const int tn = (rem + 15) / 16;
+            const double *P = M + (size_t)(k0 + 15) * N + k0;  // panel: rem x 15, row stride N
+            double *Cb = M + (size_t)(k0 + 15) * N + k0 + 15;
+            for (int tile = wave; tile < tn * tn; tile += nw) {
+                const int bi = tile / tn, bj = tile - bi * tn;
+                if (bj > bi) continue;
+                const double4_t acc = mfma_tile_f64(P, 1, N, P, 1, N, nullptr, 15, 16 * bi, 16 * bj, rem, rem);
+                const int col = 16 * bj + (lane & 15);
 #pragma unroll
-            for (int q = 0; q < 15; ++q) acc += Lr[q] * Lc[q];
-            M[(size_t)(k0 + 15 + r) * N + k0 + 15 + c] -= acc;
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * bi + (lane >> 4) + 4 * r;
+                    if (row < rem && col <= row) Cb[(size_t)row * N + col] -= acc[r];
+                }
+            }
         }
         __syncthreads();
     }
@@ -111,52 +218,53 @@ DM int cholesky_blocked(BlockShared<T> &sh, double *M, int N) {
 // solve L L^T y = b in place (y overwrites b), blocked like the factorisation; the 15x15 diagonal block is
 // staged in LDS so the sequential triangular solve never waits on global memory
 template <int T>
-DM void cholesky_solve(BlockShared<T> &sh, const double *M, int N, double *b) {
+DM void cholesky_solve(BlockShared<T> &sh, const double *M, int N, double *b, bool forward = true, bool backward = true) {
     const int t = threadIdx.x;
     const int nb = N / 15;
-    for (int kb = 0; kb < nb; ++kb) {  // forward
-        const int k0 = 15 * kb;
-        for (int i = t; i < 225; i += T) sh.blk[(i / 15) * 16 + (i % 15)] = M[(size_t)(k0 + i / 15) * N + k0 + (i % 15)];
-        if (t < 15) sh.vec[t] = b[k0 + t];
-        __syncthreads();
-        if (t == 0) {
-            for (int c = 0; c < 15; ++c) {
-                double s = sh.vec[c];
-                for (int q = 0; q < c; ++q) s -= sh.blk[c * 16 + q] * sh.vec[q];
-                sh.vec[c] = s / sh.blk[c * 16 + c];
+    if (forward)
+        for (int kb = 0; kb < nb; ++kb) {
+            const int k0 = 15 * kb;
+            for (int i = t; i < 225; i += T) sh.blk[(i / 15) * 16 + (i % 15)] = M[(size_t)(k0 + i / 15) * N + k0 + (i % 15)];
+            if (t < 15) sh.vec[t] = b[k0 + t];
+            __syncthreads();
+            if (t == 0) {
+                for (int c = 0; c < 15; ++c) {
+                    double s = sh.vec[c];
+                    for (int q = 0; q < c; ++q) s -= sh.blk[c * 16 + q] * sh.vec[q];
+                    sh.vec[c] = s / sh.blk[c * 16 + c];
+                }
             }
-        }
-        __syncthreads();
-        if (t < 15) b[k0 + t] = sh.vec[t];
-        for (int i = k0 + 15 + t; i < N; i += T) {
-            double s = b[i];
+            __syncthreads();
+            if (t < 15) b[k0 + t] = sh.vec[t];
+            for (int i = k0 + 15 + t; i < N; i += T) {
+                double s = b[i];
 #pragma unroll
-            for (int q = 0; q < 15; ++q) s -= M[(size_t)i * N + k0 + q] * sh.vec[q];
-            b[i] = s;
-        }
-        __syncthreads();
-    }
-    for (int kb = nb - 1; kb >= 0; --kb) {  // backward
-        const int k0 = 15 * kb;
-        for (int i = t; i < 225; i += T) sh.blk[(i / 15) * 16 + (i % 15)] = M[(size_t)(k0 + i / 15) * N + k0 + (i % 15)];
-        if (t < 15) sh.vec[t] = b[k0 + t];
-        __syncthreads();
-        if (t == 0) {
-            for (int c = 14; c >= 0; --c) {
-                double s = sh.vec[c];
-                for (int q = c + 1; q < 15; ++q) s -= sh.blk[q * 16 + c] * sh.vec[q];
-                sh.vec[c] = s / sh.blk[c * 16 + c];
+                for (int q = 0; q < 15; ++q) s -= M[(size_t)i * N + k0 + q] * sh.vec[q];
+                b[i] = s;
             }
+            __syncthreads();
         }
-        __syncthreads();
-        if (t < 15) b[k0 + t] = sh.vec[t];
-        for (int i = t; i < k0; i += T) {
-            double s = b[i];
+    if (backward)
+        for (int kb = nb - 1; kb >= 0; --kb) {
+            const int k0 = 15 * kb;
+            for (int i = t; i < 225; i += T) sh.blk[(i / 15) * 16 + (i % 15)] = M[(size_t)(k0 + i / 15) * N + k0 + (i % 15)];
+            if (t < 15) sh.vec[t] = b[k0 + t];
+            __syncthreads();
+            if (t == 0) {
+                for (int c = 14; c >= 0; --c) {
+                    double s = sh.vec[c];
+                    for (int q = c + 1; q < 15; ++q) s -= sh.blk[q * 16 + c] * sh.vec[q];
+                    sh.vec[c] = s / sh.blk[c * 16 + c];
+                }
+            }
+            __syncthreads();
+            if (t < 15) b[k0 + t] = sh.vec[t];
+            for (int i = t; i < k0; i += T) {
+                double s = b[i];
 #pragma unroll
-            for (int q = 0; q < 15; ++q) s -= M[(size_t)(k0 + q) * N + i] * sh.vec[q];
-            b[i] = s;
+                for (int q = 0; q < 15; ++q) s -= M[(size_t)(k0 + q) * N + i] * sh.vec[q];
+                b[i] = s;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
 }
-

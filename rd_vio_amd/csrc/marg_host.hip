@@ -110,8 +110,8 @@ static int marg_prepare(rdvio_hip_ctx *ctx, const rdvio_marg_problem *pb) {
     const size_t s_rf = dd((size_t)nf * 2), s_Jt = dd((size_t)nf * 12), s_Jr = dd((size_t)nf * 12), s_Jd = dd((size_t)nf * 2);
     const size_t s_A = dd((size_t)nl * NA), s_lmm = dd(nl), s_lmg = dd(nl), s_lmw = dd(nl);
     const size_t s_H = dd((size_t)N * N), s_eta = dd(N), s_Tm = dd((size_t)R * 15), s_Lr = dd((size_t)R * R), s_er = dd(R);
-    const size_t s_Wk = dd((size_t)Wn * Wn), s_V = dd((size_t)R * R), s_cs = dd((size_t)4 * (R / 2 + 2)), s_yv = dd(Wn);
-    const size_t s_nz = Sx.reserve((size_t)(R + 1) * sizeof(int32_t));
+    const size_t s_Wk = dd((size_t)Wn * Wn), s_V = dd((size_t)R * R), s_cs = dd((size_t)4 * (R / 2 + 2) + R), s_yv = dd(Wn);
+    const size_t s_nz = Sx.reserve((size_t)(2 * R + 2) * sizeof(int32_t));  // nz list + pivot `done` flags
     const size_t s_So = dd((size_t)R * R), s_fo = dd(R), s_lo = dd((size_t)(nfm - 1) * 16), s_Lo = dd((size_t)R * R), s_eo = dd(R), s_info = dd(4);
     if (!Sx.ok) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "marginalisation problem does not fit the device arena");
     uint8_t *B = (uint8_t *)ctx->marg_arena;
@@ -173,7 +173,7 @@ int rdvio_hip_marginalize_fetch(rdvio_hip_ctx *ctx, double *S_out, double *f_out
     if (eta_out) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(eta_out, w.eta_out, R * sizeof(double), hipMemcpyDeviceToHost, st));
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(info, w.info, sizeof info, hipMemcpyDeviceToHost, st));
     RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    if (used_fast_path) *used_fast_path = (int)info[0];
+    if (used_fast_path) *used_fast_path = (int)info[0];  // 1 plain Cholesky, 2 pivoted Cholesky, 0 eigen
     return RDVIO_OK;
 }
 

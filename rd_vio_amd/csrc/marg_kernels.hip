@@ -15,8 +15,12 @@
 // the velocity/bias rows of frames >= 2) are exact zero eigenvalues and are dropped; if the remaining block is
 // positive definite beyond the 1e-8 threshold (shifted Cholesky succeeds) NO eigenvalue is clamped and
 // S = L^T, f = L^-1 eta is an exact sqrt factor of the same (Lambda, eta) -- an O(R^3/3) blocked Cholesky
-// instead of ~1000 dependent Jacobi steps.  Otherwise the kernel falls back to a parallel-ordered two-sided
-// Jacobi eigensolver and applies the reference's clamp literally.  `info[0]` reports which path ran.
+// instead of ~1000 dependent Jacobi steps.  Otherwise (the usual case: a few directions such as parts of the
+// accelerometer bias are numerically unobservable) a diagonally-PIVOTED Cholesky peels off rank-1 terms
+// l l^T until the largest remaining diagonal entry is <= 1e-8: S = [l_1 .. l_r]^T reproduces Lambda up to a
+// remainder below the reference's own clamp threshold, f follows from the same elimination applied to eta.
+// force_eigen runs the reference's literal recipe (parallel-ordered two-sided Jacobi eigensolver + clamp);
+// `info[0]` reports which path ran (1 plain Cholesky, 2 pivoted Cholesky, 0 eigendecomposition).
 #include "ctx.hpp"
 #include "factors.hpp"
 #include "marg_ws.hpp"
@@ -36,6 +40,7 @@ DM double prior_E(const MargWs &w, int i, int a, int b) {
 // V accumulates the rotations (columns = eigenvectors).  cs: scratch for 2 * (Rp/2) rotation parameters.
 DM void jacobi_eigen(Shared &sh, double *A, double *V, double *cs, int R) {
     const int t = threadIdx.x;
+    int phase = 0;
     const int Rp = (R + 1) & ~1, half = Rp / 2;
     for (int i = t; i < R * R; i += T) V[i] = ((i / R) == (i % R)) ? 1.0 : 0.0;
     __syncthreads();
@@ -47,8 +52,12 @@ DM void jacobi_eigen(Shared &sh, double *A, double *V, double *cs, int R) {
             if (r == c) dg += v * v;
             else off += v * v;
         }
-        off = block_sum(sh, off);
-        dg = block_sum(sh, dg);
+        {
+            double v2[2] = {off, dg};
+            block_sum_n<T, 2>(sh, v2, phase);
+            off = v2[0];
+            dg = v2[1];
+        }
         if (off <= 1e-60 || off <= 1e-30 * dg) break;
         for (int step = 0; step < Rp - 1; ++step) {
             // circle method: player Rp-1 fixed, the others rotate
@@ -99,6 +108,51 @@ DM void jacobi_eigen(Shared &sh, double *A, double *V, double *cs, int R) {
     }
 }
 
+// Diagonally pivoted Cholesky of the symmetric PSD matrix A (n x n, row-major, destroyed): writes factor column j
+// (length n, zero on rows pivoted earlier) to Lc[j * n ..] and f[j]; eta (length n) is eliminated alongside.
+// Stops when the largest remaining diagonal entry is <= tol.  Returns the numerical rank.
+DM int pivoted_cholesky(Shared &sh, int &phase, double *A, double *eta, double *Lc, double *fv, double *lcol, int *done,
+                        int n, double tol) {
+    const int t = threadIdx.x;
+    for (int i = t; i < n; i += T) done[i] = 0;
+    __syncthreads();
+    int r = 0;
+    for (int j = 0; j < n; ++j) {
+        // arg max of the remaining diagonal (ties: lowest index) -- value reduction, then index reduction
+        double best = -1.0;
+        for (int i = t; i < n; i += T)
+            if (!done[i]) best = fmax(best, A[(size_t)i * n + i]);
+        best = block_max(sh, best, phase);
+        if (!(best > tol)) break;
+        double cand = 1e300;
+        for (int i = t; i < n; i += T)
+            if (!done[i] && A[(size_t)i * n + i] == best) cand = fmin(cand, (double)i);
+        const int p = (int)(-block_max(sh, -cand, phase));
+        const double d = sqrt(best);
+        for (int i = t; i < n; i += T) {
+            const double l = done[i] ? 0.0 : ((i == p) ? d : A[(size_t)i * n + p] / d);
+            lcol[i] = l;
+            Lc[(size_t)j * n + i] = l;
+        }
+        const double fj = eta[p] / d;
+        __syncthreads();
+        if (t == 0) {
+            fv[j] = fj;
+            done[p] = 1;
+        }
+        for (int i = t; i < n; i += T)
+            if (i != p && lcol[i] != 0.0) eta[i] -= lcol[i] * fj;
+        for (int o = t; o < n * n; o += T) {
+            const int i = o / n, k = o - i * n;
+            const double li = lcol[i], lk = lcol[k];
+            if (li != 0.0 && lk != 0.0) A[o] -= li * lk;
+        }
+        __syncthreads();
+        ++r;
+    }
+    return r;
+}
+
 __global__ __launch_bounds__(T) void marginalize_kernel(MargWs w) {
     __shared__ Shared sh;
     __shared__ double sM[15 * 30];
@@ -106,6 +160,7 @@ __global__ __launch_bounds__(T) void marginalize_kernel(MargWs w) {
     const int t = threadIdx.x;
     const int nfm = w.nfm, N = 15 * nfm, R = N - 15, NA = 6 * nfm, D = w.D;
     const double *W = w.extr + 14;
+    int phase = 0;
 
     // ---- (i) current prior at the current states of its frames: e, Jr^-1, Lambda = S^T S, le = S^T (S e + f)
     if (w.np > 0) {
@@ -403,6 +458,19 @@ __global__ __launch_bounds__(T) void marginalize_kernel(MargWs w) {
             __syncthreads();
         }
         for (int i = t; i < Rn; i += T) w.f_out[w.nz[i]] = w.yv[i];
+    } else if (!w.force_eigen) {
+        // rank-deficient information: pivoted Cholesky on the structurally non-zero block
+        for (int o = t; o < Rn * Rn; o += T) w.Wk[o] = w.Lr[(size_t)w.nz[o / Rn] * R + w.nz[o % Rn]];
+        for (int i = t; i < Rn; i += T) w.yv[i] = w.er[w.nz[i]];
+        __syncthreads();
+        const int rank = pivoted_cholesky(sh, phase, w.Wk, w.yv, w.V, w.cs, w.Tm, w.nz + R + 1, Rn, 1.0e-8);
+        __syncthreads();
+        for (int o = t; o < rank * Rn; o += T) {
+            const int j = o / Rn, i = o - j * Rn;
+            w.S_out[(size_t)j * R + w.nz[i]] = w.V[(size_t)j * Rn + i];
+        }
+        for (int j = t; j < rank; j += T) w.f_out[j] = w.cs[j];
+        fast = 2;
     } else {
         // literal restatement: eigendecomposition, lambda+ = lambda > 1e-8 ? lambda : 0 (:441-458)
         for (int i = t; i < R * R; i += T) w.Wk[i] = w.Lr[i];
@@ -421,7 +489,7 @@ __global__ __launch_bounds__(T) void marginalize_kernel(MargWs w) {
         }
     }
     if (t == 0) {
-        w.info[0] = fast ? 1.0 : 0.0;
+        w.info[0] = (double)fast;
         w.info[1] = (double)Rn;
     }
 }

@@ -22,6 +22,7 @@ struct MargWs {
     int32_t *nz;
     // outputs
     double *S_out, *f_out, *lin_out, *Lambda_out, *eta_out, *info;
+    double *prof;  // diagnostic phase stamps (RDVIO_PROF builds only)
 };
 
 void rdvio_launch_marginalize(hipStream_t stream, const MargWs &w);

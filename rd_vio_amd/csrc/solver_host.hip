@@ -147,14 +147,15 @@ static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdv
     auto dd = [&](size_t n) { return Sx.reserve(std::max<size_t>(n, 1) * sizeof(double)); };
     const size_t s_x = dd((size_t)nfr * 16), s_xd = dd(nl), s_xc = dd((size_t)nfr * 16), s_xdc = dd(nl), s_user = dd((size_t)nfr * 16);
     const size_t s_lfree = Sx.reserve(std::max(nl, 1));
-    const size_t s_rf = dd((size_t)nf * 2), s_Jt = dd((size_t)nf * 12), s_Jr = dd((size_t)nf * 12), s_Jd = dd((size_t)nf * 2);
+    const size_t s_fac = dd((size_t)nf * RDVIO_FAC_STRIDE);
     const size_t s_rr = dd((size_t)nrot * 2), s_Jro = dd((size_t)nrot * 6);
     const size_t s_ep = dd((size_t)npre * 15), s_G = dd((size_t)npre * 450), s_rp = dd((size_t)npre * 15), s_cp = dd((size_t)npre * 15), s_Jp = dd((size_t)npre * 450);
     const size_t s_em = dd(D), s_rm = dd(D), s_cm = dd(D), s_Jri = dd((size_t)np * 9), s_Lam = dd((size_t)D * D), s_eta0 = dd(D), s_le = dd(D), s_Ex = dd(D);
     const size_t s_H = dd((size_t)N * N), s_Sm = dd((size_t)N * N), s_g = dd(N), s_yp = dd(N);
+    const size_t s_Cm = dd((size_t)36 * nfree * nfree), s_Cg = dd((size_t)6 * nfree);
     const size_t s_lmm = dd(nl), s_lmg = dd(nl), s_lmw = dd(nl), s_A = dd((size_t)nl * 6 * nfree), s_yl = dd(nl);
     const size_t s_sigp = dd(N), s_sigl = dd(nl), s_dgp = dd(N), s_dgl = dd(nl), s_grp = dd(N), s_grl = dd(nl), s_gnp = dd(N), s_gnl = dd(nl), s_tp = dd(N), s_tl = dd(nl);
-    const size_t s_sum = dd(8);
+    const size_t s_sum = dd(80);  // summary[0..7] + diagnostic phase stamps
     if (!Sx.ok) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "BA problem does not fit the context's device arena");
 
     uint8_t *B = (uint8_t *)slot.arena;
@@ -173,10 +174,10 @@ static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdv
     w.fcol = IP(o_fcol); w.lm_first = IP(o_lmf); w.lm_count = IP(o_lmc);
     w.pair_fi = IP(o_pfi); w.pair_fj = IP(o_pfj); w.pair_off = IP(o_poff); w.pair_item = IP(o_pitem); w.diag_pair = IP(o_dp);
     w.x = DP(s_x); w.xd = DP(s_xd); w.xc = DP(s_xc); w.xdc = DP(s_xdc); w.user = DP(s_user); w.lfree = B + s_lfree;
-    w.r_f = DP(s_rf); w.Jt = DP(s_Jt); w.Jr = DP(s_Jr); w.Jd = DP(s_Jd); w.r_r = DP(s_rr); w.Jro = DP(s_Jro);
+    w.fac = DP(s_fac); w.r_r = DP(s_rr); w.Jro = DP(s_Jro);
     w.e_p = DP(s_ep); w.G = DP(s_G); w.r_p = DP(s_rp); w.c_p = DP(s_cp); w.Jp = DP(s_Jp);
     w.e_m = DP(s_em); w.r_m = DP(s_rm); w.c_m = DP(s_cm); w.Jri = DP(s_Jri); w.Lam = DP(s_Lam); w.eta0 = DP(s_eta0); w.le = DP(s_le); w.Ex = DP(s_Ex);
-    w.H = DP(s_H); w.Sm = DP(s_Sm); w.g = DP(s_g); w.yp = DP(s_yp);
+    w.H = DP(s_H); w.Sm = DP(s_Sm); w.g = DP(s_g); w.yp = DP(s_yp); w.Cm = DP(s_Cm); w.Cg = DP(s_Cg);
     w.lm_m = DP(s_lmm); w.lm_g = DP(s_lmg); w.lm_w = DP(s_lmw); w.A = DP(s_A); w.yl = DP(s_yl);
     w.sig_p = DP(s_sigp); w.sig_l = DP(s_sigl); w.diag_p = DP(s_dgp); w.diag_l = DP(s_dgl); w.grad_p = DP(s_grp); w.grad_l = DP(s_grl);
     w.gn_p = DP(s_gnp); w.gn_l = DP(s_gnl); w.tp = DP(s_tp); w.tl = DP(s_tl);
@@ -239,6 +240,14 @@ int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double 
         summary->final_cost = sum[3];
         summary->termination = (int32_t)sum[4];
     }
+    return RDVIO_OK;
+}
+
+// diagnostic (RDVIO_PROF builds): per-phase ticks / counts of the last solve in a slot; not part of the public header
+int rdvio_hip_debug_ba_prof(rdvio_hip_ctx *ctx, int slot, double *out64) {
+    if (!ctx || bad_slot(slot) || !ctx->ba[slot].ready) return RDVIO_ERR_INVALID;
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(out64, ctx->ba[slot].ws.summary + 8, 64 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return RDVIO_OK;
 }
 

@@ -8,17 +8,20 @@
 // 226-300, 349-444.
 //
 // Why one workgroup: at the reference's sizes (15(W+1) <= 270 pose columns, <= ~1000 landmarks, <= 15000
-// factors) an iteration is a chain of ~60 dependent phases of a few microseconds each; a kernel boundary
+// factors) an iteration is a chain of dependent phases of a few microseconds each; a kernel boundary
 // (~1.5 us) or a grid barrier (~4-10 us) per phase would cost more than the phase.  Inside one workgroup a
-// phase boundary is an s_barrier.  All reductions are fixed-order (strided partials + LDS tree), so the
-// result is bitwise reproducible run to run.
+// phase boundary is an s_barrier.  All reductions are fixed-order, so the result is bitwise reproducible.
 //
 // Normal equations.  With J robustified (sqrt(rho') scaling) and Jacobi-scaled by Sigma:
-//   pose block   H = J_p^T J_p  (N x N, N = 15 * free frames), assembled OUTPUT-STATIONARY from per
-//                frame-pair factor lists (no atomics);
-//   landmarks    scalar m_l = |J_l|^2, coupling row A[l, :] = J_l^T J_p  (dense L x 6 nfree);
-//   Schur        S = Sigma (H - A^T W A) Sigma + mu D^2,  w_l = sigma_l^2 / (sigma_l^2 m_l + mu d_l^2)
-//   blocked (15-wide) Cholesky of S, landmark back-substitution.
+//   pose block   H = J_p^T J_p  (N x N, N = 15 * free frames): reprojection part OUTPUT-STATIONARY, one wavefront
+//                per frame pair walking that pair's factor list (36 + 6 lanes = block entries + gradient), no atomics;
+//   landmarks    scalar m_l = |J_l|^2, coupling row A[l, :] = J_l^T J_p (dense L x 6 nfree), built from per-factor
+//                products stored at linearisation time;
+//   Schur        S = Sigma (H - A^T W A) Sigma + mu D^2,  w_l = sigma_l^2 / (sigma_l^2 m_l + mu d_l^2);
+//                A^T W A and the prior's S^T S are v_mfma_f64_16x16x4 tile products (block_linalg.hpp);
+//   blocked (15-wide) Cholesky of S with MFMA trailing updates, landmark back-substitution.
+// Model quantities (Cauchy point, model cost change) are evaluated from the assembled H, A, m, g instead of
+// re-walking the factors:  |J x|^2 = xp^T H xp + 2 sum_l xl (A_l . xp) + sum_l m_l xl^2.
 #include "ctx.hpp"
 #include "factors.hpp"
 #include "solver_ws.hpp"
@@ -27,67 +30,119 @@
 namespace {
 
 constexpr int T = RDVIO_SOLVER_THREADS;
-
+constexpr int NW = T / 64;
 using Shared = BlockShared<T>;
+
+#ifdef RDVIO_PROF
+// diagnostic build only: accumulate wall-clock ticks (100 MHz) per phase into summary[8 + id], counts into [40 + id]
+#define STAMP(id)                                                   \
+    do {                                                            \
+        if (threadIdx.x == 0) {                                     \
+            const unsigned long long n__ = wall_clock64();          \
+            w.summary[8 + (id)] += (double)(n__ - prof_last);       \
+            w.summary[40 + (id)] += 1.0;                            \
+            prof_last = n__;                                        \
+        }                                                           \
+    } while (0)
+#else
+#define STAMP(id) do {} while (0)
+#endif
 
 DM double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// E_i[a, b] of the prior Jacobian J = S E, E = blockdiag(Jr^-1(e_theta), I12) per frame
+DM double prior_E(const SolverWs &w, int i, int a, int b) {
+    if (a < 3 && b < 3) return w.Jri[9 * i + 3 * a + b];
+    return a == b ? 1.0 : 0.0;
+}
+
 // ---------------------------------------------------------------------------------------------
-// cost (and optionally the stored, robustified linearisation) at (states, invd)
+// cost (and optionally the stored, robustified linearisation) at (states, invd).
+// Waves 0..NW-2 evaluate reprojection factors while the last wave evaluates the (long, serial) preintegration
+// factors and the prior's per-frame errors, so the two overlap.
 // ---------------------------------------------------------------------------------------------
 template <bool LIN>
-DM double evaluate(const SolverWs &w, Shared &sh, const double *states, const double *invd) {
+DM double evaluate(const SolverWs &w, Shared &sh, int &phase, const double *states, const double *invd) {
     const int t = threadIdx.x;
     const double *W = w.extr + 14;
     double cost = 0.0;
-    // reprojection factors, CauchyLoss(1): cost 0.5 log(1+s); Corrector with rho'' < 0 => scale r and J by sqrt(rho')
-    for (int k = t; k < w.nf; k += T) {
-        double r[2], Jt[12], Jr[12], Jd[2];
-        const int l = w.lm[k];
-        reprojection_factor<LIN>(states + 16 * w.tgt[k], states + 16 * w.ref[k], w.tangent + 9 * (size_t)k,
-                                 w.z_ref + 3 * (size_t)l, invd[l], w.extr, W, r, Jt, Jr, Jd);
-        const double s = r[0] * r[0] + r[1] * r[1];
-        const double sum = 1.0 + s;
-        cost += 0.5 * log(sum);
-        if (LIN) {
-            const double sc = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
-            w.r_f[2 * (size_t)k] = r[0] * sc;
-            w.r_f[2 * (size_t)k + 1] = r[1] * sc;
+    constexpr int TF = T - 64;
+    if (t < TF) {
+        // reprojection factors, CauchyLoss(1): cost 0.5 log(1+s); Corrector with rho'' < 0 => scale r, J by sqrt(rho')
+        for (int k = t; k < w.nf; k += TF) {
+            double r[2], Jt[12], Jr[12], Jd[2];
+            const int l = w.lm[k];
+            reprojection_factor<LIN>(states + 16 * w.tgt[k], states + 16 * w.ref[k], w.tangent + 9 * (size_t)k,
+                                     w.z_ref + 3 * (size_t)l, invd[l], w.extr, W, r, Jt, Jr, Jd);
+            const double s = r[0] * r[0] + r[1] * r[1];
+            const double sum = 1.0 + s;
+            cost += 0.5 * log(sum);
+            if (LIN) {
+                const double sc = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
+                r[0] *= sc;
+                r[1] *= sc;
+                Jd[0] *= sc;
+                Jd[1] *= sc;
+                double *o = w.fac + RDVIO_FAC_STRIDE * (size_t)k;
 #pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                w.Jt[12 * (size_t)k + i] = Jt[i] * sc;
-                w.Jr[12 * (size_t)k + i] = Jr[i] * sc;
+                for (int i = 0; i < 12; ++i) {
+                    Jt[i] *= sc;
+                    Jr[i] *= sc;
+                    o[i] = Jt[i];
+                    o[12 + i] = Jr[i];
+                }
+                o[24] = Jd[0];
+                o[25] = Jd[1];
+                o[26] = r[0];
+                o[27] = r[1];
+                // per-factor landmark products: ht = Jd^T Jt, hr = Jd^T Jr, m = Jd^T Jd, g = Jd^T r
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    o[28 + a] = Jd[0] * Jt[a] + Jd[1] * Jt[6 + a];
+                    o[34 + a] = Jd[0] * Jr[a] + Jd[1] * Jr[6 + a];
+                }
+                o[40] = Jd[0] * Jd[0] + Jd[1] * Jd[1];
+                o[41] = Jd[0] * r[0] + Jd[1] * r[1];
             }
-            w.Jd[2 * (size_t)k] = Jd[0] * sc;
-            w.Jd[2 * (size_t)k + 1] = Jd[1] * sc;
         }
-    }
-    for (int k = t; k < w.nrot; k += T) {
-        double r[2], J[6];
-        rotation_prior_factor<LIN>(states + 16 * w.rot_tgt[k], states + 16 * w.rot_ref[k], w.rot_zref + 3 * k,
-                                   w.rot_tangent + 9 * k, w.extr, W, r, J);
-        const double s = r[0] * r[0] + r[1] * r[1];
-        const double sum = 1.0 + s;
-        cost += 0.5 * log(sum);
-        if (LIN) {
-            const double sc = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
-            w.r_r[2 * k] = r[0] * sc;
-            w.r_r[2 * k + 1] = r[1] * sc;
+        for (int k = t; k < w.nrot; k += TF) {
+            double r[2], J[6];
+            rotation_prior_factor<LIN>(states + 16 * w.rot_tgt[k], states + 16 * w.rot_ref[k], w.rot_zref + 3 * k,
+                                       w.rot_tangent + 9 * k, w.extr, W, r, J);
+            const double s = r[0] * r[0] + r[1] * r[1];
+            const double sum = 1.0 + s;
+            cost += 0.5 * log(sum);
+            if (LIN) {
+                const double sc = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
+                w.r_r[2 * k] = r[0] * sc;
+                w.r_r[2 * k + 1] = r[1] * sc;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) w.Jro[6 * k + i] = J[i] * sc;
+                for (int i = 0; i < 6; ++i) w.Jro[6 * k + i] = J[i] * sc;
+            }
+        }
+    } else {
+        const int j = t - TF;  // last wave: lanes 0..31 preintegration factors, lanes 32..63 prior frames
+        if (j < 32) {
+            for (int k = j; k < w.npre; k += 32) {
+                double *G = w.G + 450 * k;
+                if (LIN)
+                    for (int i = 0; i < 450; ++i) G[i] = 0.0;
+                preintegration_unwhitened<LIN>(states + 16 * w.pre_i[k], states + 16 * w.pre_j[k],
+                                               w.preint + (size_t)RDVIO_PREINT_SIZE * k, w.user + 16 * w.pre_i[k] + ST_BG,
+                                               w.extr, w.e_p + 15 * k, G, G + 225);
+            }
+        } else {
+            for (int i = j - 32; i < w.np; i += 32) {
+                M3 Jri;
+                marginalization_frame_error(states + 16 * w.prior_frames[i], w.lin + 16 * i, w.e_m + 15 * i, LIN ? &Jri : nullptr);
+                if (LIN)
+                    for (int q = 0; q < 9; ++q) w.Jri[9 * i + q] = Jri.m[q];
+            }
         }
     }
-    // preintegration factors: unwhitened part by one thread per factor, whitening spread over the block
+    __syncthreads();
+    // whitening of the preintegration residuals (and Jacobians)
     if (w.npre > 0) {
-        if (LIN) {
-            for (int i = t; i < w.npre * 450; i += T) w.G[i] = 0.0;
-            __syncthreads();
-        }
-        for (int k = t; k < w.npre; k += T)
-            preintegration_unwhitened<LIN>(states + 16 * w.pre_i[k], states + 16 * w.pre_j[k],
-                                           w.preint + (size_t)RDVIO_PREINT_SIZE * k, w.user + 16 * w.pre_i[k] + ST_BG,
-                                           w.extr, w.e_p + 15 * k, w.G + 450 * k, w.G + 450 * k + 225);
-        __syncthreads();
         double *r_p = LIN ? w.r_p : w.c_p;
         for (int o = t; o < w.npre * 15; o += T) {
             const int k = o / 15, row = o - 15 * k;
@@ -111,45 +166,30 @@ DM double evaluate(const SolverWs &w, Shared &sh, const double *states, const do
             }
         }
     }
-    // marginalisation prior: e, r = S e + f; Jacobian handled through Lambda = S^T S (constant) and E
+    // marginalisation prior: r = S e + f; Jacobian handled through Lambda = S^T S (constant) and E
     if (w.np > 0) {
-        for (int i = t; i < w.np; i += T) {
-            M3 Jri;
-            marginalization_frame_error(states + 16 * w.prior_frames[i], w.lin + 16 * i, w.e_m + 15 * i, LIN ? &Jri : nullptr);
-            if (LIN)
-                for (int q = 0; q < 9; ++q) w.Jri[9 * i + q] = Jri.m[q];
-        }
-        __syncthreads();
         double *r_m = LIN ? w.r_m : w.c_m;
-        for (int row = t; row < w.D; row += T) {
-            double acc = 0.0;
-            for (int c = 0; c < w.D; ++c) acc += w.S[(size_t)row * w.D + c] * w.e_m[c];
-            acc += w.f[row];
-            r_m[row] = acc;
-            cost += 0.5 * acc * acc;
-            if (LIN) {
-                double a2 = 0.0;  // (Lambda e + eta0)[row] = (S^T r)[row]
-                for (int c = 0; c < w.D; ++c) a2 += w.Lam[(size_t)row * w.D + c] * w.e_m[c];
-                w.le[row] = a2 + w.eta0[row];
-            }
-        }
+        double csum = 0.0;
+        block_matvec_rows<T>(w.S, w.D, w.D, w.D, w.e_m, [&](int row, double v) {
+            const double r = v + w.f[row];
+            r_m[row] = r;
+            csum += 0.5 * r * r;
+        });
+        cost += csum;
+        if (LIN)
+            block_matvec_rows<T>(w.Lam, w.D, w.D, w.D, w.e_m, [&](int row, double v) { w.le[row] = v + w.eta0[row]; });
     }
-    return block_sum(sh, cost);
-}
-
-// E_i[a, b] of the prior Jacobian J = S E, E = blockdiag(Jr^-1(e_theta), I12) per frame
-DM double prior_E(const SolverWs &w, int i, int a, int b) {
-    if (a < 3 && b < 3) return w.Jri[9 * i + 3 * a + b];
-    return a == b ? 1.0 : 0.0;
+    return block_sum(sh, cost, phase);
 }
 
 // ---------------------------------------------------------------------------------------------
 // normal equations from the stored linearisation: H, g, landmark scalars, coupling rows A
 // ---------------------------------------------------------------------------------------------
 DM void build_normal_equations(const SolverWs &w, Shared &sh) {
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int N = w.N, nfree = w.nfree, NA = 6 * nfree;
     for (int i = t; i < N * N; i += T) w.H[i] = 0.0;
+    for (int i = t; i < N; i += T) w.g[i] = 0.0;
     // landmarks: factors of one landmark are contiguous (lm sorted); one thread per landmark, fixed order
     for (int l = t; l < w.nl; l += T) {
         double *Arow = w.A + (size_t)l * NA;
@@ -157,58 +197,69 @@ DM void build_normal_equations(const SolverWs &w, Shared &sh) {
         double m = 0.0, gl = 0.0;
         if (w.lfree[l]) {
             for (int k = w.lm_first[l]; k < w.lm_first[l] + w.lm_count[l]; ++k) {
-                const double d0 = w.Jd[2 * (size_t)k], d1 = w.Jd[2 * (size_t)k + 1];
-                m += d0 * d0 + d1 * d1;
-                gl += d0 * w.r_f[2 * (size_t)k] + d1 * w.r_f[2 * (size_t)k + 1];
+                const double *o = w.fac + RDVIO_FAC_STRIDE * (size_t)k;
+                m += o[40];
+                gl += o[41];
                 const int ct = w.fcol[w.tgt[k]], cr = w.fcol[w.ref[k]];
                 if (ct >= 0)
-                    for (int a = 0; a < 6; ++a) Arow[6 * ct + a] += d0 * w.Jt[12 * (size_t)k + a] + d1 * w.Jt[12 * (size_t)k + 6 + a];
+                    for (int a = 0; a < 6; ++a) Arow[6 * ct + a] += o[28 + a];
                 if (cr >= 0)
-                    for (int a = 0; a < 6; ++a) Arow[6 * cr + a] += d0 * w.Jr[12 * (size_t)k + a] + d1 * w.Jr[12 * (size_t)k + 6 + a];
+                    for (int a = 0; a < 6; ++a) Arow[6 * cr + a] += o[34 + a];
             }
         }
         w.lm_m[l] = m;
         w.lm_g[l] = gl;
     }
     __syncthreads();
-    // reprojection J_p^T J_p: one thread per (frame pair, a, b), looping the pair's factor list in order
-    for (int o = t; o < w.npairs * 36; o += T) {
-        const int p = o / 36, ab = o - 36 * p, a = ab / 6, b = ab - 6 * a;
+    // reprojection J_p^T J_p and J_p^T r: one wavefront per frame pair; lanes 0..35 = block entries (a, b),
+    // lanes 36..41 = gradient entries of diagonal pairs.  Fixed item order => deterministic sums.
+    for (int p = wave; p < w.npairs; p += NW) {
         const int fi = w.pair_fi[p], fj = w.pair_fj[p];
+        const int a = (lane < 36) ? lane / 6 : lane - 36, b = (lane < 36) ? lane - 6 * (lane / 6) : 0;
+        const bool is_h = lane < 36, is_g = lane >= 36 && lane < 42 && fi == fj;
         double acc = 0.0;
-        for (int it = w.pair_off[p]; it < w.pair_off[p + 1]; ++it) {
-            const int item = w.pair_item[it], k = item >> 2, code = item & 3;
-            // code bit0: row block uses Jr (else Jt); bit1: column block uses Jr (else Jt)
-            const double *Jx = ((code & 1) ? w.Jr : w.Jt) + 12 * (size_t)k;
-            const double *Jy = ((code & 2) ? w.Jr : w.Jt) + 12 * (size_t)k;
-            acc += Jx[a] * Jy[b] + Jx[6 + a] * Jy[6 + b];
+        if (is_h || is_g) {
+            for (int it = w.pair_off[p]; it < w.pair_off[p + 1]; ++it) {
+                const int item = w.pair_item[it], k = item >> 2, code = item & 3;
+                // code bit0: row block uses Jr (else Jt); bit1: column block uses Jr (else Jt)
+                const double *o = w.fac + RDVIO_FAC_STRIDE * (size_t)k;
+                const double *Jx = o + ((code & 1) ? 12 : 0);
+                if (is_h) {
+                    const double *Jy = o + ((code & 2) ? 12 : 0);
+                    acc += Jx[a] * Jy[b] + Jx[6 + a] * Jy[6 + b];
+                } else {
+                    acc += Jx[a] * o[26] + Jx[6 + a] * o[27];
+                }
+            }
+            if (is_h) {
+                w.H[(size_t)(15 * fi + a) * N + 15 * fj + b] = acc;
+                if (fi != fj) w.H[(size_t)(15 * fj + b) * N + 15 * fi + a] = acc;
+            } else {
+                w.g[15 * fi + a] = acc;
+            }
         }
-        w.H[(size_t)(15 * fi + a) * N + 15 * fj + b] = acc;
-        if (fi != fj) w.H[(size_t)(15 * fj + b) * N + 15 * fi + a] = acc;
     }
     __syncthreads();
-    // rotation priors: theta-theta block of the target frame
-    if (w.nrot > 0) {
-        for (int o = t; o < nfree * 9; o += T) {
-            const int c = o / 9, ab = o - 9 * c, a = ab / 3, b = ab - 3 * a;
+    // preintegration factors: block (c, c2) receives J_x^T J_y of every factor touching both frames
+    if (w.npre > 0) {
+        for (int o = t; o < nfree * 3 * 225; o += T) {
+            const int c = o / 675, rem = o - 675 * c, which = rem / 225, ab = rem - 225 * which, a = ab / 15, b = ab - 15 * a;
+            const int c2 = c + which - 1;  // which: 0 -> (c, c-1), 1 -> (c, c), 2 -> (c, c+1)
+            if (c2 < 0 || c2 >= nfree) continue;
             double acc = 0.0;
-            for (int k = 0; k < w.nrot; ++k)
-                if (w.fcol[w.rot_tgt[k]] == c) acc += w.Jro[6 * k + a] * w.Jro[6 * k + b] + w.Jro[6 * k + 3 + a] * w.Jro[6 * k + 3 + b];
-            w.H[(size_t)(15 * c + a) * N + 15 * c + b] += acc;
-        }
-        __syncthreads();
-    }
-    // preintegration factors: sequential over factors (neighbouring factors share a diagonal block)
-    for (int k = 0; k < w.npre; ++k) {
-        const int cs[2] = {w.fcol[w.pre_i[k]], w.fcol[w.pre_j[k]]};
-        for (int o = t; o < 900; o += T) {
-            const int xy = o / 225, ab = o - 225 * xy, x = xy >> 1, y = xy & 1, a = ab / 15, b = ab - 15 * a;
-            if (cs[x] < 0 || cs[y] < 0) continue;
-            const double *Jx = w.Jp + 450 * k + 225 * x, *Jy = w.Jp + 450 * k + 225 * y;
-            double acc = 0.0;
+            bool any = false;
+            for (int k = 0; k < w.npre; ++k) {
+                const int ci = w.fcol[w.pre_i[k]], cj = w.fcol[w.pre_j[k]];
+                for (int x = 0; x < 2; ++x)
+                    for (int y = 0; y < 2; ++y) {
+                        if ((x ? cj : ci) != c || (y ? cj : ci) != c2) continue;
+                        const double *Jx = w.Jp + 450 * k + 225 * x, *Jy = w.Jp + 450 * k + 225 * y;
 #pragma unroll
-            for (int q = 0; q < 15; ++q) acc += Jx[q * 15 + a] * Jy[q * 15 + b];
-            w.H[(size_t)(15 * cs[x] + a) * N + 15 * cs[y] + b] += acc;
+                        for (int q = 0; q < 15; ++q) acc += Jx[q * 15 + a] * Jy[q * 15 + b];
+                        any = true;
+                    }
+            }
+            if (any) w.H[(size_t)(15 * c + a) * N + 15 * c2 + b] += acc;
         }
         __syncthreads();
     }
@@ -230,23 +281,25 @@ DM void build_normal_equations(const SolverWs &w, Shared &sh) {
             }
             w.H[(size_t)(15 * ci + a) * N + 15 * cj + b] += acc;
         }
-        __syncthreads();
     }
-    // gradient g = J_p^T r, one thread per entry
+    // rotation priors (theta-theta block of the target frame) -- rare
+    if (w.nrot > 0) {
+        __syncthreads();
+        for (int o = t; o < nfree * 9; o += T) {
+            const int c = o / 9, ab = o - 9 * c, a = ab / 3, b = ab - 3 * a;
+            double acc = 0.0;
+            for (int k = 0; k < w.nrot; ++k)
+                if (w.fcol[w.rot_tgt[k]] == c) acc += w.Jro[6 * k + a] * w.Jro[6 * k + b] + w.Jro[6 * k + 3 + a] * w.Jro[6 * k + 3 + b];
+            w.H[(size_t)(15 * c + a) * N + 15 * c + b] += acc;
+        }
+    }
+    // remaining gradient terms, one thread per entry
     for (int o = t; o < N; o += T) {
         const int c = o / 15, a = o - 15 * c;
         double acc = 0.0;
-        if (a < 6) {
-            const int p = w.diag_pair[c];
-            for (int it = w.pair_off[p]; it < w.pair_off[p + 1]; ++it) {
-                const int item = w.pair_item[it], k = item >> 2, code = item & 3;
-                const double *Jx = ((code & 1) ? w.Jr : w.Jt) + 12 * (size_t)k;
-                acc += Jx[a] * w.r_f[2 * (size_t)k] + Jx[6 + a] * w.r_f[2 * (size_t)k + 1];
-            }
-            if (a < 3)
-                for (int k = 0; k < w.nrot; ++k)
-                    if (w.fcol[w.rot_tgt[k]] == c) acc += w.Jro[6 * k + a] * w.r_r[2 * k] + w.Jro[6 * k + 3 + a] * w.r_r[2 * k + 1];
-        }
+        if (a < 3)
+            for (int k = 0; k < w.nrot; ++k)
+                if (w.fcol[w.rot_tgt[k]] == c) acc += w.Jro[6 * k + a] * w.r_r[2 * k] + w.Jro[6 * k + 3 + a] * w.r_r[2 * k + 1];
         for (int k = 0; k < w.npre; ++k) {
             for (int x = 0; x < 2; ++x) {
                 if (w.fcol[x ? w.pre_j[k] : w.pre_i[k]] != c) continue;
@@ -263,88 +316,46 @@ DM void build_normal_equations(const SolverWs &w, Shared &sh) {
                 acc += w.le[15 * i + a];
             }
         }
-        w.g[o] = acc;
+        w.g[o] += acc;  // entries a < 6 already hold the reprojection part (written by exactly one lane above)
     }
     __syncthreads();
 }
 
-// ||J x||^2 and (J x).r over all residual blocks (x: unscaled-J coordinates: tp pose entries, tl landmarks)
-DM void jx_products(const SolverWs &w, Shared &sh, const double *tp, const double *tl, double *sq_out, double *dr_out) {
+// q = x^T (J^T J) x and l = (J x) . r from the assembled normal equations; x = (xp: N pose entries, xl: landmarks)
+DM void model_products(const SolverWs &w, Shared &sh, int &phase, const double *xp, const double *xl, double *q_out,
+                       double *l_out) {
     const int t = threadIdx.x;
-    double sq = 0.0, dr = 0.0;
-    for (int k = t; k < w.nf; k += T) {
-        const int ct = w.fcol[w.tgt[k]], cr = w.fcol[w.ref[k]], l = w.lm[k];
-        const double xl = w.lfree[l] ? tl[l] : 0.0;
-#pragma unroll
-        for (int row = 0; row < 2; ++row) {
-            double v = w.Jd[2 * (size_t)k + row] * xl;
-            if (ct >= 0)
-                for (int a = 0; a < 6; ++a) v += w.Jt[12 * (size_t)k + 6 * row + a] * tp[15 * ct + a];
-            if (cr >= 0)
-                for (int a = 0; a < 6; ++a) v += w.Jr[12 * (size_t)k + 6 * row + a] * tp[15 * cr + a];
-            sq += v * v;
-            dr += v * w.r_f[2 * (size_t)k + row];
-        }
+    const int N = w.N, NA = 6 * w.nfree;
+    double v[2] = {0.0, 0.0};
+    double part = 0.0;
+    block_matvec_rows<T>(w.H, N, N, N, xp, [&](int row, double hv) { part += xp[row] * hv; });
+    v[0] = part;
+    for (int i = t; i < N; i += T) v[1] += w.g[i] * xp[i];
+    for (int l = t; l < w.nl; l += T) {
+        if (!w.lfree[l]) continue;
+        const double *Arow = w.A + (size_t)l * NA;
+        double dotp = 0.0;
+        for (int i = 0; i < NA; ++i) dotp += Arow[i] * xp[15 * (i / 6) + (i % 6)];
+        v[0] += 2.0 * xl[l] * dotp + w.lm_m[l] * xl[l] * xl[l];
+        v[1] += w.lm_g[l] * xl[l];
     }
-    for (int k = t; k < w.nrot; k += T) {
-        const int c = w.fcol[w.rot_tgt[k]];
-        if (c < 0) continue;
-        for (int row = 0; row < 2; ++row) {
-            double v = 0.0;
-            for (int a = 0; a < 3; ++a) v += w.Jro[6 * k + 3 * row + a] * tp[15 * c + a];
-            sq += v * v;
-            dr += v * w.r_r[2 * k + row];
-        }
-    }
-    for (int o = t; o < w.npre * 15; o += T) {
-        const int k = o / 15, row = o - 15 * k;
-        const int ci = w.fcol[w.pre_i[k]], cj = w.fcol[w.pre_j[k]];
-        double v = 0.0;
-        if (ci >= 0)
-            for (int a = 0; a < 15; ++a) v += w.Jp[450 * k + 15 * row + a] * tp[15 * ci + a];
-        if (cj >= 0)
-            for (int a = 0; a < 15; ++a) v += w.Jp[450 * k + 225 + 15 * row + a] * tp[15 * cj + a];
-        sq += v * v;
-        dr += v * w.r_p[o];
-    }
-    if (w.np > 0) {
-        // J x = S (E x): ||J x||^2 = (Ex)^T Lambda (Ex), (J x).r = (Ex)^T (Lambda e + eta0)
-        for (int o = t; o < w.D; o += T) {
-            const int i = o / 15, a = o - 15 * i, c = w.fcol[w.prior_frames[i]];
-            double v = 0.0;
-            if (c >= 0) {
-                if (a < 3) {
-                    for (int b = 0; b < 3; ++b) v += w.Jri[9 * i + 3 * a + b] * tp[15 * c + b];
-                } else {
-                    v = tp[15 * c + a];
-                }
-            }
-            w.Ex[o] = v;
-        }
-        __syncthreads();
-        for (int row = t; row < w.D; row += T) {
-            double acc = 0.0;
-            for (int c = 0; c < w.D; ++c) acc += w.Lam[(size_t)row * w.D + c] * w.Ex[c];
-            sq += w.Ex[row] * acc;
-            dr += w.Ex[row] * w.le[row];
-        }
-    }
-    *sq_out = block_sum(sh, sq);
-    *dr_out = block_sum(sh, dr);
+    block_sum_n<T, 2>(sh, v, phase);
+    *q_out = v[0];
+    *l_out = v[1];
 }
 
-DM double x_norm_of(const SolverWs &w, Shared &sh, const double *st, const double *dep) {
+DM double x_norm_of(const SolverWs &w, Shared &sh, int &phase, const double *st, const double *dep) {
     const int t = threadIdx.x;
     double s = 0.0;
     for (int o = t; o < w.nfr * 16; o += T)
         if (w.fcol[o / 16] >= 0) s += st[o] * st[o];
     for (int l = t; l < w.nl; l += T)
         if (w.lfree[l]) s += dep[l] * dep[l];
-    return sqrt(block_sum(sh, s));
+    return sqrt(block_sum(sh, s, phase));
 }
 
 // gradient_max_norm = || x - Plus(x, -g) ||_inf  (TrustRegionMinimizer::EvaluateGradientAndJacobian)
-DM double grad_max_norm(const SolverWs &w, Shared &sh) {
+DM double grad_max_norm(const SolverWs &w, Shared &sh, int &phase) {
     const int t = threadIdx.x;
     double m = 0.0;
     for (int i = t; i < w.nfr; i += T) {
@@ -357,25 +368,25 @@ DM double grad_max_norm(const SolverWs &w, Shared &sh) {
     }
     for (int l = t; l < w.nl; l += T)
         if (w.lfree[l]) m = fmax(m, fabs(w.lm_g[l]));
-    return block_max(sh, m);
+    return block_max(sh, m, phase);
 }
 
 __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     __shared__ Shared sh;
     const int t = threadIdx.x;
     const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree;
+    int phase = 0;
+#ifdef RDVIO_PROF
+    unsigned long long prof_last = wall_clock64();
+    if (t == 0) for (int i = 8; i < 72; ++i) w.summary[i] = 0.0;
+#endif
 
     // ------------------------------------------------------------------ setup
     for (int i = t; i < w.nfr * 16; i += T) w.user[i] = w.x[i];
     for (int l = t; l < nl; l += T) w.lfree[l] = (w.lm_count[l] > 0 && !w.lm_fixed[l]) ? 1 : 0;
     if (w.np > 0) {
-        // Lambda = S^T S, eta0 = S^T f: constant during the solve
-        for (int o = t; o < w.D * w.D; o += T) {
-            const int a = o / w.D, b = o - a * w.D;
-            double acc = 0.0;
-            for (int q = 0; q < w.D; ++q) acc += w.S[(size_t)q * w.D + a] * w.S[(size_t)q * w.D + b];
-            w.Lam[o] = acc;
-        }
+        // Lambda = S^T S (MFMA tiles), eta0 = S^T f: constant during the solve
+        block_gemm_tn<T>(w.Lam, w.D, w.S, w.D, w.S, w.D, nullptr, w.D, w.D, w.D, false);
         for (int a = t; a < w.D; a += T) {
             double acc = 0.0;
             for (int q = 0; q < w.D; ++q) acc += w.S[(size_t)q * w.D + a] * w.f[q];
@@ -385,17 +396,21 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     __syncthreads();
 
     double radius = 1e4, mu = 1e-8, alpha = 0.0, dogleg_step_norm = 0.0;
+    double gnorm = 0.0, gn_norm = 0.0, gdotgn = 0.0;
     int reuse = 0, iteration = 0, invalid_steps = 0, last_successful = 0, n_success = 0;
     int term = 1;  // NO_CONVERGENCE
-    double x_norm = x_norm_of(w, sh, w.x, w.xd);
-    double x_cost = evaluate<true>(w, sh, w.x, w.xd);
+    STAMP(0);
+    double x_norm = x_norm_of(w, sh, phase, w.x, w.xd);
+    double x_cost = evaluate<true>(w, sh, phase, w.x, w.xd);
+    STAMP(1);
     const double initial_cost = x_cost;
     build_normal_equations(w, sh);
+    STAMP(2);
     // Jacobi scaling from the iteration-0 Jacobian
     for (int i = t; i < N; i += T) w.sig_p[i] = 1.0 / (1.0 + sqrt(w.H[(size_t)i * N + i]));
     for (int l = t; l < nl; l += T) w.sig_l[l] = 1.0 / (1.0 + sqrt(w.lm_m[l]));
     __syncthreads();
-    double grad_max = grad_max_norm(w, sh);
+    double grad_max = grad_max_norm(w, sh, phase);
 
     if (N == 0 && w.n_lfree_hint == 0) term = 0;
     else
@@ -409,6 +424,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             if (radius <= 1e-32) { term = 0; break; }
             iteration++;
             last_successful = 0;
+            STAMP(10);
 
             int solve_ok = 1;
             if (!reuse) {
@@ -434,10 +450,11 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     gsq += gv * gv;
                     w.tl[l] = s * gv / d;
                 }
-                gsq = block_sum(sh, gsq);
+                gsq = block_sum(sh, gsq, phase);  // (its barrier also orders the tp/tl writes before model_products)
                 double jsq, jdr;
-                jx_products(w, sh, w.tp, w.tl, &jsq, &jdr);
+                model_products(w, sh, phase, w.tp, w.tl, &jsq, &jdr);
                 alpha = gsq / jsq;
+                STAMP(3);
                 // Gauss-Newton step: (H_s + mu D^2) y = g_s with the landmarks eliminated
                 solve_ok = 0;
                 while (mu < 1.0) {
@@ -450,18 +467,22 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                         w.lm_w[l] = wl;
                     }
                     __syncthreads();
-                    // S = Sigma (H - A^T W A) Sigma + mu D^2   (lower triangle is what the factorisation reads)
+                    // C = A^T W A (lower tiles) on the matrix cores
+                    if (NA > 0 && nl > 0) block_gemm_tn<T>(w.Cm, NA, w.A, NA, w.A, NA, w.lm_w, NA, NA, nl, true);
+                    // rhs part A^T (w g)
+                    for (int ia = t; ia < NA; ia += T) {
+                        double acc = 0.0;
+                        for (int l = 0; l < nl; ++l) acc += w.A[(size_t)l * NA + ia] * (w.lm_w[l] * w.lm_g[l]);
+                        w.Cg[ia] = acc;
+                    }
+                    __syncthreads();
+                    // S = Sigma (H - C) Sigma + mu D^2   (lower triangle is what the factorisation reads)
                     for (int o = t; o < N * N; o += T) {
                         const int i = o / N, j = o - i * N;
                         if (j > i) continue;
                         const int fi = i / 15, a = i - 15 * fi, fj = j / 15, b = j - 15 * fj;
                         double v = w.H[o];
-                        if (a < 6 && b < 6) {
-                            const int ia = 6 * fi + a, jb = 6 * fj + b;
-                            double acc = 0.0;
-                            for (int l = 0; l < nl; ++l) acc += w.A[(size_t)l * NA + ia] * w.lm_w[l] * w.A[(size_t)l * NA + jb];
-                            v -= acc;
-                        }
+                        if (a < 6 && b < 6 && nl > 0) v -= w.Cm[(size_t)(6 * fi + a) * NA + 6 * fj + b];
                         v *= w.sig_p[i] * w.sig_p[j];
                         if (i == j) v += mu * w.diag_p[i] * w.diag_p[i];
                         w.Sm[o] = v;
@@ -469,25 +490,25 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     for (int i = t; i < N; i += T) {
                         const int fi = i / 15, a = i - 15 * fi;
                         double v = w.g[i];
-                        if (a < 6) {
-                            double acc = 0.0;
-                            for (int l = 0; l < nl; ++l) acc += w.A[(size_t)l * NA + 6 * fi + a] * w.lm_w[l] * w.lm_g[l];
-                            v -= acc;
-                        }
+                        if (a < 6) v -= w.Cg[6 * fi + a];
                         w.yp[i] = v * w.sig_p[i];
                     }
                     __syncthreads();
+                    STAMP(4);
                     int ok = (N == 0) ? 1 : cholesky_blocked(sh, w.Sm, N);
+                    STAMP(5);
                     if (ok && N > 0) cholesky_solve(sh, w.Sm, N, w.yp);
+                    STAMP(6);
                     double bad = 0.0;
                     if (ok) {
                         for (int l = t; l < nl; l += T) {
                             double y = 0.0;
                             if (w.lfree[l]) {
                                 double s = w.lm_g[l];
+                                const double *Arow = w.A + (size_t)l * NA;
                                 for (int i = 0; i < NA; ++i) {
                                     const int col = 15 * (i / 6) + (i % 6);
-                                    s -= w.A[(size_t)l * NA + i] * w.sig_p[col] * w.yp[col];
+                                    s -= Arow[i] * w.sig_p[col] * w.yp[col];
                                 }
                                 const double s2 = w.sig_l[l] * w.sig_l[l];
                                 y = w.sig_l[l] * s / (s2 * w.lm_m[l] + mu * w.diag_l[l] * w.diag_l[l]);
@@ -497,7 +518,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                         }
                         for (int i = t; i < N; i += T)
                             if (!isfinite(w.yp[i])) bad = 1.0;
-                        bad = block_max(sh, bad);
+                        bad = block_max(sh, bad, phase);
                     }
                     if (!ok || bad > 0.0) {
                         mu *= 10.0;
@@ -507,18 +528,31 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     break;
                 }
                 if (solve_ok) {
-                    for (int i = t; i < N; i += T) w.gn_p[i] = -w.yp[i] * w.diag_p[i];
-                    for (int l = t; l < nl; l += T) w.gn_l[l] = -w.yl[l] * w.diag_l[l];
-                    __syncthreads();
+                    double a3[3] = {0.0, 0.0, 0.0};
+                    for (int i = t; i < N; i += T) {
+                        const double gn = -w.yp[i] * w.diag_p[i];
+                        w.gn_p[i] = gn;
+                        a3[0] += w.grad_p[i] * w.grad_p[i];
+                        a3[1] += gn * gn;
+                        a3[2] += w.grad_p[i] * gn;
+                    }
+                    for (int l = t; l < nl; l += T) {
+                        const double gn = -w.yl[l] * w.diag_l[l];
+                        w.gn_l[l] = gn;
+                        a3[0] += w.grad_l[l] * w.grad_l[l];
+                        a3[1] += gn * gn;
+                        a3[2] += w.grad_l[l] * gn;
+                    }
+                    block_sum_n<T, 3>(sh, a3, phase);
+                    gnorm = sqrt(a3[0]);
+                    gn_norm = sqrt(a3[1]);
+                    gdotgn = a3[2];
                 }
+                STAMP(7);
             }
             int step_valid = 0;
             double model_cost_change = 0.0;
             if (solve_ok) {
-                double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-                for (int i = t; i < N; i += T) { a0 += w.grad_p[i] * w.grad_p[i]; a1 += w.gn_p[i] * w.gn_p[i]; a2 += w.grad_p[i] * w.gn_p[i]; }
-                for (int l = t; l < nl; l += T) { a0 += w.grad_l[l] * w.grad_l[l]; a1 += w.gn_l[l] * w.gn_l[l]; a2 += w.grad_l[l] * w.gn_l[l]; }
-                const double gnorm = sqrt(block_sum(sh, a0)), gn_norm = sqrt(block_sum(sh, a1)), gdotgn = block_sum(sh, a2);
                 double ca, cb;
                 bool need_norm = false;
                 if (gn_norm <= radius) { ca = 0.0; cb = 1.0; dogleg_step_norm = gn_norm; }
@@ -545,13 +579,14 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     sn += v * v;
                     w.tl[l] = w.lfree[l] ? w.sig_l[l] * (v / w.diag_l[l]) : 0.0;
                 }
-                sn = block_sum(sh, sn);
+                sn = block_sum(sh, sn, phase);
                 if (need_norm) dogleg_step_norm = sqrt(sn);
                 double jsq, jdr;
-                jx_products(w, sh, w.tp, w.tl, &jsq, &jdr);
+                model_products(w, sh, phase, w.tp, w.tl, &jsq, &jdr);
                 model_cost_change = -(jdr + 0.5 * jsq);
                 step_valid = model_cost_change > 0.0;
             }
+            STAMP(8);
             if (!step_valid) {
                 if (++invalid_steps >= 5) { term = 2; break; }
                 mu *= 10.0;
@@ -570,14 +605,15 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             }
             for (int l = t; l < nl; l += T) w.xdc[l] = w.xd[l] + (w.lfree[l] ? w.tl[l] : 0.0);
             __syncthreads();
-            double cand_cost = evaluate<false>(w, sh, w.xc, w.xdc);
+            double cand_cost = evaluate<false>(w, sh, phase, w.xc, w.xdc);
             if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
+            STAMP(9);
             double sn2 = 0.0;
             for (int o = t; o < w.nfr * 16; o += T)
                 if (w.fcol[o / 16] >= 0) { const double e = w.x[o] - w.xc[o]; sn2 += e * e; }
             for (int l = t; l < nl; l += T)
                 if (w.lfree[l]) { const double e = w.xd[l] - w.xdc[l]; sn2 += e * e; }
-            const double step_norm = sqrt(block_sum(sh, sn2));
+            const double step_norm = sqrt(block_sum(sh, sn2, phase));
             if (step_norm <= 1e-8 * (x_norm + 1e-8)) { term = 0; break; }
             const double cost_change = x_cost - cand_cost;
             if (fabs(cost_change) <= 1e-6 * x_cost) { term = 0; break; }
@@ -586,10 +622,14 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                 for (int o = t; o < w.nfr * 16; o += T) w.x[o] = w.xc[o];
                 for (int l = t; l < nl; l += T) w.xd[l] = w.xdc[l];
                 __syncthreads();
-                x_norm = x_norm_of(w, sh, w.x, w.xd);
-                x_cost = evaluate<true>(w, sh, w.x, w.xd);  // `user` still holds the previous point here
+                x_norm = x_norm_of(w, sh, phase, w.x, w.xd);
+                STAMP(10);
+                x_cost = evaluate<true>(w, sh, phase, w.x, w.xd);  // `user` still holds the previous point here
+                STAMP(1);
                 build_normal_equations(w, sh);
-                grad_max = grad_max_norm(w, sh);
+                STAMP(2);
+                grad_max = grad_max_norm(w, sh, phase);
+                STAMP(11);
                 last_successful = 1;
                 n_success++;
                 if (rel < 0.25) radius *= 0.5;

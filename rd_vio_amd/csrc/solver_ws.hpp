@@ -3,6 +3,8 @@
 #include <cstdint>
 
 #define RDVIO_SOLVER_THREADS 512
+// per-factor record of the stored linearisation: Jt[12] Jr[12] Jd[2] r[2] ht[6] hr[6] m g
+#define RDVIO_FAC_STRIDE 42
 
 struct SolverWs {
     // ---- problem (read-only on the device)
@@ -27,15 +29,16 @@ struct SolverWs {
     double *xc, *xdc, *user;
     uint8_t *lfree;
     // ---- stored linearisation
-    double *r_f, *Jt, *Jr, *Jd;
+    double *fac;                         // nf x RDVIO_FAC_STRIDE
     double *r_r, *Jro;
     double *e_p, *G, *r_p, *c_p, *Jp;    // Jp: per factor [Ji 225 | Jj 225]
     double *e_m, *r_m, *c_m, *Jri, *Lam, *eta0, *le, *Ex;
     // ---- normal equations / step
-    double *H, *Sm, *g, *yp;
+    double *H, *Sm, *g, *yp, *Cm, *Cg;   // Cm: (6 nfree)^2 landmark Schur term, Cg: its gradient part
     double *lm_m, *lm_g, *lm_w, *A, *yl;
     double *sig_p, *sig_l, *diag_p, *diag_l, *grad_p, *grad_l, *gn_p, *gn_l, *tp, *tl;
-    double *summary;                     // iterations, successful steps, initial cost, final cost, termination
+    double *summary;
+    double *prof;                        // diagnostic phase stamps (RDVIO_PROF builds only)                     // iterations, successful steps, initial cost, final cost, termination
 };
 
 void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w);

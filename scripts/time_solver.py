@@ -1,5 +1,5 @@
 """Developer timing aid: wall time of the resident BA solve for problem variants (GPU box only)."""
-import sys, time
+import os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
 import rd_vio_amd
@@ -31,3 +31,12 @@ for name, kw in (("full", {}), ("no_prior", dict(with_prior=False)), ("no_preint
     for iters in (0, 1, 5, 30):
         us, it, ok = timeit(pb, iters)
         print(f"{name:12s} F={len(pb['tgt'])} max_iter={iters:2d}: {us:9.1f} us  iterations={it} successful={ok}")
+        if os.environ.get("RDVIO_PROF") and iters == 30:
+            import ctypes
+            prof = np.zeros(64)
+            ctx._lib.rdvio_hip_debug_ba_prof(ctx._h, 0, ctypes.c_void_p(prof.ctypes.data))
+            names = ["setup", "eval_lin", "build_ne", "dogleg_prep", "schur", "cholesky", "tri_solve", "lm_y+norms",
+                     "step+model", "cand_eval", "misc", "gradmax"]
+            for i, nm in enumerate(names):
+                if prof[32 + i] > 0:
+                    print(f"      {nm:12s} total {prof[i] / 100:9.1f} us  calls {int(prof[32 + i]):3d}  avg {prof[i] / 100 / prof[32 + i]:8.2f} us")
