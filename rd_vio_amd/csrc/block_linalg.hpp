@@ -16,7 +16,31 @@ struct BlockShared {
     double vec[16];
     int flag;
     int red_phase;
+    // small per-problem index tables (solver): frame -> free column block, column block -> prior frame, preintegration sources
+    int fcol[32], pcol[32], band_src[32 * 6], g_src[32 * 2];
+    double Jri[32 * 9];  // Jr^-1(e_theta) of the prior frames at the current linearisation
+    double xv[512];      // staged vector operand (pose step / prior error)
 };
+
+// sum_i a[i * sa] * x[i * sx] with the loads of U iterations issued together (memory-level parallelism: a single
+// workgroup has little other latency hiding).  Summation order is fixed.
+template <int U = 8>
+DM double dot_strided(const double *__restrict__ a, long sa, const double *__restrict__ x, long sx, int n) {
+    double acc = 0.0;
+    int i = 0;
+    for (; i + U <= n; i += U) {
+        double av[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            av[u] = a[(long)(i + u) * sa];
+            xv[u] = x[(long)(i + u) * sx];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += av[u] * xv[u];
+    }
+    for (; i < n; ++i) acc += a[(long)i * sa] * x[(long)i * sx];
+    return acc;
+}
 
 DM double wave_sum(double v) {
 #pragma unroll
@@ -267,4 +291,112 @@ DM void cholesky_solve(BlockShared<T> &sh, const double *M, int N, double *b, bo
             }
             __syncthreads();
         }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-resident Cholesky.  The lower triangle of the N x N matrix lives in LDS packed row-major:
+// entry (r, c), c <= r, at Lp[r (r + 1) / 2 + c].
+// Factorisation: un-normalised outer-product form -- for column j every remaining entry does
+//     a_rc -= a_rj a_cj / a_jj          (j < c <= r)
+// with ONE barrier per column (no separate "scale the column" phase; the 1/sqrt(a_jj) scaling is applied to all
+// columns in one pass at the end).  The chain of N dependent steps is what bounds a Cholesky at this size; in LDS a
+// step is ~500 cycles (LDS bandwidth: N^3/6 entry updates x 4 LDS operations) instead of several L2 round trips.
+// Dinv receives the inverses of the 15 x 15 diagonal blocks of L so the triangular solves are small mat-vecs.
+// ---------------------------------------------------------------------------------------------------------
+DM int tri(int r) { return r * (r + 1) / 2; }
+
+template <int T>
+DM int cholesky_lds(BlockShared<T> &sh, double *Lp, double *Dinv, int N) {
+    const int t = threadIdx.x;
+    int ok = 1;
+    for (int j = 0; j < N - 1; ++j) {
+        const double ajj = Lp[tri(j) + j];
+        if (!(ajj > 0.0) || !isfinite(ajj)) ok = 0;  // uniform: every thread reads the same value
+        const double inv = 1.0 / ajj;
+        // 4 threads per row: (row r = j + 1 + t / 4, columns c = j + 1 + t % 4, +4, ...)
+        for (int r = j + 1 + (t >> 2); r < N; r += T / 4) {
+            double *row = Lp + tri(r);
+            const double s = row[j] * inv;
+            for (int c = j + 1 + (t & 3); c <= r; c += 4) row[c] -= s * Lp[tri(c) + j];
+        }
+        __syncthreads();
+    }
+    {
+        const double ann = Lp[tri(N - 1) + N - 1];
+        if (!(ann > 0.0) || !isfinite(ann)) ok = 0;
+    }
+    // scale: L_jj = sqrt(a_jj), L_ij = a_ij / L_jj
+    double *dv = sh.xv;
+    for (int j = t; j < N; j += T) dv[j] = sqrt(fabs(Lp[tri(j) + j]));
+    __syncthreads();
+    for (int r = t >> 2; r < N; r += T / 4) {
+        double *row = Lp + tri(r);
+        for (int c = (t & 3); c <= r; c += 4) row[c] = (c == r) ? dv[c] : row[c] / dv[c];
+    }
+    __syncthreads();
+    // inverses of the diagonal blocks: column c of L_kk^-1 by forward substitution, one thread per (block, column)
+    const int nb = N / 15;
+    for (int o = t; o < nb * 15; o += T) {
+        const int kb = o / 15, c = o - 15 * kb;
+        double x[15];
+#pragma unroll
+        for (int r = 0; r < 15; ++r) {
+            const double *Lr = Lp + tri(15 * kb + r) + 15 * kb;
+            double s = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int q = 0; q < 15; ++q)
+                if (q < r) s -= Lr[q] * x[q];
+            x[r] = (r >= c) ? s / Lr[r] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 15; ++r) Dinv[225 * kb + 15 * r + c] = x[r];
+    }
+    __syncthreads();
+    return ok;
+}
+
+// solve L L^T y = b with L packed in LDS and Dinv = inverses of its 15 x 15 diagonal blocks; b in place.
+template <int T>
+DM void cholesky_solve_lds(BlockShared<T> &sh, const double *Lp, const double *Dinv, int N, double *b) {
+    const int t = threadIdx.x, nb = N / 15;
+    double *y = sh.xv;  // N <= 512
+    for (int i = t; i < N; i += T) y[i] = b[i];
+    __syncthreads();
+    for (int kb = 0; kb < nb; ++kb) {  // forward: y_k = Dinv_k y_k ; later rows -= L_ik y_k
+        double v = 0.0;
+        if (t < 15) {
+#pragma unroll
+            for (int q = 0; q < 15; ++q) v += Dinv[225 * kb + 15 * t + q] * y[15 * kb + q];
+        }
+        __syncthreads();
+        if (t < 15) y[15 * kb + t] = v;
+        __syncthreads();
+        for (int i = 15 * (kb + 1) + t; i < N; i += T) {
+            const double *Lr = Lp + tri(i) + 15 * kb;
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < 15; ++q) s += Lr[q] * y[15 * kb + q];
+            y[i] -= s;
+        }
+        __syncthreads();
+    }
+    for (int kb = nb - 1; kb >= 0; --kb) {  // backward: y_k = Dinv_k^T y_k ; earlier rows -= L_ki^T y_k
+        double v = 0.0;
+        if (t < 15) {
+#pragma unroll
+            for (int q = 0; q < 15; ++q) v += Dinv[225 * kb + 15 * q + t] * y[15 * kb + q];
+        }
+        __syncthreads();
+        if (t < 15) y[15 * kb + t] = v;
+        __syncthreads();
+        for (int i = t; i < 15 * kb; i += T) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < 15; ++q) s += Lp[tri(15 * kb + q) + i] * y[15 * kb + q];
+            y[i] -= s;
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < N; i += T) b[i] = y[i];
+    __syncthreads();
 }

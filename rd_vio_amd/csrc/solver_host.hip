@@ -42,6 +42,7 @@ static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdv
     const int nfr = pb->n_frames, nl = pb->n_landmarks, nf = pb->n_factors, nrot = pb->n_rot, npre = pb->n_preint,
               np = pb->n_prior;
     if (nfr <= 0 || nl < 0 || nf < 0 || nrot < 0 || npre < 0 || np < 0) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "negative BA sizes");
+    if (nfr > 32) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "at most 32 frames per solve");
     if (nfr > ctx->max_window + 2) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d frames exceed window capacity %d", nfr, ctx->max_window + 2);
     if (nf > ctx->max_factors || nl > ctx->max_factors || nrot > ctx->max_factors)
         return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d factors / %d landmarks exceed capacity %d", nf, nl, ctx->max_factors);
@@ -101,9 +102,42 @@ static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdv
     visit([&](int p, int) { pair_off[p + 1]++; });
     for (int p = 0; p < npairs; ++p) pair_off[p + 1] += pair_off[p];
     std::vector<int32_t> pair_item((size_t)std::max(pair_off[npairs], 1));
+    std::vector<int32_t> slot_tt(std::max(nf, 1), -1), slot_rr(std::max(nf, 1), -1), slot_tr(std::max(nf, 1), -1);
     {
         std::vector<int32_t> cur(pair_off.begin(), pair_off.end() - 1);
-        visit([&](int p, int item) { pair_item[cur[p]++] = item; });
+        visit([&](int p, int item) {
+            const int k = item >> 2, code = item & 3, slot = cur[p]++;
+            pair_item[slot] = item;
+            (code == 0 ? slot_tt : code == 3 ? slot_rr : slot_tr)[k] = slot;
+        });
+    }
+    const int nrec = pair_off[npairs];
+    // preintegration sources per block of the (block-)band and per gradient block; at most two factors touch a block
+    std::vector<int32_t> band_src((size_t)std::max(nfree, 1) * 6, -1), g_src((size_t)std::max(nfree, 1) * 2, -1), pcol(std::max(nfree, 1), -1);
+    for (int k = 0; k < npre; ++k) {
+        const int cs[2] = {fcol[pb->pre_i[k]], fcol[pb->pre_j[k]]};
+        for (int x = 0; x < 2; ++x) {
+            if (cs[x] < 0) continue;
+            for (int y = 0; y < 2; ++y) {
+                if (cs[y] < 0) continue;
+                const int which = cs[y] - cs[x] + 1;
+                if (which < 0 || which > 2) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "preintegration factor %d links non-adjacent free frames", k);
+                int32_t *dst = &band_src[((size_t)cs[x] * 3 + which) * 2];
+                if (dst[0] < 0) dst[0] = k * 4 + x * 2 + y;
+                else if (dst[1] < 0) dst[1] = k * 4 + x * 2 + y;
+                else return rdvio_fail(ctx, RDVIO_ERR_INVALID, "more than two preintegration factors on one block");
+            }
+            int32_t *gd = &g_src[(size_t)cs[x] * 2];
+            if (gd[0] < 0) gd[0] = k * 2 + x;
+            else if (gd[1] < 0) gd[1] = k * 2 + x;
+            else return rdvio_fail(ctx, RDVIO_ERR_INVALID, "more than two preintegration factors on one frame");
+        }
+    }
+    for (int i = 0; i < np; ++i) {
+        const int c = fcol[pb->prior_frames[i]];
+        if (c < 0) continue;
+        if (pcol[c] >= 0) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "frame listed twice in the prior");
+        pcol[c] = i;
     }
     std::vector<int32_t> lm_first(std::max(nl, 1), 0), lm_count(std::max(nl, 1), 0);
     for (int k = 0; k < nf; ++k) {
@@ -138,6 +172,8 @@ static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdv
     const size_t o_poff = P.put(pair_off.data(), (size_t)npairs + 1);
     const size_t o_pitem = P.put(pair_item.data(), pair_item.size());
     const size_t o_dp = P.put(diag_pair.data(), diag_pair.size());
+    const size_t o_stt = P.put(slot_tt.data(), (size_t)nf), o_srr = P.put(slot_rr.data(), (size_t)nf), o_str = P.put(slot_tr.data(), (size_t)nf);
+    const size_t o_band = P.put(band_src.data(), band_src.size()), o_gsrc = P.put(g_src.data(), g_src.size()), o_pcol = P.put(pcol.data(), pcol.size());
     if (!P.ok) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "BA problem does not fit the context's staging buffer");
     const size_t in_bytes = P.off;
 
@@ -147,7 +183,8 @@ static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdv
     auto dd = [&](size_t n) { return Sx.reserve(std::max<size_t>(n, 1) * sizeof(double)); };
     const size_t s_x = dd((size_t)nfr * 16), s_xd = dd(nl), s_xc = dd((size_t)nfr * 16), s_xdc = dd(nl), s_user = dd((size_t)nfr * 16);
     const size_t s_lfree = Sx.reserve(std::max(nl, 1));
-    const size_t s_fac = dd((size_t)nf * RDVIO_FAC_STRIDE);
+    const size_t s_fac = dd((size_t)nf * RDVIO_FAC_STRIDE), s_prec = dd((size_t)nrec * RDVIO_REC_STRIDE), s_HP = dd((size_t)npairs * 42);
+    const size_t s_PP = dd((size_t)npre * 900), s_Pg = dd((size_t)npre * 30), s_ST = dd((size_t)D * D);
     const size_t s_rr = dd((size_t)nrot * 2), s_Jro = dd((size_t)nrot * 6);
     const size_t s_ep = dd((size_t)npre * 15), s_G = dd((size_t)npre * 450), s_rp = dd((size_t)npre * 15), s_cp = dd((size_t)npre * 15), s_Jp = dd((size_t)npre * 450);
     const size_t s_em = dd(D), s_rm = dd(D), s_cm = dd(D), s_Jri = dd((size_t)np * 9), s_Lam = dd((size_t)D * D), s_eta0 = dd(D), s_le = dd(D), s_Ex = dd(D);
@@ -162,7 +199,11 @@ static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdv
     SolverWs &w = slot.ws;
     memset(&w, 0, sizeof w);
     w.nfr = nfr; w.nl = nl; w.nf = nf; w.nrot = nrot; w.npre = npre; w.np = np; w.D = D; w.nfree = nfree; w.N = N;
-    w.npairs = npairs; w.n_lfree_hint = n_lfree;
+    w.npairs = npairs; w.n_lfree_hint = n_lfree; w.nrec = nrec;
+    {
+        w.lds_chol = (nfree > 0 && nfree <= RDVIO_LDS_CHOL_MAX_FRAMES) ? 1 : 0;
+        w.lds_bytes = 0;
+    }
 #define DP(off) ((double *)(B + (off)))
 #define IP(off) ((const int32_t *)(B + (off)))
     w.lm_fixed = B + o_lmfixed;
@@ -173,8 +214,9 @@ static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdv
     w.prior_frames = IP(o_pf); w.lin = DP(o_lin); w.S = DP(o_S); w.f = DP(o_f);
     w.fcol = IP(o_fcol); w.lm_first = IP(o_lmf); w.lm_count = IP(o_lmc);
     w.pair_fi = IP(o_pfi); w.pair_fj = IP(o_pfj); w.pair_off = IP(o_poff); w.pair_item = IP(o_pitem); w.diag_pair = IP(o_dp);
+    w.slot_tt = IP(o_stt); w.slot_rr = IP(o_srr); w.slot_tr = IP(o_str); w.band_src = IP(o_band); w.g_src = IP(o_gsrc); w.pcol = IP(o_pcol);
     w.x = DP(s_x); w.xd = DP(s_xd); w.xc = DP(s_xc); w.xdc = DP(s_xdc); w.user = DP(s_user); w.lfree = B + s_lfree;
-    w.fac = DP(s_fac); w.r_r = DP(s_rr); w.Jro = DP(s_Jro);
+    w.fac = DP(s_fac); w.prec = DP(s_prec); w.HP = DP(s_HP); w.PP = DP(s_PP); w.Pg = DP(s_Pg); w.ST = DP(s_ST); w.r_r = DP(s_rr); w.Jro = DP(s_Jro);
     w.e_p = DP(s_ep); w.G = DP(s_G); w.r_p = DP(s_rp); w.c_p = DP(s_cp); w.Jp = DP(s_Jp);
     w.e_m = DP(s_em); w.r_m = DP(s_rm); w.c_m = DP(s_cm); w.Jri = DP(s_Jri); w.Lam = DP(s_Lam); w.eta0 = DP(s_eta0); w.le = DP(s_le); w.Ex = DP(s_Ex);
     w.H = DP(s_H); w.Sm = DP(s_Sm); w.g = DP(s_g); w.yp = DP(s_yp); w.Cm = DP(s_Cm); w.Cg = DP(s_Cg);

@@ -51,8 +51,8 @@ using Shared = BlockShared<T>;
 DM double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // E_i[a, b] of the prior Jacobian J = S E, E = blockdiag(Jr^-1(e_theta), I12) per frame
-DM double prior_E(const SolverWs &w, int i, int a, int b) {
-    if (a < 3 && b < 3) return w.Jri[9 * i + 3 * a + b];
+DM double prior_E(const Shared &sh, int i, int a, int b) {
+    if (a < 3 && b < 3) return sh.Jri[9 * i + 3 * a + b];
     return a == b ? 1.0 : 0.0;
 }
 
@@ -62,7 +62,7 @@ DM double prior_E(const SolverWs &w, int i, int a, int b) {
 // factors and the prior's per-frame errors, so the two overlap.
 // ---------------------------------------------------------------------------------------------
 template <bool LIN>
-DM double evaluate(const SolverWs &w, Shared &sh, int &phase, const double *states, const double *invd) {
+DM double evaluate(const SolverWs &w, Shared &sh, int &phase, const double *states, const double *invd, unsigned long long &prof_last) {
     const int t = threadIdx.x;
     const double *W = w.extr + 14;
     double cost = 0.0;
@@ -103,6 +103,27 @@ DM double evaluate(const SolverWs &w, Shared &sh, int &phase, const double *stat
                 }
                 o[40] = Jd[0] * Jd[0] + Jd[1] * Jd[1];
                 o[41] = Jd[0] * r[0] + Jd[1] * r[1];
+                // pair-ordered copies: the assembly streams them without any indirection
+                const int stt = w.slot_tt[k], srr = w.slot_rr[k], str_ = w.slot_tr[k];
+                if (stt >= 0) {
+                    double *q = w.prec + RDVIO_REC_STRIDE * (size_t)stt;
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) { q[i] = Jt[i]; q[12 + i] = Jt[i]; }
+                    q[24] = r[0]; q[25] = r[1];
+                }
+                if (srr >= 0) {
+                    double *q = w.prec + RDVIO_REC_STRIDE * (size_t)srr;
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) { q[i] = Jr[i]; q[12 + i] = Jr[i]; }
+                    q[24] = r[0]; q[25] = r[1];
+                }
+                if (str_ >= 0) {
+                    double *q = w.prec + RDVIO_REC_STRIDE * (size_t)str_;
+                    const bool rows_are_ref = (w.pair_item[str_] & 1) != 0;  // code 1: rows Jr, cols Jt; code 2: rows Jt, cols Jr
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) { q[i] = rows_are_ref ? Jr[i] : Jt[i]; q[12 + i] = rows_are_ref ? Jt[i] : Jr[i]; }
+                    q[24] = r[0]; q[25] = r[1];
+                }
             }
         }
         for (int k = t; k < w.nrot; k += TF) {
@@ -136,11 +157,13 @@ DM double evaluate(const SolverWs &w, Shared &sh, int &phase, const double *stat
                 M3 Jri;
                 marginalization_frame_error(states + 16 * w.prior_frames[i], w.lin + 16 * i, w.e_m + 15 * i, LIN ? &Jri : nullptr);
                 if (LIN)
-                    for (int q = 0; q < 9; ++q) w.Jri[9 * i + q] = Jri.m[q];
+                    for (int q = 0; q < 9; ++q) sh.Jri[9 * i + q] = Jri.m[q];
             }
         }
     }
+    STAMP(LIN ? 17 : 20);
     __syncthreads();
+    STAMP(LIN ? 18 : 21);
     // whitening of the preintegration residuals (and Jacobians)
     if (w.npre > 0) {
         double *r_p = LIN ? w.r_p : w.c_p;
@@ -166,31 +189,74 @@ DM double evaluate(const SolverWs &w, Shared &sh, int &phase, const double *stat
             }
         }
     }
-    // marginalisation prior: r = S e + f; Jacobian handled through Lambda = S^T S (constant) and E
+    STAMP(LIN ? 19 : 22);
+    // marginalisation prior: r = S e + f (S^T stored, so consecutive threads read consecutive addresses);
+    // Jacobian handled through Lambda = S^T S (constant, symmetric) and E
     if (w.np > 0) {
         double *r_m = LIN ? w.r_m : w.c_m;
-        double csum = 0.0;
-        block_matvec_rows<T>(w.S, w.D, w.D, w.D, w.e_m, [&](int row, double v) {
-            const double r = v + w.f[row];
+        const int D = w.D;
+        for (int c = t; c < D; c += T) sh.xv[c] = w.e_m[c];
+        __syncthreads();
+        for (int row = t; row < D; row += T) {
+            const double r = dot_strided(w.ST + row, D, sh.xv, 1, D) + w.f[row];
             r_m[row] = r;
-            csum += 0.5 * r * r;
-        });
-        cost += csum;
-        if (LIN)
-            block_matvec_rows<T>(w.Lam, w.D, w.D, w.D, w.e_m, [&](int row, double v) { w.le[row] = v + w.eta0[row]; });
+            cost += 0.5 * r * r;
+            if (LIN) w.le[row] = dot_strided(w.Lam + row, D, sh.xv, 1, D) + w.eta0[row];
+        }
     }
     return block_sum(sh, cost, phase);
 }
 
 // ---------------------------------------------------------------------------------------------
-// normal equations from the stored linearisation: H, g, landmark scalars, coupling rows A
+// normal equations from the stored linearisation: H, g, landmark scalars, coupling rows A.
+// Phase 1 (independent loops, no barrier between them): per-pair reprojection products HP (one wavefront per
+// frame pair streaming that pair's contiguous records), landmark rows, per-factor preintegration products.
+// Phase 2: one output-stationary pass writes every H / g entry as prior + preintegration + reprojection part.
 // ---------------------------------------------------------------------------------------------
-DM void build_normal_equations(const SolverWs &w, Shared &sh) {
+DM double prior_part(const SolverWs &w, const Shared &sh, int pi, int a, int pj, int b) {
+    const int D = w.D;
+    if (a >= 3 && b >= 3) return w.Lam[(size_t)(15 * pi + a) * D + 15 * pj + b];
+    double acc = 0.0;
+    const int a0 = a < 3 ? 0 : a, a1 = a < 3 ? 3 : a + 1, b0 = b < 3 ? 0 : b, b1 = b < 3 ? 3 : b + 1;
+    for (int aa = a0; aa < a1; ++aa)
+        for (int bb = b0; bb < b1; ++bb)
+            acc += prior_E(sh, pi, aa, a) * w.Lam[(size_t)(15 * pi + aa) * D + 15 * pj + bb] * prior_E(sh, pj, bb, b);
+    return acc;
+}
+
+DM void build_normal_equations(const SolverWs &w, Shared &sh, unsigned long long &prof_last) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int N = w.N, nfree = w.nfree, NA = 6 * nfree;
-    for (int i = t; i < N * N; i += T) w.H[i] = 0.0;
-    for (int i = t; i < N; i += T) w.g[i] = 0.0;
-    // landmarks: factors of one landmark are contiguous (lm sorted); one thread per landmark, fixed order
+    // ---- phase 1a: reprojection J_x^T J_y (36) and J_x^T r (6) per frame pair; fixed record order => deterministic
+    for (int p = wave; p < w.npairs; p += NW) {
+        if (lane < 42) {
+            const int a = (lane < 36) ? lane / 6 : lane - 36, b = (lane < 36) ? lane - 6 * (lane / 6) : 0;
+            const bool is_h = lane < 36;
+            const double *rec = w.prec + RDVIO_REC_STRIDE * (size_t)w.pair_off[p];
+            const int n = w.pair_off[p + 1] - w.pair_off[p];
+            // is_h: acc += Jx[a] Jy[b] + Jx[6+a] Jy[6+b];  else: acc += Jx[a] r0 + Jx[6+a] r1
+            const int o1 = is_h ? 12 + b : 24, o2 = is_h ? 18 + b : 25;
+            double acc = 0.0;
+            int it = 0;
+            for (; it + 4 <= n; it += 4) {
+                double x0[4], x1[4], y0[4], y1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double *q = rec + RDVIO_REC_STRIDE * (size_t)(it + u);
+                    x0[u] = q[a]; x1[u] = q[6 + a]; y0[u] = q[o1]; y1[u] = q[o2];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc += x0[u] * y0[u] + x1[u] * y1[u];
+            }
+            for (; it < n; ++it) {
+                const double *q = rec + RDVIO_REC_STRIDE * (size_t)it;
+                acc += q[a] * q[o1] + q[6 + a] * q[o2];
+            }
+            w.HP[42 * (size_t)p + lane] = acc;
+        }
+    }
+    STAMP(12);
+    // ---- phase 1b: landmarks (factors of one landmark are contiguous): scalars and coupling rows
     for (int l = t; l < w.nl; l += T) {
         double *Arow = w.A + (size_t)l * NA;
         for (int i = 0; i < NA; ++i) Arow[i] = 0.0;
@@ -200,7 +266,7 @@ DM void build_normal_equations(const SolverWs &w, Shared &sh) {
                 const double *o = w.fac + RDVIO_FAC_STRIDE * (size_t)k;
                 m += o[40];
                 gl += o[41];
-                const int ct = w.fcol[w.tgt[k]], cr = w.fcol[w.ref[k]];
+                const int ct = sh.fcol[w.tgt[k]], cr = sh.fcol[w.ref[k]];
                 if (ct >= 0)
                     for (int a = 0; a < 6; ++a) Arow[6 * ct + a] += o[28 + a];
                 if (cr >= 0)
@@ -210,115 +276,78 @@ DM void build_normal_equations(const SolverWs &w, Shared &sh) {
         w.lm_m[l] = m;
         w.lm_g[l] = gl;
     }
-    __syncthreads();
-    // reprojection J_p^T J_p and J_p^T r: one wavefront per frame pair; lanes 0..35 = block entries (a, b),
-    // lanes 36..41 = gradient entries of diagonal pairs.  Fixed item order => deterministic sums.
-    for (int p = wave; p < w.npairs; p += NW) {
-        const int fi = w.pair_fi[p], fj = w.pair_fj[p];
-        const int a = (lane < 36) ? lane / 6 : lane - 36, b = (lane < 36) ? lane - 6 * (lane / 6) : 0;
-        const bool is_h = lane < 36, is_g = lane >= 36 && lane < 42 && fi == fj;
+    STAMP(13);
+    // ---- phase 1c: per preintegration factor [Ji Jj]^T [Ji Jj] (30 x 30) and [Ji Jj]^T r (30)
+    for (int o = t; o < w.npre * 900; o += T) {
+        const int k = o / 900, rc = o - 900 * k, ra = rc / 30, cb = rc - 30 * ra;
+        const double *Jx = w.Jp + 450 * k + 225 * (ra / 15) + (ra % 15), *Jy = w.Jp + 450 * k + 225 * (cb / 15) + (cb % 15);
         double acc = 0.0;
-        if (is_h || is_g) {
-            for (int it = w.pair_off[p]; it < w.pair_off[p + 1]; ++it) {
-                const int item = w.pair_item[it], k = item >> 2, code = item & 3;
-                // code bit0: row block uses Jr (else Jt); bit1: column block uses Jr (else Jt)
-                const double *o = w.fac + RDVIO_FAC_STRIDE * (size_t)k;
-                const double *Jx = o + ((code & 1) ? 12 : 0);
-                if (is_h) {
-                    const double *Jy = o + ((code & 2) ? 12 : 0);
-                    acc += Jx[a] * Jy[b] + Jx[6 + a] * Jy[6 + b];
-                } else {
-                    acc += Jx[a] * o[26] + Jx[6 + a] * o[27];
-                }
-            }
-            if (is_h) {
-                w.H[(size_t)(15 * fi + a) * N + 15 * fj + b] = acc;
-                if (fi != fj) w.H[(size_t)(15 * fj + b) * N + 15 * fi + a] = acc;
-            } else {
-                w.g[15 * fi + a] = acc;
-            }
-        }
-    }
-    __syncthreads();
-    // preintegration factors: block (c, c2) receives J_x^T J_y of every factor touching both frames
-    if (w.npre > 0) {
-        for (int o = t; o < nfree * 3 * 225; o += T) {
-            const int c = o / 675, rem = o - 675 * c, which = rem / 225, ab = rem - 225 * which, a = ab / 15, b = ab - 15 * a;
-            const int c2 = c + which - 1;  // which: 0 -> (c, c-1), 1 -> (c, c), 2 -> (c, c+1)
-            if (c2 < 0 || c2 >= nfree) continue;
-            double acc = 0.0;
-            bool any = false;
-            for (int k = 0; k < w.npre; ++k) {
-                const int ci = w.fcol[w.pre_i[k]], cj = w.fcol[w.pre_j[k]];
-                for (int x = 0; x < 2; ++x)
-                    for (int y = 0; y < 2; ++y) {
-                        if ((x ? cj : ci) != c || (y ? cj : ci) != c2) continue;
-                        const double *Jx = w.Jp + 450 * k + 225 * x, *Jy = w.Jp + 450 * k + 225 * y;
 #pragma unroll
-                        for (int q = 0; q < 15; ++q) acc += Jx[q * 15 + a] * Jy[q * 15 + b];
-                        any = true;
-                    }
+        for (int q = 0; q < 15; ++q) acc += Jx[q * 15] * Jy[q * 15];
+        w.PP[o] = acc;
+    }
+    for (int o = t; o < w.npre * 30; o += T) {
+        const int k = o / 30, ra = o - 30 * k;
+        const double *Jx = w.Jp + 450 * k + 225 * (ra / 15) + (ra % 15);
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 15; ++q) acc += Jx[q * 15] * w.r_p[15 * k + q];
+        w.Pg[o] = acc;
+    }
+    STAMP(14);
+    __syncthreads();
+    STAMP(15);
+    // ---- phase 2: every entry of H and g, output-stationary
+    for (int o = t; o < N * N; o += T) {
+        const int i = o / N, j = o - i * N, fi = i / 15, a = i - 15 * fi, fj = j / 15, b = j - 15 * fj;
+        double v = 0.0;
+        const int pi = sh.pcol[fi], pj = sh.pcol[fj];
+        if (pi >= 0 && pj >= 0) v += prior_part(w, sh, pi, a, pj, b);
+        const int which = fj - fi + 1;
+        if (which >= 0 && which <= 2) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int src = sh.band_src[(fi * 3 + which) * 2 + s2];
+                if (src >= 0) v += w.PP[900 * (size_t)(src >> 2) + 30 * (15 * ((src >> 1) & 1) + a) + 15 * (src & 1) + b];
             }
-            if (any) w.H[(size_t)(15 * c + a) * N + 15 * c2 + b] += acc;
         }
-        __syncthreads();
-    }
-    // prior: E^T Lambda E
-    if (w.np > 0) {
-        for (int o = t; o < w.D * w.D; o += T) {
-            const int ra = o / w.D, cb = o - ra * w.D, i = ra / 15, a = ra - 15 * i, j = cb / 15, b = cb - 15 * j;
-            const int ci = w.fcol[w.prior_frames[i]], cj = w.fcol[w.prior_frames[j]];
-            if (ci < 0 || cj < 0) continue;
-            double acc;
-            if (a >= 3 && b >= 3) {
-                acc = w.Lam[(size_t)ra * w.D + cb];
-            } else {
-                acc = 0.0;
-                const int a0 = a < 3 ? 0 : a, a1 = a < 3 ? 3 : a + 1, b0 = b < 3 ? 0 : b, b1 = b < 3 ? 3 : b + 1;
-                for (int aa = a0; aa < a1; ++aa)
-                    for (int bb = b0; bb < b1; ++bb)
-                        acc += prior_E(w, i, aa, a) * w.Lam[(size_t)(15 * i + aa) * w.D + 15 * j + bb] * prior_E(w, j, bb, b);
-            }
-            w.H[(size_t)(15 * ci + a) * N + 15 * cj + b] += acc;
+        if (a < 6 && b < 6) {
+            // pairs are stored for fi <= fj; the mirrored block is the transpose
+            const int lo = fi <= fj ? fi : fj, hi = fi <= fj ? fj : fi;
+            const int p = lo * nfree - lo * (lo - 1) / 2 + (hi - lo);
+            v += (fi <= fj) ? w.HP[42 * (size_t)p + 6 * a + b] : w.HP[42 * (size_t)p + 6 * b + a];
+            if (fi == fj && a < 3 && b < 3)
+                for (int k = 0; k < w.nrot; ++k)
+                    if (sh.fcol[w.rot_tgt[k]] == fi) v += w.Jro[6 * k + a] * w.Jro[6 * k + b] + w.Jro[6 * k + 3 + a] * w.Jro[6 * k + 3 + b];
         }
+        w.H[o] = v;
     }
-    // rotation priors (theta-theta block of the target frame) -- rare
-    if (w.nrot > 0) {
-        __syncthreads();
-        for (int o = t; o < nfree * 9; o += T) {
-            const int c = o / 9, ab = o - 9 * c, a = ab / 3, b = ab - 3 * a;
-            double acc = 0.0;
-            for (int k = 0; k < w.nrot; ++k)
-                if (w.fcol[w.rot_tgt[k]] == c) acc += w.Jro[6 * k + a] * w.Jro[6 * k + b] + w.Jro[6 * k + 3 + a] * w.Jro[6 * k + 3 + b];
-            w.H[(size_t)(15 * c + a) * N + 15 * c + b] += acc;
-        }
-    }
-    // remaining gradient terms, one thread per entry
     for (int o = t; o < N; o += T) {
         const int c = o / 15, a = o - 15 * c;
         double acc = 0.0;
-        if (a < 3)
-            for (int k = 0; k < w.nrot; ++k)
-                if (w.fcol[w.rot_tgt[k]] == c) acc += w.Jro[6 * k + a] * w.r_r[2 * k] + w.Jro[6 * k + 3 + a] * w.r_r[2 * k + 1];
-        for (int k = 0; k < w.npre; ++k) {
-            for (int x = 0; x < 2; ++x) {
-                if (w.fcol[x ? w.pre_j[k] : w.pre_i[k]] != c) continue;
-                const double *Jx = w.Jp + 450 * k + 225 * x;
+        if (a < 6) {
+            acc += w.HP[42 * (size_t)w.diag_pair[c] + 36 + a];
+            if (a < 3)
+                for (int k = 0; k < w.nrot; ++k)
+                    if (sh.fcol[w.rot_tgt[k]] == c) acc += w.Jro[6 * k + a] * w.r_r[2 * k] + w.Jro[6 * k + 3 + a] * w.r_r[2 * k + 1];
+        }
 #pragma unroll
-                for (int q = 0; q < 15; ++q) acc += Jx[q * 15 + a] * w.r_p[15 * k + q];
-            }
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int src = sh.g_src[2 * c + s2];
+            if (src >= 0) acc += w.Pg[30 * (size_t)(src >> 1) + 15 * (src & 1) + a];
         }
-        for (int i = 0; i < w.np; ++i) {
-            if (w.fcol[w.prior_frames[i]] != c) continue;
+        const int pi = sh.pcol[c];
+        if (pi >= 0) {
             if (a < 3) {
-                for (int aa = 0; aa < 3; ++aa) acc += prior_E(w, i, aa, a) * w.le[15 * i + aa];
+                for (int aa = 0; aa < 3; ++aa) acc += prior_E(sh, pi, aa, a) * w.le[15 * pi + aa];
             } else {
-                acc += w.le[15 * i + a];
+                acc += w.le[15 * pi + a];
             }
         }
-        w.g[o] += acc;  // entries a < 6 already hold the reprojection part (written by exactly one lane above)
+        w.g[o] = acc;
     }
     __syncthreads();
+    STAMP(16);
 }
 
 // q = x^T (J^T J) x and l = (J x) . r from the assembled normal equations; x = (xp: N pose entries, xl: landmarks)
@@ -327,15 +356,24 @@ DM void model_products(const SolverWs &w, Shared &sh, int &phase, const double *
     const int t = threadIdx.x;
     const int N = w.N, NA = 6 * w.nfree;
     double v[2] = {0.0, 0.0};
-    double part = 0.0;
-    block_matvec_rows<T>(w.H, N, N, N, xp, [&](int row, double hv) { part += xp[row] * hv; });
-    v[0] = part;
-    for (int i = t; i < N; i += T) v[1] += w.g[i] * xp[i];
+    for (int c = t; c < N; c += T) sh.xv[c] = xp[c];
+    __syncthreads();
+    for (int r = t; r < N; r += T) {
+        const double acc = dot_strided(w.H + r, N, sh.xv, 1, N);
+        v[0] += sh.xv[r] * acc;
+        v[1] += w.g[r] * sh.xv[r];
+    }
     for (int l = t; l < w.nl; l += T) {
         if (!w.lfree[l]) continue;
         const double *Arow = w.A + (size_t)l * NA;
         double dotp = 0.0;
-        for (int i = 0; i < NA; ++i) dotp += Arow[i] * xp[15 * (i / 6) + (i % 6)];
+        for (int f = 0; f < w.nfree; ++f) {
+            double av[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) av[a] = Arow[6 * f + a];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) dotp += av[a] * sh.xv[15 * f + a];
+        }
         v[0] += 2.0 * xl[l] * dotp + w.lm_m[l] * xl[l] * xl[l];
         v[1] += w.lm_g[l] * xl[l];
     }
@@ -373,18 +411,31 @@ DM double grad_max_norm(const SolverWs &w, Shared &sh, int &phase) {
 
 __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     __shared__ Shared sh;
+    // packed 15x15 blocks of S and the inverses of its diagonal factors, LDS-resident when the window has at most
+    // RDVIO_LDS_CHOL_MAX_FRAMES free frames (138.6 KB of the CU's 160 KB); larger windows factor in global memory
+    constexpr int NMAX = 15 * RDVIO_LDS_CHOL_MAX_FRAMES;
+    __shared__ __attribute__((aligned(16))) double lds_chol_buf[NMAX * (NMAX + 1) / 2 + 225 * RDVIO_LDS_CHOL_MAX_FRAMES];
+    double *Sl = lds_chol_buf, *Dinv = lds_chol_buf + w.N * (w.N + 1) / 2;
     const int t = threadIdx.x;
     const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree;
     int phase = 0;
+    unsigned long long prof_last = 0;
 #ifdef RDVIO_PROF
-    unsigned long long prof_last = wall_clock64();
+    prof_last = wall_clock64();
     if (t == 0) for (int i = 8; i < 72; ++i) w.summary[i] = 0.0;
 #endif
 
     // ------------------------------------------------------------------ setup
     for (int i = t; i < w.nfr * 16; i += T) w.user[i] = w.x[i];
     for (int l = t; l < nl; l += T) w.lfree[l] = (w.lm_count[l] > 0 && !w.lm_fixed[l]) ? 1 : 0;
+    for (int i = t; i < 32; i += T) {
+        sh.fcol[i] = (i < w.nfr) ? w.fcol[i] : -1;
+        sh.pcol[i] = (i < nfree) ? w.pcol[i] : -1;
+    }
+    for (int i = t; i < nfree * 6; i += T) sh.band_src[i] = w.band_src[i];
+    for (int i = t; i < nfree * 2; i += T) sh.g_src[i] = w.g_src[i];
     if (w.np > 0) {
+        for (int o = t; o < w.D * w.D; o += T) w.ST[o] = w.S[(size_t)(o % w.D) * w.D + o / w.D];
         // Lambda = S^T S (MFMA tiles), eta0 = S^T f: constant during the solve
         block_gemm_tn<T>(w.Lam, w.D, w.S, w.D, w.S, w.D, nullptr, w.D, w.D, w.D, false);
         for (int a = t; a < w.D; a += T) {
@@ -401,10 +452,10 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     int term = 1;  // NO_CONVERGENCE
     STAMP(0);
     double x_norm = x_norm_of(w, sh, phase, w.x, w.xd);
-    double x_cost = evaluate<true>(w, sh, phase, w.x, w.xd);
+    double x_cost = evaluate<true>(w, sh, phase, w.x, w.xd, prof_last);
     STAMP(1);
     const double initial_cost = x_cost;
-    build_normal_equations(w, sh);
+    build_normal_equations(w, sh, prof_last);
     STAMP(2);
     // Jacobi scaling from the iteration-0 Jacobian
     for (int i = t; i < N; i += T) w.sig_p[i] = 1.0 / (1.0 + sqrt(w.H[(size_t)i * N + i]));
@@ -470,13 +521,11 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     // C = A^T W A (lower tiles) on the matrix cores
                     if (NA > 0 && nl > 0) block_gemm_tn<T>(w.Cm, NA, w.A, NA, w.A, NA, w.lm_w, NA, NA, nl, true);
                     // rhs part A^T (w g)
-                    for (int ia = t; ia < NA; ia += T) {
-                        double acc = 0.0;
-                        for (int l = 0; l < nl; ++l) acc += w.A[(size_t)l * NA + ia] * (w.lm_w[l] * w.lm_g[l]);
-                        w.Cg[ia] = acc;
-                    }
+                    for (int l = t; l < nl; l += T) w.yl[l] = w.lm_w[l] * w.lm_g[l];  // scratch: overwritten below
                     __syncthreads();
-                    // S = Sigma (H - C) Sigma + mu D^2   (lower triangle is what the factorisation reads)
+                    for (int ia = t; ia < NA; ia += T) w.Cg[ia] = dot_strided(w.A + ia, NA, w.yl, 1, nl);
+                    __syncthreads();
+                    // S = Sigma (H - C) Sigma + mu D^2   (lower triangle); packed LDS blocks when they fit
                     for (int o = t; o < N * N; o += T) {
                         const int i = o / N, j = o - i * N;
                         if (j > i) continue;
@@ -485,7 +534,8 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                         if (a < 6 && b < 6 && nl > 0) v -= w.Cm[(size_t)(6 * fi + a) * NA + 6 * fj + b];
                         v *= w.sig_p[i] * w.sig_p[j];
                         if (i == j) v += mu * w.diag_p[i] * w.diag_p[i];
-                        w.Sm[o] = v;
+                        if (w.lds_chol) Sl[tri(i) + j] = v;
+                        else w.Sm[o] = v;
                     }
                     for (int i = t; i < N; i += T) {
                         const int fi = i / 15, a = i - 15 * fi;
@@ -495,20 +545,29 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     }
                     __syncthreads();
                     STAMP(4);
-                    int ok = (N == 0) ? 1 : cholesky_blocked(sh, w.Sm, N);
+                    int ok = 1;
+                    if (N > 0) ok = w.lds_chol ? cholesky_lds(sh, Sl, Dinv, N) : cholesky_blocked(sh, w.Sm, N);
                     STAMP(5);
-                    if (ok && N > 0) cholesky_solve(sh, w.Sm, N, w.yp);
+                    if (ok && N > 0) {
+                        if (w.lds_chol) cholesky_solve_lds(sh, Sl, Dinv, N, w.yp);
+                        else cholesky_solve(sh, w.Sm, N, w.yp);
+                    }
                     STAMP(6);
                     double bad = 0.0;
                     if (ok) {
+                        for (int i = t; i < N; i += T) sh.xv[i] = w.sig_p[i] * w.yp[i];
+                        __syncthreads();
                         for (int l = t; l < nl; l += T) {
                             double y = 0.0;
                             if (w.lfree[l]) {
                                 double s = w.lm_g[l];
                                 const double *Arow = w.A + (size_t)l * NA;
-                                for (int i = 0; i < NA; ++i) {
-                                    const int col = 15 * (i / 6) + (i % 6);
-                                    s -= Arow[i] * w.sig_p[col] * w.yp[col];
+                                for (int f = 0; f < nfree; ++f) {
+                                    double av[6];
+#pragma unroll
+                                    for (int a = 0; a < 6; ++a) av[a] = Arow[6 * f + a];
+#pragma unroll
+                                    for (int a = 0; a < 6; ++a) s -= av[a] * sh.xv[15 * f + a];
                                 }
                                 const double s2 = w.sig_l[l] * w.sig_l[l];
                                 y = w.sig_l[l] * s / (s2 * w.lm_m[l] + mu * w.diag_l[l] * w.diag_l[l]);
@@ -605,7 +664,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             }
             for (int l = t; l < nl; l += T) w.xdc[l] = w.xd[l] + (w.lfree[l] ? w.tl[l] : 0.0);
             __syncthreads();
-            double cand_cost = evaluate<false>(w, sh, phase, w.xc, w.xdc);
+            double cand_cost = evaluate<false>(w, sh, phase, w.xc, w.xdc, prof_last);
             if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
             STAMP(9);
             double sn2 = 0.0;
@@ -624,9 +683,9 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                 __syncthreads();
                 x_norm = x_norm_of(w, sh, phase, w.x, w.xd);
                 STAMP(10);
-                x_cost = evaluate<true>(w, sh, phase, w.x, w.xd);  // `user` still holds the previous point here
+                x_cost = evaluate<true>(w, sh, phase, w.x, w.xd, prof_last);  // `user` still holds the previous point here
                 STAMP(1);
-                build_normal_equations(w, sh);
+                build_normal_equations(w, sh, prof_last);
                 STAMP(2);
                 grad_max = grad_max_norm(w, sh, phase);
                 STAMP(11);

@@ -5,6 +5,8 @@
 #define RDVIO_SOLVER_THREADS 512
 // per-factor record of the stored linearisation: Jt[12] Jr[12] Jd[2] r[2] ht[6] hr[6] m g
 #define RDVIO_FAC_STRIDE 42
+#define RDVIO_REC_STRIDE 26
+#define RDVIO_LDS_CHOL_MAX_FRAMES 11
 
 struct SolverWs {
     // ---- problem (read-only on the device)
@@ -24,12 +26,22 @@ struct SolverWs {
     const int32_t *fcol;                 // frame -> free slot or -1
     const int32_t *lm_first, *lm_count;  // factors of a landmark are contiguous
     const int32_t *pair_fi, *pair_fj, *pair_off, *pair_item, *diag_pair;
+    const int32_t *slot_tt, *slot_rr, *slot_tr;  // per factor: destination record in the pair-ordered array (-1: none)
+    const int32_t *band_src;             // nfree x 3 x 2: preintegration sources of H block (c, c+which-1): k*4+x*2+y or -1
+    const int32_t *g_src;                // nfree x 2: preintegration sources of g block c: k*2+x or -1
+    const int32_t *pcol;                 // nfree: prior frame index of a free column block or -1
+    int nrec;
+    int lds_chol, lds_bytes;             // packed LDS Cholesky when 15-blocks of S (+ inverses) fit in LDS
     // ---- state
     double *x, *xd;                      // in/out: frame states, inverse depths
     double *xc, *xdc, *user;
     uint8_t *lfree;
     // ---- stored linearisation
     double *fac;                         // nf x RDVIO_FAC_STRIDE
+    double *prec;                        // nrec x RDVIO_REC_STRIDE: pair-ordered [Jx(12) Jy(12) r(2)] records
+    double *HP;                          // npairs x 42: per pair J_x^T J_y (36) and, for diagonal pairs, J_x^T r (6)
+    double *PP, *Pg;                     // npre x 900 / npre x 30: per preintegration factor [Ji Jj]^T [Ji Jj], [Ji Jj]^T r
+    double *ST;                          // D x D: transpose of the prior's S (coalesced S e)
     double *r_r, *Jro;
     double *e_p, *G, *r_p, *c_p, *Jp;    // Jp: per factor [Ji 225 | Jj 225]
     double *e_m, *r_m, *c_m, *Jri, *Lam, *eta0, *le, *Ex;
