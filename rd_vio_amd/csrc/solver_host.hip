@@ -59,6 +59,18 @@ static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdv
             return rdvio_fail(ctx, RDVIO_ERR_INVALID, "factor %d indexes out of range", k);
         if (k > 0 && pb->lm[k] < pb->lm[k - 1]) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "factors must be ordered by landmark (factor %d)", k);
     }
+    // a track is anchored in ONE frame (Track::first_frame) and observed at most once per frame (track.h keypoint_refs)
+    for (int k = 0; k < nf;) {
+        int e = k;
+        uint32_t seen = 0;
+        while (e < nf && pb->lm[e] == pb->lm[k]) {
+            if (pb->ref[e] != pb->ref[k]) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "landmark %d has two anchor frames", pb->lm[k]);
+            if (pb->tgt[e] == pb->ref[e] || (seen >> pb->tgt[e]) & 1u) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "landmark %d observed twice in one frame", pb->lm[k]);
+            seen |= 1u << pb->tgt[e];
+            ++e;
+        }
+        k = e;
+    }
     for (int k = 0; k < nrot; ++k)
         if (pb->rot_tgt[k] < 0 || pb->rot_tgt[k] >= nfr || pb->rot_ref[k] < 0 || pb->rot_ref[k] >= nfr)
             return rdvio_fail(ctx, RDVIO_ERR_INVALID, "rotation prior %d indexes out of range", k);
@@ -87,31 +99,40 @@ static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdv
                 ++p;
             }
     }
-    std::vector<int32_t> pair_off(npairs + 1, 0);
-    auto visit = [&](auto &&emit) {
-        for (int k = 0; k < nf; ++k) {
-            const int ct = fcol[pb->tgt[k]], cr = fcol[pb->ref[k]];
-            if (ct >= 0) emit(pair_index[(size_t)ct * nfree + ct], k * 4 + 0);  // Jt^T Jt
-            if (cr >= 0) emit(pair_index[(size_t)cr * nfree + cr], k * 4 + 3);  // Jr^T Jr
-            if (ct >= 0 && cr >= 0 && ct != cr) {
-                if (ct < cr) emit(pair_index[(size_t)ct * nfree + cr], k * 4 + 2);  // rows Jt, cols Jr
-                else emit(pair_index[(size_t)cr * nfree + ct], k * 4 + 1);          // rows Jr, cols Jt
-            }
+    // Factor groups: every factor belongs to exactly ONE group = the unordered pair (lo, hi) of its free frames
+    // (lo == hi when only one of its two frames is free).  Its record [J_lo | J_hi | r] is written in group order at
+    // linearisation time; one MFMA accumulation per group then yields the four blocks (lo,lo) (lo,hi) (hi,lo) (hi,hi)
+    // and the two gradient segments at once.
+    std::vector<int32_t> grp_off(npairs + 1, 0), gslot(std::max(nf, 1), -1), gflip(std::max(nf, 1), 0);
+    auto group_of = [&](int k, int &flip) {
+        const int ct = fcol[pb->tgt[k]], cr = fcol[pb->ref[k]];
+        flip = 0;
+        if (ct < 0 && cr < 0) return -1;
+        if (ct >= 0 && cr >= 0) {
+            flip = cr < ct;  // first slot = J of the lower-numbered frame: Jr when the anchor comes first
+            return pair_index[(size_t)std::min(ct, cr) * nfree + std::max(ct, cr)];
         }
+        flip = ct < 0;       // only the anchor is free: first slot = Jr, second slot = 0
+        const int c = ct >= 0 ? ct : cr;
+        return pair_index[(size_t)c * nfree + c];
     };
-    visit([&](int p, int) { pair_off[p + 1]++; });
-    for (int p = 0; p < npairs; ++p) pair_off[p + 1] += pair_off[p];
-    std::vector<int32_t> pair_item((size_t)std::max(pair_off[npairs], 1));
-    std::vector<int32_t> slot_tt(std::max(nf, 1), -1), slot_rr(std::max(nf, 1), -1), slot_tr(std::max(nf, 1), -1);
-    {
-        std::vector<int32_t> cur(pair_off.begin(), pair_off.end() - 1);
-        visit([&](int p, int item) {
-            const int k = item >> 2, code = item & 3, slot = cur[p]++;
-            pair_item[slot] = item;
-            (code == 0 ? slot_tt : code == 3 ? slot_rr : slot_tr)[k] = slot;
-        });
+    for (int k = 0; k < nf; ++k) {
+        int flip;
+        const int g = group_of(k, flip);
+        if (g >= 0) grp_off[g + 1]++;
     }
-    const int nrec = pair_off[npairs];
+    for (int p = 0; p < npairs; ++p) grp_off[p + 1] += grp_off[p];
+    {
+        std::vector<int32_t> cur(grp_off.begin(), grp_off.end() - 1);
+        for (int k = 0; k < nf; ++k) {
+            int flip;
+            const int g = group_of(k, flip);
+            if (g < 0) continue;
+            gslot[k] = cur[g]++;
+            gflip[k] = flip;
+        }
+    }
+    const int nrec = grp_off[npairs];
     // preintegration sources per block of the (block-)band and per gradient block; at most two factors touch a block
     std::vector<int32_t> band_src((size_t)std::max(nfree, 1) * 6, -1), g_src((size_t)std::max(nfree, 1) * 2, -1), pcol(std::max(nfree, 1), -1);
     for (int k = 0; k < npre; ++k) {
@@ -169,10 +190,9 @@ static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdv
     const size_t o_fcol = P.put(fcol.data(), (size_t)nfr);
     const size_t o_lmf = P.put(lm_first.data(), (size_t)nl), o_lmc = P.put(lm_count.data(), (size_t)nl);
     const size_t o_pfi = P.put(pair_fi.data(), (size_t)npairs), o_pfj = P.put(pair_fj.data(), (size_t)npairs);
-    const size_t o_poff = P.put(pair_off.data(), (size_t)npairs + 1);
-    const size_t o_pitem = P.put(pair_item.data(), pair_item.size());
+    const size_t o_goff = P.put(grp_off.data(), (size_t)npairs + 1);
     const size_t o_dp = P.put(diag_pair.data(), diag_pair.size());
-    const size_t o_stt = P.put(slot_tt.data(), (size_t)nf), o_srr = P.put(slot_rr.data(), (size_t)nf), o_str = P.put(slot_tr.data(), (size_t)nf);
+    const size_t o_gslot = P.put(gslot.data(), (size_t)nf), o_gflip = P.put(gflip.data(), (size_t)nf);
     const size_t o_band = P.put(band_src.data(), band_src.size()), o_gsrc = P.put(g_src.data(), g_src.size()), o_pcol = P.put(pcol.data(), pcol.size());
     if (!P.ok) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "BA problem does not fit the context's staging buffer");
     const size_t in_bytes = P.off;
@@ -183,7 +203,7 @@ static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdv
     auto dd = [&](size_t n) { return Sx.reserve(std::max<size_t>(n, 1) * sizeof(double)); };
     const size_t s_x = dd((size_t)nfr * 16), s_xd = dd(nl), s_xc = dd((size_t)nfr * 16), s_xdc = dd(nl), s_user = dd((size_t)nfr * 16);
     const size_t s_lfree = Sx.reserve(std::max(nl, 1));
-    const size_t s_fac = dd((size_t)nf * RDVIO_FAC_STRIDE), s_prec = dd((size_t)nrec * RDVIO_REC_STRIDE), s_HP = dd((size_t)npairs * 42);
+    const size_t s_fac = dd((size_t)nf * RDVIO_FAC_STRIDE), s_prec = dd((size_t)nrec * RDVIO_REC_STRIDE), s_GP = dd((size_t)npairs * 256);
     const size_t s_PP = dd((size_t)npre * 900), s_Pg = dd((size_t)npre * 30), s_ST = dd((size_t)D * D);
     const size_t s_rr = dd((size_t)nrot * 2), s_Jro = dd((size_t)nrot * 6);
     const size_t s_ep = dd((size_t)npre * 15), s_G = dd((size_t)npre * 450), s_rp = dd((size_t)npre * 15), s_cp = dd((size_t)npre * 15), s_Jp = dd((size_t)npre * 450);
@@ -213,10 +233,10 @@ static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdv
     w.pre_i = IP(o_pi); w.pre_j = IP(o_pj); w.preint = DP(o_pre);
     w.prior_frames = IP(o_pf); w.lin = DP(o_lin); w.S = DP(o_S); w.f = DP(o_f);
     w.fcol = IP(o_fcol); w.lm_first = IP(o_lmf); w.lm_count = IP(o_lmc);
-    w.pair_fi = IP(o_pfi); w.pair_fj = IP(o_pfj); w.pair_off = IP(o_poff); w.pair_item = IP(o_pitem); w.diag_pair = IP(o_dp);
-    w.slot_tt = IP(o_stt); w.slot_rr = IP(o_srr); w.slot_tr = IP(o_str); w.band_src = IP(o_band); w.g_src = IP(o_gsrc); w.pcol = IP(o_pcol);
+    w.pair_fi = IP(o_pfi); w.pair_fj = IP(o_pfj); w.grp_off = IP(o_goff); w.diag_pair = IP(o_dp);
+    w.gslot = IP(o_gslot); w.gflip = IP(o_gflip); w.band_src = IP(o_band); w.g_src = IP(o_gsrc); w.pcol = IP(o_pcol);
     w.x = DP(s_x); w.xd = DP(s_xd); w.xc = DP(s_xc); w.xdc = DP(s_xdc); w.user = DP(s_user); w.lfree = B + s_lfree;
-    w.fac = DP(s_fac); w.prec = DP(s_prec); w.HP = DP(s_HP); w.PP = DP(s_PP); w.Pg = DP(s_Pg); w.ST = DP(s_ST); w.r_r = DP(s_rr); w.Jro = DP(s_Jro);
+    w.fac = DP(s_fac); w.prec = DP(s_prec); w.GP = DP(s_GP); w.PP = DP(s_PP); w.Pg = DP(s_Pg); w.ST = DP(s_ST); w.r_r = DP(s_rr); w.Jro = DP(s_Jro);
     w.e_p = DP(s_ep); w.G = DP(s_G); w.r_p = DP(s_rp); w.c_p = DP(s_cp); w.Jp = DP(s_Jp);
     w.e_m = DP(s_em); w.r_m = DP(s_rm); w.c_m = DP(s_cm); w.Jri = DP(s_Jri); w.Lam = DP(s_Lam); w.eta0 = DP(s_eta0); w.le = DP(s_le); w.Ex = DP(s_Ex);
     w.H = DP(s_H); w.Sm = DP(s_Sm); w.g = DP(s_g); w.yp = DP(s_yp); w.Cm = DP(s_Cm); w.Cg = DP(s_Cg);

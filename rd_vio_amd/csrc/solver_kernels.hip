@@ -62,7 +62,7 @@ DM double prior_E(const Shared &sh, int i, int a, int b) {
 // factors and the prior's per-frame errors, so the two overlap.
 // ---------------------------------------------------------------------------------------------
 template <bool LIN>
-DM double evaluate(const SolverWs &w, Shared &sh, int &phase, const double *states, const double *invd, unsigned long long &prof_last) {
+__device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &sh, int &phase, const double *states, const double *invd, unsigned long long &prof_last) {
     const int t = threadIdx.x;
     const double *W = w.extr + 14;
     double cost = 0.0;
@@ -103,26 +103,19 @@ DM double evaluate(const SolverWs &w, Shared &sh, int &phase, const double *stat
                 }
                 o[40] = Jd[0] * Jd[0] + Jd[1] * Jd[1];
                 o[41] = Jd[0] * r[0] + Jd[1] * r[1];
-                // pair-ordered copies: the assembly streams them without any indirection
-                const int stt = w.slot_tt[k], srr = w.slot_rr[k], str_ = w.slot_tr[k];
-                if (stt >= 0) {
-                    double *q = w.prec + RDVIO_REC_STRIDE * (size_t)stt;
+                // group-ordered record [J_lo | J_hi | r]: the assembly streams these with no indirection
+                const int gs = w.gslot[k];
+                if (gs >= 0) {
+                    double *q = w.prec + RDVIO_REC_STRIDE * (size_t)gs;
+                    const bool flip = w.gflip[k] != 0;          // first slot holds Jr
+                    const bool both = sh.fcol[w.tgt[k]] >= 0 && sh.fcol[w.ref[k]] >= 0;
 #pragma unroll
-                    for (int i = 0; i < 12; ++i) { q[i] = Jt[i]; q[12 + i] = Jt[i]; }
-                    q[24] = r[0]; q[25] = r[1];
-                }
-                if (srr >= 0) {
-                    double *q = w.prec + RDVIO_REC_STRIDE * (size_t)srr;
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) { q[i] = Jr[i]; q[12 + i] = Jr[i]; }
-                    q[24] = r[0]; q[25] = r[1];
-                }
-                if (str_ >= 0) {
-                    double *q = w.prec + RDVIO_REC_STRIDE * (size_t)str_;
-                    const bool rows_are_ref = (w.pair_item[str_] & 1) != 0;  // code 1: rows Jr, cols Jt; code 2: rows Jt, cols Jr
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) { q[i] = rows_are_ref ? Jr[i] : Jt[i]; q[12 + i] = rows_are_ref ? Jt[i] : Jr[i]; }
-                    q[24] = r[0]; q[25] = r[1];
+                    for (int i = 0; i < 12; ++i) {
+                        q[i] = flip ? Jr[i] : Jt[i];
+                        q[12 + i] = both ? (flip ? Jt[i] : Jr[i]) : 0.0;
+                    }
+                    q[24] = r[0];
+                    q[25] = r[1];
                 }
             }
         }
@@ -224,54 +217,70 @@ DM double prior_part(const SolverWs &w, const Shared &sh, int pi, int a, int pj,
     return acc;
 }
 
-DM void build_normal_equations(const SolverWs &w, Shared &sh, unsigned long long &prof_last) {
+// index of the frame pair (lo <= hi) in the host's enumeration
+DM int pair_id(int lo, int hi, int nfree) { return lo * nfree - lo * (lo - 1) / 2 + (hi - lo); }
+
+__device__ __attribute__((noinline)) void build_normal_equations(const SolverWs &w, Shared &sh, unsigned long long &prof_last) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int N = w.N, nfree = w.nfree, NA = 6 * nfree;
-    // ---- phase 1a: reprojection J_x^T J_y (36) and J_x^T r (6) per frame pair; fixed record order => deterministic
-    for (int p = wave; p < w.npairs; p += NW) {
-        if (lane < 42) {
-            const int a = (lane < 36) ? lane / 6 : lane - 36, b = (lane < 36) ? lane - 6 * (lane / 6) : 0;
-            const bool is_h = lane < 36;
-            const double *rec = w.prec + RDVIO_REC_STRIDE * (size_t)w.pair_off[p];
-            const int n = w.pair_off[p + 1] - w.pair_off[p];
-            // is_h: acc += Jx[a] Jy[b] + Jx[6+a] Jy[6+b];  else: acc += Jx[a] r0 + Jx[6+a] r1
-            const int o1 = is_h ? 12 + b : 24, o2 = is_h ? 18 + b : 25;
-            double acc = 0.0;
-            int it = 0;
-            for (; it + 4 <= n; it += 4) {
-                double x0[4], x1[4], y0[4], y1[4];
+    // ---- phase 1a: per factor group, X^T X with X = [J_lo | J_hi | r] (2 n_g x 13) on the matrix cores:
+    //      lane l feeds A[i = l & 15][k] and B[k][j = l & 15] (the same record element for i = j < 12), k = (item, row)
+    for (int g = wave; g < w.npairs; g += NW) {
+        const int n = w.grp_off[g + 1] - w.grp_off[g];
+        double *out = w.GP + 256 * (size_t)g;
+        const int i = lane & 15, kk = lane >> 4;
+        const int item_off = kk >> 1, row = kk & 1;
+        // element of the record this lane supplies: i < 6: first[row][i]; 6 <= i < 12: second[row][i - 6]; i == 12: r[row]
+        const int eo = (i < 6) ? row * 6 + i : (i < 12 ? 12 + row * 6 + (i - 6) : 24 + row);
+        const bool has = i < 13;
+        const double *rec = w.prec + RDVIO_REC_STRIDE * (size_t)w.grp_off[g] + eo;
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        int it = 0;
+        for (; it + 16 <= n; it += 16) {  // 8 MFMAs (16 items) per trip, loads issued together
+            double v[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const double *q = rec + RDVIO_REC_STRIDE * (size_t)(it + u);
-                    x0[u] = q[a]; x1[u] = q[6 + a]; y0[u] = q[o1]; y1[u] = q[o2];
-                }
+            for (int u = 0; u < 8; ++u) v[u] = has ? rec[RDVIO_REC_STRIDE * (size_t)(it + 2 * u + item_off)] : 0.0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc += x0[u] * y0[u] + x1[u] * y1[u];
-            }
-            for (; it < n; ++it) {
-                const double *q = rec + RDVIO_REC_STRIDE * (size_t)it;
-                acc += q[a] * q[o1] + q[6 + a] * q[o2];
-            }
-            w.HP[42 * (size_t)p + lane] = acc;
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v[u] : 0.0, v[u], acc, 0, 0, 0);
         }
+        for (; it < n; it += 2) {
+            const int item = it + item_off;
+            const double v = (has && item < n) ? rec[RDVIO_REC_STRIDE * (size_t)item] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v : 0.0, v, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[16 * ((lane >> 4) + 4 * r) + (lane & 15)] = acc[r];
     }
     STAMP(12);
-    // ---- phase 1b: landmarks (factors of one landmark are contiguous): scalars and coupling rows
+    // ---- phase 1b: landmarks (factors of one landmark are contiguous): scalars and coupling rows.
+    // A track is observed at most once per frame (host-checked), so every target slot is written by exactly one
+    // factor (plain store) and only the anchor slot accumulates (in registers): no read-modify-write on global memory.
     for (int l = t; l < w.nl; l += T) {
         double *Arow = w.A + (size_t)l * NA;
-        for (int i = 0; i < NA; ++i) Arow[i] = 0.0;
-        double m = 0.0, gl = 0.0;
+        for (int i2 = 0; i2 < NA; ++i2) Arow[i2] = 0.0;
+        double m = 0.0, gl = 0.0, ha[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        int ca = -1;
         if (w.lfree[l]) {
             for (int k = w.lm_first[l]; k < w.lm_first[l] + w.lm_count[l]; ++k) {
                 const double *o = w.fac + RDVIO_FAC_STRIDE * (size_t)k;
-                m += o[40];
-                gl += o[41];
+                double hv[14];
+#pragma unroll
+                for (int a = 0; a < 14; ++a) hv[a] = o[28 + a];
                 const int ct = sh.fcol[w.tgt[k]], cr = sh.fcol[w.ref[k]];
+                m += hv[12];
+                gl += hv[13];
                 if (ct >= 0)
-                    for (int a = 0; a < 6; ++a) Arow[6 * ct + a] += o[28 + a];
-                if (cr >= 0)
-                    for (int a = 0; a < 6; ++a) Arow[6 * cr + a] += o[34 + a];
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) Arow[6 * ct + a] = hv[a];
+                if (cr >= 0) {
+                    ca = cr;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) ha[a] += hv[6 + a];
+                }
             }
+            if (ca >= 0)
+#pragma unroll
+                for (int a = 0; a < 6; ++a) Arow[6 * ca + a] = ha[a];
         }
         w.lm_m[l] = m;
         w.lm_g[l] = gl;
@@ -281,9 +290,12 @@ DM void build_normal_equations(const SolverWs &w, Shared &sh, unsigned long long
     for (int o = t; o < w.npre * 900; o += T) {
         const int k = o / 900, rc = o - 900 * k, ra = rc / 30, cb = rc - 30 * ra;
         const double *Jx = w.Jp + 450 * k + 225 * (ra / 15) + (ra % 15), *Jy = w.Jp + 450 * k + 225 * (cb / 15) + (cb % 15);
+        double xa[15], ya[15];
+#pragma unroll
+        for (int q = 0; q < 15; ++q) { xa[q] = Jx[q * 15]; ya[q] = Jy[q * 15]; }
         double acc = 0.0;
 #pragma unroll
-        for (int q = 0; q < 15; ++q) acc += Jx[q * 15] * Jy[q * 15];
+        for (int q = 0; q < 15; ++q) acc += xa[q] * ya[q];
         w.PP[o] = acc;
     }
     for (int o = t; o < w.npre * 30; o += T) {
@@ -297,36 +309,60 @@ DM void build_normal_equations(const SolverWs &w, Shared &sh, unsigned long long
     STAMP(14);
     __syncthreads();
     STAMP(15);
-    // ---- phase 2: every entry of H and g, output-stationary
-    for (int o = t; o < N * N; o += T) {
-        const int i = o / N, j = o - i * N, fi = i / 15, a = i - 15 * fi, fj = j / 15, b = j - 15 * fj;
-        double v = 0.0;
+    // ---- phase 2: every entry of H, output-stationary: prior + preintegration band + reprojection groups.
+    // One wavefront per 15 x 15 block (block-level conditions are wave-uniform), four lane passes per block whose
+    // loads are independent and issued together.
+    for (int blk = wave; blk < nfree * nfree; blk += NW) {
+        const int fi = blk / nfree, fj = blk - fi * nfree;
         const int pi = sh.pcol[fi], pj = sh.pcol[fj];
-        if (pi >= 0 && pj >= 0) v += prior_part(w, sh, pi, a, pj, b);
+        const bool has_prior = pi >= 0 && pj >= 0;
         const int which = fj - fi + 1;
-        if (which >= 0 && which <= 2) {
+        const int src0 = (which >= 0 && which <= 2) ? sh.band_src[(fi * 3 + which) * 2] : -1;
+        const int src1 = (which >= 0 && which <= 2) ? sh.band_src[(fi * 3 + which) * 2 + 1] : -1;
+        double v[4];
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int src = sh.band_src[(fi * 3 + which) * 2 + s2];
-                if (src >= 0) v += w.PP[900 * (size_t)(src >> 2) + 30 * (15 * ((src >> 1) & 1) + a) + 15 * (src & 1) + b];
+        for (int u = 0; u < 4; ++u) {
+            const int e = lane + 64 * u;
+            const int a = e / 15, b = e - 15 * a;
+            double acc = 0.0;
+            if (e < 225) {
+                if (has_prior) acc += prior_part(w, sh, pi, a, pj, b);
+                if (src0 >= 0) acc += w.PP[900 * (size_t)(src0 >> 2) + 30 * (15 * ((src0 >> 1) & 1) + a) + 15 * (src0 & 1) + b];
+                if (src1 >= 0) acc += w.PP[900 * (size_t)(src1 >> 2) + 30 * (15 * ((src1 >> 1) & 1) + a) + 15 * (src1 & 1) + b];
+                if (a < 6 && b < 6) {
+                    if (fi == fj) {
+                        for (int f2 = 0; f2 < nfree; ++f2) {
+                            const int lo = f2 < fi ? f2 : fi, hi = f2 < fi ? fi : f2;
+                            const int off = (fi == lo) ? 0 : 6;  // quadrant (lo,lo) or (hi,hi); the single group (f,f) uses (lo,lo)
+                            acc += w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + off + b];
+                        }
+                        if (a < 3 && b < 3)
+                            for (int k = 0; k < w.nrot; ++k)
+                                if (sh.fcol[w.rot_tgt[k]] == fi) acc += w.Jro[6 * k + a] * w.Jro[6 * k + b] + w.Jro[6 * k + 3 + a] * w.Jro[6 * k + 3 + b];
+                    } else if (fi < fj) {
+                        acc += w.GP[256 * (size_t)pair_id(fi, fj, nfree) + 16 * a + 6 + b];
+                    } else {
+                        acc += w.GP[256 * (size_t)pair_id(fj, fi, nfree) + 16 * b + 6 + a];
+                    }
+                }
             }
+            v[u] = acc;
         }
-        if (a < 6 && b < 6) {
-            // pairs are stored for fi <= fj; the mirrored block is the transpose
-            const int lo = fi <= fj ? fi : fj, hi = fi <= fj ? fj : fi;
-            const int p = lo * nfree - lo * (lo - 1) / 2 + (hi - lo);
-            v += (fi <= fj) ? w.HP[42 * (size_t)p + 6 * a + b] : w.HP[42 * (size_t)p + 6 * b + a];
-            if (fi == fj && a < 3 && b < 3)
-                for (int k = 0; k < w.nrot; ++k)
-                    if (sh.fcol[w.rot_tgt[k]] == fi) v += w.Jro[6 * k + a] * w.Jro[6 * k + b] + w.Jro[6 * k + 3 + a] * w.Jro[6 * k + 3 + b];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = lane + 64 * u;
+            if (e < 225) w.H[(size_t)(15 * fi + e / 15) * N + 15 * fj + e % 15] = v[u];
         }
-        w.H[o] = v;
     }
     for (int o = t; o < N; o += T) {
         const int c = o / 15, a = o - 15 * c;
         double acc = 0.0;
         if (a < 6) {
-            acc += w.HP[42 * (size_t)w.diag_pair[c] + 36 + a];
+            for (int f2 = 0; f2 < nfree; ++f2) {
+                const int lo = f2 < c ? f2 : c, hi = f2 < c ? c : f2;
+                const int off = (c == lo) ? 0 : 6;
+                acc += w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + 12];
+            }
             if (a < 3)
                 for (int k = 0; k < w.nrot; ++k)
                     if (sh.fcol[w.rot_tgt[k]] == c) acc += w.Jro[6 * k + a] * w.r_r[2 * k] + w.Jro[6 * k + 3 + a] * w.r_r[2 * k + 1];
@@ -380,6 +416,70 @@ DM void model_products(const SolverWs &w, Shared &sh, int &phase, const double *
     block_sum_n<T, 2>(sh, v, phase);
     *q_out = v[0];
     *l_out = v[1];
+}
+
+// Quadratic-model scalars of the two dogleg directions u = Sigma gradient_/D (steepest descent) and v = Sigma gn/D
+// (Gauss-Newton), both in unscaled-J coordinates:  q_xy = (J x)^T (J y),  l_x = (J x)^T r.  Every dogleg step is
+// delta = ca u + cb v, so |J delta|^2 and (J delta).r follow from these five numbers for ANY trust-region radius:
+// a rejected step re-interpolates without touching H again.
+__device__ __attribute__((noinline)) void model_scalars(const SolverWs &w, Shared &sh, int &phase, double (&out)[5]) {
+    const int t = threadIdx.x;
+    const int N = w.N, NA = 6 * w.nfree;
+    double *u = sh.xv, *v = sh.xv + 256;
+    for (int i = t; i < N; i += T) {
+        const double sd = w.sig_p[i] / w.diag_p[i];
+        u[i] = sd * w.grad_p[i];
+        v[i] = sd * w.gn_p[i];
+    }
+    __syncthreads();
+    double a5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    {
+        // H u and H v: `parts` threads per row, each walking a slice of the (symmetric) column, partial sums in order
+        const int parts = (N > 0 && T / N >= 1) ? (T / N > 4 ? 4 : T / N) : 1;
+        const int r = t % (N > 0 ? N : 1), part = t / (N > 0 ? N : 1);
+        const int chunk = (N + parts - 1) / parts;
+        double hu = 0.0, hv = 0.0;
+        if (N > 0 && part < parts) {
+            const int c0 = part * chunk, c1 = (c0 + chunk < N) ? c0 + chunk : N;
+            if (c1 > c0) {
+                hu = dot_strided(w.H + (size_t)c0 * N + r, N, u + c0, 1, c1 - c0);
+                hv = dot_strided(w.H + (size_t)c0 * N + r, N, v + c0, 1, c1 - c0);
+            }
+            a5[0] += u[r] * hu;
+            a5[1] += u[r] * hv;
+            a5[2] += v[r] * hv;
+            if (part == 0) {
+                a5[3] += w.g[r] * u[r];
+                a5[4] += w.g[r] * v[r];
+            }
+        }
+    }
+    for (int l = t; l < w.nl; l += T) {
+        if (!w.lfree[l]) continue;
+        const double sd = w.sig_l[l] / w.diag_l[l];
+        const double ul = sd * w.grad_l[l], vl = sd * w.gn_l[l];
+        const double *Arow = w.A + (size_t)l * NA;
+        double au = 0.0, av = 0.0;
+        for (int f = 0; f < w.nfree; ++f) {
+            double x6[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) x6[a] = Arow[6 * f + a];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                au += x6[a] * u[15 * f + a];
+                av += x6[a] * v[15 * f + a];
+            }
+        }
+        const double m = w.lm_m[l];
+        a5[0] += 2.0 * ul * au + m * ul * ul;
+        a5[1] += ul * av + vl * au + m * ul * vl;
+        a5[2] += 2.0 * vl * av + m * vl * vl;
+        a5[3] += w.lm_g[l] * ul;
+        a5[4] += w.lm_g[l] * vl;
+    }
+    block_sum_n<T, 5>(sh, a5, phase);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) out[i] = a5[i];
 }
 
 DM double x_norm_of(const SolverWs &w, Shared &sh, int &phase, const double *st, const double *dep) {
@@ -447,7 +547,8 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     __syncthreads();
 
     double radius = 1e4, mu = 1e-8, alpha = 0.0, dogleg_step_norm = 0.0;
-    double gnorm = 0.0, gn_norm = 0.0, gdotgn = 0.0;
+    double gnorm = 0.0, gn_norm = 0.0, gdotgn = 0.0, gsq_keep = 0.0;
+    double msc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // q_uu q_uv q_vv l_u l_v of the current linearisation
     int reuse = 0, iteration = 0, invalid_steps = 0, last_successful = 0, n_success = 0;
     int term = 1;  // NO_CONVERGENCE
     STAMP(0);
@@ -489,22 +590,18 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     const double gv = s * w.g[i] / d;
                     w.grad_p[i] = gv;
                     gsq += gv * gv;
-                    w.tp[i] = s * gv / d;
                 }
                 for (int l = t; l < nl; l += T) {
-                    if (!w.lfree[l]) { w.diag_l[l] = 1.0; w.grad_l[l] = 0.0; w.tl[l] = 0.0; continue; }
+                    if (!w.lfree[l]) { w.diag_l[l] = 1.0; w.grad_l[l] = 0.0; continue; }
                     const double s = w.sig_l[l];
                     const double d = sqrt(clampd(s * s * w.lm_m[l], 1e-6, 1e32));
                     w.diag_l[l] = d;
                     const double gv = s * w.lm_g[l] / d;
                     w.grad_l[l] = gv;
                     gsq += gv * gv;
-                    w.tl[l] = s * gv / d;
                 }
-                gsq = block_sum(sh, gsq, phase);  // (its barrier also orders the tp/tl writes before model_products)
-                double jsq, jdr;
-                model_products(w, sh, phase, w.tp, w.tl, &jsq, &jdr);
-                alpha = gsq / jsq;
+                gsq = block_sum(sh, gsq, phase);
+                gsq_keep = gsq;
                 STAMP(3);
                 // Gauss-Newton step: (H_s + mu D^2) y = g_s with the landmarks eliminated
                 solve_ok = 0;
@@ -525,17 +622,35 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     __syncthreads();
                     for (int ia = t; ia < NA; ia += T) w.Cg[ia] = dot_strided(w.A + ia, NA, w.yl, 1, nl);
                     __syncthreads();
-                    // S = Sigma (H - C) Sigma + mu D^2   (lower triangle); packed LDS blocks when they fit
-                    for (int o = t; o < N * N; o += T) {
-                        const int i = o / N, j = o - i * N;
-                        if (j > i) continue;
-                        const int fi = i / 15, a = i - 15 * fi, fj = j / 15, b = j - 15 * fj;
-                        double v = w.H[o];
-                        if (a < 6 && b < 6 && nl > 0) v -= w.Cm[(size_t)(6 * fi + a) * NA + 6 * fj + b];
-                        v *= w.sig_p[i] * w.sig_p[j];
-                        if (i == j) v += mu * w.diag_p[i] * w.diag_p[i];
-                        if (w.lds_chol) Sl[tri(i) + j] = v;
-                        else w.Sm[o] = v;
+                    // S = Sigma (H - C) Sigma + mu D^2   (lower triangle); one wave per 15 x 15 block, 4 passes in flight
+                    for (int i = t; i < N; i += T) sh.xv[i] = w.sig_p[i];
+                    __syncthreads();
+                    for (int blk = t >> 6; blk < nfree * nfree; blk += NW) {
+                        const int fi = blk / nfree, fj = blk - fi * nfree;
+                        if (fj > fi) continue;
+                        double vv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int e = (t & 63) + 64 * u, a = e / 15, b = e - 15 * a;
+                            double v = 0.0;
+                            if (e < 225 && (fi != fj || b <= a)) {
+                                const int i = 15 * fi + a, j = 15 * fj + b;
+                                v = w.H[(size_t)i * N + j];
+                                if (a < 6 && b < 6 && nl > 0) v -= w.Cm[(size_t)(6 * fi + a) * NA + 6 * fj + b];
+                                v *= sh.xv[i] * sh.xv[j];
+                                if (i == j) v += mu * w.diag_p[i] * w.diag_p[i];
+                            }
+                            vv[u] = v;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int e = (t & 63) + 64 * u, a = e / 15, b = e - 15 * a;
+                            if (e < 225 && (fi != fj || b <= a)) {
+                                const int i = 15 * fi + a, j = 15 * fj + b;
+                                if (w.lds_chol) Sl[tri(i) + j] = vv[u];
+                                else w.Sm[(size_t)i * N + j] = vv[u];
+                            }
+                        }
                     }
                     for (int i = t; i < N; i += T) {
                         const int fi = i / 15, a = i - 15 * fi;
@@ -606,6 +721,8 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     gnorm = sqrt(a3[0]);
                     gn_norm = sqrt(a3[1]);
                     gdotgn = a3[2];
+                    model_scalars(w, sh, phase, msc);
+                    alpha = gsq_keep / msc[0];
                 }
                 STAMP(7);
             }
@@ -627,21 +744,14 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     cb = beta;
                     need_norm = true;
                 }
-                double sn = 0.0;
-                for (int i = t; i < N; i += T) {
-                    const double v = ca * w.grad_p[i] + cb * w.gn_p[i];
-                    sn += v * v;
-                    w.tp[i] = w.sig_p[i] * (v / w.diag_p[i]);  // delta = step * jacobi scaling
-                }
-                for (int l = t; l < nl; l += T) {
-                    const double v = ca * w.grad_l[l] + cb * w.gn_l[l];
-                    sn += v * v;
-                    w.tl[l] = w.lfree[l] ? w.sig_l[l] * (v / w.diag_l[l]) : 0.0;
-                }
-                sn = block_sum(sh, sn, phase);
-                if (need_norm) dogleg_step_norm = sqrt(sn);
-                double jsq, jdr;
-                model_products(w, sh, phase, w.tp, w.tl, &jsq, &jdr);
+                for (int i = t; i < N; i += T)
+                    w.tp[i] = w.sig_p[i] * ((ca * w.grad_p[i] + cb * w.gn_p[i]) / w.diag_p[i]);  // delta = step * jacobi scaling
+                for (int l = t; l < nl; l += T)
+                    w.tl[l] = w.lfree[l] ? w.sig_l[l] * ((ca * w.grad_l[l] + cb * w.gn_l[l]) / w.diag_l[l]) : 0.0;
+                __syncthreads();  // tp / tl are read by other threads when the candidate is formed
+                if (need_norm) dogleg_step_norm = sqrt(ca * ca * gnorm * gnorm + 2.0 * ca * cb * gdotgn + cb * cb * gn_norm * gn_norm);
+                const double jsq = ca * ca * msc[0] + 2.0 * ca * cb * msc[1] + cb * cb * msc[2];
+                const double jdr = ca * msc[3] + cb * msc[4];
                 model_cost_change = -(jdr + 0.5 * jsq);
                 step_valid = model_cost_change > 0.0;
             }

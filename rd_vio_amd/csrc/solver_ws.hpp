@@ -25,8 +25,8 @@ struct SolverWs {
     // graph index structures (built on the host with the problem: A16, sliding_window_tracker.cpp:226-300)
     const int32_t *fcol;                 // frame -> free slot or -1
     const int32_t *lm_first, *lm_count;  // factors of a landmark are contiguous
-    const int32_t *pair_fi, *pair_fj, *pair_off, *pair_item, *diag_pair;
-    const int32_t *slot_tt, *slot_rr, *slot_tr;  // per factor: destination record in the pair-ordered array (-1: none)
+    const int32_t *pair_fi, *pair_fj, *grp_off, *diag_pair;  // frame pairs (lo <= hi); factor groups per pair
+    const int32_t *gslot, *gflip;        // per factor: record slot in group order (-1: none), 1 if the first slot holds Jr
     const int32_t *band_src;             // nfree x 3 x 2: preintegration sources of H block (c, c+which-1): k*4+x*2+y or -1
     const int32_t *g_src;                // nfree x 2: preintegration sources of g block c: k*2+x or -1
     const int32_t *pcol;                 // nfree: prior frame index of a free column block or -1
@@ -38,8 +38,8 @@ struct SolverWs {
     uint8_t *lfree;
     // ---- stored linearisation
     double *fac;                         // nf x RDVIO_FAC_STRIDE
-    double *prec;                        // nrec x RDVIO_REC_STRIDE: pair-ordered [Jx(12) Jy(12) r(2)] records
-    double *HP;                          // npairs x 42: per pair J_x^T J_y (36) and, for diagonal pairs, J_x^T r (6)
+    double *prec;                        // nrec x RDVIO_REC_STRIDE: group-ordered [J_lo(12) J_hi(12) r(2)] records
+    double *GP;                          // npairs x 256: per group the 16x16 MFMA tile [J_lo J_hi r]^T [J_lo J_hi r]
     double *PP, *Pg;                     // npre x 900 / npre x 30: per preintegration factor [Ji Jj]^T [Ji Jj], [Ji Jj]^T r
     double *ST;                          // D x D: transpose of the prior's S (coalesced S e)
     double *r_r, *Jro;
