@@ -20,6 +20,9 @@ struct BlockShared {
     int fcol[32], pcol[32], band_src[32 * 6], g_src[32 * 2];
     double Jri[32 * 9];  // Jr^-1(e_theta) of the prior frames at the current linearisation
     double xv[512];      // staged vector operand (pose step / prior error)
+    double st[32 * 16];  // frame states being evaluated (x or the candidate)
+    double ub[32 * 6];   // user-state biases (bias linearisation of the preintegration factors)
+    double ext[18];      // extrinsics (14) + sqrt_inv_cov (4)
 };
 
 // sum_i a[i * sa] * x[i * sx] with the loads of U iterations issued together (memory-level parallelism: a single
@@ -39,6 +42,27 @@ DM double dot_strided(const double *__restrict__ a, long sa, const double *__res
         for (int u = 0; u < U; ++u) acc += av[u] * xv[u];
     }
     for (; i < n; ++i) acc += a[(long)i * sa] * x[(long)i * sx];
+    return acc;
+}
+
+// y[r] = sum_c M[c * ld + r] * x[c] for the row r = t / 4 owned by lanes 4r .. 4r+3 (c = part, part + 4, ...), combined
+// with two xor-shuffles: every lane of the quad returns the row's sum.  Call with r < R for all four lanes or none.
+DM double quad_col_dot(const double *__restrict__ M, long ld, const double *__restrict__ x, int C, int r, int part) {
+    double acc = 0.0;
+    int c = part;
+    for (; c + 28 < C; c += 32) {
+        double mv[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            mv[u] = M[(long)(c + 4 * u) * ld + r];
+            xv[u] = x[c + 4 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += mv[u] * xv[u];
+    }
+    for (; c < C; c += 4) acc += M[(long)c * ld + r] * x[c];
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
     return acc;
 }
 
@@ -137,7 +161,7 @@ DM void block_gemm_tn(double *__restrict__ C, int ldc, const double *__restrict_
     const int tm = (M + 15) / 16, tn = (N + 15) / 16;
     for (int tile = wave; tile < tm * tn; tile += nw) {
         const int bi = tile / tn, bj = tile - bi * tn;
-        if (lower_only && bj > bi) continue;
+        if (lower_only && bj > bi && 16 * bj + 16 < N) continue;  // (a trailing extra column, N = M + 1, is always computed)
         const double4_t acc = mfma_tile_f64(A, lda, 1, B, ldb, 1, w, K, 16 * bi, 16 * bj, M, N);
         const int col = 16 * bj + (lane & 15);
 #pragma unroll

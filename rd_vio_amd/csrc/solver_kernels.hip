@@ -64,7 +64,12 @@ DM double prior_E(const Shared &sh, int i, int a, int b) {
 template <bool LIN>
 __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &sh, int &phase, const double *states, const double *invd, unsigned long long &prof_last) {
     const int t = threadIdx.x;
-    const double *W = w.extr + 14;
+    // small hot data in LDS: every factor reads two frame states; L2 round trips would dominate the evaluation
+    for (int i = t; i < w.nfr * 16; i += T) sh.st[i] = states[i];
+    for (int i = t; i < w.nfr * 6; i += T) sh.ub[i] = w.user[16 * (i / 6) + ST_BG + (i % 6)];
+    __syncthreads();
+    states = sh.st;
+    const double *W = sh.ext + 14, *extr = sh.ext;
     double cost = 0.0;
     constexpr int TF = T - 64;
     if (t < TF) {
@@ -73,7 +78,7 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
             double r[2], Jt[12], Jr[12], Jd[2];
             const int l = w.lm[k];
             reprojection_factor<LIN>(states + 16 * w.tgt[k], states + 16 * w.ref[k], w.tangent + 9 * (size_t)k,
-                                     w.z_ref + 3 * (size_t)l, invd[l], w.extr, W, r, Jt, Jr, Jd);
+                                     w.z_ref + 3 * (size_t)l, invd[l], extr, W, r, Jt, Jr, Jd);
             const double s = r[0] * r[0] + r[1] * r[1];
             const double sum = 1.0 + s;
             cost += 0.5 * log(sum);
@@ -103,6 +108,16 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
                 }
                 o[40] = Jd[0] * Jd[0] + Jd[1] * Jd[1];
                 o[41] = Jd[0] * r[0] + Jd[1] * r[1];
+                // coupling row of the landmark: the target frame's slot belongs to this factor alone (one observation per
+                // (track, frame)), so it is a plain store; the anchor slot is summed in the landmark pass
+                {
+                    const int ctc = sh.fcol[w.tgt[k]];
+                    if (ctc >= 0 && w.lfree[l]) {
+                        double *Arow = w.A + (size_t)l * (6 * w.nfree + 2) + 6 * ctc;
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) Arow[a] = o[28 + a];
+                    }
+                }
                 // group-ordered record [J_lo | J_hi | r]: the assembly streams these with no indirection
                 const int gs = w.gslot[k];
                 if (gs >= 0) {
@@ -122,7 +137,7 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
         for (int k = t; k < w.nrot; k += TF) {
             double r[2], J[6];
             rotation_prior_factor<LIN>(states + 16 * w.rot_tgt[k], states + 16 * w.rot_ref[k], w.rot_zref + 3 * k,
-                                       w.rot_tangent + 9 * k, w.extr, W, r, J);
+                                       w.rot_tangent + 9 * k, extr, W, r, J);
             const double s = r[0] * r[0] + r[1] * r[1];
             const double sum = 1.0 + s;
             cost += 0.5 * log(sum);
@@ -142,8 +157,8 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
                 if (LIN)
                     for (int i = 0; i < 450; ++i) G[i] = 0.0;
                 preintegration_unwhitened<LIN>(states + 16 * w.pre_i[k], states + 16 * w.pre_j[k],
-                                               w.preint + (size_t)RDVIO_PREINT_SIZE * k, w.user + 16 * w.pre_i[k] + ST_BG,
-                                               w.extr, w.e_p + 15 * k, G, G + 225);
+                                               w.preint + (size_t)RDVIO_PREINT_SIZE * k, sh.ub + 6 * w.pre_i[k],
+                                               extr, w.e_p + 15 * k, G, G + 225);
             }
         } else {
             for (int i = j - 32; i < w.np; i += 32) {
@@ -190,11 +205,19 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
         const int D = w.D;
         for (int c = t; c < D; c += T) sh.xv[c] = w.e_m[c];
         __syncthreads();
-        for (int row = t; row < D; row += T) {
-            const double r = dot_strided(w.ST + row, D, sh.xv, 1, D) + w.f[row];
-            r_m[row] = r;
-            cost += 0.5 * r * r;
-            if (LIN) w.le[row] = dot_strided(w.Lam + row, D, sh.xv, 1, D) + w.eta0[row];
+        for (int base = 0; base < D; base += T / 4) {
+            const int row = base + (t >> 2), part = t & 3;
+            if (row < D) {
+                const double r = quad_col_dot(w.ST, D, sh.xv, D, row, part) + w.f[row];
+                if (part == 0) {
+                    r_m[row] = r;
+                    cost += 0.5 * r * r;
+                }
+                if (LIN) {
+                    const double le = quad_col_dot(w.Lam, D, sh.xv, D, row, part) + w.eta0[row];
+                    if (part == 0) w.le[row] = le;
+                }
+            }
         }
     }
     return block_sum(sh, cost, phase);
@@ -222,7 +245,7 @@ DM int pair_id(int lo, int hi, int nfree) { return lo * nfree - lo * (lo - 1) / 
 
 __device__ __attribute__((noinline)) void build_normal_equations(const SolverWs &w, Shared &sh, unsigned long long &prof_last) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int N = w.N, nfree = w.nfree, NA = 6 * nfree;
+    const int N = w.N, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
     // ---- phase 1a: per factor group, X^T X with X = [J_lo | J_hi | r] (2 n_g x 13) on the matrix cores:
     //      lane l feeds A[i = l & 15][k] and B[k][j = l & 15] (the same record element for i = j < 12), k = (item, row)
     for (int g = wave; g < w.npairs; g += NW) {
@@ -252,36 +275,37 @@ __device__ __attribute__((noinline)) void build_normal_equations(const SolverWs 
         for (int r = 0; r < 4; ++r) out[16 * ((lane >> 4) + 4 * r) + (lane & 15)] = acc[r];
     }
     STAMP(12);
-    // ---- phase 1b: landmarks (factors of one landmark are contiguous): scalars and coupling rows.
-    // A track is observed at most once per frame (host-checked), so every target slot is written by exactly one
-    // factor (plain store) and only the anchor slot accumulates (in registers): no read-modify-write on global memory.
+    // ---- phase 1b: landmarks (factors of one landmark are contiguous): scalars m, g and the anchor slot of the
+    // coupling row (target slots were stored at linearisation time; untouched slots stay zero from the setup).
+    // Column NA of the row holds g_l so that A^T W [A | g] yields the Schur gradient term with the same GEMM.
     for (int l = t; l < w.nl; l += T) {
-        double *Arow = w.A + (size_t)l * NA;
-        for (int i2 = 0; i2 < NA; ++i2) Arow[i2] = 0.0;
+        if (!w.lfree[l]) continue;
         double m = 0.0, gl = 0.0, ha[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        int ca = -1;
-        if (w.lfree[l]) {
-            for (int k = w.lm_first[l]; k < w.lm_first[l] + w.lm_count[l]; ++k) {
-                const double *o = w.fac + RDVIO_FAC_STRIDE * (size_t)k;
-                double hv[14];
+        const int k0 = w.lm_first[l], k1 = k0 + w.lm_count[l];
+        for (int k = k0; k < k1; k += 2) {
+            double h0[8], h1[8];
+            const double *o0 = w.fac + RDVIO_FAC_STRIDE * (size_t)k + 34;
+            const bool two = k + 1 < k1;
+            const double *o1 = two ? o0 + RDVIO_FAC_STRIDE : o0;
 #pragma unroll
-                for (int a = 0; a < 14; ++a) hv[a] = o[28 + a];
-                const int ct = sh.fcol[w.tgt[k]], cr = sh.fcol[w.ref[k]];
-                m += hv[12];
-                gl += hv[13];
-                if (ct >= 0)
+            for (int a = 0; a < 8; ++a) { h0[a] = o0[a]; h1[a] = o1[a]; }
 #pragma unroll
-                    for (int a = 0; a < 6; ++a) Arow[6 * ct + a] = hv[a];
-                if (cr >= 0) {
-                    ca = cr;
+            for (int a = 0; a < 6; ++a) ha[a] += h0[a];
+            m += h0[6];
+            gl += h0[7];
+            if (two) {
 #pragma unroll
-                    for (int a = 0; a < 6; ++a) ha[a] += hv[6 + a];
-                }
+                for (int a = 0; a < 6; ++a) ha[a] += h1[a];
+                m += h1[6];
+                gl += h1[7];
             }
-            if (ca >= 0)
-#pragma unroll
-                for (int a = 0; a < 6; ++a) Arow[6 * ca + a] = ha[a];
         }
+        double *Arow = w.A + (size_t)l * NAs;
+        const int ca = sh.fcol[w.ref[k0]];
+        if (ca >= 0)
+#pragma unroll
+            for (int a = 0; a < 6; ++a) Arow[6 * ca + a] = ha[a];
+        Arow[NA] = gl;
         w.lm_m[l] = m;
         w.lm_g[l] = gl;
     }
@@ -433,22 +457,14 @@ __device__ __attribute__((noinline)) void model_scalars(const SolverWs &w, Share
     }
     __syncthreads();
     double a5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    {
-        // H u and H v: `parts` threads per row, each walking a slice of the (symmetric) column, partial sums in order
-        const int parts = (N > 0 && T / N >= 1) ? (T / N > 4 ? 4 : T / N) : 1;
-        const int r = t % (N > 0 ? N : 1), part = t / (N > 0 ? N : 1);
-        const int chunk = (N + parts - 1) / parts;
-        double hu = 0.0, hv = 0.0;
-        if (N > 0 && part < parts) {
-            const int c0 = part * chunk, c1 = (c0 + chunk < N) ? c0 + chunk : N;
-            if (c1 > c0) {
-                hu = dot_strided(w.H + (size_t)c0 * N + r, N, u + c0, 1, c1 - c0);
-                hv = dot_strided(w.H + (size_t)c0 * N + r, N, v + c0, 1, c1 - c0);
-            }
-            a5[0] += u[r] * hu;
-            a5[1] += u[r] * hv;
-            a5[2] += v[r] * hv;
+    for (int base = 0; base < N; base += T / 4) {
+        const int r = base + (t >> 2), part = t & 3;
+        if (r < N) {
+            const double hu = quad_col_dot(w.H, N, u, N, r, part), hv = quad_col_dot(w.H, N, v, N, r, part);
             if (part == 0) {
+                a5[0] += u[r] * hu;
+                a5[1] += u[r] * hv;
+                a5[2] += v[r] * hv;
                 a5[3] += w.g[r] * u[r];
                 a5[4] += w.g[r] * v[r];
             }
@@ -458,7 +474,7 @@ __device__ __attribute__((noinline)) void model_scalars(const SolverWs &w, Share
         if (!w.lfree[l]) continue;
         const double sd = w.sig_l[l] / w.diag_l[l];
         const double ul = sd * w.grad_l[l], vl = sd * w.gn_l[l];
-        const double *Arow = w.A + (size_t)l * NA;
+        const double *Arow = w.A + (size_t)l * (NA + 2);
         double au = 0.0, av = 0.0;
         for (int f = 0; f < w.nfree; ++f) {
             double x6[6];
@@ -517,7 +533,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     __shared__ __attribute__((aligned(16))) double lds_chol_buf[NMAX * (NMAX + 1) / 2 + 225 * RDVIO_LDS_CHOL_MAX_FRAMES];
     double *Sl = lds_chol_buf, *Dinv = lds_chol_buf + w.N * (w.N + 1) / 2;
     const int t = threadIdx.x;
-    const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree;
+    const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
     int phase = 0;
     unsigned long long prof_last = 0;
 #ifdef RDVIO_PROF
@@ -532,6 +548,8 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
         sh.fcol[i] = (i < w.nfr) ? w.fcol[i] : -1;
         sh.pcol[i] = (i < nfree) ? w.pcol[i] : -1;
     }
+    for (int i = t; i < 18; i += T) sh.ext[i] = w.extr[i];
+    for (size_t i = t; i < (size_t)nl * NAs; i += T) w.A[i] = 0.0;  // slots of frames that do not observe a landmark stay zero
     for (int i = t; i < nfree * 6; i += T) sh.band_src[i] = w.band_src[i];
     for (int i = t; i < nfree * 2; i += T) sh.g_src[i] = w.g_src[i];
     if (w.np > 0) {
@@ -615,12 +633,8 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                         w.lm_w[l] = wl;
                     }
                     __syncthreads();
-                    // C = A^T W A (lower tiles) on the matrix cores
-                    if (NA > 0 && nl > 0) block_gemm_tn<T>(w.Cm, NA, w.A, NA, w.A, NA, w.lm_w, NA, NA, nl, true);
-                    // rhs part A^T (w g)
-                    for (int l = t; l < nl; l += T) w.yl[l] = w.lm_w[l] * w.lm_g[l];  // scratch: overwritten below
-                    __syncthreads();
-                    for (int ia = t; ia < NA; ia += T) w.Cg[ia] = dot_strided(w.A + ia, NA, w.yl, 1, nl);
+                    // [C | Cg] = A^T W [A | g] (lower tiles + the gradient column) on the matrix cores
+                    if (NA > 0 && nl > 0) block_gemm_tn<T>(w.Cm, NAs, w.A, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, true);
                     __syncthreads();
                     // S = Sigma (H - C) Sigma + mu D^2   (lower triangle); one wave per 15 x 15 block, 4 passes in flight
                     for (int i = t; i < N; i += T) sh.xv[i] = w.sig_p[i];
@@ -636,7 +650,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                             if (e < 225 && (fi != fj || b <= a)) {
                                 const int i = 15 * fi + a, j = 15 * fj + b;
                                 v = w.H[(size_t)i * N + j];
-                                if (a < 6 && b < 6 && nl > 0) v -= w.Cm[(size_t)(6 * fi + a) * NA + 6 * fj + b];
+                                if (a < 6 && b < 6 && nl > 0) v -= w.Cm[(size_t)(6 * fi + a) * NAs + 6 * fj + b];
                                 v *= sh.xv[i] * sh.xv[j];
                                 if (i == j) v += mu * w.diag_p[i] * w.diag_p[i];
                             }
@@ -655,7 +669,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     for (int i = t; i < N; i += T) {
                         const int fi = i / 15, a = i - 15 * fi;
                         double v = w.g[i];
-                        if (a < 6) v -= w.Cg[6 * fi + a];
+                        if (a < 6 && nl > 0) v -= w.Cm[(size_t)(6 * fi + a) * NAs + NA];
                         w.yp[i] = v * w.sig_p[i];
                     }
                     __syncthreads();
@@ -676,7 +690,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                             double y = 0.0;
                             if (w.lfree[l]) {
                                 double s = w.lm_g[l];
-                                const double *Arow = w.A + (size_t)l * NA;
+                                const double *Arow = w.A + (size_t)l * NAs;
                                 for (int f = 0; f < nfree; ++f) {
                                     double av[6];
 #pragma unroll
