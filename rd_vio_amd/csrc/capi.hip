@@ -129,12 +129,12 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
         }
     }
     {
-        const size_t F = (size_t)max_factors, Nmax = 15 * (size_t)nfr;
-        size_t bytes = (1 << 16) + F * 420 + F * (64 + 48 * (size_t)nfr) + Nmax * Nmax * 8 * 8;
-        bytes += bytes / 4;
+        // marginalisation slot: a BA problem with every frame free + the tail's dense scratch (8 N x N matrices)
+        const size_t Nmax = 15 * (size_t)nfr;
+        const size_t bytes = ctx->ba_arena_bytes + Nmax * Nmax * 8 * 8 + (1 << 16);
         ctx->marg_bytes = bytes;
-        CTX_ALLOC(ctx->marg_arena, bytes);
-        if (hipHostMalloc(&ctx->marg_host, bytes, hipHostMallocDefault) != hipSuccess) {
+        CTX_ALLOC(ctx->marg.arena, bytes);
+        if (hipHostMalloc(&ctx->marg.host, bytes, hipHostMallocDefault) != hipSuccess) {
             rdvio_fail(ctx, RDVIO_ERR_HIP, "hipHostMalloc(marg host blob) failed");
             *out = ctx;
             return RDVIO_ERR_HIP;
@@ -164,8 +164,8 @@ void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
                     ctx->ba_Jd, ctx->pre_imu, ctx->pre_par, ctx->pre_out, ctx->pre_off};
     for (void *b : bufs) (void)hipFree(b);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-    if (ctx->marg_host) (void)hipHostFree(ctx->marg_host);
-    (void)hipFree(ctx->marg_arena);
+    if (ctx->marg.host) (void)hipHostFree(ctx->marg.host);
+    (void)hipFree(ctx->marg.arena);
     for (int s = 0; s < RDVIO_BA_SLOTS; ++s) {
         if (ctx->ba[s].host) (void)hipHostFree(ctx->ba[s].host);
         (void)hipFree(ctx->ba[s].arena);

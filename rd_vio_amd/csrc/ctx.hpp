@@ -10,7 +10,6 @@
 
 #include "../../include/rdvio_hip.h"
 #include "solver_ws.hpp"
-#include "marg_ws.hpp"
 
 #define RDVIO_NUM_SLOTS 2
 #define RDVIO_MAX_TILES 256  // CLAHE tile grid (8x8 in configs/setting.yaml:17-19)
@@ -64,11 +63,9 @@ struct rdvio_hip_ctx {
         bool ready = false;
     } ba[RDVIO_BA_SLOTS];
     size_t ba_host_bytes = 0, ba_arena_bytes = 0;
-    // marginalisation
-    void *marg_host = nullptr, *marg_arena = nullptr;
-    size_t marg_bytes = 0, marg_in_bytes = 0;
-    MargWs marg_ws{};
-    bool marg_ready = false;
+    // marginalisation: a solver slot of its own (the linearisation is shared with the solver) + tail scratch
+    BaSlot marg;
+    size_t marg_bytes = 0;
 
     // pinned host staging
     void *pinned = nullptr;
@@ -94,6 +91,10 @@ inline int rdvio_fail(rdvio_hip_ctx *ctx, int code, const char *fmt, ...) {
             return rdvio_fail(ctx, RDVIO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
                               __FILE__, __LINE__);                                                     \
     } while (0)
+
+// solver_host.hip: validate + index + pack a BA problem into `slot` (capacity `cap` bytes of pinned blob and arena);
+// with_marg_tail also carves the marginalisation tail's scratch and outputs
+int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvio_ba_problem *pb, size_t cap, bool with_marg_tail);
 
 // kernel launchers (defined in the .hip files)
 int rdvio_launch_preprocess(rdvio_hip_ctx *ctx, int slot, const uint8_t *gray_dev, int w, int h, int stride,

@@ -37,7 +37,7 @@ struct Packer {
 
 }  // namespace
 
-static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvio_ba_problem *pb) {
+int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvio_ba_problem *pb, size_t cap, bool with_marg_tail) {
     if (!pb) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null BA problem");
     const int nfr = pb->n_frames, nl = pb->n_landmarks, nf = pb->n_factors, nrot = pb->n_rot, npre = pb->n_preint,
               np = pb->n_prior;
@@ -170,7 +170,7 @@ static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdv
         if (lm_count[l] > 0 && !pb->lm_fixed[l]) n_lfree++;
 
     // ---- pack inputs into the pinned blob (one H2D copy), then carve device scratch behind it
-    Packer P{(uint8_t *)slot.host, ctx->ba_host_bytes};
+    Packer P{(uint8_t *)slot.host, cap};
     double extr18[18];
     memcpy(extr18, pb->extr, 14 * sizeof(double));
     memcpy(extr18 + 14, pb->sqrt_inv_cov, 4 * sizeof(double));
@@ -198,7 +198,7 @@ static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdv
     const size_t in_bytes = P.off;
 
     // scratch (device only): bump-allocate behind the inputs
-    Packer Sx{nullptr, ctx->ba_arena_bytes};
+    Packer Sx{nullptr, cap};
     Sx.off = in_bytes;
     auto dd = [&](size_t n) { return Sx.reserve(std::max<size_t>(n, 1) * sizeof(double)); };
     const size_t s_x = dd((size_t)nfr * 16), s_xd = dd(nl), s_xc = dd((size_t)nfr * 16), s_xdc = dd(nl), s_user = dd((size_t)nfr * 16);
@@ -213,6 +213,15 @@ static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdv
     const size_t s_lmm = dd(nl), s_lmg = dd(nl), s_lmw = dd(nl), s_A = dd((size_t)nl * (6 * nfree + 2)), s_yl = dd(nl);
     const size_t s_sigp = dd(N), s_sigl = dd(nl), s_dgp = dd(N), s_dgl = dd(nl), s_grp = dd(N), s_grl = dd(nl), s_gnp = dd(N), s_gnl = dd(nl), s_tp = dd(N), s_tl = dd(nl);
     const size_t s_sum = dd(80);  // summary[0..7] + diagnostic phase stamps
+    // marginalisation tail (victim = frame 0): R = N - 15 retained rows
+    const int R = N >= 15 ? N - 15 : 0, Rb = (R + 14) / 15 * 15, Wn = std::max(R, Rb);
+    size_t s_mTm = 0, s_mLr = 0, s_mer = 0, s_mWk = 0, s_mV = 0, s_mcs = 0, s_myv = 0, s_mnz = 0, s_So = 0, s_fo = 0, s_lo = 0, s_Lo = 0, s_eo = 0, s_info = 0;
+    if (with_marg_tail) {
+        s_mTm = dd((size_t)R * 15); s_mLr = dd((size_t)R * R); s_mer = dd(R); s_mWk = dd((size_t)Wn * Wn); s_mV = dd((size_t)R * R);
+        s_mcs = dd((size_t)4 * (R / 2 + 2) + R); s_myv = dd(Wn);
+        s_mnz = Sx.reserve((size_t)(2 * R + 2) * sizeof(int32_t));  // nz list + pivot `done` flags
+        s_So = dd((size_t)R * R); s_fo = dd(R); s_lo = dd((size_t)(nfr - 1) * 16); s_Lo = dd((size_t)R * R); s_eo = dd(R); s_info = dd(4);
+    }
     if (!Sx.ok) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "BA problem does not fit the context's device arena");
 
     uint8_t *B = (uint8_t *)slot.arena;
@@ -244,6 +253,12 @@ static int ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdv
     w.sig_p = DP(s_sigp); w.sig_l = DP(s_sigl); w.diag_p = DP(s_dgp); w.diag_l = DP(s_dgl); w.grad_p = DP(s_grp); w.grad_l = DP(s_grl);
     w.gn_p = DP(s_gnp); w.gn_l = DP(s_gnl); w.tp = DP(s_tp); w.tl = DP(s_tl);
     w.summary = DP(s_sum);
+    if (with_marg_tail) {
+        w.no_loss = 1;
+        w.m_Tm = DP(s_mTm); w.m_Lr = DP(s_mLr); w.m_er = DP(s_mer); w.m_Wk = DP(s_mWk); w.m_V = DP(s_mV); w.m_cs = DP(s_mcs);
+        w.m_yv = DP(s_myv); w.m_nz = (int32_t *)(B + s_mnz);
+        w.S_out = DP(s_So); w.f_out = DP(s_fo); w.lin_out = DP(s_lo); w.Lambda_out = DP(s_Lo); w.eta_out = DP(s_eo); w.m_info = DP(s_info);
+    }
 #undef DP
 #undef IP
     slot.in_states_off = o_states;
@@ -263,7 +278,7 @@ int rdvio_hip_ba_upload(rdvio_hip_ctx *ctx, int slot, const rdvio_ba_problem *pb
     S.ready = false;
     // the pinned blob may still be in flight from a previous upload on this stream
     RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (int rc = ba_prepare(ctx, S, pb)) return rc;
+    if (int rc = rdvio_ba_prepare(ctx, S, pb, ctx->ba_arena_bytes, false)) return rc;
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(S.arena, S.host, S.in_bytes, hipMemcpyHostToDevice, ctx->stream));
     return RDVIO_OK;
 }

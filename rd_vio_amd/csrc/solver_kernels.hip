@@ -26,6 +26,7 @@
 #include "factors.hpp"
 #include "solver_ws.hpp"
 #include "block_linalg.hpp"
+#include "marg_tail.hpp"
 
 namespace {
 
@@ -81,9 +82,9 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
                                      w.z_ref + 3 * (size_t)l, invd[l], extr, W, r, Jt, Jr, Jd);
             const double s = r[0] * r[0] + r[1] * r[1];
             const double sum = 1.0 + s;
-            cost += 0.5 * log(sum);
+            cost += w.no_loss ? 0.5 * s : 0.5 * log(sum);
             if (LIN) {
-                const double sc = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
+                const double sc = w.no_loss ? 1.0 : sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
                 r[0] *= sc;
                 r[1] *= sc;
                 Jd[0] *= sc;
@@ -525,23 +526,11 @@ DM double grad_max_norm(const SolverWs &w, Shared &sh, int &phase) {
     return block_max(sh, m, phase);
 }
 
-__global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
-    __shared__ Shared sh;
-    // packed 15x15 blocks of S and the inverses of its diagonal factors, LDS-resident when the window has at most
-    // RDVIO_LDS_CHOL_MAX_FRAMES free frames (138.6 KB of the CU's 160 KB); larger windows factor in global memory
-    constexpr int NMAX = 15 * RDVIO_LDS_CHOL_MAX_FRAMES;
-    __shared__ __attribute__((aligned(16))) double lds_chol_buf[NMAX * (NMAX + 1) / 2 + 225 * RDVIO_LDS_CHOL_MAX_FRAMES];
-    double *Sl = lds_chol_buf, *Dinv = lds_chol_buf + w.N * (w.N + 1) / 2;
+// per-launch setup shared by the solver and the marginalisation kernel: user state, free-landmark flags, LDS index
+// tables, zeroed coupling rows, and the constant parts of the prior (S^T, Lambda = S^T S, eta0 = S^T f)
+DM void solver_setup(const SolverWs &w, Shared &sh) {
     const int t = threadIdx.x;
-    const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
-    int phase = 0;
-    unsigned long long prof_last = 0;
-#ifdef RDVIO_PROF
-    prof_last = wall_clock64();
-    if (t == 0) for (int i = 8; i < 72; ++i) w.summary[i] = 0.0;
-#endif
-
-    // ------------------------------------------------------------------ setup
+    const int nl = w.nl, nfree = w.nfree, NAs = 6 * nfree + 2;
     for (int i = t; i < w.nfr * 16; i += T) w.user[i] = w.x[i];
     for (int l = t; l < nl; l += T) w.lfree[l] = (w.lm_count[l] > 0 && !w.lm_fixed[l]) ? 1 : 0;
     for (int i = t; i < 32; i += T) {
@@ -563,6 +552,25 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
         }
     }
     __syncthreads();
+}
+
+__global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
+    __shared__ Shared sh;
+    // packed 15x15 blocks of S and the inverses of its diagonal factors, LDS-resident when the window has at most
+    // RDVIO_LDS_CHOL_MAX_FRAMES free frames (138.6 KB of the CU's 160 KB); larger windows factor in global memory
+    constexpr int NMAX = 15 * RDVIO_LDS_CHOL_MAX_FRAMES;
+    __shared__ __attribute__((aligned(16))) double lds_chol_buf[NMAX * (NMAX + 1) / 2 + 225 * RDVIO_LDS_CHOL_MAX_FRAMES];
+    double *Sl = lds_chol_buf, *Dinv = lds_chol_buf + w.N * (w.N + 1) / 2;
+    const int t = threadIdx.x;
+    const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
+    int phase = 0;
+    unsigned long long prof_last = 0;
+#ifdef RDVIO_PROF
+    prof_last = wall_clock64();
+    if (t == 0) for (int i = 8; i < 72; ++i) w.summary[i] = 0.0;
+#endif
+
+    solver_setup(w, sh);
 
     double radius = 1e4, mu = 1e-8, alpha = 0.0, dogleg_step_norm = 0.0;
     double gnorm = 0.0, gn_norm = 0.0, gdotgn = 0.0, gsq_keep = 0.0;
@@ -833,7 +841,34 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     }
 }
 
+// CeresMarginalizationFactor::marginalize(0): linearise the marginalisation graph at the current states (no robust
+// loss), assemble the normal equations with the solver's own routines, then Schur out the landmarks and the victim
+// frame and rebuild the sqrt prior (marg_tail.hpp).
+__global__ __launch_bounds__(T) void marginalize_kernel(SolverWs w) {
+    __shared__ Shared sh;
+    constexpr int NMAX = 15 * RDVIO_LDS_CHOL_MAX_FRAMES;
+    __shared__ __attribute__((aligned(16))) double lds_buf[NMAX * (NMAX + 1) / 2 + 225 * RDVIO_LDS_CHOL_MAX_FRAMES];
+    int phase = 0;
+    unsigned long long prof_last = 0;
+#ifdef RDVIO_PROF
+    prof_last = wall_clock64();
+    if (threadIdx.x == 0) for (int i = 8; i < 72; ++i) w.summary[i] = 0.0;
+#endif
+    solver_setup(w, sh);
+    STAMP(0);
+    (void)evaluate<true>(w, sh, phase, w.x, w.xd, prof_last);
+    STAMP(1);
+    build_normal_equations(w, sh, prof_last);
+    STAMP(2);
+    marginalize_tail<T>(w, sh, phase, lds_buf);
+    STAMP(3);
+}
+
 }  // namespace
+
+void rdvio_launch_marginalize(hipStream_t stream, const SolverWs &w) {
+    hipLaunchKernelGGL(marginalize_kernel, dim3(1), dim3(T), 0, stream, w);
+}
 
 void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w) {
     hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(T), 0, stream, w);

@@ -50,7 +50,14 @@ struct SolverWs {
     double *lm_m, *lm_g, *lm_w, *A, *yl;
     double *sig_p, *sig_l, *diag_p, *diag_l, *grad_p, *grad_l, *gn_p, *gn_l, *tp, *tl;
     double *summary;
+    // ---- marginalisation mode (rdvio_hip_marginalize): the same linearisation + normal equations without the robust
+    // loss, then the victim frame's Schur complement and the new sqrt prior (marg_tail.hpp)
+    int no_loss, marg_force_eigen;
+    double *m_Tm, *m_Lr, *m_er, *m_Wk, *m_V, *m_cs, *m_yv;
+    int32_t *m_nz;
+    double *S_out, *f_out, *lin_out, *Lambda_out, *eta_out, *m_info;
     double *prof;                        // diagnostic phase stamps (RDVIO_PROF builds only)                     // iterations, successful steps, initial cost, final cost, termination
 };
 
 void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w);
+void rdvio_launch_marginalize(hipStream_t stream, const SolverWs &w);
