@@ -60,6 +60,16 @@ __global__ __launch_bounds__(256) void reprojection_eval_kernel(int nf, const in
 // Segments longer than 64 samples are processed in chunks of 64 with the running state carried over.
 // ---------------------------------------------------------------------------------------------
 DM double shfl_d(double v, int src) { return __shfl(v, src); }
+DM double readlane_dd(double v, int src_lane) {  // src_lane wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+DM double wave_max_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
 DM Q4 shfl_q(const Q4 &q, int src) { return Q4{shfl_d(q.x, src), shfl_d(q.y, src), shfl_d(q.z, src), shfl_d(q.w, src)}; }
 DM V3 shfl_v(const V3 &v, int src) { return V3{shfl_d(v.x, src), shfl_d(v.y, src), shfl_d(v.z, src)}; }
 
@@ -69,12 +79,13 @@ __global__ __launch_bounds__(64) void preintegrate_kernel(int nseg, const int32_
                                                           const double *__restrict__ noise, int cj, int cc,
                                                           double *__restrict__ out) {
     __shared__ double s_cov[15 * 15];
-    __shared__ double s_A[9 * 9];
     __shared__ double s_T[9 * 9];
-    __shared__ double s_N[9 * 9];   // B Q B^T
     __shared__ double s_jac[5 * 9];
-    __shared__ double s_m[3][9];    // per-step 3x3 operands: R(dq), R hat(a), E^T ; Jr kept in s_jr
-    __shared__ double s_jr[9];
+    // per-sample operands of the chunk, built by the sample's own lane (row stride odd: conflict-free):
+    // A_k (9x9), N_k = B Q B^T (9x9), and the 3x3 blocks R(dq), R hat(a), E^T, Jr for the bias Jacobians
+    __shared__ double s_Ak[64][81];
+    __shared__ double s_Nk[64][81];
+    __shared__ double s_Mk[64][37];
     const int seg = blockIdx.x;
     if (seg >= nseg) return;
     const int lane = threadIdx.x;
@@ -139,72 +150,72 @@ __global__ __launch_bounds__(64) void preintegrate_kernel(int nseg, const int32_
             V3 ov = shfl_v(dp_inc, max(lane - off, 0));
             if (lane >= off) dp_inc = ov + dp_inc;
         }
-        // ---- phase 3: covariance / Jacobian recurrences, sequential over the chunk's samples
+        // ---- phase 3: covariance / Jacobian recurrences.  First every lane builds its own sample's matrices
+        // (parallel over samples), then the recurrence walks the samples with two barriers per step and nothing but
+        // 9-term dot products in the dependent chain.
         if (cj || cc) {
-            for (int j = 0; j < cnt; ++j) {
-                // broadcast sample j's quantities to the whole wave
-                const Q4 dq_j = shfl_q(dq_pre, j);
-                const V3 a_j = shfl_v(a, j), wdt_j = shfl_v(wdt, j);
-                const Q4 e_j = shfl_q(e, j);
-                const double dt_j = shfl_d(dt, j);
-                if (lane == 0) {
-                    M3 R = to_mat(dq_j);
-                    M3 RHa = R * hat(a_j);
-                    M3 Et = to_mat(conj(e_j));
-                    M3 Jr = right_jacobian(wdt_j);
+            if (lane < cnt) {
+                const M3 R = to_mat(dq_pre);
+                const M3 RHa = R * hat(a);
+                const M3 Et = to_mat(conj(e));
+                const M3 Jr = right_jacobian(wdt);
+                double *mk = s_Mk[lane];
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) { s_m[0][i] = R.m[i]; s_m[1][i] = RHa.m[i]; s_m[2][i] = Et.m[i]; s_jr[i] = Jr.m[i]; }
-                }
-                __syncthreads();
+                for (int i = 0; i < 9; ++i) { mk[i] = R.m[i]; mk[9 + i] = RHa.m[i]; mk[18 + i] = Et.m[i]; mk[27 + i] = Jr.m[i]; }
+                mk[36] = dt;
                 if (cc) {
-                    // A (9x9) and N = B Q B^T (9x9), built entry-wise
-                    for (int i = lane; i < 81; i += 64) {
-                        int r = i / 9, c = i - r * 9, rb = r / 3, cb = c / 3, ri = r % 3, ci = c % 3;
-                        double av = (r == c) ? 1.0 : 0.0;
-                        if (rb == 0 && cb == 0) av = s_m[2][ri * 3 + ci];                       // A[q,q] = E^T
-                        else if (rb == 2 && cb == 0) av = -dt_j * s_m[1][ri * 3 + ci];          // A[v,q]
-                        else if (rb == 1 && cb == 0) av = -0.5 * dt_j * dt_j * s_m[1][ri * 3 + ci];  // A[p,q]
-                        else if (rb == 1 && cb == 2) av = (ri == ci) ? dt_j : 0.0;              // A[p,v]
-                        s_A[i] = av;
-                        // B rows: q: [dt Jr, 0], p: [0, 0.5 dt^2 R], v: [0, dt R];  Q = diag(cov_w, cov_a)/max(dt,1e-7)
-                        const double inv_dt = 1.0 / fmax(dt_j, 1.0e-7);
-                        double nv = 0.0;
-                        // N[r,c] = sum_{x,y} B[r,x] Q[x,y] B[c,y]; B has one non-zero 3x3 block per block-row
-                        const double *Br = (rb == 0) ? s_jr : s_m[0];
-                        const double *Bc = (cb == 0) ? s_jr : s_m[0];
-                        const double sr = (rb == 0) ? dt_j : (rb == 1 ? 0.5 * dt_j * dt_j : dt_j);
-                        const double sc = (cb == 0) ? dt_j : (cb == 1 ? 0.5 * dt_j * dt_j : dt_j);
-                        const bool same = ((rb == 0) == (cb == 0));  // both gyro-driven or both acc-driven
-                        if (same) {
-                            const double *Qm = noise + ((rb == 0) ? 0 : 9);
+                    // G_w = Jr Q_w Jr^T, G_a = R Q_a R^T: the two distinct 3x3 blocks of B Q B^T
+                    double Gw[9], Ga[9];
+#pragma unroll
+                    for (int ri = 0; ri < 3; ++ri)
+#pragma unroll
+                        for (int ci = 0; ci < 3; ++ci) {
+                            double gw = 0.0, ga = 0.0;
 #pragma unroll
                             for (int x = 0; x < 3; ++x)
 #pragma unroll
-                                for (int y = 0; y < 3; ++y) nv += Br[ri * 3 + x] * Qm[x * 3 + y] * Bc[ci * 3 + y];
-                            nv *= sr * sc * inv_dt;
+                                for (int y = 0; y < 3; ++y) {
+                                    gw += Jr.m[ri * 3 + x] * noise[x * 3 + y] * Jr.m[ci * 3 + y];
+                                    ga += R.m[ri * 3 + x] * noise[9 + x * 3 + y] * R.m[ci * 3 + y];
+                                }
+                            Gw[ri * 3 + ci] = gw;
+                            Ga[ri * 3 + ci] = ga;
                         }
-                        s_N[i] = nv;
-                    }
-                    __syncthreads();
-                    for (int i = lane; i < 81; i += 64) {  // T = A * cov9
-                        int r = i / 9, c = i - r * 9;
-                        double acc = 0.0;
+                    const double inv_dt = 1.0 / fmax(dt, 1.0e-7);
+                    double *Ak = s_Ak[lane], *Nk = s_Nk[lane];
 #pragma unroll
-                        for (int x = 0; x < 9; ++x) acc += s_A[r * 9 + x] * s_cov[x * 15 + c];
-                        s_T[i] = acc;
+                    for (int i = 0; i < 81; ++i) {
+                        const int r = i / 9, c = i - r * 9, rb = r / 3, cb = c / 3, ri = r % 3, ci = c % 3;
+                        double av = (r == c) ? 1.0 : 0.0;
+                        if (rb == 0 && cb == 0) av = Et.m[ri * 3 + ci];                         // A[q,q] = E^T
+                        else if (rb == 2 && cb == 0) av = -dt * RHa.m[ri * 3 + ci];             // A[v,q]
+                        else if (rb == 1 && cb == 0) av = -0.5 * dt * dt * RHa.m[ri * 3 + ci];  // A[p,q]
+                        else if (rb == 1 && cb == 2) av = (ri == ci) ? dt : 0.0;                // A[p,v]
+                        Ak[i] = av;
+                        // B rows: q: [dt Jr, 0], p: [0, 0.5 dt^2 R], v: [0, dt R];  Q = diag(cov_w, cov_a)/max(dt,1e-7)
+                        const double sr = (rb == 0) ? dt : (rb == 1 ? 0.5 * dt * dt : dt);
+                        const double sc = (cb == 0) ? dt : (cb == 1 ? 0.5 * dt * dt : dt);
+                        double nv = 0.0;
+                        if ((rb == 0) == (cb == 0)) nv = ((rb == 0) ? Gw[ri * 3 + ci] : Ga[ri * 3 + ci]) * (sr * sc * inv_dt);
+                        Nk[i] = nv;
                     }
-                    __syncthreads();
-                    for (int i = lane; i < 81; i += 64) {  // cov9 = T A^T + N
-                        int r = i / 9, c = i - r * 9;
-                        double acc = 0.0;
+                }
+            }
+            __syncthreads();
+            for (int j = 0; j < cnt; ++j) {
+                const double *Aj = s_Ak[j], *Nj = s_Nk[j], *mk = s_Mk[j];
+                const double dt_j = mk[36];
+                double T0 = 0.0, T1 = 0.0;
+                if (cc) {  // T = A * cov9
+                    {
+                        const int r = lane / 9, c = lane - r * 9;
 #pragma unroll
-                        for (int x = 0; x < 9; ++x) acc += s_T[r * 9 + x] * s_A[c * 9 + x];
-                        s_cov[r * 15 + c] = acc + s_N[i];
+                        for (int x = 0; x < 9; ++x) T0 += Aj[r * 9 + x] * s_cov[x * 15 + c];
                     }
-                    if (lane < 18) {
-                        int which = lane / 9, i9 = lane % 9, r = i9 / 3, c = i9 % 3;
-                        int o0 = which ? ES_BA : ES_BG;
-                        s_cov[(o0 + r) * 15 + o0 + c] += noise[18 + 9 * which + i9] * dt_j;
+                    if (lane < 17) {
+                        const int i = lane + 64, r = i / 9, c = i - r * 9;
+#pragma unroll
+                        for (int x = 0; x < 9; ++x) T1 += Aj[r * 9 + x] * s_cov[x * 15 + c];
                     }
                 }
                 // one entry of each 3x3 Jacobian per lane (preintegrator.cpp:59-70; old values feed p and v)
@@ -215,15 +226,19 @@ __global__ __launch_bounds__(64) void preintegrate_kernel(int nseg, const int32_
                     double t_rha = 0.0, t_et = 0.0;
 #pragma unroll
                     for (int x = 0; x < 3; ++x) {
-                        t_rha += s_m[1][r * 3 + x] * dq_dbg[x * 3 + c];
-                        t_et += s_m[2][r * 3 + x] * dq_dbg[x * 3 + c];
+                        t_rha += mk[9 + r * 3 + x] * dq_dbg[x * 3 + c];
+                        t_et += mk[18 + r * 3 + x] * dq_dbg[x * 3 + c];
                     }
-                    const double Rrc = s_m[0][lane];
+                    const double Rrc = mk[lane];
                     n_dp_dbg = s_jac[9 + lane] + dt_j * dv_dbg[lane] - 0.5 * dt_j * dt_j * t_rha;
                     n_dp_dba = s_jac[18 + lane] + dt_j * dv_dba[lane] - 0.5 * dt_j * dt_j * Rrc;
                     n_dv_dbg = dv_dbg[lane] - dt_j * t_rha;
                     n_dv_dba = dv_dba[lane] - dt_j * Rrc;
-                    n_dq_dbg = t_et - dt_j * s_jr[lane];
+                    n_dq_dbg = t_et - dt_j * mk[27 + lane];
+                }
+                if (cc) {
+                    s_T[lane] = T0;
+                    if (lane < 17) s_T[lane + 64] = T1;
                 }
                 __syncthreads();
                 if (cj && lane < 9) {
@@ -232,6 +247,26 @@ __global__ __launch_bounds__(64) void preintegrate_kernel(int nseg, const int32_
                     s_jac[18 + lane] = n_dp_dba;
                     s_jac[27 + lane] = n_dv_dbg;
                     s_jac[36 + lane] = n_dv_dba;
+                }
+                if (cc) {  // cov9 = T A^T + N; bias random walks
+                    {
+                        const int r = lane / 9, c = lane - r * 9;
+                        double acc = 0.0;
+#pragma unroll
+                        for (int x = 0; x < 9; ++x) acc += s_T[r * 9 + x] * Aj[c * 9 + x];
+                        s_cov[r * 15 + c] = acc + Nj[lane];
+                    }
+                    if (lane < 17) {
+                        const int i = lane + 64, r = i / 9, c = i - r * 9;
+                        double acc = 0.0;
+#pragma unroll
+                        for (int x = 0; x < 9; ++x) acc += s_T[r * 9 + x] * Aj[c * 9 + x];
+                        s_cov[r * 15 + c] = acc + Nj[i];
+                    } else if (lane < 35) {
+                        const int q = lane - 17, which = q / 9, i9 = q % 9, r = i9 / 3, c = i9 % 3;
+                        const int o0 = which ? ES_BA : ES_BG;
+                        s_cov[(o0 + r) * 15 + o0 + c] += noise[18 + 9 * which + i9] * dt_j;
+                    }
                 }
                 __syncthreads();
             }
@@ -261,65 +296,57 @@ __global__ __launch_bounds__(64) void preintegrate_kernel(int nseg, const int32_
         for (int i = lane; i < 225; i += 64) o[PRE_SIC + i] = 0.0;
         return;
     }
-    // ---- compute_sqrt_inv_cov (:97-100): inverse by Gauss-Jordan with partial pivoting on [cov | I]
-    //      (15 x 30 in LDS, one column per lane), then LLT of the inverse, transposed.
-    __shared__ double s_M[15 * 30];
-    __shared__ double s_L[15 * 15];
-    for (int i = lane; i < 15 * 30; i += 64) {
-        int r = i / 30, c = i - r * 30;
-        s_M[i] = (c < 15) ? s_cov[r * 15 + c] : ((c - 15 == r) ? 1.0 : 0.0);
+    // ---- compute_sqrt_inv_cov (:97-100): inverse by Gauss-Jordan with partial pivoting on [cov | I], then LLT of the
+    //      inverse, transposed.  Both run in registers: lane r holds row r, pivot rows / multipliers travel through
+    //      v_readlane, so the 15-step dependent chains never touch LDS.  Rows are not swapped physically; the lane that
+    //      supplied the pivot of column c ends up holding row c of the inverse.
+    __shared__ double s_inv[15 * 15];
+    {
+        double a[30];
+#pragma unroll
+        for (int c = 0; c < 30; ++c) a[c] = (lane < 15) ? ((c < 15) ? s_cov[lane * 15 + c] : ((c - 15 == lane) ? 1.0 : 0.0)) : 0.0;
+        bool used = lane >= 15;
+        int mycol = -1;
+#pragma unroll
+        for (int c = 0; c < 15; ++c) {
+            const double v = used ? -1.0 : fabs(a[c]);
+            const double m = wave_max_d(v);
+            const unsigned long long tie = __ballot(v == m && !used);
+            const int piv = __builtin_amdgcn_readfirstlane(tie ? (int)__builtin_ctzll(tie) : 0);
+            const double inv_d = 1.0 / readlane_dd(a[c], piv);  // one divide per column; the row is scaled by the reciprocal
+            const double f = a[c];
+#pragma unroll
+            for (int k = 0; k < 30; ++k) {
+                const double pr = readlane_dd(a[k], piv) * inv_d;
+                a[k] = (lane == piv) ? pr : a[k] - f * pr;
+            }
+            if (lane == piv) { used = true; mycol = c; }
+        }
+        if (mycol >= 0) {
+#pragma unroll
+            for (int k = 0; k < 15; ++k) s_inv[mycol * 15 + k] = a[15 + k];
+        }
     }
     __syncthreads();
-    for (int c = 0; c < 15; ++c) {
-        int piv = c;
-        double best = fabs(s_M[c * 30 + c]);
-        for (int r = c + 1; r < 15; ++r) {
-            double v = fabs(s_M[r * 30 + c]);
-            if (v > best) { best = v; piv = r; }
-        }
-        __syncthreads();
-        if (piv != c && lane < 30) {
-            double t = s_M[c * 30 + lane];
-            s_M[c * 30 + lane] = s_M[piv * 30 + lane];
-            s_M[piv * 30 + lane] = t;
-        }
-        __syncthreads();
-        const double d = s_M[c * 30 + c];
-        __syncthreads();
-        if (lane < 30) s_M[c * 30 + lane] /= d;
-        __syncthreads();
-        if (lane < 30) {
-            const double pc = s_M[c * 30 + lane];
-            for (int r = 0; r < 15; ++r) {
-                if (r == c) continue;
-                const double f = s_M[r * 30 + c];
-                // every lane reads column c of row r before any lane overwrites it: lane c writes last value itself
-                __builtin_amdgcn_wave_barrier();
-                s_M[r * 30 + lane] -= f * pc;
-                __builtin_amdgcn_wave_barrier();
+    {
+        double a[15];
+#pragma unroll
+        for (int c = 0; c < 15; ++c) a[c] = (lane < 15 && c <= lane) ? s_inv[lane * 15 + c] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 15; ++j) {
+            const double dj = sqrt(readlane_dd(a[j], j));
+            const double lj = (lane == j) ? dj : a[j] * (1.0 / dj);
+            a[j] = lj;
+#pragma unroll
+            for (int c = j + 1; c < 15; ++c) {
+                const double lc = readlane_dd(lj, c);
+                a[c] -= lj * lc;
             }
         }
-        __syncthreads();
-    }
-    // LLT of inv (lower), sequential over columns, rows in parallel
-    for (int i = lane; i < 225; i += 64) s_L[i] = 0.0;
-    __syncthreads();
-    for (int j = 0; j < 15; ++j) {
-        double sdiag = s_M[j * 30 + 15 + j];
-        for (int k2 = 0; k2 < j; ++k2) sdiag -= s_L[j * 15 + k2] * s_L[j * 15 + k2];
-        const double dj = sqrt(sdiag);
-        __syncthreads();
-        if (lane == j) s_L[j * 15 + j] = dj;
-        if (lane > j && lane < 15) {
-            double t = s_M[lane * 30 + 15 + j];
-            for (int k2 = 0; k2 < j; ++k2) t -= s_L[lane * 15 + k2] * s_L[j * 15 + k2];
-            s_L[lane * 15 + j] = t / dj;
+        if (lane < 15) {
+#pragma unroll
+            for (int r = 0; r < 15; ++r) o[PRE_SIC + r * 15 + lane] = (r <= lane) ? a[r] : 0.0;  // matrixL().transpose()
         }
-        __syncthreads();
-    }
-    for (int i = lane; i < 225; i += 64) {
-        int r = i / 15, c = i - r * 15;
-        o[PRE_SIC + i] = s_L[c * 15 + r];  // matrixL().transpose()
     }
 }
 

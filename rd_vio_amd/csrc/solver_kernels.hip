@@ -337,14 +337,13 @@ __device__ __attribute__((noinline)) void build_normal_equations(const SolverWs 
     // ---- phase 2: every entry of H, output-stationary: prior + preintegration band + reprojection groups.
     // One wavefront per 15 x 15 block (block-level conditions are wave-uniform), four lane passes per block whose
     // loads are independent and issued together.
-    for (int blk = wave; blk < nfree * nfree; blk += NW) {
+    auto block_entries = [&](int blk, double (&v)[4]) {
         const int fi = blk / nfree, fj = blk - fi * nfree;
         const int pi = sh.pcol[fi], pj = sh.pcol[fj];
         const bool has_prior = pi >= 0 && pj >= 0;
         const int which = fj - fi + 1;
         const int src0 = (which >= 0 && which <= 2) ? sh.band_src[(fi * 3 + which) * 2] : -1;
         const int src1 = (which >= 0 && which <= 2) ? sh.band_src[(fi * 3 + which) * 2 + 1] : -1;
-        double v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = lane + 64 * u;
@@ -373,11 +372,23 @@ __device__ __attribute__((noinline)) void build_normal_equations(const SolverWs 
             }
             v[u] = acc;
         }
+    };
+    auto block_store = [&](int blk, const double (&v)[4]) {
+        const int fi = blk / nfree, fj = blk - fi * nfree;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = lane + 64 * u;
             if (e < 225) w.H[(size_t)(15 * fi + e / 15) * N + 15 * fj + e % 15] = v[u];
         }
+    };
+    // two blocks per trip: their loads are independent, so twice as many are in flight per L2 round trip
+    for (int blk = wave; blk < nfree * nfree; blk += 2 * NW) {
+        double v0[4], v1[4];
+        const bool two = blk + NW < nfree * nfree;
+        block_entries(blk, v0);
+        if (two) block_entries(blk + NW, v1);
+        block_store(blk, v0);
+        if (two) block_store(blk + NW, v1);
     }
     for (int o = t; o < N; o += T) {
         const int c = o / 15, a = o - 15 * c;
@@ -559,7 +570,8 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     // packed 15x15 blocks of S and the inverses of its diagonal factors, LDS-resident when the window has at most
     // RDVIO_LDS_CHOL_MAX_FRAMES free frames (138.6 KB of the CU's 160 KB); larger windows factor in global memory
     constexpr int NMAX = 15 * RDVIO_LDS_CHOL_MAX_FRAMES;
-    __shared__ __attribute__((aligned(16))) double lds_chol_buf[NMAX * (NMAX + 1) / 2 + 225 * RDVIO_LDS_CHOL_MAX_FRAMES];
+    constexpr size_t LDS_CAP = NMAX * (NMAX + 1) / 2 + 225 * RDVIO_LDS_CHOL_MAX_FRAMES;
+    __shared__ __attribute__((aligned(16))) double lds_chol_buf[LDS_CAP];
     double *Sl = lds_chol_buf, *Dinv = lds_chol_buf + w.N * (w.N + 1) / 2;
     const int t = threadIdx.x;
     const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
@@ -641,8 +653,20 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                         w.lm_w[l] = wl;
                     }
                     __syncthreads();
-                    // [C | Cg] = A^T W [A | g] (lower tiles + the gradient column) on the matrix cores
-                    if (NA > 0 && nl > 0) block_gemm_tn<T>(w.Cm, NAs, w.A, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, true);
+                    // [C | Cg] = A^T W [A | g] (lower tiles + the gradient column) on the matrix cores.  The operand is
+                    // first staged into the (currently idle) LDS Cholesky buffer with one batch of coalesced loads: a
+                    // K-loop over global memory is a chain of ~nl/16 dependent L2 round trips per tile.
+                    if (NA > 0 && nl > 0) {
+                        if (w.lds_chol && (size_t)nl * NAs + nl <= LDS_CAP) {
+                            double *As = lds_chol_buf, *ws = lds_chol_buf + (size_t)nl * NAs;
+                            for (int i = t; i < nl * NAs; i += T) As[i] = w.A[i];
+                            for (int l = t; l < nl; l += T) ws[l] = w.lm_w[l];
+                            __syncthreads();
+                            block_gemm_tn<T>(w.Cm, NAs, As, NAs, As, NAs, ws, NA, NA + 1, nl, true);
+                        } else {
+                            block_gemm_tn<T>(w.Cm, NAs, w.A, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, true);
+                        }
+                    }
                     __syncthreads();
                     // S = Sigma (H - C) Sigma + mu D^2   (lower triangle); one wave per 15 x 15 block, 4 passes in flight
                     for (int i = t; i < N; i += T) sh.xv[i] = w.sig_p[i];
