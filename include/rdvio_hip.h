@@ -126,7 +126,8 @@ typedef struct {
     int32_t n_frames;
     const double *states;          /* n_frames x 16 (initial values) */
     const uint8_t *frame_fixed;    /* n_frames: 1 = constant block (FT_FIX_POSE|FT_FIX_MOTION, solver.cpp:92-113,
-                                      or a frame that is not a parameter of this solve) */
+                                      or a frame that is not a parameter of this solve); 2 = pose constant, motion
+                                      free (FT_FIX_POSE alone: the initializer's first keyframe, initializer.cpp:82) */
     const double *extr;            /* 14 */
     const double *sqrt_inv_cov;    /* 2 x 2 */
     int32_t n_landmarks;

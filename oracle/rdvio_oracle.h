@@ -152,7 +152,7 @@ int ro_detect_keypoints(const uint8_t *img, int w, int h, int stride, int max_co
  * reprojection factor whose anchor frame and landmark are fixed; a PreIntegrationPriorFactor has frame i fixed. */
 typedef struct {
     int n_frames;
-    const uint8_t *frame_fixed;   /* 1 = constant (FT_FIX_POSE|FT_FIX_MOTION, or not a parameter of this solve) */
+    const uint8_t *frame_fixed;   /* 1 = constant (FT_FIX_POSE|FT_FIX_MOTION, or not a parameter of this solve); 2 = pose constant, motion free (FT_FIX_POSE only) */
     const double *extr;           /* 14 */
     const double *sqrt_inv_cov;   /* 4 */
     int n_landmarks;

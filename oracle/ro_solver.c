@@ -114,6 +114,22 @@ static double evaluate(lin_t *L, const double *states, const double *invd, const
         cost += 0.5 * s;
     }
     if (!want_jac) return cost;
+    /* frame_fixed == 2: pose constant, motion free (FT_FIX_POSE without FT_FIX_MOTION, solver.cpp:92-97).  The frame
+     * keeps its 15 columns; the 6 pose columns of every Jacobian are zeroed, which leaves them decoupled with zero
+     * gradient (the dogleg diagonal's lower clamp keeps the reduced system positive definite; their step is 0). */
+    for (int k = 0; k < L->nf; ++k) {
+        if (pb->frame_fixed[pb->tgt[k]] == 2) for (int i = 0; i < 12; ++i) L->Jt[12 * k + i] = 0.0;
+        if (pb->frame_fixed[pb->ref[k]] == 2) for (int i = 0; i < 12; ++i) L->Jr[12 * k + i] = 0.0;
+    }
+    for (int k = 0; k < L->nrot; ++k)
+        if (pb->frame_fixed[pb->rot_tgt[k]] == 2) for (int i = 0; i < 6; ++i) L->Jro[6 * k + i] = 0.0;
+    for (int k = 0; k < L->npre; ++k) {
+        if (pb->frame_fixed[pb->pre_i[k]] == 2) for (int q = 0; q < 15; ++q) for (int a = 0; a < 6; ++a) L->Ji[225 * k + 15 * q + a] = 0.0;
+        if (pb->frame_fixed[pb->pre_j[k]] == 2) for (int q = 0; q < 15; ++q) for (int a = 0; a < 6; ++a) L->Jj[225 * k + 15 * q + a] = 0.0;
+    }
+    for (int i = 0; i < L->np; ++i)
+        if (pb->frame_fixed[pb->prior_frames[i]] == 2)
+            for (int q = 0; q < L->D; ++q) for (int a = 0; a < 6; ++a) L->Jm[(size_t)q * L->D + 15 * i + a] = 0.0;
 
     /* ---- normal equations: H (pose block), g, landmark scalars and couplings ---- */
     int N = L->N, nfree = L->nfree;
@@ -266,7 +282,7 @@ int ro_ba_solve(const ro_ba_problem *pb, int max_iterations, double *states_io, 
     L->nrot = pb->n_rot; L->np = pb->np; L->D = 15 * pb->np;
     L->fcol = (int *)malloc(sizeof(int) * L->nfr);
     L->nfree = 0;
-    for (int i = 0; i < L->nfr; ++i) L->fcol[i] = pb->frame_fixed[i] ? -1 : L->nfree++;
+    for (int i = 0; i < L->nfr; ++i) L->fcol[i] = (pb->frame_fixed[i] == 1) ? -1 : L->nfree++;
     L->N = 15 * L->nfree;
     int N = L->N, nl = L->nl, nfree = L->nfree;
     L->lfree = (int *)calloc(nl > 0 ? nl : 1, sizeof(int));
@@ -306,7 +322,7 @@ int ro_ba_solve(const ro_ba_problem *pb, int max_iterations, double *states_io, 
     do {                                                                                  \
         double s__ = 0;                                                                   \
         for (int i = 0; i < L->nfr; ++i)                                                  \
-            if (L->fcol[i] >= 0) for (int a = 0; a < 16; ++a) s__ += (st)[16 * i + a] * (st)[16 * i + a]; \
+            if (L->fcol[i] >= 0) for (int a = (pb->frame_fixed[i] == 2 ? 7 : 0); a < 16; ++a) s__ += (st)[16 * i + a] * (st)[16 * i + a]; \
         for (int l = 0; l < nl; ++l) if (L->lfree[l]) s__ += (dep)[l] * (dep)[l];        \
         (out) = sqrt(s__);                                                                \
     } while (0)
@@ -328,7 +344,7 @@ int ro_ba_solve(const ro_ba_problem *pb, int max_iterations, double *states_io, 
             double d15[15], o[16];                                                         \
             for (int a = 0; a < 15; ++a) d15[a] = -L->g[15 * c + a];                       \
             state_plus(x + 16 * i, d15, o);                                                \
-            for (int a = 0; a < 16; ++a) { double e__ = fabs(x[16 * i + a] - o[a]); if (e__ > m__) m__ = e__; } \
+            for (int a = (pb->frame_fixed[i] == 2 ? 7 : 0); a < 16; ++a) { double e__ = fabs(x[16 * i + a] - o[a]); if (e__ > m__) m__ = e__; } \
         }                                                                                  \
         for (int l = 0; l < nl; ++l) if (L->lfree[l]) { double e__ = fabs(L->lm_g[l]); if (e__ > m__) m__ = e__; } \
         (out) = m__;                                                                       \
@@ -480,7 +496,10 @@ int ro_ba_solve(const ro_ba_problem *pb, int max_iterations, double *states_io, 
         for (int i = 0; i < L->nfr; ++i) {
             int c = L->fcol[i];
             if (c < 0) memcpy(xc + 16 * i, x + 16 * i, 16 * sizeof(double));
-            else state_plus(x + 16 * i, tp + 15 * c, xc + 16 * i);
+            else {
+                state_plus(x + 16 * i, tp + 15 * c, xc + 16 * i);
+                if (pb->frame_fixed[i] == 2) memcpy(xc + 16 * i, x + 16 * i, 7 * sizeof(double)); /* constant pose block */
+            }
         }
         for (int l = 0; l < nl; ++l) xdc[l] = xd[l] + (L->lfree[l] ? tl[l] : 0.0);
         double cand_cost = evaluate(L, xc, xdc, user, 0);
@@ -488,7 +507,7 @@ int ro_ba_solve(const ro_ba_problem *pb, int max_iterations, double *states_io, 
         /* ParameterToleranceReached: ambient-space step norm */
         double step_norm = 0;
         for (int i = 0; i < L->nfr; ++i)
-            if (L->fcol[i] >= 0) for (int a = 0; a < 16; ++a) { double e = x[16 * i + a] - xc[16 * i + a]; step_norm += e * e; }
+            if (L->fcol[i] >= 0) for (int a = (pb->frame_fixed[i] == 2 ? 7 : 0); a < 16; ++a) { double e = x[16 * i + a] - xc[16 * i + a]; step_norm += e * e; }
         for (int l = 0; l < nl; ++l) if (L->lfree[l]) { double e = xd[l] - xdc[l]; step_norm += e * e; }
         step_norm = sqrt(step_norm);
         if (step_norm <= 1e-8 * (x_norm + 1e-8)) { term = RO_TERM_CONVERGENCE; break; }

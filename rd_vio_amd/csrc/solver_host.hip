@@ -83,7 +83,7 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     // ---- graph index structures
     std::vector<int32_t> fcol(nfr);
     int nfree = 0;
-    for (int i = 0; i < nfr; ++i) fcol[i] = pb->frame_fixed[i] ? -1 : nfree++;
+    for (int i = 0; i < nfr; ++i) fcol[i] = (pb->frame_fixed[i] == 1) ? -1 : nfree++;
     const int N = 15 * nfree, D = 15 * np;
     const int npairs = nfree * (nfree + 1) / 2;
     std::vector<int32_t> pair_fi(npairs), pair_fj(npairs), diag_pair(std::max(nfree, 1));
@@ -188,6 +188,7 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     const size_t o_pf = P.put(pb->prior_frames, (size_t)np), o_lin = P.put(pb->prior_lin, (size_t)np * 16);
     const size_t o_S = P.put(pb->prior_S, (size_t)D * D), o_f = P.put(pb->prior_f, (size_t)D);
     const size_t o_fcol = P.put(fcol.data(), (size_t)nfr);
+    const size_t o_ffix = P.put(pb->frame_fixed, (size_t)nfr);
     const size_t o_lmf = P.put(lm_first.data(), (size_t)nl), o_lmc = P.put(lm_count.data(), (size_t)nl);
     const size_t o_pfi = P.put(pair_fi.data(), (size_t)npairs), o_pfj = P.put(pair_fj.data(), (size_t)npairs);
     const size_t o_goff = P.put(grp_off.data(), (size_t)npairs + 1);
@@ -241,7 +242,7 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     w.rot_tgt = IP(o_rt); w.rot_ref = IP(o_rr); w.rot_zref = DP(o_rz); w.rot_tangent = DP(o_rtan);
     w.pre_i = IP(o_pi); w.pre_j = IP(o_pj); w.preint = DP(o_pre);
     w.prior_frames = IP(o_pf); w.lin = DP(o_lin); w.S = DP(o_S); w.f = DP(o_f);
-    w.fcol = IP(o_fcol); w.lm_first = IP(o_lmf); w.lm_count = IP(o_lmc);
+    w.fcol = IP(o_fcol); w.frame_fixed = B + o_ffix; w.lm_first = IP(o_lmf); w.lm_count = IP(o_lmc);
     w.pair_fi = IP(o_pfi); w.pair_fj = IP(o_pfj); w.grp_off = IP(o_goff); w.diag_pair = IP(o_dp);
     w.gslot = IP(o_gslot); w.gflip = IP(o_gflip); w.band_src = IP(o_band); w.g_src = IP(o_gsrc); w.pcol = IP(o_pcol);
     w.x = DP(s_x); w.xd = DP(s_xd); w.xc = DP(s_xc); w.xdc = DP(s_xdc); w.user = DP(s_user); w.lfree = B + s_lfree;

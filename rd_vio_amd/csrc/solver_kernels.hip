@@ -90,10 +90,12 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
                 Jd[0] *= sc;
                 Jd[1] *= sc;
                 double *o = w.fac + RDVIO_FAC_STRIDE * (size_t)k;
+                // pose-constant frames (frame_fixed == 2) keep their columns, with zero pose Jacobians
+                const double zt = sh.pfix[w.tgt[k]] ? 0.0 : sc, zr = sh.pfix[w.ref[k]] ? 0.0 : sc;
 #pragma unroll
                 for (int i = 0; i < 12; ++i) {
-                    Jt[i] *= sc;
-                    Jr[i] *= sc;
+                    Jt[i] *= zt;
+                    Jr[i] *= zr;
                     o[i] = Jt[i];
                     o[12 + i] = Jr[i];
                 }
@@ -146,8 +148,9 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
                 const double sc = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
                 w.r_r[2 * k] = r[0] * sc;
                 w.r_r[2 * k + 1] = r[1] * sc;
+                const double zs = sh.pfix[w.rot_tgt[k]] ? 0.0 : sc;
 #pragma unroll
-                for (int i = 0; i < 6; ++i) w.Jro[6 * k + i] = J[i] * sc;
+                for (int i = 0; i < 6; ++i) w.Jro[6 * k + i] = J[i] * zs;
             }
         }
     } else {
@@ -194,6 +197,7 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
                 double acc = 0.0;
 #pragma unroll
                 for (int q = 0; q < 15; ++q) acc += Sic[row * 15 + q] * G[q * 15 + col];
+                if (col < 6 && sh.pfix[which ? w.pre_j[k] : w.pre_i[k]]) acc = 0.0;
                 w.Jp[o] = acc;
             }
         }
@@ -350,7 +354,7 @@ __device__ __attribute__((noinline)) void build_normal_equations(const SolverWs 
             const int a = e / 15, b = e - 15 * a;
             double acc = 0.0;
             if (e < 225) {
-                if (has_prior) acc += prior_part(w, sh, pi, a, pj, b);
+                if (has_prior && !((a < 6 && sh.pfixc[fi]) || (b < 6 && sh.pfixc[fj]))) acc += prior_part(w, sh, pi, a, pj, b);
                 if (src0 >= 0) acc += w.PP[900 * (size_t)(src0 >> 2) + 30 * (15 * ((src0 >> 1) & 1) + a) + 15 * (src0 & 1) + b];
                 if (src1 >= 0) acc += w.PP[900 * (size_t)(src1 >> 2) + 30 * (15 * ((src1 >> 1) & 1) + a) + 15 * (src1 & 1) + b];
                 if (a < 6 && b < 6) {
@@ -409,7 +413,7 @@ __device__ __attribute__((noinline)) void build_normal_equations(const SolverWs 
             if (src >= 0) acc += w.Pg[30 * (size_t)(src >> 1) + 15 * (src & 1) + a];
         }
         const int pi = sh.pcol[c];
-        if (pi >= 0) {
+        if (pi >= 0 && !(a < 6 && sh.pfixc[c])) {
             if (a < 3) {
                 for (int aa = 0; aa < 3; ++aa) acc += prior_E(sh, pi, aa, a) * w.le[15 * pi + aa];
             } else {
@@ -514,7 +518,7 @@ DM double x_norm_of(const SolverWs &w, Shared &sh, int &phase, const double *st,
     const int t = threadIdx.x;
     double s = 0.0;
     for (int o = t; o < w.nfr * 16; o += T)
-        if (w.fcol[o / 16] >= 0) s += st[o] * st[o];
+        if (w.fcol[o / 16] >= 0 && !(sh.pfix[o / 16] && (o & 15) < 7)) s += st[o] * st[o];
     for (int l = t; l < w.nl; l += T)
         if (w.lfree[l]) s += dep[l] * dep[l];
     return sqrt(block_sum(sh, s, phase));
@@ -530,7 +534,7 @@ DM double grad_max_norm(const SolverWs &w, Shared &sh, int &phase) {
         double d15[15], o[16];
         for (int a = 0; a < 15; ++a) d15[a] = -w.g[15 * c + a];
         state_plus(w.x + 16 * i, d15, o);
-        for (int a = 0; a < 16; ++a) m = fmax(m, fabs(w.x[16 * i + a] - o[a]));
+        for (int a = sh.pfix[i] ? 7 : 0; a < 16; ++a) m = fmax(m, fabs(w.x[16 * i + a] - o[a]));
     }
     for (int l = t; l < w.nl; l += T)
         if (w.lfree[l]) m = fmax(m, fabs(w.lm_g[l]));
@@ -547,7 +551,12 @@ DM void solver_setup(const SolverWs &w, Shared &sh) {
     for (int i = t; i < 32; i += T) {
         sh.fcol[i] = (i < w.nfr) ? w.fcol[i] : -1;
         sh.pcol[i] = (i < nfree) ? w.pcol[i] : -1;
+        sh.pfix[i] = (i < w.nfr && w.frame_fixed[i] == 2) ? 1 : 0;
+        sh.pfixc[i] = 0;
     }
+    __syncthreads();
+    for (int i = t; i < w.nfr; i += T)
+        if (w.fcol[i] >= 0) sh.pfixc[w.fcol[i]] = (w.frame_fixed[i] == 2) ? 1 : 0;
     for (int i = t; i < 18; i += T) sh.ext[i] = w.extr[i];
     for (size_t i = t; i < (size_t)nl * NAs; i += T) w.A[i] = 0.0;  // slots of frames that do not observe a landmark stay zero
     for (int i = t; i < nfree * 6; i += T) sh.band_src[i] = w.band_src[i];
@@ -816,6 +825,8 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     for (int a = 0; a < 16; ++a) w.xc[16 * i + a] = w.x[16 * i + a];
                 } else {
                     state_plus(w.x + 16 * i, w.tp + 15 * c, w.xc + 16 * i);
+                    if (sh.pfix[i])
+                        for (int a = 0; a < 7; ++a) w.xc[16 * i + a] = w.x[16 * i + a];  // constant pose block
                 }
             }
             for (int l = t; l < nl; l += T) w.xdc[l] = w.xd[l] + (w.lfree[l] ? w.tl[l] : 0.0);
@@ -825,7 +836,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             STAMP(9);
             double sn2 = 0.0;
             for (int o = t; o < w.nfr * 16; o += T)
-                if (w.fcol[o / 16] >= 0) { const double e = w.x[o] - w.xc[o]; sn2 += e * e; }
+                if (w.fcol[o / 16] >= 0 && !(sh.pfix[o / 16] && (o & 15) < 7)) { const double e = w.x[o] - w.xc[o]; sn2 += e * e; }
             for (int l = t; l < nl; l += T)
                 if (w.lfree[l]) { const double e = w.xd[l] - w.xdc[l]; sn2 += e * e; }
             const double step_norm = sqrt(block_sum(sh, sn2, phase));

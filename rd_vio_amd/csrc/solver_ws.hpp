@@ -24,6 +24,7 @@ struct SolverWs {
     const double *lin, *S, *f;
     // graph index structures (built on the host with the problem: A16, sliding_window_tracker.cpp:226-300)
     const int32_t *fcol;                 // frame -> free slot or -1
+    const uint8_t *frame_fixed;          // per frame: 0 free, 1 constant, 2 pose constant / motion free
     const int32_t *lm_first, *lm_count;  // factors of a landmark are contiguous
     const int32_t *pair_fi, *pair_fj, *grp_off, *diag_pair;  // frame pairs (lo <= hi); factor groups per pair
     const int32_t *gslot, *gflip;        // per factor: record slot in group order (-1: none), 1 if the first slot holds Jr

@@ -1,0 +1,651 @@
+// Host-side geometry for the per-frame orchestration (rows A4, A5, A17, A18 of SURVEY.md section 8): small fixed-size
+// FP64 algebra plus the two-view solvers Frame::track_keypoints runs between the LK kernel and the BA kernels.
+// Dependency-free C++17 (the reference uses Eigen; it is not available in this build image).
+//
+// Reference behaviour restated here:
+//   apply_k / remove_k / triangulate_point      /root/reference/src/rdvio_geometry/include/rdvio/geometry/stereo.h:7-20,83-93
+//   find_essential_matrix / find_rotation_matrix /root/reference/src/rdvio_geometry/src/stereo.cpp:38-91
+//   Ransac<>                                     /root/reference/src/rdvio_util/include/rdvio/util/ransac.h:8-103
+//   LotBox                                       /root/reference/src/rdvio_util/include/rdvio/util/random.h:79-126
+//   solve_essential_5pt (Groebner action matrix) /root/reference/src/rdvio_geometry/src/essential.cpp:8-299
+//   solve_rotation_2pt (Wahba / Kabsch)          /root/reference/src/rdvio_geometry/include/rdvio/geometry/wahba.h:8-26
+// Where the reference calls Eigen::JacobiSVD / Eigen::EigenSolver the same quantities are obtained with a cyclic
+// Jacobi eigensolver on A^T A and a Hessenberg-QR eigenvalue iteration + inverse iteration; the sign / basis freedom
+// of those decompositions does not reach the results used downstream (inlier masks, R = V E U^T, dehomogenised points).
+#pragma once
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <numeric>
+#include <random>
+#include <vector>
+
+namespace rdvio_pipe {
+
+struct V2 { double x = 0, y = 0; };
+struct V3 { double x = 0, y = 0, z = 0; };
+struct Q4 { double x = 0, y = 0, z = 0, w = 1; };
+struct M3 { double m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; };  // row-major
+
+inline V2 operator-(const V2 &a, const V2 &b) { return {a.x - b.x, a.y - b.y}; }
+inline double norm(const V2 &a) { return std::sqrt(a.x * a.x + a.y * a.y); }
+inline double sqnorm(const V2 &a) { return a.x * a.x + a.y * a.y; }
+
+inline V3 operator+(const V3 &a, const V3 &b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(const V3 &a, const V3 &b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator-(const V3 &a) { return {-a.x, -a.y, -a.z}; }
+inline V3 operator*(double s, const V3 &a) { return {s * a.x, s * a.y, s * a.z}; }
+inline V3 operator*(const V3 &a, double s) { return {s * a.x, s * a.y, s * a.z}; }
+inline V3 operator/(const V3 &a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+inline double dot(const V3 &a, const V3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(const V3 &a, const V3 &b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double norm(const V3 &a) { return std::sqrt(dot(a, a)); }
+inline V3 normalized(const V3 &a) { return a / norm(a); }
+inline V2 hnormalized(const V3 &a) { return {a.x / a.z, a.y / a.z}; }
+
+inline Q4 conj(const Q4 &q) { return {-q.x, -q.y, -q.z, q.w}; }
+inline Q4 operator*(const Q4 &a, const Q4 &b) {
+    return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+            a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+inline Q4 normalized(const Q4 &q) {
+    const double n = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    return {q.x / n, q.y / n, q.z / n, q.w / n};
+}
+// q * v (Eigen's Quaternion::_transformVector)
+inline V3 rot(const Q4 &q, const V3 &v) {
+    const V3 u{q.x, q.y, q.z};
+    V3 uv = cross(u, v);
+    uv = uv + uv;
+    return v + q.w * uv + cross(u, uv);
+}
+inline M3 to_mat(const Q4 &q) {
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    M3 R;
+    R.m[0] = 1 - (tyy + tzz); R.m[1] = txy - twz;       R.m[2] = txz + twy;
+    R.m[3] = txy + twz;       R.m[4] = 1 - (txx + tzz); R.m[5] = tyz - twx;
+    R.m[6] = txz - twy;       R.m[7] = tyz + twx;       R.m[8] = 1 - (txx + tyy);
+    return R;
+}
+// lie_algebra.h:9-15 (Eigen::AngleAxis path): exp(w) as a unit quaternion
+inline Q4 expmap(const V3 &w) {
+    const double th = norm(w);
+    if (th == 0.0) return Q4{0, 0, 0, 1};  // AngleAxis(0, NaN-axis) guard: identity
+    const double s = std::sin(0.5 * th) / th;
+    return {s * w.x, s * w.y, s * w.z, std::cos(0.5 * th)};
+}
+inline V3 operator*(const M3 &A, const V3 &v) {
+    return {A.m[0] * v.x + A.m[1] * v.y + A.m[2] * v.z, A.m[3] * v.x + A.m[4] * v.y + A.m[5] * v.z,
+            A.m[6] * v.x + A.m[7] * v.y + A.m[8] * v.z};
+}
+inline M3 operator*(const M3 &A, const M3 &B) {
+    M3 C;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += A.m[3 * i + k] * B.m[3 * k + j];
+            C.m[3 * i + j] = s;
+        }
+    return C;
+}
+inline M3 transpose(const M3 &A) {
+    M3 T;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) T.m[3 * i + j] = A.m[3 * j + i];
+    return T;
+}
+inline double det(const M3 &A) {
+    return A.m[0] * (A.m[4] * A.m[8] - A.m[5] * A.m[7]) - A.m[1] * (A.m[3] * A.m[8] - A.m[5] * A.m[6]) +
+           A.m[2] * (A.m[3] * A.m[7] - A.m[4] * A.m[6]);
+}
+
+// stereo.h:7-14.  K row-major 3x3.
+inline V2 apply_k(const V3 &p, const double *K) { return {p.x / p.z * K[0] + K[2], p.y / p.z * K[4] + K[5]}; }
+inline V3 remove_k(const V2 &p, const double *K) { return normalized(V3{(p.x - K[2]) / K[0], (p.y - K[5]) / K[4], 1.0}); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (row-major, destroyed); V columns = eigenvectors
+// ------------------------------------------------------------------------------------------------------------------
+inline void sym_eigen(int n, double *A, double *V, double *lam) {
+    for (int i = 0; i < n * n; ++i) V[i] = (i / n == i % n) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0, dg = 0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) (i == j ? dg : off) += A[i * n + j] * A[i * n + j];
+        if (off <= 1e-300 || off <= 1e-32 * dg) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; ++i) lam[i] = A[i * n + i];
+}
+
+// indices of the eigenvalues in ascending order
+inline std::vector<int> ascending_order(int n, const double *lam) {
+    std::vector<int> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return lam[a] < lam[b]; });
+    return idx;
+}
+
+// SVD of a 3x3 matrix A = U diag(s) V^T, s descending, U and V orthogonal (completed by cross products when A is
+// rank deficient).  Used for Wahba's problem where only V E U^T matters.
+inline void svd3(const M3 &A, M3 &U, double s[3], M3 &V) {
+    double AtA[9], Vv[9], lam[3];
+    const M3 At = transpose(A);
+    const M3 P = At * A;
+    for (int i = 0; i < 9; ++i) AtA[i] = P.m[i];
+    sym_eigen(3, AtA, Vv, lam);
+    std::vector<int> ord = ascending_order(3, lam);
+    std::reverse(ord.begin(), ord.end());
+    V3 v[3], u[3];
+    for (int c = 0; c < 3; ++c) {
+        v[c] = V3{Vv[0 * 3 + ord[c]], Vv[1 * 3 + ord[c]], Vv[2 * 3 + ord[c]]};
+        s[c] = std::sqrt(std::max(lam[ord[c]], 0.0));
+    }
+    v[2] = cross(v[0], v[1]);  // right-handed completion (also fixes a degenerate third vector)
+    const double tol = 1e-12 * std::max(s[0], 1e-300);
+    u[0] = s[0] > tol ? (A * v[0]) / s[0] : V3{1, 0, 0};
+    if (s[1] > tol) {
+        u[1] = (A * v[1]) / s[1];
+        u[1] = normalized(u[1] - dot(u[1], u[0]) * u[0]);
+    } else {
+        const V3 a = std::fabs(u[0].x) < 0.9 ? V3{1, 0, 0} : V3{0, 1, 0};
+        u[1] = normalized(cross(u[0], a));
+    }
+    if (s[2] > tol) {
+        u[2] = (A * v[2]) / s[2];
+        u[2] = u[2] - dot(u[2], u[0]) * u[0];
+        u[2] = normalized(u[2] - dot(u[2], u[1]) * u[1]);
+    } else {
+        u[2] = cross(u[0], u[1]);
+    }
+    for (int c = 0; c < 3; ++c) {
+        U.m[0 * 3 + c] = u[c].x; U.m[1 * 3 + c] = u[c].y; U.m[2 * 3 + c] = u[c].z;
+        V.m[0 * 3 + c] = v[c].x; V.m[1 * 3 + c] = v[c].y; V.m[2 * 3 + c] = v[c].z;
+    }
+}
+
+// wahba.h:8-26:  h(p2) = R h(p1)
+inline M3 solve_rotation_2pt(const std::array<V3, 2> &p1, const std::array<V3, 2> &p2) {
+    M3 cov;
+    for (int i = 0; i < 9; ++i) cov.m[i] = 0.0;
+    for (int k = 0; k < 2; ++k) {
+        const double a[3] = {p1[k].x, p1[k].y, p1[k].z}, b[3] = {p2[k].x, p2[k].y, p2[k].z};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) cov.m[3 * i + j] += a[i] * b[j];
+    }
+    for (int i = 0; i < 9; ++i) cov.m[i] *= 0.5;
+    M3 U, V;
+    double s[3];
+    svd3(cov, U, s, V);
+    M3 E;
+    E.m[8] = (det(V * transpose(U)) >= 0.0) ? 1.0 : -1.0;
+    return V * E * transpose(U);
+}
+
+// essential.h:14-19
+inline double essential_geometric_error(const M3 &E, const V2 &p1, const V2 &p2) {
+    const V3 Ep1 = E * V3{p1.x, p1.y, 1.0};
+    const double r = p2.x * Ep1.x + p2.y * Ep1.y + Ep1.z;
+    return r * r / (Ep1.x * Ep1.x + Ep1.y * Ep1.y);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// eigenvalues of a general real n x n matrix: elimination to Hessenberg form + QR with implicit double shifts (the
+// classic EISPACK elmhes / hqr recipe); right eigenvectors of the real eigenvalues by inverse iteration.
+// ------------------------------------------------------------------------------------------------------------------
+inline bool real_eigenvalues(int n, std::vector<double> a, std::vector<double> &wr, std::vector<double> &wi) {
+    auto A = [&](int i, int j) -> double & { return a[(size_t)i * n + j]; };
+    for (int m = 1; m < n - 1; ++m) {
+        double x = 0.0;
+        int i = m;
+        for (int j = m; j < n; ++j)
+            if (std::fabs(A(j, m - 1)) > std::fabs(x)) { x = A(j, m - 1); i = j; }
+        if (i != m) {
+            for (int j = m - 1; j < n; ++j) std::swap(A(i, j), A(m, j));
+            for (int j = 0; j < n; ++j) std::swap(A(j, i), A(j, m));
+        }
+        if (x != 0.0)
+            for (i = m + 1; i < n; ++i) {
+                double y = A(i, m - 1);
+                if (y != 0.0) {
+                    y /= x;
+                    A(i, m - 1) = y;
+                    for (int j = m; j < n; ++j) A(i, j) -= y * A(m, j);
+                    for (int j = 0; j < n; ++j) A(j, m) += y * A(j, i);
+                }
+            }
+    }
+    for (int i = 2; i < n; ++i)
+        for (int j = 0; j < i - 1; ++j) A(i, j) = 0.0;
+    wr.assign(n, 0.0);
+    wi.assign(n, 0.0);
+    double anorm = 0.0;
+    for (int i = 0; i < n; ++i)
+        for (int j = std::max(i - 1, 0); j < n; ++j) anorm += std::fabs(A(i, j));
+    int nn = n - 1;
+    double t = 0.0, p = 0, q = 0, r = 0, s = 0, x = 0, y = 0, z = 0, w = 0, u = 0, v = 0;
+    while (nn >= 0) {
+        int its = 0, l;
+        do {
+            for (l = nn; l >= 1; --l) {
+                s = std::fabs(A(l - 1, l - 1)) + std::fabs(A(l, l));
+                if (s == 0.0) s = anorm;
+                if (std::fabs(A(l, l - 1)) + s == s) { A(l, l - 1) = 0.0; break; }
+            }
+            x = A(nn, nn);
+            if (l == nn) {
+                wr[nn] = x + t;
+                wi[nn--] = 0.0;
+            } else {
+                y = A(nn - 1, nn - 1);
+                w = A(nn, nn - 1) * A(nn - 1, nn);
+                if (l == nn - 1) {
+                    p = 0.5 * (y - x);
+                    q = p * p + w;
+                    z = std::sqrt(std::fabs(q));
+                    x += t;
+                    if (q >= 0.0) {
+                        z = p + std::copysign(z, p);
+                        wr[nn - 1] = wr[nn] = x + z;
+                        if (z != 0.0) wr[nn] = x - w / z;
+                        wi[nn - 1] = wi[nn] = 0.0;
+                    } else {
+                        wr[nn - 1] = wr[nn] = x + p;
+                        wi[nn - 1] = -(wi[nn] = z);
+                    }
+                    nn -= 2;
+                } else {
+                    if (its == 90) return false;
+                    if (its == 10 || its == 20 || its == 40) {
+                        t += x;
+                        for (int i = 0; i <= nn; ++i) A(i, i) -= x;
+                        s = std::fabs(A(nn, nn - 1)) + std::fabs(A(nn - 1, nn - 2));
+                        y = x = 0.75 * s;
+                        w = -0.4375 * s * s;
+                    }
+                    ++its;
+                    int m;
+                    for (m = nn - 2; m >= l; --m) {
+                        z = A(m, m);
+                        r = x - z;
+                        s = y - z;
+                        p = (r * s - w) / A(m + 1, m) + A(m, m + 1);
+                        q = A(m + 1, m + 1) - z - r - s;
+                        r = A(m + 2, m + 1);
+                        s = std::fabs(p) + std::fabs(q) + std::fabs(r);
+                        p /= s; q /= s; r /= s;
+                        if (m == l) break;
+                        u = std::fabs(A(m, m - 1)) * (std::fabs(q) + std::fabs(r));
+                        v = std::fabs(p) * (std::fabs(A(m - 1, m - 1)) + std::fabs(z) + std::fabs(A(m + 1, m + 1)));
+                        if (u + v == v) break;
+                    }
+                    for (int i = m + 2; i <= nn; ++i) {
+                        A(i, i - 2) = 0.0;
+                        if (i != m + 2) A(i, i - 3) = 0.0;
+                    }
+                    for (int k = m; k <= nn - 1; ++k) {
+                        if (k != m) {
+                            p = A(k, k - 1);
+                            q = A(k + 1, k - 1);
+                            r = 0.0;
+                            if (k != nn - 1) r = A(k + 2, k - 1);
+                            if ((x = std::fabs(p) + std::fabs(q) + std::fabs(r)) != 0.0) { p /= x; q /= x; r /= x; }
+                        }
+                        if ((s = std::copysign(std::sqrt(p * p + q * q + r * r), p)) != 0.0) {
+                            if (k == m) {
+                                if (l != m) A(k, k - 1) = -A(k, k - 1);
+                            } else {
+                                A(k, k - 1) = -s * x;
+                            }
+                            p += s;
+                            x = p / s; y = q / s; z = r / s;
+                            q /= p; r /= p;
+                            for (int j = k; j <= nn; ++j) {
+                                p = A(k, j) + q * A(k + 1, j);
+                                if (k != nn - 1) { p += r * A(k + 2, j); A(k + 2, j) -= p * z; }
+                                A(k + 1, j) -= p * y;
+                                A(k, j) -= p * x;
+                            }
+                            const int mmin = nn < k + 3 ? nn : k + 3;
+                            for (int i = l; i <= mmin; ++i) {
+                                p = x * A(i, k) + y * A(i, k + 1);
+                                if (k != nn - 1) { p += z * A(i, k + 2); A(i, k + 2) -= p * r; }
+                                A(i, k + 1) -= p * q;
+                                A(i, k) -= p;
+                            }
+                        }
+                    }
+                }
+            }
+        } while (l < nn - 1);
+    }
+    return true;
+}
+
+// right eigenvector of `a` (n x n row-major) for the real eigenvalue lambda: inverse iteration with partial-pivot LU
+inline std::vector<double> eigenvector_for(int n, const std::vector<double> &a, double lambda) {
+    std::vector<double> M(a);
+    double scale = 0.0;
+    for (double v : a) scale = std::max(scale, std::fabs(v));
+    const double shift = lambda + 1e-10 * std::max(std::fabs(lambda), scale > 0 ? scale : 1.0);
+    for (int i = 0; i < n; ++i) M[(size_t)i * n + i] -= shift;
+    std::vector<int> piv(n);
+    const double tiny = 1e-300 + 1e-16 * scale;
+    for (int c = 0; c < n; ++c) {
+        int p = c;
+        for (int r = c + 1; r < n; ++r)
+            if (std::fabs(M[(size_t)r * n + c]) > std::fabs(M[(size_t)p * n + c])) p = r;
+        piv[c] = p;
+        if (p != c)
+            for (int j = 0; j < n; ++j) std::swap(M[(size_t)c * n + j], M[(size_t)p * n + j]);
+        if (std::fabs(M[(size_t)c * n + c]) < tiny) M[(size_t)c * n + c] = tiny;
+        for (int r = c + 1; r < n; ++r) {
+            const double f = M[(size_t)r * n + c] / M[(size_t)c * n + c];
+            M[(size_t)r * n + c] = f;
+            for (int j = c + 1; j < n; ++j) M[(size_t)r * n + j] -= f * M[(size_t)c * n + j];
+        }
+    }
+    std::vector<double> x(n, 1.0);
+    for (int it = 0; it < 3; ++it) {
+        for (int c = 0; c < n; ++c) {
+            if (piv[c] != c) std::swap(x[c], x[piv[c]]);
+            for (int r = c + 1; r < n; ++r) x[r] -= M[(size_t)r * n + c] * x[c];
+        }
+        for (int c = n - 1; c >= 0; --c) {
+            for (int j = c + 1; j < n; ++j) x[c] -= M[(size_t)c * n + j] * x[j];
+            x[c] /= M[(size_t)c * n + c];
+        }
+        double nrm = 0.0;
+        for (double v : x) nrm += v * v;
+        nrm = std::sqrt(nrm);
+        if (!(nrm > 0.0) || !std::isfinite(nrm)) break;
+        for (double &v : x) v /= nrm;
+    }
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// five-point essential matrix (essential.cpp:8-299): null-space basis, ten cubic constraints in GRevLex order,
+// Gauss-Jordan to the action matrix of multiplication by x, real eigenvectors -> (x, y, z).
+// ------------------------------------------------------------------------------------------------------------------
+namespace five_point {
+enum Mono { XXX = 0, XXY, XYY, YYY, XXZ, XYZ, YYZ, XZZ, YZZ, ZZZ, XX, XY, YY, XZ, YZ, ZZ, X, Y, Z, I };
+struct Poly {
+    double v[20];
+    Poly() { for (double &c : v) c = 0.0; }
+    static Poly linear(double x, double y, double z, double w) {
+        Poly p;
+        p.v[X] = x; p.v[Y] = y; p.v[Z] = z; p.v[I] = w;
+        return p;
+    }
+    Poly operator+(const Poly &b) const { Poly r; for (int i = 0; i < 20; ++i) r.v[i] = v[i] + b.v[i]; return r; }
+    Poly operator-(const Poly &b) const { Poly r; for (int i = 0; i < 20; ++i) r.v[i] = v[i] - b.v[i]; return r; }
+    Poly scaled(double s) const { Poly r; for (int i = 0; i < 20; ++i) r.v[i] = s * v[i]; return r; }
+    // product truncated at degree 3, term by term as essential.cpp:50-104
+    Poly operator*(const Poly &b) const {
+        Poly r;
+        const double *a = v, *c = b.v;
+        r.v[I] = a[I] * c[I];
+        r.v[Z] = a[I] * c[Z] + a[Z] * c[I];
+        r.v[Y] = a[I] * c[Y] + a[Y] * c[I];
+        r.v[X] = a[I] * c[X] + a[X] * c[I];
+        r.v[ZZ] = a[I] * c[ZZ] + a[Z] * c[Z] + a[ZZ] * c[I];
+        r.v[YZ] = a[I] * c[YZ] + a[Z] * c[Y] + a[Y] * c[Z] + a[YZ] * c[I];
+        r.v[XZ] = a[I] * c[XZ] + a[Z] * c[X] + a[X] * c[Z] + a[XZ] * c[I];
+        r.v[YY] = a[I] * c[YY] + a[Y] * c[Y] + a[YY] * c[I];
+        r.v[XY] = a[I] * c[XY] + a[Y] * c[X] + a[X] * c[Y] + a[XY] * c[I];
+        r.v[XX] = a[I] * c[XX] + a[X] * c[X] + a[XX] * c[I];
+        r.v[ZZZ] = a[I] * c[ZZZ] + a[Z] * c[ZZ] + a[ZZ] * c[Z] + a[ZZZ] * c[I];
+        r.v[YZZ] = a[I] * c[YZZ] + a[Z] * c[YZ] + a[Y] * c[ZZ] + a[ZZ] * c[Y] + a[YZ] * c[Z] + a[YZZ] * c[I];
+        r.v[XZZ] = a[I] * c[XZZ] + a[Z] * c[XZ] + a[X] * c[ZZ] + a[ZZ] * c[X] + a[XZ] * c[Z] + a[XZZ] * c[I];
+        r.v[YYZ] = a[I] * c[YYZ] + a[Z] * c[YY] + a[Y] * c[YZ] + a[YZ] * c[Y] + a[YY] * c[Z] + a[YYZ] * c[I];
+        r.v[XYZ] = a[I] * c[XYZ] + a[Z] * c[XY] + a[Y] * c[XZ] + a[X] * c[YZ] + a[YZ] * c[X] + a[XZ] * c[Y] +
+                   a[XY] * c[Z] + a[XYZ] * c[I];
+        r.v[XXZ] = a[I] * c[XXZ] + a[Z] * c[XX] + a[X] * c[XZ] + a[XZ] * c[X] + a[XX] * c[Z] + a[XXZ] * c[I];
+        r.v[YYY] = a[I] * c[YYY] + a[Y] * c[YY] + a[YY] * c[Y] + a[YYY] * c[I];
+        r.v[XYY] = a[I] * c[XYY] + a[Y] * c[XY] + a[X] * c[YY] + a[YY] * c[X] + a[XY] * c[Y] + a[XYY] * c[I];
+        r.v[XXY] = a[I] * c[XXY] + a[Y] * c[XX] + a[X] * c[XY] + a[XY] * c[X] + a[XX] * c[Y] + a[XXY] * c[I];
+        r.v[XXX] = a[I] * c[XXX] + a[X] * c[XX] + a[XX] * c[X] + a[XXX] * c[I];
+        return r;
+    }
+};
+}  // namespace five_point
+
+inline std::vector<M3> solve_essential_5pt(const std::array<V2, 5> &pts1, const std::array<V2, 5> &pts2) {
+    using namespace five_point;
+    // null space of the 5 x 9 epipolar constraint matrix (essential.cpp:119-131): rows h = p1 p2^T flattened row-wise
+    double A[5][9];
+    for (int i = 0; i < 5; ++i) {
+        const double a[3] = {pts1[i].x, pts1[i].y, 1.0}, b[3] = {pts2[i].x, pts2[i].y, 1.0};
+        for (int j = 0; j < 3; ++j)
+            for (int k = 0; k < 3; ++k) A[i][3 * j + k] = a[j] * b[k];
+    }
+    double AtA[81], Vv[81], lam[9];
+    for (int i = 0; i < 9; ++i)
+        for (int j = 0; j < 9; ++j) {
+            double s = 0;
+            for (int k = 0; k < 5; ++k) s += A[k][i] * A[k][j];
+            AtA[9 * i + j] = s;
+        }
+    sym_eigen(9, AtA, Vv, lam);
+    const std::vector<int> ord = ascending_order(9, lam);
+    // basis columns: singular vectors 5..8 in JacobiSVD's descending order = ascending eigenvalues 3, 2, 1, 0
+    double basis[9][4];
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 9; ++r) basis[r][c] = Vv[9 * r + ord[3 - c]];
+    // E(x, y, z) = x Ex + y Ey + z Ez + Ew with E_c = to_matrix(basis.col(c)) (COLUMNS of E are the 3-segments)
+    Poly Ep[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Ep[i][j] = Poly::linear(basis[3 * j + i][0], basis[3 * j + i][1], basis[3 * j + i][2], basis[3 * j + i][3]);
+    Poly EEt[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            Poly s;
+            for (int k = 0; k < 3; ++k) s = s + Ep[i][k] * Ep[j][k];
+            EEt[i][j] = s;
+        }
+    const Poly half_trace = (EEt[0][0] + EEt[1][1] + EEt[2][2]).scaled(0.5);
+    std::vector<double> polys(10 * 20);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            Poly s;
+            for (int k = 0; k < 3; ++k) s = s + EEt[i][k] * Ep[k][j];
+            s = s - half_trace * Ep[i][j];
+            for (int c = 0; c < 20; ++c) polys[(3 * i + j) * 20 + c] = s.v[c];
+        }
+    {
+        const Poly d = Ep[0][0] * (Ep[1][1] * Ep[2][2] - Ep[1][2] * Ep[2][1]) - Ep[0][1] * (Ep[1][0] * Ep[2][2] - Ep[1][2] * Ep[2][0]) +
+                       Ep[0][2] * (Ep[1][0] * Ep[2][1] - Ep[1][1] * Ep[2][0]);
+        for (int c = 0; c < 20; ++c) polys[9 * 20 + c] = d.v[c];
+    }
+    // Gauss-Jordan with the reference's row-permutation bookkeeping (essential.cpp:167-190)
+    auto P = [&](int r, int c) -> double & { return polys[(size_t)r * 20 + c]; };
+    int perm[10];
+    for (int i = 0; i < 10; ++i) perm[i] = i;
+    for (int i = 0; i < 10; ++i) {
+        for (int j = i + 1; j < 10; ++j)
+            if (std::fabs(P(perm[i], i)) < std::fabs(P(perm[j], i))) std::swap(perm[i], perm[j]);
+        if (P(perm[i], i) == 0.0) continue;
+        const double d = P(perm[i], i);
+        for (int c = 0; c < 20; ++c) P(perm[i], c) /= d;
+        for (int j = i + 1; j < 10; ++j) {
+            const double f = P(perm[j], i);
+            for (int c = 0; c < 20; ++c) P(perm[j], c) -= P(perm[i], c) * f;
+        }
+    }
+    for (int i = 9; i > 0; --i)
+        for (int j = 0; j < i; ++j) {
+            const double f = P(perm[j], i);
+            for (int c = 0; c < 20; ++c) P(perm[j], c) -= P(perm[i], c) * f;
+        }
+    std::vector<double> action(100, 0.0);
+    const int rows[6] = {XXX, XXY, XYY, XXZ, XYZ, XZZ};
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 10; ++c) action[r * 10 + c] = -P(perm[rows[r]], XX + c);
+    action[6 * 10 + (XX - XX)] = 1.0;
+    action[7 * 10 + (XY - XX)] = 1.0;
+    action[8 * 10 + (XZ - XX)] = 1.0;
+    action[9 * 10 + (X - XX)] = 1.0;
+    std::vector<double> wr, wi;
+    std::vector<M3> results;
+    if (!real_eigenvalues(10, action, wr, wi)) return results;
+    for (int i = 0; i < 10; ++i) {
+        if (std::fabs(wi[i]) >= 1.0e-10) continue;
+        const std::vector<double> h = eigenvector_for(10, action, wr[i]);
+        const double w = h[I - XX];
+        const double sx = h[X - XX] / w, sy = h[Y - XX] / w, sz = h[Z - XX] / w;
+        M3 E;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                const int k = 3 * c + r;  // to_matrix: column c = segment c
+                E.m[3 * r + c] = basis[k][0] * sx + basis[k][1] * sy + basis[k][2] * sz + basis[k][3];
+            }
+        results.push_back(E);
+    }
+    return results;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LotBox + Ransac (random.h:79-126, ransac.h:8-103).  std::default_random_engine and
+// std::uniform_int_distribution<size_t> are the same library types the reference draws from, seeded identically.
+// ------------------------------------------------------------------------------------------------------------------
+class LotBox {
+  public:
+    explicit LotBox(size_t size) : cap(0), lots(size) { std::iota(lots.begin(), lots.end(), 0); }
+    size_t draw_without_replacement() {
+        if (remaining() > 1) {
+            std::swap(lots[cap], lots[next(cap, lots.size() - 1)]);
+            return lots[cap++];
+        } else if (remaining() == 1) {
+            cap++;
+            return lots.back();
+        }
+        return size_t(-1);
+    }
+    void refill_all() { cap = 0; }
+    size_t remaining() const { return lots.size() - cap; }
+    void seed(unsigned int value) { engine.seed(value); }
+
+  private:
+    size_t next(size_t left, size_t right) {
+        return distribution(engine, std::uniform_int_distribution<size_t>::param_type(left, right));
+    }
+    size_t cap;
+    std::vector<size_t> lots;
+    std::default_random_engine engine;
+    std::uniform_int_distribution<size_t> distribution{0, std::numeric_limits<size_t>::max()};
+};
+
+// Generic RANSAC loop.  solve(sample indices) -> models; error(model, i) -> double.
+template <size_t DoF, class Model, class SolveFn, class ErrorFn>
+Model ransac(size_t size, double threshold, double confidence, size_t max_iteration, int seed, SolveFn solve, ErrorFn error,
+             std::vector<char> &inlier_mask, Model model = Model()) {
+    LotBox lotbox(size);
+    lotbox.seed((unsigned int)seed);
+    const double K = std::log(std::max(1 - confidence, 1.0e-5));
+    size_t inlier_count = 0;
+    inlier_mask.assign(size, 0);
+    if (size < DoF) return model;
+    inlier_mask.clear();  // ransac.h leaves the member mask empty until a model beats zero inliers
+    size_t iter_max = max_iteration;
+    for (size_t iter = 0; iter < iter_max; ++iter) {
+        std::array<size_t, DoF> sample;
+        lotbox.refill_all();
+        for (size_t si = 0; si < DoF; ++si) sample[si] = lotbox.draw_without_replacement();
+        const std::vector<Model> models = solve(sample);
+        for (const Model &current : models) {
+            size_t count = 0;
+            std::vector<char> mask(size, 0);
+            for (size_t i = 0; i < size; ++i)
+                if (error(current, i) <= threshold) {
+                    count++;
+                    mask[i] = 1;
+                }
+            if (count > inlier_count) {
+                model = current;
+                inlier_count = count;
+                inlier_mask.swap(mask);
+                const double ratio = inlier_count / (double)size;
+                const double N = K / std::log(1 - std::pow(ratio, 5));
+                if (N < (double)iter_max) iter_max = (size_t)std::ceil(N);
+            }
+        }
+    }
+    return model;
+}
+
+// stereo.cpp:38-66
+inline M3 find_essential_matrix(const std::vector<V2> &p1, const std::vector<V2> &p2, std::vector<char> &mask, double threshold = 1.0,
+                                double confidence = 0.999, size_t max_iteration = 1000, int seed = 0) {
+    const double t1 = 3.84;
+    auto solve = [&](const std::array<size_t, 5> &s) {
+        std::array<V2, 5> a, b;
+        for (int i = 0; i < 5; ++i) { a[i] = p1[s[i]]; b[i] = p2[s[i]]; }
+        return solve_essential_5pt(a, b);
+    };
+    auto err = [&](const M3 &E, size_t i) {
+        return essential_geometric_error(E, p1[i], p2[i]) + essential_geometric_error(transpose(E), p2[i], p1[i]);
+    };
+    return ransac<5, M3>(p1.size(), 2.0 * t1 * threshold * threshold, confidence, max_iteration, seed, solve, err, mask);
+}
+
+// stereo.cpp:68-91
+inline M3 find_rotation_matrix(const std::vector<V3> &p1, const std::vector<V3> &p2, std::vector<char> &mask, double threshold = 1.0,
+                               double confidence = 0.999, size_t max_iteration = 1000, int seed = 0) {
+    const double t2 = 5.99;
+    auto solve = [&](const std::array<size_t, 2> &s) {
+        return std::vector<M3>{solve_rotation_2pt({p1[s[0]], p1[s[1]]}, {p2[s[0]], p2[s[1]]})};
+    };
+    auto err = [&](const M3 &R, size_t i) { return std::acos(dot(R * p1[i], p2[i])); };
+    return ransac<2, M3>(p1.size(), t2 * threshold * threshold, confidence, max_iteration, seed, solve, err, mask);
+}
+
+// stereo.h:83-93: N-view DLT.  Ps: 3x4 row-major projection matrices.  Returns the homogeneous point (smallest right
+// singular vector of the 2m x 4 system = eigenvector of A^T A with the smallest eigenvalue).
+inline std::array<double, 4> triangulate_point(const std::vector<std::array<double, 12>> &Ps, const std::vector<V3> &points) {
+    double AtA[16] = {0};
+    for (size_t i = 0; i < points.size(); ++i) {
+        const double *P = Ps[i].data();
+        const double pt[3] = {points[i].x, points[i].y, points[i].z};
+        for (int rrow = 0; rrow < 2; ++rrow) {
+            double row[4];
+            for (int c = 0; c < 4; ++c) row[c] = pt[rrow] * P[8 + c] - pt[2] * P[4 * rrow + c];
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) AtA[4 * a + b] += row[a] * row[b];
+        }
+    }
+    double V[16], lam[4];
+    sym_eigen(4, AtA, V, lam);
+    const int k = ascending_order(4, lam)[0];
+    return {V[0 * 4 + k], V[1 * 4 + k], V[2 * 4 + k], V[3 * 4 + k]};
+}
+
+}  // namespace rdvio_pipe

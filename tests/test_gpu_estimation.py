@@ -92,13 +92,18 @@ def _oracle_pre(oracle):
     (11, 300, 649, {}),                                  # config 3: window 10, 300 features
     (9, 150, 650, dict(with_preint=False, fix2=True)),   # vision only (no IMU quirk): converges
     (5, 40, 651, dict(with_prior=False, fix2=True)),     # no marginalisation prior
+    (9, 150, 653, dict(pose_fix0=True)),                 # FT_FIX_POSE on the first keyframe (initializer.cpp:82)
+    (6, 60, 654, dict(with_prior=False, pose_fix0=True)),
 ])
 def test_ba_solve_parity(ctx, oracle, nfr, nl, seed, kw):
     kw = dict(kw)
     fix2 = kw.pop("fix2", False)
+    pose_fix0 = kw.pop("pose_fix0", False)
     pb = synth.make_window_problem(nfr, nl, seed, preintegrate=_oracle_pre(oracle), **kw)
     if fix2:
         pb["frame_fixed"][:2] = 1
+    if pose_fix0:
+        pb["frame_fixed"][0] = 2   # pose constant, motion free
     ref_s, ref_d, ref_sm = oracle.ba_solve(pb, 30)
     got_s, got_d, got_sm = ctx.ba_solve(pb, 30)
     assert got_sm.iterations == ref_sm.iterations and got_sm.successful_steps == ref_sm.successful_steps
@@ -111,6 +116,8 @@ def test_ba_solve_parity(ctx, oracle, nfr, nl, seed, kw):
     assert np.abs(got_s - ref_s).max() < 1e-6
     assert np.abs(got_d - ref_d).max() < 1e-6
     assert ref_sm.final_cost < ref_sm.initial_cost
+    if pose_fix0:
+        assert (got_s[0, :7] == pb["states"][0, :7]).all() and (ref_s[0, :7] == pb["states"][0, :7]).all()
 
 
 def test_ba_solve_localize_shape(ctx, oracle):

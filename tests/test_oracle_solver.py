@@ -71,3 +71,13 @@ def test_fixed_landmarks_and_frames_are_constant(oracle):
     assert (st[:2] == pb["states"][:2]).all()
     assert (invd[::2] == pb["inv_depth"][::2]).all()
     assert sm.final_cost < sm.initial_cost
+
+
+def test_pose_fixed_frame_keeps_pose_and_frees_motion(oracle):
+    # FT_FIX_POSE without FT_FIX_MOTION (solver.cpp:92-97; the initializer's first keyframe, initializer.cpp:82)
+    pb = synth.make_window_problem(6, 60, 7, preintegrate=_pre(oracle), with_prior=False)
+    pb["frame_fixed"][0] = 2
+    st, invd, sm = oracle.ba_solve(pb, 20)
+    assert (st[0, :7] == pb["states"][0, :7]).all()
+    assert np.abs(st[0, 7:] - pb["states"][0, 7:]).max() > 0     # v / biases of that frame did move
+    assert sm.final_cost < sm.initial_cost
