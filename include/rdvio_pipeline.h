@@ -1,0 +1,127 @@
+/*
+ * rdvio_pipeline.h -- C ABI of the per-frame host orchestration around the HIP hot path: the push-image / push-IMU /
+ * get-pose surface of rdvio::Odometry on top of librdvio_hip.so.
+ *
+ * Reference interfaces replaced (file:line under /root/reference):
+ *   rdvio::Odometry                     src/rdvio/include/rdvio/rdvio.hpp:25-115   (addFrame, addMotion, addGyro, addAcc,
+ *                                                                                   transform_world_cam, state)
+ *   Handler (sensor interleave)         src/rdvio/src/handler.cpp:15-227
+ *   FeatureTracker::run                 src/rdvio/src/feature_tracker.cpp:26-111   (row A6)
+ *   Frame::track_keypoints / detect     src/rdvio_map/src/frame.cpp:55-172         (rows A4, A5)
+ *   Frontend::run                       src/rdvio/src/frontend.cpp:27-70
+ *   SlidingWindowTracker                src/rdvio/src/sliding_window_tracker.cpp:16-456 (row A16)
+ *   Track::triangulate                  src/rdvio_map/src/track.cpp:46-76          (row A18)
+ *   Map::marginalize_frame              src/rdvio_map/src/map.cpp:50-62
+ *
+ * The orchestration is host C++ (like the reference's); everything data-parallel goes through the `rdvio_backend`
+ * function table, whose product implementation is the HIP library (rdvio_pipeline_create_hip).  The table exists so
+ * that the test-suite can run the SAME orchestration over the CPU oracle and compare trajectories and feature index
+ * sets (SURVEY.md 8d metrics 2 and 3); the product never constructs a non-HIP backend.
+ *
+ * Not built in this round: the SfM/IMU initializer (N4) -- the window is bootstrapped from externally
+ * supplied states of the first keyframes (rdvio_pipeline_set_init_states), every later pose comes from the pipeline;
+ * the RD dynamic-outlier path (N2, parsac_flag) is rejected at create time.
+ */
+#ifndef RDVIO_PIPELINE_H
+#define RDVIO_PIPELINE_H
+
+#include <stdint.h>
+
+#include "rdvio_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The two plugin seams of the reference (rdvio::Image, rdvio::Solver / PreIntegrator / MarginalizationFactor) as a
+ * function table.  All functions return RDVIO_OK (0) or an RDVIO_ERR_* code. */
+typedef struct rdvio_backend {
+    void *user;
+    /* rdvio::Image (types.h:153-177).  An image handle owns a private copy of the pixels (OpenCvImage::image). */
+    int (*image_create)(void *user, const uint8_t *gray, int width, int height, int stride, void **image_out);
+    int (*image_preprocess)(void *user, void *image, double clahe_clip, int tiles_x, int tiles_y);
+    int (*image_detect)(void *user, void *image, double *keypoints, int n_existing, int capacity, int max_points,
+                        double min_distance, int *n_out);
+    int (*image_track)(void *user, void *image_curr, void *image_next, int n, const double *curr_xy, double *next_xy,
+                       int has_guess, uint8_t *status);
+    void (*image_release)(void *user, void *image); /* release_image_buffer */
+    void (*image_destroy)(void *user, void *image);
+    /* PreIntegrator::integrate: imu n x 7 (t, gyro, acc), noise 4 x 9 (cov_w cov_a cov_bg cov_ba) */
+    int (*preintegrate)(void *user, int n, const double *imu, double t_end, const double *bg, const double *ba,
+                        const double *noise, int compute_jacobian, int compute_covariance, double *preint_out);
+    /* Solver::solve on the SoA problem; states_out / inv_depth_out receive the optimised values */
+    int (*ba_solve)(void *user, const rdvio_ba_problem *pb, int max_iterations, double *states_out, double *inv_depth_out,
+                    rdvio_ba_summary *summary);
+    /* MarginalizationFactor::marginalize(0) */
+    int (*marginalize)(void *user, const rdvio_marg_problem *pb, double *S_out, double *f_out, double *lin_out);
+    const char *(*last_error)(void *user);
+} rdvio_backend;
+
+/* rdvio::Config (types.h:85-151) with the defaults of src/rdvio/src/config.cpp; rdvio_pipeline_config_default fills
+ * them.  Matrices row-major, quaternions (x, y, z, w). */
+typedef struct rdvio_pipeline_config {
+    int32_t width, height;
+    double K[9];
+    double q_bc[4], p_bc[3]; /* camera_to_body_rotation / translation */
+    double q_bi[4], p_bi[3]; /* imu_to_body_rotation / translation */
+    double q_bo[4], p_bo[3]; /* output_to_body */
+    double keypoint_noise_cov[4];
+    double gyroscope_noise_cov[9], accelerometer_noise_cov[9], gyroscope_bias_noise_cov[9], accelerometer_bias_noise_cov[9];
+    int32_t sliding_window_size, sliding_window_subframe_size, sliding_window_force_keyframe_landmarks,
+        sliding_window_tracker_frequent;
+    double feature_tracker_min_keypoint_distance;
+    int32_t feature_tracker_max_keypoint_detection, feature_tracker_max_init_frames, feature_tracker_max_frames;
+    double feature_tracker_clahe_clip_limit;
+    int32_t feature_tracker_clahe_width, feature_tracker_clahe_height, feature_tracker_predict_keypoints;
+    int32_t initializer_keyframe_num, initializer_keyframe_gap;
+    int32_t solver_iteration_limit;
+    double rotation_misalignment_threshold, rotation_ransac_threshold;
+    int32_t random;
+    int32_t parsac_flag; /* must be 0 in this round */
+} rdvio_pipeline_config;
+
+void rdvio_pipeline_config_default(rdvio_pipeline_config *cfg);
+
+typedef struct rdvio_pipeline rdvio_pipeline;
+
+/* Product entry point: the pipeline over the HIP context (the context must outlive the pipeline). */
+int rdvio_pipeline_create_hip(rdvio_pipeline **out, const rdvio_pipeline_config *cfg, rdvio_hip_ctx *ctx);
+/* Generic entry point (function table copied). */
+int rdvio_pipeline_create(rdvio_pipeline **out, const rdvio_pipeline_config *cfg, const rdvio_backend *backend);
+void rdvio_pipeline_destroy(rdvio_pipeline *p);
+const char *rdvio_pipeline_last_error(const rdvio_pipeline *p);
+
+/* Bootstrap states of the first keyframes: n rows of (t, q(4), p(3), v(3), bg(3), ba(3)) = 17 doubles, body frame in
+ * the world frame with gravity along -z.  A keyframe whose timestamp matches a row within 1e-6 s takes that state. */
+int rdvio_pipeline_set_init_states(rdvio_pipeline *p, int n, const double *rows17);
+
+/* Odometry::addFrame (rdvio.hpp:41-56): gray u8 image; pose_out (may be NULL) = predicted output pose q(4) p(3), all
+ * zeros before the first optimised state (handler.cpp:178-181). */
+int rdvio_pipeline_add_frame(rdvio_pipeline *p, double t, const uint8_t *gray, int width, int height, int stride,
+                             double *pose_out);
+/* Odometry::addMotion / addGyro / addAcc (rdvio.hpp:58-69): gyro is pushed first */
+int rdvio_pipeline_add_motion(rdvio_pipeline *p, double t, const double *acc, const double *gyro);
+int rdvio_pipeline_add_gyro(rdvio_pipeline *p, double t, const double *gyro);
+int rdvio_pipeline_add_acc(rdvio_pipeline *p, double t, const double *acc);
+/* Odometry::state: 0 initialising, 1 tracking, 2 crash, 3 unknown */
+int rdvio_pipeline_state(const rdvio_pipeline *p);
+/* Handler::get_latest_state (handler.cpp:190-206): time + body pose of the newest tracked frame; returns 0 if none */
+int rdvio_pipeline_latest_state(const rdvio_pipeline *p, double *t, double *pose7);
+/* full state (q p v bg ba) of the newest frame of the sliding window (SlidingWindowTracker::get_latest_state) */
+int rdvio_pipeline_window_state(const rdvio_pipeline *p, double *t, double *state16);
+/* Odometry::transform_world_cam (rdvio.hpp:71-77): 4x4 row-major */
+int rdvio_pipeline_transform_world_cam(const rdvio_pipeline *p, double *T16);
+/* Odometry::local_map: valid triangulated landmarks (world frame, without the reference's axis swap); returns count */
+int rdvio_pipeline_local_map(const rdvio_pipeline *p, double *xyz, int capacity);
+
+/* Diagnostics for the index-parity metric: keypoints of the newest frame of the feature-tracking map.
+ * track_ids[i] = id of the track through keypoint i or -1; xy in pixels.  Returns the number of keypoints. */
+int rdvio_pipeline_last_frame_keypoints(const rdvio_pipeline *p, int64_t *track_ids, double *xy, int capacity);
+/* counters: [0] frames tracked, [1] window solves, [2] keyframes inserted, [3] marginalisations, [4] localisations,
+ * [5] subwindow solves, [6] frame id of the newest tracked frame, [7] tracks in the window map */
+int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

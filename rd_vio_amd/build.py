@@ -23,7 +23,34 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+PIPE_DIR = os.path.join(HERE, "host", "pipeline")
+PIPE_LIB = os.path.join(HERE, "librdvio_pipeline.so")
+PIPE_SOURCES = ["map.cpp", "pipeline.cpp", "hip_backend.cpp"]
+
+
+def build_pipeline(force=False, verbose=False):
+    """librdvio_pipeline.so: the host orchestration (plain C++17, no device code) on top of librdvio_hip.so."""
+    deps = [os.path.join(PIPE_DIR, f) for f in os.listdir(PIPE_DIR)] + [os.path.join(HERE, "..", "include", f)
+                                                                          for f in ("rdvio_hip.h", "rdvio_pipeline.h")] + [LIB]
+    if not force and os.path.exists(PIPE_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(PIPE_LIB) for d in deps):
+        return PIPE_LIB
+    cxx = os.environ.get("CXX", "g++")
+    # same no-FMA-contraction rule as the device code: the CPU-path comparison runs this very code over the oracle
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-ffp-contract=off", "-o", PIPE_LIB] + \
+          [os.path.join(PIPE_DIR, s) for s in PIPE_SOURCES] + ["-L" + HERE, "-lrdvio_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return PIPE_LIB
+
+
 def build(force=False, verbose=False):
+    lib = _build_hip(force, verbose)
+    build_pipeline(force, verbose)
+    return lib
+
+
+def _build_hip(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <numeric>
 #include <random>
+#include <unordered_map>
 #include <vector>
 
 namespace rdvio_pipe {
@@ -647,5 +648,40 @@ inline std::array<double, 4> triangulate_point(const std::vector<std::array<doub
     const int k = ascending_order(4, lam)[0];
     return {V[0 * 4 + k], V[1 * 4 + k], V[2 * 4 + k], V[3 * 4 + k]};
 }
+
+// PoissonDiskFilter<2> (/root/reference/src/rdvio_util/include/rdvio/util/poisson_disk_filter.h:8-112), kept literally:
+// a sparse grid with ONE point index per cell (later points overwrite, :20-24) and the reference's neighbourhood walk,
+// which skips the first cell of the window and visits one cell past its end (:77-92).
+class PoissonDisk2 {
+  public:
+    explicit PoissonDisk2(double radius) : r2_(radius * radius), cell_(radius / std::sqrt(2.0)), span_((int)std::ceil(std::sqrt(2.0))) {}
+    void preset_point(const V2 &p) {
+        grid_[key(ix(p.x), ix(p.y))] = pts_.size();
+        pts_.push_back(p);
+    }
+    bool permit_point(const V2 &p) const {
+        const int cx = ix(p.x), cy = ix(p.y);
+        const int bx = cx - span_, by = cy - span_, ex = cx + span_, ey = cy + span_;
+        int x0 = bx, y0 = by;
+        while (y0 <= ey) {
+            ++x0;
+            if (x0 > ex) {
+                x0 = bx;
+                ++y0;
+            }
+            auto it = grid_.find(key(x0, y0));
+            if (it != grid_.end() && sqnorm(p - pts_[it->second]) < r2_) return false;
+        }
+        return true;
+    }
+
+  private:
+    int ix(double v) const { return (int)std::floor(v / cell_); }
+    static int64_t key(int x, int y) { return ((int64_t)x << 32) ^ (uint32_t)y; }
+    double r2_, cell_;
+    int span_;
+    std::vector<V2> pts_;
+    std::unordered_map<int64_t, size_t> grid_;
+};
 
 }  // namespace rdvio_pipe

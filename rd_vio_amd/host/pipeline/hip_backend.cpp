@@ -1,0 +1,105 @@
+// The product backend of the orchestration: every seam call goes to librdvio_hip.so (include/rdvio_hip.h).
+// Images live in the context's two pyramid slots -- the tracker keeps exactly two consecutive frames alive
+// (feature_tracker.cpp:94), so frame k uses slot k % 2.
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../../../include/rdvio_pipeline.h"
+
+namespace {
+
+struct HipImage {
+    std::vector<uint8_t> gray;  // OpenCvImage::image (a private copy until preprocess uploads it)
+    int width, height, slot;
+};
+
+struct HipBackend {
+    rdvio_hip_ctx *ctx;
+    int next_slot = 0;
+};
+
+int image_create(void *user, const uint8_t *gray, int width, int height, int stride, void **out) {
+    (void)user;
+    auto *img = new HipImage();
+    img->width = width;
+    img->height = height;
+    img->slot = -1;
+    img->gray.resize((size_t)width * height);
+    for (int y = 0; y < height; ++y) std::memcpy(&img->gray[(size_t)y * width], gray + (size_t)y * stride, (size_t)width);
+    *out = img;
+    return RDVIO_OK;
+}
+
+int image_preprocess(void *user, void *image, double clip, int tx, int ty) {
+    auto *b = static_cast<HipBackend *>(user);
+    auto *img = static_cast<HipImage *>(image);
+    img->slot = b->next_slot;
+    b->next_slot ^= 1;
+    const int rc = rdvio_hip_image_preprocess(b->ctx, img->slot, img->gray.data(), img->width, img->height, img->width, clip, tx, ty);
+    std::vector<uint8_t>().swap(img->gray);  // the pyramid is resident in HBM from here on
+    return rc;
+}
+
+int image_detect(void *user, void *image, double *kps, int n_existing, int capacity, int max_points, double min_distance, int *n_out) {
+    auto *b = static_cast<HipBackend *>(user);
+    return rdvio_hip_detect_keypoints(b->ctx, static_cast<HipImage *>(image)->slot, kps, n_existing, capacity, max_points, min_distance, n_out);
+}
+
+int image_track(void *user, void *curr, void *next, int n, const double *curr_xy, double *next_xy, int has_guess, uint8_t *status) {
+    auto *b = static_cast<HipBackend *>(user);
+    return rdvio_hip_track_keypoints(b->ctx, static_cast<HipImage *>(curr)->slot, static_cast<HipImage *>(next)->slot, n, curr_xy, next_xy,
+                                     has_guess, status);
+}
+
+void image_release(void *user, void *image) {
+    auto *b = static_cast<HipBackend *>(user);
+    auto *img = static_cast<HipImage *>(image);
+    if (img->slot >= 0) (void)rdvio_hip_image_release(b->ctx, img->slot);
+    img->slot = -1;
+}
+
+void image_destroy(void *user, void *image) {
+    (void)user;
+    delete static_cast<HipImage *>(image);
+}
+
+int preintegrate(void *user, int n, const double *imu, double t_end, const double *bg, const double *ba, const double *noise, int cj, int cc,
+                 double *out) {
+    auto *b = static_cast<HipBackend *>(user);
+    const int32_t off[2] = {0, n};
+    return rdvio_hip_preintegrate(b->ctx, 1, off, imu, &t_end, bg, ba, noise, cj, cc, out);
+}
+
+int ba_solve(void *user, const rdvio_ba_problem *pb, int max_iter, double *states, double *invd, rdvio_ba_summary *sm) {
+    return rdvio_hip_ba_solve(static_cast<HipBackend *>(user)->ctx, pb, max_iter, states, invd, sm);
+}
+
+int marginalize(void *user, const rdvio_marg_problem *pb, double *S, double *f, double *lin) {
+    return rdvio_hip_marginalize(static_cast<HipBackend *>(user)->ctx, pb, 0, S, f, lin, nullptr, nullptr, nullptr);
+}
+
+const char *last_error(void *user) { return rdvio_hip_last_error(static_cast<HipBackend *>(user)->ctx); }
+
+}  // namespace
+
+extern "C" int rdvio_pipeline_create_hip(rdvio_pipeline **out, const rdvio_pipeline_config *cfg, rdvio_hip_ctx *ctx) {
+    if (!out || !cfg || !ctx) return RDVIO_ERR_INVALID;
+    // the backend record lives as long as the process-wide context it wraps (one Odometry per process)
+    auto *b = new HipBackend{ctx};
+    rdvio_backend fn;
+    fn.user = b;
+    fn.image_create = image_create;
+    fn.image_preprocess = image_preprocess;
+    fn.image_detect = image_detect;
+    fn.image_track = image_track;
+    fn.image_release = image_release;
+    fn.image_destroy = image_destroy;
+    fn.preintegrate = preintegrate;
+    fn.ba_solve = ba_solve;
+    fn.marginalize = marginalize;
+    fn.last_error = last_error;
+    const int rc = rdvio_pipeline_create(out, cfg, &fn);
+    if (rc != RDVIO_OK) delete b;
+    return rc;
+}

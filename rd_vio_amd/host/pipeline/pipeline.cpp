@@ -1,0 +1,1163 @@
+// Per-frame orchestration around the HIP hot path.  Each block cites the reference code whose behaviour it keeps;
+// everything data-parallel is a call through the backend table (include/rdvio_pipeline.h).
+#include "pipeline.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+#include <unordered_set>
+
+namespace rdvio_pipe {
+
+namespace {
+V2 v2(const double *p) { return {p[0], p[1]}; }
+}  // namespace
+
+// =====================================================================================================================
+// BaBuilder: Solver::add_* -> SoA (solver.cpp:88-178), Solver::solve (solver.cpp:180-194)
+// =====================================================================================================================
+int BaBuilder::frame_index(Frame *frame) const {
+    auto it = fidx.find(frame);
+    return it == fidx.end() ? -1 : it->second;
+}
+
+int BaBuilder::add_frame_states(Frame *frame) {
+    if (int i = frame_index(frame); i >= 0) return i;
+    // FT_FIX_POSE & FT_FIX_MOTION -> constant; FT_FIX_POSE alone -> pose constant, motion free (solver.cpp:92-113)
+    uint8_t fixed = 0;
+    if (frame->tag(FT_FIX_POSE)) fixed = frame->tag(FT_FIX_MOTION) ? 1 : 2;
+    fidx[frame] = (int)frames.size();
+    frames.push_back(frame);
+    frame_fixed.push_back(fixed);
+    return (int)frames.size() - 1;
+}
+
+int BaBuilder::add_constant_frame(Frame *frame) {
+    // a frame that a "prior" factor reads but does not differentiate.  If the frame is also a free parameter of this
+    // solve, the factor sees a constant copy of its value at the start of the solve (the reference reads it live
+    // through a pointer; the two differ only by that frame's own update during the solve).
+    if (int i = frame_index(frame); i >= 0 && frame_fixed[i] == 1) return i;
+    for (size_t i = 0; i < frames.size(); ++i)
+        if (frames[i] == frame && frame_fixed[i] == 1) return (int)i;
+    if (frame_index(frame) < 0) fidx[frame] = (int)frames.size();
+    frames.push_back(frame);
+    frame_fixed.push_back(1);
+    return (int)frames.size() - 1;
+}
+
+int BaBuilder::add_track_states(Track *track, bool constant) {
+    auto it = lidx.find(track);
+    if (it != lidx.end()) return it->second;
+    lidx[track] = (int)lms.size();
+    lms.push_back(track);
+    lm_fixed.push_back(constant ? 1 : 0);
+    return (int)lms.size() - 1;
+}
+
+void BaBuilder::add_reprojection_error(Frame *frame, size_t keypoint_index) {
+    Track *track = frame->get_track(keypoint_index);
+    Frame *ref = track->first_frame();
+    int t = frame_index(frame), r = frame_index(ref);
+    if (t < 0) t = add_constant_frame(frame);
+    if (r < 0) r = add_constant_frame(ref);
+    const int l = add_track_states(track, false);
+    facs.push_back({t, r, l, frame->tangents[keypoint_index].data()});
+}
+
+void BaBuilder::add_reprojection_prior(Frame *frame, Track *track) {
+    // CeresReprojectionPriorFactor (reprojection_factor.h:99-121): anchor pose and inverse depth held constant
+    int t = frame_index(frame);
+    if (t < 0) t = add_constant_frame(frame);
+    const int r = add_constant_frame(track->first_frame());
+    const int l = add_track_states(track, true);
+    facs.push_back({t, r, l, frame->tangents[track->get_keypoint_index(frame)].data()});
+}
+
+void BaBuilder::add_rotation_prior(Frame *frame, Track *track) {
+    int t = frame_index(frame);
+    if (t < 0) t = add_constant_frame(frame);
+    const auto [ref, ref_kp] = track->first_keypoint();
+    const int r = add_constant_frame(ref);
+    rots.push_back({t, r, ref->get_keypoint(ref_kp), frame->tangents[track->get_keypoint_index(frame)].data()});
+}
+
+void BaBuilder::add_preintegration(Frame *frame_i, Frame *frame_j, const PreIntegrator &pre, bool is_prior) {
+    int i = is_prior ? add_constant_frame(frame_i) : frame_index(frame_i);
+    if (i < 0) i = add_constant_frame(frame_i);
+    int j = frame_index(frame_j);
+    if (j < 0) j = add_constant_frame(frame_j);
+    pres.push_back({i, j, pre.delta.data()});
+}
+
+bool BaBuilder::solve(rdvio_ba_summary *summary_out) {
+    const int nfr = (int)frames.size(), nl = (int)lms.size();
+    std::vector<double> states((size_t)nfr * 16), invd((size_t)std::max(nl, 1)), zref((size_t)std::max(nl, 1) * 3);
+    for (int i = 0; i < nfr; ++i) frames[i]->get_state(&states[16 * (size_t)i]);
+    for (int l = 0; l < nl; ++l) {
+        invd[l] = lms[l]->inv_depth;
+        const auto [ref, kp] = lms[l]->first_keypoint();
+        const V3 &z = ref->get_keypoint(kp);
+        zref[3 * l] = z.x; zref[3 * l + 1] = z.y; zref[3 * l + 2] = z.z;
+    }
+    std::stable_sort(facs.begin(), facs.end(), [](const Fac &a, const Fac &b) { return a.lm < b.lm; });
+    const int nf = (int)facs.size(), nrot = (int)rots.size(), npre = (int)pres.size();
+    std::vector<int32_t> tgt(std::max(nf, 1)), ref(std::max(nf, 1)), lm(std::max(nf, 1));
+    std::vector<double> tangent((size_t)std::max(nf, 1) * 9);
+    for (int k = 0; k < nf; ++k) {
+        tgt[k] = facs[k].tgt; ref[k] = facs[k].ref; lm[k] = facs[k].lm;
+        std::copy(facs[k].tangent, facs[k].tangent + 9, &tangent[9 * (size_t)k]);
+    }
+    std::vector<int32_t> rot_tgt(std::max(nrot, 1)), rot_ref(std::max(nrot, 1));
+    std::vector<double> rot_zref((size_t)std::max(nrot, 1) * 3), rot_tangent((size_t)std::max(nrot, 1) * 9);
+    for (int k = 0; k < nrot; ++k) {
+        rot_tgt[k] = rots[k].tgt; rot_ref[k] = rots[k].ref;
+        rot_zref[3 * k] = rots[k].zref.x; rot_zref[3 * k + 1] = rots[k].zref.y; rot_zref[3 * k + 2] = rots[k].zref.z;
+        std::copy(rots[k].tangent, rots[k].tangent + 9, &rot_tangent[9 * (size_t)k]);
+    }
+    std::vector<int32_t> pre_i(std::max(npre, 1)), pre_j(std::max(npre, 1));
+    std::vector<double> preint((size_t)std::max(npre, 1) * RDVIO_PREINT_SIZE);
+    for (int k = 0; k < npre; ++k) {
+        pre_i[k] = pres[k].i; pre_j[k] = pres[k].j;
+        std::copy(pres[k].delta, pres[k].delta + RDVIO_PREINT_SIZE, &preint[(size_t)k * RDVIO_PREINT_SIZE]);
+    }
+    std::vector<int32_t> prior_frames;
+    if (prior)
+        for (Frame *f : prior->frames) {
+            const int i = frame_index(f);
+            if (i < 0) throw std::runtime_error("marginalisation prior covers a frame that is not a state of the solve");
+            prior_frames.push_back(i);
+        }
+    double extr[14];
+    const Frame *f0 = frames[0];
+    extr[0] = f0->camera.q_cs.x; extr[1] = f0->camera.q_cs.y; extr[2] = f0->camera.q_cs.z; extr[3] = f0->camera.q_cs.w;
+    extr[4] = f0->camera.p_cs.x; extr[5] = f0->camera.p_cs.y; extr[6] = f0->camera.p_cs.z;
+    extr[7] = f0->imu.q_cs.x; extr[8] = f0->imu.q_cs.y; extr[9] = f0->imu.q_cs.z; extr[10] = f0->imu.q_cs.w;
+    extr[11] = f0->imu.p_cs.x; extr[12] = f0->imu.p_cs.y; extr[13] = f0->imu.p_cs.z;
+
+    rdvio_ba_problem pb;
+    std::memset(&pb, 0, sizeof pb);
+    pb.n_frames = nfr;
+    pb.states = states.data();
+    pb.frame_fixed = frame_fixed.data();
+    pb.extr = extr;
+    pb.sqrt_inv_cov = f0->sqrt_inv_cov;
+    pb.n_landmarks = nl;
+    pb.z_ref = zref.data();
+    pb.inv_depth = invd.data();
+    pb.lm_fixed = lm_fixed.empty() ? reinterpret_cast<const uint8_t *>("") : lm_fixed.data();
+    pb.n_factors = nf;
+    pb.tgt = tgt.data(); pb.ref = ref.data(); pb.lm = lm.data();
+    pb.tangent = tangent.data();
+    pb.n_rot = nrot;
+    pb.rot_tgt = rot_tgt.data(); pb.rot_ref = rot_ref.data();
+    pb.rot_zref = rot_zref.data(); pb.rot_tangent = rot_tangent.data();
+    pb.n_preint = npre;
+    pb.pre_i = pre_i.data(); pb.pre_j = pre_j.data(); pb.preint = preint.data();
+    pb.n_prior = (int)prior_frames.size();
+    if (prior) {
+        pb.prior_frames = prior_frames.data();
+        pb.prior_lin = prior->lin.data();
+        pb.prior_S = prior->S.data();
+        pb.prior_f = prior->f.data();
+    }
+    std::vector<double> states_out(states.size()), invd_out(invd.size());
+    rdvio_ba_summary sm;
+    std::memset(&sm, 0, sizeof sm);
+    sh.backend.check(sh.backend.fn.ba_solve(sh.backend.fn.user, &pb, sh.cfg.solver_iteration_limit, states_out.data(), invd_out.data(), &sm),
+                     "ba_solve");
+    // the reference's parameter blocks ARE the Frame / Track members (solver.cpp:88-114): copy the result back
+    for (int i = 0; i < nfr; ++i)
+        if (frame_fixed[i] != 1) frames[i]->set_state(&states_out[16 * (size_t)i]);
+    for (int l = 0; l < nl; ++l)
+        if (!lm_fixed[l]) lms[l]->inv_depth = invd_out[l];
+    if (summary_out) *summary_out = sm;
+    return sm.termination != 2;
+}
+
+// =====================================================================================================================
+// FeatureTracker (feature_tracker.cpp:14-124) with Frame::detect_keypoints / track_keypoints (frame.cpp:55-172)
+// =====================================================================================================================
+FeatureTracker::FeatureTracker(Shared &sh) : sh(sh) { map = std::make_unique<Map>(sh.ids); }
+
+void FeatureTracker::track_frame(std::unique_ptr<Frame> frame) {
+    frames.emplace_back(std::move(frame));
+    run();
+}
+
+void FeatureTracker::detect_keypoints(Frame *frame) {
+    const int max_points = sh.cfg.feature_tracker_max_keypoint_detection;
+    const size_t n0 = frame->bearings.size();
+    std::vector<double> kps((n0 + (size_t)max_points + 8) * 2);
+    for (size_t i = 0; i < n0; ++i) {
+        const V2 p = apply_k(frame->bearings[i], frame->K);
+        kps[2 * i] = p.x;
+        kps[2 * i + 1] = p.y;
+    }
+    int n_out = 0;
+    Backend &be = sh.backend;
+    be.check(be.fn.image_detect(be.fn.user, frame->image->handle, kps.data(), (int)n0, (int)(kps.size() / 2), max_points,
+                                sh.cfg.feature_tracker_min_keypoint_distance, &n_out),
+             "detect_keypoints");
+    for (size_t i = n0; i < (size_t)n_out; ++i) frame->append_keypoint(remove_k(v2(&kps[2 * i]), frame->K));
+}
+
+void FeatureTracker::track_keypoints(Frame *frame, Frame *next_frame) {
+    const size_t n = frame->bearings.size();
+    std::vector<V2> curr(n);
+    std::vector<double> curr_xy(2 * std::max<size_t>(n, 1)), next_xy(2 * std::max<size_t>(n, 1));
+    for (size_t i = 0; i < n; ++i) {
+        curr[i] = apply_k(frame->bearings[i], frame->K);
+        curr_xy[2 * i] = curr[i].x;
+        curr_xy[2 * i + 1] = curr[i].y;
+    }
+    const bool predict = sh.cfg.feature_tracker_predict_keypoints != 0;
+    if (predict) {
+        // rotation-only prediction from the gyro preintegration (frame.cpp:82-94)
+        const Q4 delta_key_q = conj(conj(frame->camera.q_cs) * frame->imu.q_cs * next_frame->preintegration.dq() *
+                                    conj(next_frame->imu.q_cs) * next_frame->camera.q_cs);
+        for (size_t i = 0; i < n; ++i) {
+            const V2 p = apply_k(rot(delta_key_q, frame->bearings[i]), next_frame->K);
+            next_xy[2 * i] = p.x;
+            next_xy[2 * i + 1] = p.y;
+        }
+    } else {
+        next_xy = curr_xy;  // the image seam starts LK at the current position when no guess is given
+    }
+    std::vector<uint8_t> status(std::max<size_t>(n, 1), 0);
+    Backend &be = sh.backend;
+    if (n > 0)
+        be.check(be.fn.image_track(be.fn.user, frame->image->handle, next_frame->image->handle, (int)n, curr_xy.data(), next_xy.data(),
+                                   predict ? 1 : 0, status.data()),
+                 "track_keypoints");
+    status.resize(n);
+
+    std::vector<V2> curr_h(n), next_h(n);
+    std::vector<V3> next_bearings(n);
+    for (size_t i = 0; i < n; ++i) {
+        curr_h[i] = hnormalized(frame->bearings[i]);
+        next_bearings[i] = remove_k(v2(&next_xy[2 * i]), next_frame->K);
+        next_h[i] = hnormalized(next_bearings[i]);
+    }
+    // epipolar gate over ALL points, survivors or not (frame.cpp:108-114)
+    std::vector<char> mask;
+    (void)find_essential_matrix(curr_h, next_h, mask, 1.0);
+    mask.resize(n, 0);  // (the reference indexes an empty mask when no model was found; treated as "no inliers")
+    for (size_t i = 0; i < n; ++i)
+        if (!mask[i]) status[i] = 0;
+    const M3 R = find_rotation_matrix(frame->bearings, next_bearings, mask, (M_PI / 180.0) * sh.cfg.rotation_ransac_threshold);
+    mask.resize(n, 0);
+    std::vector<double> angles;
+    for (size_t i = 0; i < n; ++i)
+        if (mask[i]) angles.push_back(std::acos(dot(R * frame->bearings[i], next_bearings[i])) * 180 / M_PI);
+    std::sort(angles.begin(), angles.end());
+    const double misalignment = angles.size() > 0 ? angles[angles.size() * 7 / 10] : 0;
+    if (misalignment < sh.cfg.rotation_misalignment_threshold) next_frame->set_tag(FT_NO_TRANSLATION, true);
+
+    // longest tracks first, Poisson-disk thinning in the next image (frame.cpp:134-161)
+    std::vector<std::pair<size_t, size_t>> by_length;
+    by_length.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (status[i] == 0) continue;
+        Track *track = frame->get_track(i);
+        if (track == nullptr) continue;
+        by_length.emplace_back(i, track->keypoint_num());
+    }
+    std::sort(by_length.begin(), by_length.end(), [](const auto &a, const auto &b) { return a.second > b.second; });
+    PoissonDisk2 filter(sh.cfg.feature_tracker_min_keypoint_distance);
+    for (const auto &[keypoint_index, track_length] : by_length) {
+        (void)track_length;
+        const V2 pt = v2(&next_xy[2 * keypoint_index]);
+        Track *track = frame->get_track(keypoint_index);
+        if (filter.permit_point(pt) && (!track || !track->tag(TT_TRASH))) filter.preset_point(pt);
+        else status[keypoint_index] = 0;
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (status[i]) {
+            const size_t next_index = next_frame->keypoint_num();
+            next_frame->append_keypoint(next_bearings[i]);
+            frame->get_track(i, nullptr)->add_keypoint(next_frame, next_index);
+        }
+}
+
+void FeatureTracker::run() {
+    if (frames.empty()) return;
+    std::unique_ptr<Frame> frame = std::move(frames.front());
+    frames.pop_front();
+    Backend &be = sh.backend;
+    be.check(be.fn.image_preprocess(be.fn.user, frame->image->handle, sh.cfg.feature_tracker_clahe_clip_limit, sh.cfg.feature_tracker_clahe_width,
+                                    sh.cfg.feature_tracker_clahe_height),
+             "preprocess");
+
+    auto [latest_optimized_time, latest_optimized_frame_id, latest_optimized_pose, latest_optimized_motion] = frontend->get_latest_state();
+    (void)latest_optimized_time;
+    const bool is_initialized = latest_optimized_frame_id != nil;
+    const bool sliding_window_frame_tag = !is_initialized || frame->id() % (size_t)sh.cfg.sliding_window_tracker_frequent == 0;
+    if (map->frame_num() > 0) {
+        if (is_initialized) {
+            const size_t idx = map->frame_index_by_id(latest_optimized_frame_id);
+            if (idx != nil) {
+                Frame *latest = map->get_frame(idx);
+                latest->pose = latest_optimized_pose;
+                latest->motion = latest_optimized_motion;
+                for (size_t j = idx + 1; j < map->frame_num(); ++j) {
+                    Frame *frame_i = map->get_frame(j - 1), *frame_j = map->get_frame(j);
+                    frame_j->preintegration.integrate(be, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba, false, false);
+                    frame_j->preintegration.predict(frame_i, frame_j);
+                }
+            } else {
+                latest_state.reset();  // the sliding window cannot catch up (feature_tracker.cpp:62-68)
+            }
+        }
+        Frame *last_frame = map->get_frame(map->frame_num() - 1);
+        if (!last_frame->preintegration.data.empty()) {
+            if (frame->preintegration.data.empty() || (frame->preintegration.data.front().t - last_frame->image->t > 1.0e-5)) {
+                ImuData imu = last_frame->preintegration.data.back();
+                imu.t = last_frame->image->t;
+                frame->preintegration.data.insert(frame->preintegration.data.begin(), imu);
+            }
+        }
+        frame->preintegration.integrate(be, frame->image->t, last_frame->motion.bg, last_frame->motion.ba, false, false);
+        track_keypoints(last_frame, frame.get());
+        if (is_initialized) {
+            frame->preintegration.predict(last_frame, frame.get());
+            latest_state = std::make_tuple(frame->image->t, frame->pose, frame->motion);
+        }
+        be.fn.image_release(be.fn.user, last_frame->image->handle);
+    }
+    if (sliding_window_frame_tag) detect_keypoints(frame.get());
+    map->attach_frame(std::move(frame));
+    sh.counters.frames_tracked++;
+    while (map->frame_num() > (size_t)(is_initialized ? sh.cfg.feature_tracker_max_frames : sh.cfg.feature_tracker_max_init_frames) &&
+           map->get_frame(0)->id() < latest_optimized_frame_id)
+        map->erase_frame(0);
+    if (sliding_window_frame_tag) frontend->issue_frame(map->get_frame(map->frame_num() - 1));
+}
+
+// =====================================================================================================================
+// Frontend (frontend.cpp:14-110)
+// =====================================================================================================================
+Frontend::Frontend(FeatureTracker *ft, Shared &sh) : feature_tracker(ft), sh(sh) {
+    initializer = std::make_unique<Initializer>(sh);
+    latest_state = std::make_tuple(0.0, nil, PoseState{}, MotionState{});
+}
+
+void Frontend::issue_frame(Frame *frame) {
+    pending_frame_ids.push_back(frame->id());
+    run();
+}
+
+void Frontend::run() {
+    if (pending_frame_ids.empty()) return;
+    if (initializer) {
+        const size_t pending_frame_id = pending_frame_ids.front();
+        pending_frame_ids.clear();
+        initializer->mirror_keyframe_map(feature_tracker->map.get(), pending_frame_id);
+        if ((sliding_window_tracker = initializer->initialize())) {
+            auto [t, pose, motion] = sliding_window_tracker->get_latest_state();
+            latest_state = std::make_tuple(t, pending_frame_id, pose, motion);
+            initializer.reset();
+        }
+    } else if (sliding_window_tracker) {
+        const size_t pending_frame_id = pending_frame_ids.front();
+        pending_frame_ids.pop_front();
+        sliding_window_tracker->mirror_frame(feature_tracker->map.get(), pending_frame_id);
+        if (sliding_window_tracker->track()) {
+            auto [t, pose, motion] = sliding_window_tracker->get_latest_state();
+            latest_state = std::make_tuple(t, pending_frame_id, pose, motion);
+        } else {
+            latest_state = std::make_tuple(0.0, nil, PoseState{}, MotionState{});
+            initializer = std::make_unique<Initializer>(sh);
+            sliding_window_tracker.reset();
+        }
+    }
+}
+
+// =====================================================================================================================
+// Bootstrap (initializer.cpp:20-140 without init_sfm / init_imu)
+// =====================================================================================================================
+void Initializer::mirror_keyframe_map(Map *ftmap, size_t init_frame_id) {
+    const size_t last = ftmap->frame_index_by_id(init_frame_id);
+    const size_t gap = (size_t)sh.cfg.initializer_keyframe_gap;
+    const size_t distance = gap * ((size_t)sh.cfg.initializer_keyframe_num - 1);
+    if (last == nil || last < distance) {
+        map.reset();
+        return;
+    }
+    const size_t first = last - distance;
+    std::vector<size_t> indices;
+    for (size_t i = 0; i < (size_t)sh.cfg.initializer_keyframe_num; ++i) indices.push_back(first + i * gap);
+    map = std::make_unique<Map>(sh.ids);
+    for (size_t index : indices) map->attach_frame(ftmap->get_frame(index)->clone());
+    for (size_t j = 1; j < map->frame_num(); ++j) {
+        Frame *old_i = ftmap->get_frame(indices[j - 1]), *old_j = ftmap->get_frame(indices[j]);
+        Frame *new_i = map->get_frame(j - 1), *new_j = map->get_frame(j);
+        for (size_t ki = 0; ki < old_i->keypoint_num(); ++ki)
+            if (Track *track = old_i->get_track(ki))
+                if (size_t kj = track->get_keypoint_index(old_j); kj != nil) new_i->get_track(ki, nullptr)->add_keypoint(new_j, kj);
+        new_j->preintegration.data.clear();
+        for (size_t f = indices[j - 1]; f < indices[j]; ++f) {
+            const std::vector<ImuData> &old_data = ftmap->get_frame(f + 1)->preintegration.data;
+            new_j->preintegration.data.insert(new_j->preintegration.data.end(), old_data.begin(), old_data.end());
+        }
+    }
+}
+
+std::unique_ptr<SlidingWindowTracker> Initializer::initialize() {
+    if (!map) return nullptr;
+    // externally supplied states replace init_sfm / init_imu (initializer.cpp:142-420)
+    for (size_t i = 0; i < map->frame_num(); ++i) {
+        Frame *frame = map->get_frame(i);
+        const std::array<double, 17> *row = nullptr;
+        for (const auto &r : sh.init_states)
+            if (std::fabs(r[0] - frame->image->t) < 1.0e-6) { row = &r; break; }
+        if (!row) return nullptr;
+        frame->set_state(row->data() + 1);
+    }
+    // triangulate every track of the keyframe map (initializer.cpp:305-315), drop the failures (:361-364)
+    for (size_t i = 0; i < map->track_num(); ++i) {
+        Track *track = map->get_track(i);
+        if (track->tag(TT_VALID)) continue;
+        if (auto p = track->triangulate()) {
+            track->set_landmark_point(p.value());
+            track->set_tag(TT_VALID, true);
+            track->set_tag(TT_TRIANGULATED, true);
+        }
+    }
+    map->prune_tracks([](const Track *track) { return !track->tag(TT_VALID); });
+
+    // closing visual-inertial BA (initializer.cpp:82-127)
+    map->get_frame(0)->set_tag(FT_FIX_POSE, true);
+    BaBuilder solver(sh);
+    for (size_t i = 0; i < map->frame_num(); ++i) solver.add_frame_states(map->get_frame(i));
+    std::unordered_set<Track *> visited;
+    for (size_t i = 0; i < map->frame_num(); ++i) {
+        Frame *frame = map->get_frame(i);
+        for (size_t j = 0; j < frame->keypoint_num(); ++j) {
+            Track *track = frame->get_track(j);
+            if (!track || !track->tag(TT_VALID) || visited.count(track)) continue;
+            visited.insert(track);
+            solver.add_track_states(track, false);
+        }
+    }
+    for (size_t i = 0; i < map->frame_num(); ++i) {
+        Frame *frame = map->get_frame(i);
+        for (size_t j = 0; j < frame->keypoint_num(); ++j) {
+            Track *track = frame->get_track(j);
+            if (!track || !track->all_tagged({TT_VALID, TT_TRIANGULATED}) || frame == track->first_frame()) continue;
+            solver.add_reprojection_error(frame, j);
+        }
+    }
+    for (size_t j = 1; j < map->frame_num(); ++j) {
+        Frame *frame_i = map->get_frame(j - 1), *frame_j = map->get_frame(j);
+        if (frame_j->preintegration.integrate(sh.backend, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba, true, true))
+            solver.add_preintegration(frame_i, frame_j, frame_j->preintegration, false);
+    }
+    solver.solve();
+    for (size_t i = 0; i < map->frame_num(); ++i) map->get_frame(i)->set_tag(FT_KEYFRAME, true);
+    return std::make_unique<SlidingWindowTracker>(std::move(map), sh);
+}
+
+// =====================================================================================================================
+// SlidingWindowTracker (sliding_window_tracker.cpp:16-456)
+// =====================================================================================================================
+SlidingWindowTracker::SlidingWindowTracker(std::unique_ptr<Map> keyframe_map, Shared &sh) : map(std::move(keyframe_map)), sh(sh) {
+    for (size_t j = 1; j < map->frame_num(); ++j) {
+        Frame *frame_i = map->get_frame(j - 1), *frame_j = map->get_frame(j);
+        frame_j->preintegration.integrate(sh.backend, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba, true, true);
+    }
+}
+
+void SlidingWindowTracker::mirror_frame(Map *ftmap, size_t frame_id) {
+    Frame *keyframe = map->get_frame(map->frame_num() - 1);
+    Frame *new_frame_i = keyframe;
+    if (!keyframe->subframes.empty()) new_frame_i = keyframe->subframes.back().get();
+    const size_t index_i = ftmap->frame_index_by_id(new_frame_i->id()), index_j = ftmap->frame_index_by_id(frame_id);
+    if (index_i == nil || index_j == nil) return;
+    Frame *old_frame_i = ftmap->get_frame(index_i), *old_frame_j = ftmap->get_frame(index_j);
+    std::unique_ptr<Frame> curr_frame = old_frame_j->clone();
+    std::vector<ImuData> &new_data = curr_frame->preintegration.data;
+    for (size_t index = index_j - 1; index > index_i; --index) {
+        const std::vector<ImuData> &old_data = ftmap->get_frame(index)->preintegration.data;
+        new_data.insert(new_data.begin(), old_data.begin(), old_data.end());
+    }
+    map->attach_frame(std::move(curr_frame));
+    Frame *new_frame_j = map->get_frame(map->frame_num() - 1);
+    for (size_t ki = 0; ki < old_frame_i->keypoint_num(); ++ki)
+        if (Track *track = old_frame_i->get_track(ki))
+            if (size_t kj = track->get_keypoint_index(old_frame_j); kj != nil) {
+                Track *new_track = new_frame_i->get_track(ki, map.get());
+                new_track->add_keypoint(new_frame_j, kj);
+                track->set_tag(TT_TRASH, new_track->tag(TT_TRASH) && !new_track->tag(TT_STATIC));
+            }
+    map->prune_tracks([](const Track *track) { return track->tag(TT_TRASH) && !track->tag(TT_STATIC); });
+    new_frame_j->preintegration.integrate(sh.backend, new_frame_j->image->t, new_frame_i->motion.bg, new_frame_i->motion.ba, true, true);
+    new_frame_j->preintegration.predict(new_frame_i, new_frame_j);
+}
+
+bool SlidingWindowTracker::track() {
+    // parsac_flag (judge_track_status / update_track_status, :557-769) is rejected at create time
+    localize_newframe();
+    if (manage_keyframe()) {
+        track_landmark();
+        refine_window();
+        slide_window();
+    } else {
+        refine_subwindow();
+    }
+    return true;
+}
+
+void SlidingWindowTracker::localize_newframe() {
+    BaBuilder solver(sh);
+    Frame *frame_i = map->get_frame(map->frame_num() - 2);
+    if (!frame_i->subframes.empty()) frame_i = frame_i->subframes.back().get();
+    Frame *frame_j = map->get_frame(map->frame_num() - 1);
+    solver.add_frame_states(frame_j);
+    solver.add_preintegration(frame_i, frame_j, frame_j->preintegration, true);
+    for (size_t k = 0; k < frame_j->keypoint_num(); ++k)
+        if (Track *track = frame_j->get_track(k))
+            if (track->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) solver.add_reprojection_prior(frame_j, track);
+    solver.solve();
+    sh.counters.localizations++;
+}
+
+bool SlidingWindowTracker::manage_keyframe() {
+    Frame *keyframe_i = map->get_frame(map->frame_num() - 2);
+    Frame *newframe_j = map->get_frame(map->frame_num() - 1);
+    if (!keyframe_i->subframes.empty()) {
+        if (keyframe_i->subframes.back()->tag(FT_NO_TRANSLATION)) {
+            if (newframe_j->tag(FT_NO_TRANSLATION)) {
+                // [T]...........<-[R]   keeps accumulating rotation-only subframes
+            } else {
+                keyframe_i->subframes.back()->set_tag(FT_KEYFRAME, true);
+                map->attach_frame(std::move(keyframe_i->subframes.back()), map->frame_num() - 1);
+                keyframe_i->subframes.pop_back();
+                newframe_j->set_tag(FT_KEYFRAME, true);
+                return true;
+            }
+        } else {
+            if (newframe_j->tag(FT_NO_TRANSLATION)) {
+                std::unique_ptr<Frame> frame_lifted = std::move(keyframe_i->subframes.back());
+                keyframe_i->subframes.pop_back();
+                frame_lifted->set_tag(FT_KEYFRAME, true);
+                frame_lifted->subframes.emplace_back(map->detach_frame(map->frame_num() - 1));
+                map->attach_frame(std::move(frame_lifted));
+                return true;
+            } else if (keyframe_i->subframes.size() >= (size_t)sh.cfg.sliding_window_subframe_size) {
+                newframe_j->set_tag(FT_KEYFRAME, true);
+                return true;
+            }
+        }
+    }
+    size_t mapped_landmark_count = 0;
+    for (size_t k = 0; k < newframe_j->keypoint_num(); ++k)
+        if (Track *track = newframe_j->get_track(k))
+            if (track->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) mapped_landmark_count++;
+    const bool is_keyframe = mapped_landmark_count < (size_t)sh.cfg.sliding_window_force_keyframe_landmarks;
+    if (is_keyframe) {
+        newframe_j->set_tag(FT_KEYFRAME, true);
+        return true;
+    }
+    keyframe_i->subframes.emplace_back(map->detach_frame(map->frame_num() - 1));
+    return false;
+}
+
+void SlidingWindowTracker::track_landmark() {
+    Frame *newframe_j = map->get_frame(map->frame_num() - 1);
+    for (size_t k = 0; k < newframe_j->keypoint_num(); ++k)
+        if (Track *track = newframe_j->get_track(k))
+            if (!track->tag(TT_TRIANGULATED)) {
+                if (auto p = track->triangulate()) {
+                    track->set_landmark_point(p.value());
+                    track->set_tag(TT_TRIANGULATED, true);
+                    track->set_tag(TT_VALID, true);
+                    track->set_tag(TT_STATIC, true);
+                } else {
+                    track->inv_depth = -1.0;
+                    track->set_tag(TT_TRIANGULATED, false);
+                    track->set_tag(TT_VALID, false);
+                }
+            }
+}
+
+void SlidingWindowTracker::refine_window() {
+    BaBuilder solver(sh);
+    if (!map->marginalization_factor) {
+        // MarginalizationFactor::MarginalizationFactor (marginalization_factor.h:16-32): every frame but the newest, the
+        // pose of frame 0 pinned with 1e15
+        auto prior = std::make_unique<MarginalizationPrior>();
+        const size_t n = map->frame_num() - 1, D = 15 * n;
+        prior->frames.resize(n);
+        prior->lin.assign(16 * n, 0.0);
+        for (size_t i = 0; i < n; ++i) {
+            prior->frames[i] = map->get_frame(i);
+            map->get_frame(i)->get_state(&prior->lin[16 * i]);
+        }
+        prior->f.assign(D, 0.0);
+        prior->S.assign(D * D, 0.0);
+        for (size_t a = 0; a < 6; ++a) prior->S[a * D + a] = 1.0e15;
+        map->marginalization_factor = std::move(prior);
+    }
+    for (size_t i = 0; i < map->frame_num(); ++i) solver.add_frame_states(map->get_frame(i));
+    std::unordered_set<Track *> visited;
+    for (size_t i = 0; i < map->frame_num(); ++i) {
+        Frame *frame = map->get_frame(i);
+        for (size_t j = 0; j < frame->keypoint_num(); ++j) {
+            Track *track = frame->get_track(j);
+            if (!track || visited.count(track)) continue;
+            visited.insert(track);
+            if (!track->tag(TT_VALID) || !track->tag(TT_STATIC) || !track->first_frame()->tag(FT_KEYFRAME)) continue;
+            solver.add_track_states(track, false);
+        }
+    }
+    solver.add_marginalization(map->marginalization_factor.get());
+    for (size_t i = 0; i < map->frame_num(); ++i) {
+        Frame *frame = map->get_frame(i);
+        for (size_t j = 0; j < frame->keypoint_num(); ++j) {
+            Track *track = frame->get_track(j);
+            if (!track || !track->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) continue;
+            if (!track->first_frame()->tag(FT_KEYFRAME) || frame == track->first_frame()) continue;
+            solver.add_reprojection_error(frame, j);
+        }
+    }
+    for (size_t j = 1; j < map->frame_num(); ++j) {
+        Frame *frame_i = map->get_frame(j - 1), *frame_j = map->get_frame(j);
+        frame_j->keyframe_preintegration = frame_j->preintegration;
+        if (!frame_i->subframes.empty()) {
+            std::vector<ImuData> imu_data;
+            for (const auto &sub : frame_i->subframes) imu_data.insert(imu_data.end(), sub->preintegration.data.begin(), sub->preintegration.data.end());
+            frame_j->keyframe_preintegration.data.insert(frame_j->keyframe_preintegration.data.begin(), imu_data.begin(), imu_data.end());
+        }
+        if (frame_j->keyframe_preintegration.integrate(sh.backend, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba, true, true))
+            solver.add_preintegration(frame_i, frame_j, frame_j->keyframe_preintegration, false);
+    }
+    solver.solve();
+    sh.counters.window_solves++;
+    sh.counters.keyframes++;
+
+    // depth / reprojection culling (:304-336)
+    for (size_t k = 0; k < map->track_num(); ++k) {
+        Track *track = map->get_track(k);
+        if (track->tag(TT_TRIANGULATED)) {
+            bool is_valid = true;
+            const V3 x = track->get_landmark_point();
+            double rpe = 0.0, rpe_count = 0.0;
+            for (const auto &kv : track->keypoint_map()) {
+                Frame *frame = kv.second.first;
+                if (!frame->tag(FT_KEYFRAME)) continue;
+                const PoseState pose = frame->get_pose(frame->camera);
+                const V3 y = rot(conj(pose.q), x - pose.p);
+                if (y.z <= 1.0e-3 || y.z > 50) {
+                    is_valid = false;
+                    break;
+                }
+                rpe += norm(apply_k(y, frame->K) - apply_k(frame->get_keypoint(kv.second.second), frame->K));
+                rpe_count += 1.0;
+            }
+            is_valid = is_valid && (rpe / std::max(rpe_count, 1.0) < 3.0);
+            track->set_tag(TT_VALID, is_valid);
+        } else {
+            track->inv_depth = -1.0;
+        }
+    }
+    for (size_t k = 0; k < map->track_num(); ++k) {
+        Track *track = map->get_track(k);
+        if (!track->tag(TT_VALID)) track->set_tag(TT_TRASH, true);
+    }
+}
+
+void SlidingWindowTracker::slide_window() {
+    while (map->frame_num() > (size_t)sh.cfg.sliding_window_size) {
+        Frame *frame = map->get_frame(0);
+        for (auto &sub : frame->subframes) map->untrack_frame(sub.get());
+        marginalize_frame0();
+    }
+}
+
+// Map::marginalize_frame(0) (map.cpp:50-62) with the graph of CeresMarginalizationFactor::marginalize
+// (ceres/marginalization_factor.h:95-380) exported as SoA
+void SlidingWindowTracker::marginalize_frame0() {
+    MarginalizationPrior &prior = *map->marginalization_factor;
+    const int nfm = (int)map->frame_num();
+    std::unordered_map<const Frame *, int> index;
+    std::vector<double> states((size_t)nfm * 16);
+    for (int i = 0; i < nfm; ++i) {
+        index[map->get_frame(i)] = i;
+        map->get_frame(i)->get_state(&states[16 * (size_t)i]);
+    }
+    std::vector<int32_t> prior_frames;
+    for (Frame *f : prior.frames) prior_frames.push_back(index.at(f));
+    Frame *victim = map->get_frame(0);
+    std::vector<int32_t> tgt, ref, lm;
+    std::vector<double> tangent, zref, invd;
+    for (size_t j = 0; j < victim->keypoint_num(); ++j) {
+        Track *track = victim->get_track(j);
+        if (!track || !track->tag(TT_VALID)) continue;
+        const auto [frame_ref, ref_kp] = track->first_keypoint();
+        if (!frame_ref->tag(FT_KEYFRAME)) continue;
+        auto ir = index.find(frame_ref);
+        if (ir == index.end()) continue;
+        const int l = (int)invd.size();
+        bool any = false;
+        for (const auto &kv : track->keypoint_map()) {
+            Frame *frame_tgt = kv.second.first;
+            if (frame_tgt == frame_ref) continue;
+            auto it = index.find(frame_tgt);
+            if (it == index.end()) continue;  // a subframe
+            tgt.push_back(it->second);
+            ref.push_back(ir->second);
+            lm.push_back(l);
+            const auto &tg = frame_tgt->tangents[kv.second.second];
+            tangent.insert(tangent.end(), tg.begin(), tg.end());
+            any = true;
+        }
+        if (any) {
+            const V3 &z = frame_ref->get_keypoint(ref_kp);
+            zref.insert(zref.end(), {z.x, z.y, z.z});
+            invd.push_back(track->inv_depth);
+        }
+    }
+    double extr[14];
+    extr[0] = victim->camera.q_cs.x; extr[1] = victim->camera.q_cs.y; extr[2] = victim->camera.q_cs.z; extr[3] = victim->camera.q_cs.w;
+    extr[4] = victim->camera.p_cs.x; extr[5] = victim->camera.p_cs.y; extr[6] = victim->camera.p_cs.z;
+    extr[7] = victim->imu.q_cs.x; extr[8] = victim->imu.q_cs.y; extr[9] = victim->imu.q_cs.z; extr[10] = victim->imu.q_cs.w;
+    extr[11] = victim->imu.p_cs.x; extr[12] = victim->imu.p_cs.y; extr[13] = victim->imu.p_cs.z;
+    rdvio_marg_problem pb;
+    std::memset(&pb, 0, sizeof pb);
+    pb.n_frames = nfm;
+    pb.states = states.data();
+    pb.extr = extr;
+    pb.sqrt_inv_cov = victim->sqrt_inv_cov;
+    pb.n_prior = (int)prior_frames.size();
+    pb.prior_frames = prior_frames.data();
+    pb.prior_lin = prior.lin.data();
+    pb.prior_S = prior.S.data();
+    pb.prior_f = prior.f.data();
+    pb.preint01 = nfm >= 2 ? map->get_frame(1)->keyframe_preintegration.delta.data() : nullptr;
+    pb.n_landmarks = (int)invd.size();
+    pb.z_ref = zref.data();
+    pb.inv_depth = invd.data();
+    pb.n_factors = (int)tgt.size();
+    pb.tgt = tgt.data(); pb.ref = ref.data(); pb.lm = lm.data();
+    pb.tangent = tangent.data();
+    const size_t R = 15 * (size_t)(nfm - 1);
+    std::vector<double> S(R * R), f(R), lin(16 * (size_t)(nfm - 1));
+    sh.backend.check(sh.backend.fn.marginalize(sh.backend.fn.user, &pb, S.data(), f.data(), lin.data()), "marginalize");
+    prior.frames.clear();
+    for (int i = 1; i < nfm; ++i) prior.frames.push_back(map->get_frame(i));
+    prior.S.swap(S);
+    prior.f.swap(f);
+    prior.lin.swap(lin);
+    for (size_t i = 0; i < victim->keypoint_num(); ++i)
+        if (Track *track = victim->get_track(i)) track->remove_keypoint(victim);
+    map->drop_front_frame();
+    sh.counters.marginalizations++;
+}
+
+void SlidingWindowTracker::refine_subwindow() {
+    Frame *frame = map->get_frame(map->frame_num() - 1);
+    if (frame->subframes.empty()) return;
+    if (frame->subframes[0]->tag(FT_NO_TRANSLATION)) {
+        if (frame->subframes.size() >= 9) {
+            // compress a long rotation-only run: keep every third subframe, merging the IMU data (:353-371)
+            for (size_t i = frame->subframes.size() / 3; i > 0; --i) {
+                Frame *tgt_frame = frame->subframes[i * 3 - 1].get();
+                std::vector<ImuData> imu_data;
+                for (size_t j = i * 3 - 1; j > (i - 1) * 3; --j) {
+                    Frame *src_frame = frame->subframes[j - 1].get();
+                    imu_data.insert(imu_data.begin(), src_frame->preintegration.data.begin(), src_frame->preintegration.data.end());
+                    map->untrack_frame(src_frame);
+                    frame->subframes.erase(frame->subframes.begin() + (std::ptrdiff_t)(j - 1));
+                }
+                tgt_frame->preintegration.data.insert(tgt_frame->preintegration.data.begin(), imu_data.begin(), imu_data.end());
+            }
+        }
+        BaBuilder solver(sh);
+        frame->set_tag(FT_FIX_POSE, true);
+        frame->set_tag(FT_FIX_MOTION, true);
+        solver.add_frame_states(frame);
+        for (size_t i = 0; i < frame->subframes.size(); ++i) {
+            Frame *subframe = frame->subframes[i].get();
+            solver.add_frame_states(subframe);
+            Frame *prev_frame = (i == 0 ? frame : frame->subframes[i - 1].get());
+            subframe->preintegration.integrate(sh.backend, subframe->image->t, prev_frame->motion.bg, prev_frame->motion.ba, true, true);
+            solver.add_preintegration(prev_frame, subframe, subframe->preintegration, false);
+        }
+        Frame *last_subframe = frame->subframes.back().get();
+        for (size_t k = 0; k < last_subframe->keypoint_num(); ++k)
+            if (Track *track = last_subframe->get_track(k))
+                if (track->tag(TT_VALID)) {
+                    if (track->tag(TT_TRIANGULATED)) {
+                        if (track->tag(TT_STATIC)) solver.add_reprojection_prior(last_subframe, track);
+                    } else {
+                        solver.add_rotation_prior(last_subframe, track);
+                    }
+                }
+        solver.solve();
+        frame->set_tag(FT_FIX_POSE, false);
+        frame->set_tag(FT_FIX_MOTION, false);
+    } else {
+        BaBuilder solver(sh);
+        frame->set_tag(FT_FIX_POSE, true);
+        frame->set_tag(FT_FIX_MOTION, true);
+        solver.add_frame_states(frame);
+        for (size_t i = 0; i < frame->subframes.size(); ++i) {
+            Frame *subframe = frame->subframes[i].get();
+            solver.add_frame_states(subframe);
+            Frame *prev_frame = (i == 0 ? frame : frame->subframes[i - 1].get());
+            subframe->preintegration.integrate(sh.backend, subframe->image->t, prev_frame->motion.bg, prev_frame->motion.ba, true, true);
+            solver.add_preintegration(prev_frame, subframe, subframe->preintegration, false);
+            for (size_t k = 0; k < subframe->keypoint_num(); ++k)
+                if (Track *track = subframe->get_track(k))
+                    if (track->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) {
+                        if (track->first_frame()->tag(FT_KEYFRAME)) solver.add_reprojection_prior(subframe, track);
+                        // else: tracks anchored in a later subframe -- the reference indexes the KEYFRAME's factor list
+                        // with the SUBFRAME's keypoint index here (:431-434), which reads an unrelated or out-of-range
+                        // entry; that access is not reproduced ("deliberate deviations")
+                    }
+        }
+        solver.solve();
+        frame->set_tag(FT_FIX_POSE, false);
+        frame->set_tag(FT_FIX_MOTION, false);
+    }
+    sh.counters.subwindow_solves++;
+}
+
+std::tuple<double, PoseState, MotionState> SlidingWindowTracker::get_latest_state() const {
+    const Frame *frame = map->get_frame(map->frame_num() - 1);
+    if (!frame->subframes.empty()) frame = frame->subframes.back().get();
+    return {frame->image->t, frame->pose, frame->motion};
+}
+
+// =====================================================================================================================
+// Handler (handler.cpp:15-227)
+// =====================================================================================================================
+namespace {
+void propagate_state(double &state_time, PoseState &pose, MotionState &motion, double t, const V3 &w, const V3 &a) {
+    const V3 gravity{0, 0, -GRAVITY_NOMINAL};
+    const double dt = t - state_time;
+    pose.p = pose.p + dt * motion.v + 0.5 * dt * dt * (gravity + rot(pose.q, a - motion.ba));
+    motion.v = motion.v + dt * (gravity + rot(pose.q, a - motion.ba));
+    pose.q = normalized(pose.q * expmap((w - motion.bg) * dt));
+    state_time = t;
+}
+}  // namespace
+
+Handler::Handler(Shared &sh) : feature_tracker(sh), frontend(&feature_tracker, sh), sh(sh) { feature_tracker.set_frontend(&frontend); }
+
+PoseState Handler::track_gyroscope(double t, double x, double y, double z) {
+    if (!accelerometers.empty()) {
+        if (t < accelerometers.front().t) {
+            gyroscopes.clear();
+        } else {
+            while (!accelerometers.empty() && t >= accelerometers.front().t) {
+                const Acc acc = accelerometers.front();
+                const double lambda = (acc.t - gyroscopes[0].t) / (t - gyroscopes[0].t);
+                const V3 w = gyroscopes[0].w + lambda * (V3{x, y, z} - gyroscopes[0].w);
+                track_imu({acc.t, w, acc.a});
+                accelerometers.pop_front();
+            }
+            if (!accelerometers.empty())
+                while (!gyroscopes.empty() && gyroscopes.front().t < t) gyroscopes.pop_front();
+        }
+    }
+    gyroscopes.push_back({t, {x, y, z}});
+    return predict_pose(t);
+}
+
+PoseState Handler::track_accelerometer(double t, double x, double y, double z) {
+    if (!gyroscopes.empty() && t >= gyroscopes.front().t) {
+        if (t > gyroscopes.back().t) {
+            while (gyroscopes.size() > 1) gyroscopes.pop_front();
+            accelerometers.push_back({t, {x, y, z}});
+        } else if (t == gyroscopes.back().t) {
+            while (gyroscopes.size() > 1) gyroscopes.pop_front();
+            track_imu({t, gyroscopes.front().w, {x, y, z}});
+        } else {
+            while (t >= gyroscopes[1].t) gyroscopes.pop_front();
+            const double lambda = (t - gyroscopes[0].t) / (gyroscopes[1].t - gyroscopes[0].t);
+            const V3 w = gyroscopes[0].w + lambda * (gyroscopes[1].w - gyroscopes[0].w);
+            track_imu({t, w, {x, y, z}});
+        }
+    }
+    return predict_pose(t);
+}
+
+PoseState Handler::track_camera(std::shared_ptr<ImageRef> image) {
+    const rdvio_pipeline_config &c = sh.cfg;
+    std::unique_ptr<Frame> frame = std::make_unique<Frame>(sh.ids);
+    std::copy(c.K, c.K + 9, frame->K);
+    frame->image = image;
+    frame->sqrt_inv_cov[0] = c.K[0] / std::sqrt(c.keypoint_noise_cov[0]);
+    frame->sqrt_inv_cov[1] = c.K[1];
+    frame->sqrt_inv_cov[2] = c.K[3];
+    frame->sqrt_inv_cov[3] = c.K[4] / std::sqrt(c.keypoint_noise_cov[3]);
+    frame->camera.q_cs = {c.q_bc[0], c.q_bc[1], c.q_bc[2], c.q_bc[3]};
+    frame->camera.p_cs = {c.p_bc[0], c.p_bc[1], c.p_bc[2]};
+    frame->imu.q_cs = {c.q_bi[0], c.q_bi[1], c.q_bi[2], c.q_bi[3]};
+    frame->imu.p_cs = {c.p_bi[0], c.p_bi[1], c.p_bi[2]};
+    double *nz = frame->preintegration.noise;
+    std::copy(c.gyroscope_noise_cov, c.gyroscope_noise_cov + 9, nz);
+    std::copy(c.accelerometer_noise_cov, c.accelerometer_noise_cov + 9, nz + 9);
+    std::copy(c.gyroscope_bias_noise_cov, c.gyroscope_bias_noise_cov + 9, nz + 18);
+    std::copy(c.accelerometer_bias_noise_cov, c.accelerometer_bias_noise_cov + 9, nz + 27);
+    std::copy(nz, nz + 36, frame->keyframe_preintegration.noise);
+    const double t = image->t;
+    frames.emplace_back(std::move(frame));
+    return predict_pose(t);
+}
+
+void Handler::track_imu(const ImuData &imu) {
+    frontal_imus.push_back(imu);
+    imus.push_back(imu);
+    while (!imus.empty() && !frames.empty()) {
+        if (imus.front().t <= frames.front()->image->t) {
+            frames.front()->preintegration.data.push_back(imus.front());
+            imus.pop_front();
+        } else {
+            feature_tracker.track_frame(std::move(frames.front()));
+            frames.pop_front();
+        }
+    }
+}
+
+PoseState Handler::predict_pose(double t) {
+    PoseState out;
+    if (auto maybe = feature_tracker.get_latest_state()) {
+        auto [state_time, pose, motion] = maybe.value();
+        while (!frontal_imus.empty() && frontal_imus.front().t <= state_time) frontal_imus.pop_front();
+        for (const ImuData &imu : frontal_imus)
+            if (imu.t <= t) propagate_state(state_time, pose, motion, imu.t, imu.w, imu.a);
+        const Q4 q_bo{sh.cfg.q_bo[0], sh.cfg.q_bo[1], sh.cfg.q_bo[2], sh.cfg.q_bo[3]};
+        out.q = pose.q * q_bo;
+        out.p = pose.p + rot(pose.q, V3{sh.cfg.p_bo[0], sh.cfg.p_bo[1], sh.cfg.p_bo[2]});
+    } else {
+        out.q = {0, 0, 0, 0};
+        out.p = {0, 0, 0};
+    }
+    return out;
+}
+
+std::tuple<double, PoseState> Handler::get_latest_state() const {
+    PoseState out;
+    double timestamp = 0.0;
+    if (auto maybe = feature_tracker.get_latest_state()) {
+        auto [state_time, pose, motion] = maybe.value();
+        (void)motion;
+        out = pose;
+        timestamp = state_time;
+    } else {
+        out.q = {0, 0, 0, 0};
+        out.p = {0, 0, 0};
+    }
+    return {timestamp, out};
+}
+
+}  // namespace rdvio_pipe
+
+// =====================================================================================================================
+// C ABI
+// =====================================================================================================================
+using namespace rdvio_pipe;
+
+extern "C" {
+
+void rdvio_pipeline_config_default(rdvio_pipeline_config *c) {
+    std::memset(c, 0, sizeof *c);
+    c->q_bc[3] = c->q_bi[3] = c->q_bo[3] = 1.0;
+    c->keypoint_noise_cov[0] = c->keypoint_noise_cov[3] = 1.0;
+    // config.cpp:8-82
+    c->sliding_window_size = 10;
+    c->sliding_window_subframe_size = 3;
+    c->sliding_window_force_keyframe_landmarks = 35;
+    c->sliding_window_tracker_frequent = 1;
+    c->feature_tracker_min_keypoint_distance = 20.0;
+    c->feature_tracker_max_keypoint_detection = 150;
+    c->feature_tracker_max_init_frames = 60;
+    c->feature_tracker_max_frames = 200;
+    c->feature_tracker_clahe_clip_limit = 6.0;
+    c->feature_tracker_clahe_width = 8;
+    c->feature_tracker_clahe_height = 8;
+    c->feature_tracker_predict_keypoints = 1;
+    c->initializer_keyframe_num = 8;
+    c->initializer_keyframe_gap = 5;
+    c->solver_iteration_limit = 10;
+    c->rotation_misalignment_threshold = 0.1;
+    c->rotation_ransac_threshold = 10;
+    c->random = 648;
+    c->parsac_flag = 0;
+}
+
+int rdvio_pipeline_create(rdvio_pipeline **out, const rdvio_pipeline_config *cfg, const rdvio_backend *backend) {
+    if (!out || !cfg || !backend) return RDVIO_ERR_INVALID;
+    *out = nullptr;
+    if (!backend->image_create || !backend->image_preprocess || !backend->image_detect || !backend->image_track || !backend->image_release ||
+        !backend->image_destroy || !backend->preintegrate || !backend->ba_solve || !backend->marginalize)
+        return RDVIO_ERR_INVALID;
+    if (cfg->parsac_flag) return RDVIO_ERR_INVALID;  // RD dynamic-outlier path: SURVEY.md 8f N2
+    if (cfg->width <= 0 || cfg->height <= 0 || cfg->sliding_window_size < 2 || cfg->sliding_window_tracker_frequent < 1 ||
+        cfg->initializer_keyframe_num < 2 || cfg->initializer_keyframe_gap < 1 || cfg->feature_tracker_max_keypoint_detection < 1)
+        return RDVIO_ERR_INVALID;
+    auto *p = new rdvio_pipeline();
+    p->shared.cfg = *cfg;
+    p->shared.backend.fn = *backend;
+    p->handler = std::make_unique<Handler>(p->shared);
+    *out = p;
+    return RDVIO_OK;
+}
+
+void rdvio_pipeline_destroy(rdvio_pipeline *p) { delete p; }
+
+const char *rdvio_pipeline_last_error(const rdvio_pipeline *p) { return p ? p->error.c_str() : "null pipeline"; }
+
+int rdvio_pipeline_set_init_states(rdvio_pipeline *p, int n, const double *rows17) {
+    if (!p || n < 0 || (n > 0 && !rows17)) return RDVIO_ERR_INVALID;
+    p->shared.init_states.resize((size_t)n);
+    for (int i = 0; i < n; ++i) std::copy(rows17 + 17 * (size_t)i, rows17 + 17 * (size_t)(i + 1), p->shared.init_states[(size_t)i].begin());
+    return RDVIO_OK;
+}
+
+#define PIPE_GUARD(stmt)                          \
+    try {                                         \
+        stmt;                                     \
+    } catch (const std::exception &e) {           \
+        p->error = e.what();                      \
+        return RDVIO_ERR_HIP;                     \
+    }
+
+static void store_pose(const PoseState &ps, double *pose7) {
+    pose7[0] = ps.q.x; pose7[1] = ps.q.y; pose7[2] = ps.q.z; pose7[3] = ps.q.w;
+    pose7[4] = ps.p.x; pose7[5] = ps.p.y; pose7[6] = ps.p.z;
+}
+
+int rdvio_pipeline_add_frame(rdvio_pipeline *p, double t, const uint8_t *gray, int width, int height, int stride, double *pose_out) {
+    if (!p || !gray || width != p->shared.cfg.width || height != p->shared.cfg.height || stride < width) {
+        if (p) p->error = "add_frame: image shape does not match the configured camera resolution";
+        return RDVIO_ERR_INVALID;
+    }
+    PIPE_GUARD({
+        Backend &be = p->shared.backend;
+        auto image = std::make_shared<ImageRef>();
+        image->backend = &be;
+        image->t = t;
+        image->width = width;
+        image->height = height;
+        be.check(be.fn.image_create(be.fn.user, gray, width, height, stride, &image->handle), "image_create");
+        const PoseState ps = p->handler->track_camera(image);
+        if (pose_out) store_pose(ps, pose_out);
+    })
+    return RDVIO_OK;
+}
+
+int rdvio_pipeline_add_gyro(rdvio_pipeline *p, double t, const double *gyro) {
+    if (!p || !gyro) return RDVIO_ERR_INVALID;
+    PIPE_GUARD(p->handler->track_gyroscope(t, gyro[0], gyro[1], gyro[2]))
+    return RDVIO_OK;
+}
+
+int rdvio_pipeline_add_acc(rdvio_pipeline *p, double t, const double *acc) {
+    if (!p || !acc) return RDVIO_ERR_INVALID;
+    PIPE_GUARD(p->handler->track_accelerometer(t, acc[0], acc[1], acc[2]))
+    return RDVIO_OK;
+}
+
+int rdvio_pipeline_add_motion(rdvio_pipeline *p, double t, const double *acc, const double *gyro) {
+    if (int rc = rdvio_pipeline_add_gyro(p, t, gyro)) return rc;  // gyro first (rdvio.hpp:59-60)
+    return rdvio_pipeline_add_acc(p, t, acc);
+}
+
+int rdvio_pipeline_state(const rdvio_pipeline *p) { return p ? p->handler->frontend.get_system_state() : 3; }
+
+int rdvio_pipeline_latest_state(const rdvio_pipeline *p, double *t, double *pose7) {
+    if (!p) return 0;
+    auto [ts, ps] = p->handler->get_latest_state();
+    if (t) *t = ts;
+    if (pose7) store_pose(ps, pose7);
+    return p->handler->feature_tracker.get_latest_state().has_value() ? 1 : 0;
+}
+
+int rdvio_pipeline_window_state(const rdvio_pipeline *p, double *t, double *state16) {
+    if (!p || !p->handler->frontend.sliding_window_tracker) return 0;
+    auto [ts, pose, motion] = p->handler->frontend.sliding_window_tracker->get_latest_state();
+    if (t) *t = ts;
+    if (state16) {
+        store_pose(pose, state16);
+        const double m[9] = {motion.v.x, motion.v.y, motion.v.z, motion.bg.x, motion.bg.y, motion.bg.z, motion.ba.x, motion.ba.y, motion.ba.z};
+        std::copy(m, m + 9, state16 + 7);
+    }
+    return 1;
+}
+
+int rdvio_pipeline_transform_world_cam(const rdvio_pipeline *p, double *T) {
+    if (!p || !T) return RDVIO_ERR_INVALID;
+    // rdvio.hpp:71-77: T_imu_to_cv * Twb * T_cam_to_body with T_imu_to_cv = [1 0 0; 0 0 -1; 0 1 0] (rdvio.hpp:16-23)
+    auto [ts, ps] = p->handler->get_latest_state();
+    (void)ts;
+    const rdvio_pipeline_config &c = p->shared.cfg;
+    auto make = [](const Q4 &q, const V3 &t, double *M) {
+        const M3 R = (q.x == 0 && q.y == 0 && q.z == 0 && q.w == 0) ? M3{{0, 0, 0, 0, 0, 0, 0, 0, 0}} : to_mat(q);
+        const double v[16] = {R.m[0], R.m[1], R.m[2], t.x, R.m[3], R.m[4], R.m[5], t.y, R.m[6], R.m[7], R.m[8], t.z, 0, 0, 0, 1};
+        std::copy(v, v + 16, M);
+    };
+    auto mul = [](const double *A, const double *B, double *C) {
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double s = 0;
+                for (int k = 0; k < 4; ++k) s += A[4 * i + k] * B[4 * k + j];
+                C[4 * i + j] = s;
+            }
+    };
+    double Twb[16], Tcb[16], tmp[16];
+    make(ps.q, ps.p, Twb);
+    make(Q4{c.q_bc[0], c.q_bc[1], c.q_bc[2], c.q_bc[3]}, V3{c.p_bc[0], c.p_bc[1], c.p_bc[2]}, Tcb);
+    const double Ticv[16] = {1, 0, 0, 0, 0, 0, -1, 0, 0, 1, 0, 0, 0, 0, 0, 1};
+    mul(Ticv, Twb, tmp);
+    mul(tmp, Tcb, T);
+    return RDVIO_OK;
+}
+
+int rdvio_pipeline_local_map(const rdvio_pipeline *p, double *xyz, int capacity) {
+    if (!p || !p->handler->frontend.sliding_window_tracker) return 0;
+    const Map *map = p->handler->frontend.sliding_window_tracker->map.get();
+    int n = 0;
+    for (size_t i = 0; i < map->track_num(); ++i) {
+        const Track *track = map->get_track(i);
+        if (!track->all_tagged({TT_VALID, TT_TRIANGULATED})) continue;
+        if (xyz && n < capacity) {
+            const V3 x = track->get_landmark_point();
+            xyz[3 * n] = x.x; xyz[3 * n + 1] = x.y; xyz[3 * n + 2] = x.z;
+        }
+        ++n;
+    }
+    return n;
+}
+
+int rdvio_pipeline_last_frame_keypoints(const rdvio_pipeline *p, int64_t *track_ids, double *xy, int capacity) {
+    if (!p) return 0;
+    const Map *map = p->handler->feature_tracker.map.get();
+    if (map->frame_num() == 0) return 0;
+    const Frame *frame = map->get_frame(map->frame_num() - 1);
+    const int n = (int)frame->keypoint_num();
+    for (int i = 0; i < n && i < capacity; ++i) {
+        if (track_ids) track_ids[i] = frame->get_track((size_t)i) ? (int64_t)frame->get_track((size_t)i)->id() : -1;
+        if (xy) {
+            const V2 px = apply_k(frame->get_keypoint((size_t)i), frame->K);
+            xy[2 * i] = px.x;
+            xy[2 * i + 1] = px.y;
+        }
+    }
+    return n;
+}
+
+int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out) {
+    if (!p || !out) return RDVIO_ERR_INVALID;
+    const Counters &c = p->shared.counters;
+    const Map *ft = p->handler->feature_tracker.map.get();
+    out[0] = c.frames_tracked; out[1] = c.window_solves; out[2] = c.keyframes; out[3] = c.marginalizations;
+    out[4] = c.localizations; out[5] = c.subwindow_solves;
+    out[6] = ft->frame_num() ? (int64_t)ft->get_frame(ft->frame_num() - 1)->id() : -1;
+    out[7] = p->handler->frontend.sliding_window_tracker ? (int64_t)p->handler->frontend.sliding_window_tracker->map->track_num() : 0;
+    return RDVIO_OK;
+}
+
+}  // extern "C"

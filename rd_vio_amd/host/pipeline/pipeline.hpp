@@ -1,0 +1,158 @@
+// The per-frame orchestration: Handler -> FeatureTracker -> Frontend -> (bootstrap | SlidingWindowTracker).
+// Single-threaded (the reference's THREADING=OFF path: FeatureTracker::track_frame and Frontend::issue_frame run
+// synchronously, feature_tracker.cpp:113-118, frontend.cpp:72-77).
+#pragma once
+
+#include <array>
+#include <deque>
+#include <optional>
+#include <tuple>
+
+#include "map.hpp"
+
+namespace rdvio_pipe {
+
+struct Counters {
+    int64_t frames_tracked = 0, window_solves = 0, keyframes = 0, marginalizations = 0, localizations = 0, subwindow_solves = 0;
+};
+
+struct Shared {  // what every stage needs
+    rdvio_pipeline_config cfg;
+    Backend backend;
+    IdGenerator ids;
+    Counters counters;
+    std::vector<std::array<double, 17>> init_states;
+};
+
+// SoA export of one Solver problem (row A16): frames / landmarks / factors by index, ordered by landmark
+class BaBuilder {
+  public:
+    explicit BaBuilder(Shared &sh) : sh(sh) {}
+    // Solver::add_frame_states: constancy from the frame's FT_FIX_POSE / FT_FIX_MOTION tags (solver.cpp:88-114)
+    int add_frame_states(Frame *frame);
+    // a frame whose values are read by a factor but which is not a parameter of this solve
+    int add_constant_frame(Frame *frame);
+    int add_track_states(Track *track, bool constant);
+    void add_reprojection_error(Frame *frame, size_t keypoint_index);   // Solver::add_factor(ReprojectionErrorFactor *)
+    void add_reprojection_prior(Frame *frame, Track *track);            // create_reprojection_prior_factor
+    void add_rotation_prior(Frame *frame, Track *track);                // create_rotation_prior_factor
+    void add_preintegration(Frame *frame_i, Frame *frame_j, const PreIntegrator &pre, bool prior);
+    void add_marginalization(const MarginalizationPrior *prior) { this->prior = prior; }
+    bool solve(rdvio_ba_summary *summary = nullptr);                    // Solver::solve + in-place state update
+
+  private:
+    struct Fac { int tgt, ref, lm; const double *tangent; };
+    struct Rot { int tgt, ref; V3 zref; const double *tangent; };
+    struct Pre { int i, j; const double *delta; };
+    int frame_index(Frame *frame) const;
+    Shared &sh;
+    std::vector<Frame *> frames;
+    std::vector<uint8_t> frame_fixed;
+    std::unordered_map<const Frame *, int> fidx;
+    std::vector<Track *> lms;
+    std::vector<uint8_t> lm_fixed;
+    std::unordered_map<const Track *, int> lidx;
+    std::vector<Fac> facs;
+    std::vector<Rot> rots;
+    std::vector<Pre> pres;
+    const MarginalizationPrior *prior = nullptr;
+};
+
+class SlidingWindowTracker {
+  public:
+    SlidingWindowTracker(std::unique_ptr<Map> keyframe_map, Shared &sh);
+    void mirror_frame(Map *feature_tracking_map, size_t frame_id);
+    bool track();
+    std::tuple<double, PoseState, MotionState> get_latest_state() const;
+    std::unique_ptr<Map> map;
+
+  private:
+    void localize_newframe();
+    bool manage_keyframe();
+    void track_landmark();
+    void refine_window();
+    void slide_window();
+    void refine_subwindow();
+    void marginalize_frame0();
+    Shared &sh;
+};
+
+// Bootstrap of the window from externally supplied keyframe states (the reference's Initializer without its SfM /
+// IMU-alignment stages).  mirror_keyframe_map and the closing BA follow initializer.cpp:20-140.
+class Initializer {
+  public:
+    explicit Initializer(Shared &sh) : sh(sh) {}
+    void mirror_keyframe_map(Map *feature_tracking_map, size_t init_frame_id);
+    std::unique_ptr<SlidingWindowTracker> initialize();
+
+  private:
+    Shared &sh;
+    std::unique_ptr<Map> map;
+};
+
+class FeatureTracker;
+
+class Frontend {
+  public:
+    Frontend(FeatureTracker *ft, Shared &sh);
+    void issue_frame(Frame *frame);
+    std::tuple<double, size_t, PoseState, MotionState> get_latest_state() const { return latest_state; }
+    int get_system_state() const { return initializer ? 0 : (sliding_window_tracker ? 1 : 3); }
+    std::unique_ptr<SlidingWindowTracker> sliding_window_tracker;
+
+  private:
+    void run();
+    FeatureTracker *feature_tracker;
+    Shared &sh;
+    std::unique_ptr<Initializer> initializer;
+    std::deque<size_t> pending_frame_ids;
+    std::tuple<double, size_t, PoseState, MotionState> latest_state;
+};
+
+class FeatureTracker {
+  public:
+    explicit FeatureTracker(Shared &sh);
+    void set_frontend(Frontend *f) { frontend = f; }
+    void track_frame(std::unique_ptr<Frame> frame);
+    std::optional<std::tuple<double, PoseState, MotionState>> get_latest_state() const { return latest_state; }
+    std::unique_ptr<Map> map;
+
+  private:
+    void run();
+    void detect_keypoints(Frame *frame);                       // Frame::detect_keypoints, frame.cpp:55-72
+    void track_keypoints(Frame *frame, Frame *next_frame);     // Frame::track_keypoints, frame.cpp:74-172
+    Shared &sh;
+    Frontend *frontend = nullptr;
+    std::deque<std::unique_ptr<Frame>> frames;
+    std::optional<std::tuple<double, PoseState, MotionState>> latest_state;
+};
+
+class Handler {
+  public:
+    explicit Handler(Shared &sh);
+    PoseState track_gyroscope(double t, double x, double y, double z);
+    PoseState track_accelerometer(double t, double x, double y, double z);
+    PoseState track_camera(std::shared_ptr<ImageRef> image);
+    std::tuple<double, PoseState> get_latest_state() const;
+    FeatureTracker feature_tracker;
+    Frontend frontend;
+
+  private:
+    struct Gyro { double t; V3 w; };
+    struct Acc { double t; V3 a; };
+    void track_imu(const ImuData &imu);
+    PoseState predict_pose(double t);
+    Shared &sh;
+    std::deque<Gyro> gyroscopes;
+    std::deque<Acc> accelerometers;
+    std::deque<ImuData> imus, frontal_imus;
+    std::deque<std::unique_ptr<Frame>> frames;
+};
+
+}  // namespace rdvio_pipe
+
+struct rdvio_pipeline {
+    rdvio_pipe::Shared shared;
+    std::unique_ptr<rdvio_pipe::Handler> handler;
+    std::string error;
+};

@@ -323,3 +323,79 @@ def make_marg_inputs(pb, with_full_prior=False, seed=9):
     keep = np.array([l in seen for l in pb["lm"]], dtype=bool)
     return (pb["states"], pb["extr"], pb["sqrt_inv_cov"], np.arange(npf, dtype=np.int32), lin, S, f, pb["preint"][0],
             pb["tgt"][keep], pb["ref"][keep], pb["lm"][keep], pb["tangent"][keep], pb["z_ref"], pb["inv_depth"])
+
+
+# ------------------------------------------------------------------ 3-D consistent synthetic stream (pipeline tests)
+ROOM_HALF = np.array([6.0, 6.0, 2.5])   # the 12 x 12 x 5 m box of SURVEY.md 8d (config 5)
+
+
+def _hash01(ix, iy, seed):
+    hsh = (ix * 73856093) ^ (iy * 19349663) ^ (seed * 83492791)
+    hsh = (hsh ^ (hsh >> 13)) * 1274126177
+    hsh = hsh ^ (hsh >> 16)
+    return (hsh & 0xFFFFFF) / float(0x1000000)
+
+
+def _wall_texture(u, v, seed):
+    """grey value of a wall at plane coordinates (u, v) in metres: 4-octave value noise + a jittered lattice of
+    Gaussian blobs (one per 0.3 m cell, sigma 2-4 cm) -- corner-rich at 2-6 m viewing distance."""
+    img = np.full(u.shape, 110.0)
+    for o, cell in enumerate((1.2, 0.6, 0.3, 0.15)):
+        img += (80.0 / (1.75 * (1 << o))) * (_value_noise(u, v, seed + o, cell) - 0.5) * 2.0
+    cell = 0.3
+    cu = np.floor(u / cell).astype(np.int64)
+    cv = np.floor(v / cell).astype(np.int64)
+    for du in (-1, 0, 1):
+        for dv in (-1, 0, 1):
+            ix, iy = cu + du, cv + dv
+            bx = (ix + _hash01(ix, iy, seed + 11)) * cell
+            by = (iy + _hash01(ix, iy, seed + 12)) * cell
+            sg = 0.02 + 0.02 * _hash01(ix, iy, seed + 13)
+            am = (60.0 + 140.0 * _hash01(ix, iy, seed + 14)) * np.where(_hash01(ix, iy, seed + 15) < 0.35, -0.5, 1.0)
+            img += am * np.exp(-((u - bx) ** 2 + (v - by) ** 2) / (2 * sg * sg))
+    return img
+
+
+def render_room(q_wb, p_wb, K, w, h, extr=EUROC_EXTR, seed=648):
+    """u8 image seen by the camera of a body at pose (q_wb, p_wb) inside the textured box room: per-pixel ray cast
+    against the six walls (geometrically consistent across frames: true parallax and perspective)."""
+    q_wc = q_mul(q_wb, extr[0:4])
+    R = q_to_mat(q_wc)
+    c = p_wb + q_to_mat(q_wb) @ extr[4:7]
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    d_c = np.stack([(xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1], np.ones_like(xs)], axis=-1)
+    d = d_c @ R.T
+    best_t = np.full((h, w), np.inf)
+    img = np.zeros((h, w))
+    plane = 0
+    for axis in range(3):
+        for sign in (-1.0, 1.0):
+            plane += 1
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = (sign * ROOM_HALF[axis] - c[axis]) / d[..., axis]
+            ok = (t > 1e-6) & (t < best_t)
+            hit = c[None, None, :] + t[..., None] * d
+            a1, a2 = [a for a in range(3) if a != axis]
+            ok &= (np.abs(hit[..., a1]) <= ROOM_HALF[a1] + 1e-9) & (np.abs(hit[..., a2]) <= ROOM_HALF[a2] + 1e-9)
+            if not ok.any():
+                continue
+            tex = _wall_texture(hit[..., a1][ok], hit[..., a2][ok], seed + 100 * plane)
+            img[ok] = tex
+            best_t[ok] = t[ok]
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def make_stream(n_frames, w=752, h=480, K=EUROC_K, t0=1.0, cam_rate=20.0, imu_rate=200.0, seed=648, imu_noise=True):
+    """A synthetic EuRoC-shaped stream on the SURVEY.md 8d trajectory: images (n_frames x h x w u8), frame times, IMU rows
+    (t, gyro, acc) covering the frames with the constant biases TRUE_BG / TRUE_BA added, and the ground-truth body
+    states at the frame times as rows (t, q, p, v, bg, ba)."""
+    rng = np.random.default_rng(seed + 1)
+    ts = t0 + np.arange(n_frames) / cam_rate
+    frames = np.stack([render_room(*traj_pose(t), K, w, h, seed=seed) for t in ts])
+    imu = make_imu_segment(t0 - 0.5 / imu_rate - 2.0 / imu_rate, ts[-1] + 3.0 / imu_rate, rate=imu_rate, rng=rng if imu_noise else None,
+                           noise=imu_noise, bg=TRUE_BG, ba=TRUE_BA)
+    gt = np.zeros((n_frames, 17))
+    for i, t in enumerate(ts):
+        q, p = traj_pose(t)
+        gt[i] = np.concatenate([[t], q, p, traj_vel(t), TRUE_BG, TRUE_BA])
+    return frames, ts, imu, gt

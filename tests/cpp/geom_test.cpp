@@ -1,0 +1,148 @@
+// Self-consistency checks of the host geometry (rd_vio_amd/host/pipeline/geom.hpp): the two-view solvers recover a
+// known configuration.  PARITY UNPINNED: the reference has no tests or fixtures for these functions.
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "../../rd_vio_amd/host/pipeline/geom.hpp"
+
+using namespace rdvio_pipe;
+
+static int fails = 0;
+#define CHECK(cond, ...)                          \
+    do {                                          \
+        if (!(cond)) {                            \
+            std::printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+            std::printf(__VA_ARGS__);             \
+            std::printf("\n");                    \
+            ++fails;                              \
+        }                                         \
+    } while (0)
+
+int main() {
+    std::mt19937 rng(648);
+    std::uniform_real_distribution<double> U(-1.0, 1.0);
+    // --- real eigenvalues / eigenvectors of a non-symmetric matrix with a known spectrum
+    {
+        const int n = 6;
+        std::vector<double> D(n * n, 0.0), P(n * n), Pinv(n * n), A(n * n, 0.0);
+        const double ev[n] = {3.0, -1.5, 0.25, 7.0, 1.0, -4.0};
+        for (int i = 0; i < n; ++i) D[i * n + i] = ev[i];
+        for (double &v : P) v = U(rng);
+        for (int i = 0; i < n; ++i) P[i * n + i] += 3.0;
+        // invert P by Gauss-Jordan
+        std::vector<double> M(n * 2 * n, 0.0);
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < n; ++j) M[i * 2 * n + j] = P[i * n + j];
+            M[i * 2 * n + n + i] = 1.0;
+        }
+        for (int c = 0; c < n; ++c) {
+            int p = c;
+            for (int r = c + 1; r < n; ++r)
+                if (std::fabs(M[r * 2 * n + c]) > std::fabs(M[p * 2 * n + c])) p = r;
+            for (int j = 0; j < 2 * n; ++j) std::swap(M[c * 2 * n + j], M[p * 2 * n + j]);
+            const double d = M[c * 2 * n + c];
+            for (int j = 0; j < 2 * n; ++j) M[c * 2 * n + j] /= d;
+            for (int r = 0; r < n; ++r)
+                if (r != c) {
+                    const double f = M[r * 2 * n + c];
+                    for (int j = 0; j < 2 * n; ++j) M[r * 2 * n + j] -= f * M[c * 2 * n + j];
+                }
+        }
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) Pinv[i * n + j] = M[i * 2 * n + n + j];
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j)
+                for (int k = 0; k < n; ++k) A[i * n + j] += P[i * n + k] * ev[k] * Pinv[k * n + j];
+        std::vector<double> wr, wi;
+        CHECK(real_eigenvalues(n, A, wr, wi), "hqr did not converge");
+        for (int k = 0; k < n; ++k) {
+            double best = 1e9;
+            for (int i = 0; i < n; ++i) best = std::min(best, std::fabs(wr[i] - ev[k]) + std::fabs(wi[i]));
+            CHECK(best < 1e-9, "eigenvalue %g missing (err %g)", ev[k], best);
+            const std::vector<double> x = eigenvector_for(n, A, ev[k]);
+            double res = 0;
+            for (int i = 0; i < n; ++i) {
+                double s = -ev[k] * x[i];
+                for (int j = 0; j < n; ++j) s += A[i * n + j] * x[j];
+                res = std::max(res, std::fabs(s));
+            }
+            CHECK(res < 1e-8, "eigenvector residual %g", res);
+        }
+    }
+    // --- two views of random points: 5-point solver, rotation solver, triangulation
+    const Q4 q = normalized(Q4{0.05, -0.08, 0.03, 1.0});
+    const M3 R = to_mat(q);
+    const V3 t{0.3, -0.1, 0.05};
+    std::vector<V3> X;
+    std::vector<V2> p1, p2;
+    std::vector<V3> b1, b2;
+    for (int i = 0; i < 60; ++i) {
+        const V3 x{2.0 * U(rng), 1.5 * U(rng), 4.0 + U(rng)};
+        const V3 y = R * x + t;
+        X.push_back(x);
+        p1.push_back(hnormalized(x));
+        p2.push_back(hnormalized(y));
+        b1.push_back(normalized(x));
+        b2.push_back(normalized(R * x));  // pure rotation pair for the Wahba solver
+    }
+    {
+        // true essential matrix E = [t]x R: p2^T E p1 = 0
+        const M3 tx{{0, -t.z, t.y, t.z, 0, -t.x, -t.y, t.x, 0}};
+        const M3 Et = tx * R;
+        std::array<V2, 5> s1{p1[0], p1[1], p1[2], p1[3], p1[4]}, s2{p2[0], p2[1], p2[2], p2[3], p2[4]};
+        const std::vector<M3> sols = solve_essential_5pt(s1, s2);
+        CHECK(!sols.empty(), "5-point solver returned no solution");
+        double best = 1e9;
+        for (const M3 &E : sols) {
+            double n1 = 0, n2 = 0, d = 0;
+            for (int i = 0; i < 9; ++i) { n1 += E.m[i] * E.m[i]; n2 += Et.m[i] * Et.m[i]; d += E.m[i] * Et.m[i]; }
+            best = std::min(best, 1.0 - std::fabs(d) / std::sqrt(n1 * n2));
+            for (int i = 0; i < 5; ++i) {
+                const V3 Ep = E * V3{s1[i].x, s1[i].y, 1.0};
+                const double r = s2[i].x * Ep.x + s2[i].y * Ep.y + Ep.z;
+                CHECK(std::fabs(r) < 1e-8 * std::sqrt(n1), "solution violates an epipolar constraint: %g", r);
+            }
+        }
+        CHECK(best < 1e-8, "no 5-point solution matches the true E (best 1-cos %g)", best);
+        std::vector<char> mask;
+        const M3 E = find_essential_matrix(p1, p2, mask, 1.0);
+        (void)E;
+        size_t inl = 0;
+        for (char c : mask) inl += c;
+        CHECK(mask.size() == p1.size() && inl == p1.size(), "RANSAC inliers %zu of %zu", inl, p1.size());
+    }
+    {
+        std::vector<char> mask;
+        const M3 Rr = find_rotation_matrix(b1, b2, mask, (M_PI / 180.0) * 10.0);
+        double err = 0;
+        for (int i = 0; i < 9; ++i) err = std::max(err, std::fabs(Rr.m[i] - R.m[i]));
+        CHECK(err < 1e-9, "rotation error %g", err);
+        CHECK(std::fabs(det(Rr) - 1.0) < 1e-12, "det %g", det(Rr));
+    }
+    {
+        std::vector<std::array<double, 12>> Ps = {{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0},
+                                                  {R.m[0], R.m[1], R.m[2], t.x, R.m[3], R.m[4], R.m[5], t.y, R.m[6], R.m[7], R.m[8], t.z}};
+        for (int i = 0; i < 10; ++i) {
+            const V3 y = R * X[i] + t;
+            const auto h = triangulate_point(Ps, {normalized(X[i]), normalized(y)});
+            const V3 x{h[0] / h[3], h[1] / h[3], h[2] / h[3]};
+            CHECK(norm(x - X[i]) < 1e-9, "triangulation error %g", norm(x - X[i]));
+        }
+    }
+    {
+        // LotBox draws are a permutation prefix
+        LotBox box(10);
+        box.seed(0);
+        bool seen[10] = {false};
+        for (int i = 0; i < 10; ++i) {
+            const size_t k = box.draw_without_replacement();
+            CHECK(k < 10 && !seen[k], "LotBox repeated %zu", k);
+            seen[k] = true;
+        }
+        CHECK(box.draw_without_replacement() == size_t(-1), "LotBox should be empty");
+    }
+    if (fails) return 1;
+    std::printf("OK geometry\n");
+    return 0;
+}

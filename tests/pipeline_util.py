@@ -1,0 +1,175 @@
+"""Test harness for the per-frame orchestration (librdvio_pipeline.so): builds the oracle-backed rdvio_backend shim
+(tests/cpp/oracle_backend.c -> tests/_build/), feeds a synthetic stream through rdvio_pipeline_* exactly like the
+reference's test_euroc loop (examples/test_euroc.cpp:46-95: IMU and camera interleaved by timestamp) and collects the
+trajectory, the per-frame keypoint/track tables and the counters."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "tests", "_build")
+
+
+class PipelineConfig(ctypes.Structure):
+    _fields_ = [
+        ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+        ("K", ctypes.c_double * 9),
+        ("q_bc", ctypes.c_double * 4), ("p_bc", ctypes.c_double * 3),
+        ("q_bi", ctypes.c_double * 4), ("p_bi", ctypes.c_double * 3),
+        ("q_bo", ctypes.c_double * 4), ("p_bo", ctypes.c_double * 3),
+        ("keypoint_noise_cov", ctypes.c_double * 4),
+        ("gyroscope_noise_cov", ctypes.c_double * 9), ("accelerometer_noise_cov", ctypes.c_double * 9),
+        ("gyroscope_bias_noise_cov", ctypes.c_double * 9), ("accelerometer_bias_noise_cov", ctypes.c_double * 9),
+        ("sliding_window_size", ctypes.c_int32), ("sliding_window_subframe_size", ctypes.c_int32),
+        ("sliding_window_force_keyframe_landmarks", ctypes.c_int32), ("sliding_window_tracker_frequent", ctypes.c_int32),
+        ("feature_tracker_min_keypoint_distance", ctypes.c_double),
+        ("feature_tracker_max_keypoint_detection", ctypes.c_int32), ("feature_tracker_max_init_frames", ctypes.c_int32),
+        ("feature_tracker_max_frames", ctypes.c_int32),
+        ("feature_tracker_clahe_clip_limit", ctypes.c_double),
+        ("feature_tracker_clahe_width", ctypes.c_int32), ("feature_tracker_clahe_height", ctypes.c_int32),
+        ("feature_tracker_predict_keypoints", ctypes.c_int32),
+        ("initializer_keyframe_num", ctypes.c_int32), ("initializer_keyframe_gap", ctypes.c_int32),
+        ("solver_iteration_limit", ctypes.c_int32),
+        ("rotation_misalignment_threshold", ctypes.c_double), ("rotation_ransac_threshold", ctypes.c_double),
+        ("random", ctypes.c_int32), ("parsac_flag", ctypes.c_int32),
+    ]
+
+
+class Backend(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("user", "image_create", "image_preprocess", "image_detect", "image_track", "image_release",
+                                               "image_destroy", "preintegrate", "ba_solve", "marginalize", "last_error")]
+
+
+PIPELINE_EXPORTS = [
+    "rdvio_pipeline_config_default", "rdvio_pipeline_create_hip", "rdvio_pipeline_create", "rdvio_pipeline_destroy",
+    "rdvio_pipeline_last_error", "rdvio_pipeline_set_init_states", "rdvio_pipeline_add_frame", "rdvio_pipeline_add_motion",
+    "rdvio_pipeline_add_gyro", "rdvio_pipeline_add_acc", "rdvio_pipeline_state", "rdvio_pipeline_latest_state",
+    "rdvio_pipeline_window_state", "rdvio_pipeline_transform_world_cam", "rdvio_pipeline_local_map",
+    "rdvio_pipeline_last_frame_keypoints", "rdvio_pipeline_counters",
+]
+
+
+def load_pipeline_lib():
+    from rd_vio_amd import build as rbuild
+    rbuild.build()
+    lib = ctypes.CDLL(rbuild.PIPE_LIB)
+    lib.rdvio_pipeline_last_error.restype = ctypes.c_char_p
+    return lib
+
+
+def build_oracle_backend():
+    """gcc the shim against liboracle.so; returns the loaded library (exports rdvio_oracle_backend_fill)."""
+    import oracle
+    oracle.build()
+    os.makedirs(BUILD, exist_ok=True)
+    out = os.path.join(BUILD, "liboracle_backend.so")
+    src = os.path.join(ROOT, "tests", "cpp", "oracle_backend.c")
+    odir = os.path.join(ROOT, "oracle")
+    deps = [src, os.path.join(odir, "liboracle.so"), os.path.join(ROOT, "include", "rdvio_pipeline.h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-Wall", "-o", out, src, "-L" + odir, "-loracle",
+                               "-Wl,-rpath," + odir, "-lm"])
+    return ctypes.CDLL(out)
+
+
+def default_config(lib, K, w, h, extr, noise, **over):
+    cfg = PipelineConfig()
+    lib.rdvio_pipeline_config_default(ctypes.byref(cfg))
+    cfg.width, cfg.height = w, h
+    cfg.K[:] = list(np.asarray(K, dtype=np.float64).ravel())
+    cfg.q_bc[:] = list(extr[0:4])
+    cfg.p_bc[:] = list(extr[4:7])
+    cfg.q_bi[:] = list(extr[7:11])
+    cfg.p_bi[:] = list(extr[11:14])
+    cfg.keypoint_noise_cov[:] = [0.5, 0.0, 0.0, 0.5]      # configs/euroc_sensor.yaml keypoint noise
+    cfg.gyroscope_noise_cov[:] = list(noise[0:9])
+    cfg.accelerometer_noise_cov[:] = list(noise[9:18])
+    cfg.gyroscope_bias_noise_cov[:] = list(noise[18:27])
+    cfg.accelerometer_bias_noise_cov[:] = list(noise[27:36])
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def run_stream(lib, make_pipeline, frames, ts, imu, gt, max_kp=600):
+    """make_pipeline(handle_out) -> rc creates the pipeline.  Returns dict(traj, keypoints, counters, states)."""
+    h = ctypes.c_void_p()
+    rc = make_pipeline(ctypes.byref(h))
+    assert rc == 0, rc
+    try:
+        gt = np.ascontiguousarray(gt, dtype=np.float64)
+        assert lib.rdvio_pipeline_set_init_states(h, len(gt), gt.ctypes.data_as(ctypes.c_void_p)) == 0
+        traj, kps, states, sys_state = [], [], [], []
+        ids = np.zeros(max_kp, dtype=np.int64)
+        xy = np.zeros((max_kp, 2))
+        pose = np.zeros(7)
+        st16 = np.zeros(16)
+        tt = ctypes.c_double(0)
+        ii = 0
+        last_seen = -1
+
+        def snapshot():
+            nonlocal last_seen
+            cnt = np.zeros(8, dtype=np.int64)
+            lib.rdvio_pipeline_counters(h, cnt.ctypes.data_as(ctypes.c_void_p))
+            if cnt[0] == last_seen:
+                return
+            last_seen = cnt[0]
+            n = lib.rdvio_pipeline_last_frame_keypoints(h, ids.ctypes.data_as(ctypes.c_void_p), xy.ctypes.data_as(ctypes.c_void_p), max_kp)
+            kps.append((ids[:n].copy(), xy[:n].copy()))
+            ok = lib.rdvio_pipeline_latest_state(h, ctypes.byref(tt), pose.ctypes.data_as(ctypes.c_void_p))
+            traj.append(np.concatenate([[tt.value if ok else np.nan], pose.copy() if ok else np.full(7, np.nan)]))
+            okw = lib.rdvio_pipeline_window_state(h, ctypes.byref(tt), st16.ctypes.data_as(ctypes.c_void_p))
+            states.append(np.concatenate([[tt.value if okw else np.nan], st16.copy() if okw else np.full(16, np.nan)]))
+            sys_state.append(lib.rdvio_pipeline_state(h))
+
+        def check(rc):
+            if rc != 0:
+                raise RuntimeError(lib.rdvio_pipeline_last_error(h).decode())
+
+        for k, t in enumerate(ts):
+            while ii < len(imu) and imu[ii, 0] <= t:
+                acc = np.ascontiguousarray(imu[ii, 4:7])
+                gyr = np.ascontiguousarray(imu[ii, 1:4])
+                check(lib.rdvio_pipeline_add_motion(h, ctypes.c_double(imu[ii, 0]), acc.ctypes.data_as(ctypes.c_void_p),
+                                                    gyr.ctypes.data_as(ctypes.c_void_p)))
+                snapshot()
+                ii += 1
+            img = np.ascontiguousarray(frames[k])
+            check(lib.rdvio_pipeline_add_frame(h, ctypes.c_double(t), img.ctypes.data_as(ctypes.c_void_p), img.shape[1], img.shape[0],
+                                               img.shape[1], None))
+        while ii < len(imu):   # flush: the last frame is processed when the first later IMU sample arrives
+            acc = np.ascontiguousarray(imu[ii, 4:7])
+            gyr = np.ascontiguousarray(imu[ii, 1:4])
+            check(lib.rdvio_pipeline_add_motion(h, ctypes.c_double(imu[ii, 0]), acc.ctypes.data_as(ctypes.c_void_p),
+                                                gyr.ctypes.data_as(ctypes.c_void_p)))
+            snapshot()
+            ii += 1
+        cnt = np.zeros(8, dtype=np.int64)
+        lib.rdvio_pipeline_counters(h, cnt.ctypes.data_as(ctypes.c_void_p))
+        return dict(traj=np.array(traj), keypoints=kps, counters=cnt, states=np.array(states), sys_state=np.array(sys_state))
+    finally:
+        lib.rdvio_pipeline_destroy(h)
+
+
+def oracle_pipeline_factory(lib, shim, cfg):
+    be = Backend()
+    shim.rdvio_oracle_backend_fill(ctypes.byref(be))
+    return lambda out: lib.rdvio_pipeline_create(out, ctypes.byref(cfg), ctypes.byref(be))
+
+
+def hip_pipeline_factory(lib, ctx, cfg):
+    return lambda out: lib.rdvio_pipeline_create_hip(out, ctypes.byref(cfg), ctx._h)
+
+
+def ate_rmse(p_est, p_ref):
+    """position RMSE after the best rigid (Umeyama, no scale) alignment of p_est onto p_ref."""
+    a, b = np.asarray(p_est), np.asarray(p_ref)
+    ma, mb = a.mean(0), b.mean(0)
+    H = (a - ma).T @ (b - mb)
+    U, _, Vt = np.linalg.svd(H)
+    D = np.diag([1, 1, np.sign(np.linalg.det(Vt.T @ U.T))])
+    R = Vt.T @ D @ U.T
+    return float(np.sqrt(np.mean(np.sum(((a - ma) @ R.T + mb - b) ** 2, axis=1))))

@@ -1,0 +1,45 @@
+"""SURVEY.md 8d metrics (2) and (3) on the synthetic stream: the product pipeline over the HIP backend against the SAME
+orchestration over the CPU oracle backend -- per-frame feature index sets and pixel positions bit-exact, trajectories
+within 1 mm (the ATE criterion of BASELINE.json).  The CPU path is the oracle (parity unpinned, see oracle/ headers)."""
+import numpy as np
+import pytest
+
+import pipeline_util as pu
+import rd_vio_amd
+from rd_vio_amd import synth
+
+W, H = 752, 480
+K = synth.EUROC_K
+OVER = dict(sliding_window_size=8, feature_tracker_max_keypoint_detection=150, feature_tracker_min_keypoint_distance=10.0,
+            solver_iteration_limit=30, initializer_keyframe_gap=2, feature_tracker_max_frames=20,
+            sliding_window_force_keyframe_landmarks=50, sliding_window_subframe_size=3, rotation_misalignment_threshold=0.02)
+
+
+@pytest.mark.gpu
+def test_hip_pipeline_reproduces_the_cpu_path():
+    frames, ts, imu, gt = synth.make_stream(36, W, H, K)
+    lib, shim = pu.load_pipeline_lib(), pu.build_oracle_backend()
+    cfg = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **OVER)
+    cpu = pu.run_stream(lib, pu.oracle_pipeline_factory(lib, shim, cfg), frames, ts, imu, gt)
+    ctx = rd_vio_amd.Context(max_width=W, max_height=H, max_features=1024, max_window=16, max_factors=20000)
+    try:
+        gpu = pu.run_stream(lib, pu.hip_pipeline_factory(lib, ctx, cfg), frames, ts, imu, gt)
+    finally:
+        ctx.close()
+    assert (gpu["counters"] == cpu["counters"]).all(), (gpu["counters"], cpu["counters"])
+    assert (gpu["sys_state"] == cpu["sys_state"]).all() and gpu["sys_state"][-1] == 1
+    # metric (3): tracked-feature index sets (and their pixel positions) per frame are identical
+    assert len(gpu["keypoints"]) == len(cpu["keypoints"]) == len(ts)
+    for k, ((ig, xg), (ic, xc)) in enumerate(zip(gpu["keypoints"], cpu["keypoints"])):
+        assert np.array_equal(ig, ic), f"frame {k}: track ids differ"
+        assert np.array_equal(xg, xc), f"frame {k}: keypoint positions differ"
+    # metric (2): trajectory of the GPU path vs the CPU path, 1 mm
+    sg, sc = gpu["states"], cpu["states"]
+    ok = ~np.isnan(sc[:, 0])
+    assert ok.sum() >= 15 and np.array_equal(np.isnan(sg[:, 0]), np.isnan(sc[:, 0]))
+    assert np.abs(sg[ok, 5:8] - sc[ok, 5:8]).max() < 1e-3
+    assert pu.ate_rmse(sg[ok, 5:8], sc[ok, 5:8]) < 1e-3
+    assert np.abs(sg[ok, 1:5] - sc[ok, 1:5]).max() < 1e-3     # orientation (quaternion components)
+    # and both stay on the ground truth
+    p_gt = np.array([synth.traj_pose(t)[1] for t in sc[ok, 0]])
+    assert np.linalg.norm(sg[ok, 5:8] - p_gt, axis=1).max() < 0.15
