@@ -108,7 +108,7 @@ def run_stream(lib, make_pipeline, frames, ts, imu, gt, max_kp=600):
         st16 = np.zeros(16)
         tt = ctypes.c_double(0)
         ii = 0
-        last_seen = -1
+        last_seen = 0
 
         def snapshot():
             nonlocal last_seen
