@@ -169,6 +169,82 @@ def cpu_baseline(cfg, wl, budget_s=12.0, max_frames=400):
                        f"{el:.1f} s")
 
 
+def end_to_end(cfg, ctx, n_frames, with_cpu_path):
+    """SURVEY.md 8d metric (1)-(3) on a geometrically consistent synthetic stream: the product pipeline
+    (librdvio_pipeline.so: feature tracker + sliding-window tracker over the HIP backend) fed like test_euroc feeds
+    rdvio::Odometry.  This rate is PCIe-inclusive (host images in, host-built BA graphs in, states out every frame), so
+    it is reported beside `value`, never as `value`.  With `with_cpu_path` the same orchestration runs over the CPU
+    oracle backend (cpu_baseline leg) for the trajectory / feature-index comparison."""
+    import ctypes
+
+    from rd_vio_amd import pipeline_run as pr
+    from rd_vio_amd import synth
+
+    w, h = cfg["width"], cfg["height"]
+    K = synth.EUROC_K.copy()
+    if (w, h) != (752, 480):
+        K = np.array([[900.0, 0, w / 2.0], [0, 900.0, h / 2.0], [0, 0, 1.0]])
+    frames, ts, imu, gt = synth.make_stream(n_frames, w, h, K)
+    lib = pr.load_pipeline_lib()
+    pcfg = pr.default_config(lib, K, w, h, synth.EUROC_EXTR, synth.EUROC_NOISE, sliding_window_size=cfg["window"],
+                             feature_tracker_max_keypoint_detection=cfg["features"], feature_tracker_min_keypoint_distance=10.0,
+                             solver_iteration_limit=cfg["iters"], feature_tracker_max_frames=20,
+                             sliding_window_force_keyframe_landmarks=50, sliding_window_subframe_size=3,
+                             rotation_misalignment_threshold=0.02)
+    gt_c = np.ascontiguousarray(gt)
+
+    def run(handle):
+        states, kps, stamps = [], [], []
+        ids = np.zeros(4096, dtype=np.int64)
+        xy = np.zeros((4096, 2))
+        st16 = np.zeros(16)
+        tt = ctypes.c_double(0)
+        t_start = time.perf_counter()
+
+        def snap(_n):
+            n = lib.rdvio_pipeline_last_frame_keypoints(handle, ids.ctypes.data_as(ctypes.c_void_p), xy.ctypes.data_as(ctypes.c_void_p), 4096)
+            kps.append((ids[:n].copy(), xy[:n].copy()))
+            ok = lib.rdvio_pipeline_window_state(handle, ctypes.byref(tt), st16.ctypes.data_as(ctypes.c_void_p))
+            states.append(np.concatenate([[tt.value], st16]) if ok else np.full(17, np.nan))
+            stamps.append(time.perf_counter() - t_start)
+
+        assert lib.rdvio_pipeline_set_init_states(handle, len(gt_c), gt_c.ctypes.data_as(ctypes.c_void_p)) == 0
+        spent = pr.feed_stream(lib, handle, frames, ts, imu, per_frame=snap)
+        cnt = np.zeros(10, dtype=np.int64)
+        lib.rdvio_pipeline_counters(handle, cnt.ctypes.data_as(ctypes.c_void_p))
+        lib.rdvio_pipeline_destroy(handle)
+        return np.array(states), kps, np.array(stamps), spent, cnt
+
+    sg, kg, stamps, spent, cnt = run(pr.create_hip_pipeline(lib, ctx, pcfg))
+    tracking = ~np.isnan(sg[:, 0])
+    out = {"frames": int(cnt[0]), "frames_tracking": int(tracking.sum()), "fps": round(float(cnt[0] / spent), 2),
+           "window_solves": int(cnt[1]), "marginalizations": int(cnt[3]), "localizations": int(cnt[4]), "subwindow_solves": int(cnt[5]),
+           "largest_solve": {"frames": int(cnt[8]), "factors": int(cnt[9])},
+           "note": "product pipeline over the HIP backend, host buffers in/out every frame (PCIe-inclusive)"}
+    if tracking.sum() >= 2:
+        i0 = int(np.argmax(tracking))
+        out["fps_tracking_phase"] = round(float((len(stamps) - 1 - i0) / (stamps[-1] - stamps[i0])), 2)
+        p_gt = np.array([synth.traj_pose(t)[1] for t in sg[tracking, 0]])
+        out["position_error_vs_ground_truth_m"] = {"max": round(float(np.linalg.norm(sg[tracking, 5:8] - p_gt, axis=1).max()), 4),
+                                                   "final": round(float(np.linalg.norm(sg[tracking, 5:8][-1] - p_gt[-1])), 4)}
+    if with_cpu_path:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import pipeline_util as pu
+
+        shim = pu.build_oracle_backend()
+        hc = ctypes.c_void_p()
+        assert pu.oracle_pipeline_factory(lib, shim, pcfg)(ctypes.byref(hc)) == 0
+        sc, kc, stamps_c, spent_c, cnt_c = run(hc)
+        same_idx = len(kc) == len(kg) and all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(kg, kc))
+        both = tracking & ~np.isnan(sc[:, 0]) if len(sc) == len(sg) else np.zeros(0, dtype=bool)
+        out["cpu_path"] = {"fps": round(float(cnt_c[0] / spent_c), 2),
+                           "feature_indices_identical": bool(same_idx),
+                           "ate_rmse_gpu_vs_cpu_path_mm": round(1e3 * pu.ate_rmse(sg[both, 5:8], sc[both, 5:8]), 6) if both.sum() >= 3 else None,
+                           "max_position_difference_mm": round(1e3 * float(np.abs(sg[both, 5:8] - sc[both, 5:8]).max()), 6) if both.sum() else None,
+                           "kind": "the same orchestration over the CPU oracle backend (tests/cpp/oracle_backend.c), 1 thread"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,6 +252,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="euroc_v101", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--end-to-end-frames", type=int, default=100, help="frames of the pipeline run (0 = skip)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -299,6 +376,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, wl)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 2)
+        if world == 1 and args.end_to_end_frames > 0:
+            out["end_to_end"] = end_to_end(cfg, ctx, args.end_to_end_frames, with_cpu_path=not args.no_cpu_baseline)
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

@@ -118,8 +118,9 @@ int rdvio_pipeline_local_map(const rdvio_pipeline *p, double *xyz, int capacity)
  * track_ids[i] = id of the track through keypoint i or -1; xy in pixels.  Returns the number of keypoints. */
 int rdvio_pipeline_last_frame_keypoints(const rdvio_pipeline *p, int64_t *track_ids, double *xy, int capacity);
 /* counters: [0] frames tracked, [1] window solves, [2] keyframes inserted, [3] marginalisations, [4] localisations,
- * [5] subwindow solves, [6] frame id of the newest tracked frame, [7] tracks in the window map */
-int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out8);
+ * [5] subwindow solves, [6] frame id of the newest tracked frame, [7] tracks in the window map, [8] largest number of
+ * frames in one solve, [9] largest number of reprojection factors in one solve */
+int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out10);
 
 #ifdef __cplusplus
 }

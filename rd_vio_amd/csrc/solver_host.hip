@@ -42,8 +42,7 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     const int nfr = pb->n_frames, nl = pb->n_landmarks, nf = pb->n_factors, nrot = pb->n_rot, npre = pb->n_preint,
               np = pb->n_prior;
     if (nfr <= 0 || nl < 0 || nf < 0 || nrot < 0 || npre < 0 || np < 0) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "negative BA sizes");
-    if (nfr > 32) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "at most 32 frames per solve");
-    if (nfr > ctx->max_window + 2) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d frames exceed window capacity %d", nfr, ctx->max_window + 2);
+    if (nfr > 64) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "at most 64 frames per solve (32 of them free)");
     if (nf > ctx->max_factors || nl > ctx->max_factors || nrot > ctx->max_factors)
         return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d factors / %d landmarks exceed capacity %d", nf, nl, ctx->max_factors);
     if (npre > nfr + 8 || np > nfr) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "too many preintegration factors / prior frames");
@@ -84,6 +83,8 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     std::vector<int32_t> fcol(nfr);
     int nfree = 0;
     for (int i = 0; i < nfr; ++i) fcol[i] = (pb->frame_fixed[i] == 1) ? -1 : nfree++;
+    if (nfree > 32) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "at most 32 free frames per solve");
+    if (nfree > ctx->max_window + 2) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d free frames exceed window capacity %d", nfree, ctx->max_window + 2);
     const int N = 15 * nfree, D = 15 * np;
     const int npairs = nfree * (nfree + 1) / 2;
     std::vector<int32_t> pair_fi(npairs), pair_fj(npairs), diag_pair(std::max(nfree, 1));

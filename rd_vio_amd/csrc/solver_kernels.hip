@@ -548,11 +548,13 @@ DM void solver_setup(const SolverWs &w, Shared &sh) {
     const int nl = w.nl, nfree = w.nfree, NAs = 6 * nfree + 2;
     for (int i = t; i < w.nfr * 16; i += T) w.user[i] = w.x[i];
     for (int l = t; l < nl; l += T) w.lfree[l] = (w.lm_count[l] > 0 && !w.lm_fixed[l]) ? 1 : 0;
-    for (int i = t; i < 32; i += T) {
+    for (int i = t; i < 64; i += T) {
         sh.fcol[i] = (i < w.nfr) ? w.fcol[i] : -1;
-        sh.pcol[i] = (i < nfree) ? w.pcol[i] : -1;
         sh.pfix[i] = (i < w.nfr && w.frame_fixed[i] == 2) ? 1 : 0;
-        sh.pfixc[i] = 0;
+        if (i < 32) {
+            sh.pcol[i] = (i < nfree) ? w.pcol[i] : -1;
+            sh.pfixc[i] = 0;
+        }
     }
     __syncthreads();
     for (int i = t; i < w.nfr; i += T)

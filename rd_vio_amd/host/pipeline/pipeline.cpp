@@ -160,6 +160,8 @@ bool BaBuilder::solve(rdvio_ba_summary *summary_out) {
         pb.prior_S = prior->S.data();
         pb.prior_f = prior->f.data();
     }
+    sh.counters.max_problem_frames = std::max<int64_t>(sh.counters.max_problem_frames, nfr);
+    sh.counters.max_problem_factors = std::max<int64_t>(sh.counters.max_problem_factors, nf);
     std::vector<double> states_out(states.size()), invd_out(invd.size());
     rdvio_ba_summary sm;
     std::memset(&sm, 0, sizeof sm);
@@ -1157,6 +1159,8 @@ int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out) {
     out[4] = c.localizations; out[5] = c.subwindow_solves;
     out[6] = ft->frame_num() ? (int64_t)ft->get_frame(ft->frame_num() - 1)->id() : -1;
     out[7] = p->handler->frontend.sliding_window_tracker ? (int64_t)p->handler->frontend.sliding_window_tracker->map->track_num() : 0;
+    out[8] = c.max_problem_frames;
+    out[9] = c.max_problem_factors;
     return RDVIO_OK;
 }
 

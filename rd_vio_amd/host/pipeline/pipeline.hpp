@@ -14,6 +14,7 @@ namespace rdvio_pipe {
 
 struct Counters {
     int64_t frames_tracked = 0, window_solves = 0, keyframes = 0, marginalizations = 0, localizations = 0, subwindow_solves = 0;
+    int64_t max_problem_frames = 0, max_problem_factors = 0;
 };
 
 struct Shared {  // what every stage needs

@@ -8,33 +8,10 @@ import subprocess
 
 import numpy as np
 
+from rd_vio_amd.pipeline_run import PipelineConfig, default_config, feed_stream, load_pipeline_lib  # noqa: F401
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "tests", "_build")
-
-
-class PipelineConfig(ctypes.Structure):
-    _fields_ = [
-        ("width", ctypes.c_int32), ("height", ctypes.c_int32),
-        ("K", ctypes.c_double * 9),
-        ("q_bc", ctypes.c_double * 4), ("p_bc", ctypes.c_double * 3),
-        ("q_bi", ctypes.c_double * 4), ("p_bi", ctypes.c_double * 3),
-        ("q_bo", ctypes.c_double * 4), ("p_bo", ctypes.c_double * 3),
-        ("keypoint_noise_cov", ctypes.c_double * 4),
-        ("gyroscope_noise_cov", ctypes.c_double * 9), ("accelerometer_noise_cov", ctypes.c_double * 9),
-        ("gyroscope_bias_noise_cov", ctypes.c_double * 9), ("accelerometer_bias_noise_cov", ctypes.c_double * 9),
-        ("sliding_window_size", ctypes.c_int32), ("sliding_window_subframe_size", ctypes.c_int32),
-        ("sliding_window_force_keyframe_landmarks", ctypes.c_int32), ("sliding_window_tracker_frequent", ctypes.c_int32),
-        ("feature_tracker_min_keypoint_distance", ctypes.c_double),
-        ("feature_tracker_max_keypoint_detection", ctypes.c_int32), ("feature_tracker_max_init_frames", ctypes.c_int32),
-        ("feature_tracker_max_frames", ctypes.c_int32),
-        ("feature_tracker_clahe_clip_limit", ctypes.c_double),
-        ("feature_tracker_clahe_width", ctypes.c_int32), ("feature_tracker_clahe_height", ctypes.c_int32),
-        ("feature_tracker_predict_keypoints", ctypes.c_int32),
-        ("initializer_keyframe_num", ctypes.c_int32), ("initializer_keyframe_gap", ctypes.c_int32),
-        ("solver_iteration_limit", ctypes.c_int32),
-        ("rotation_misalignment_threshold", ctypes.c_double), ("rotation_ransac_threshold", ctypes.c_double),
-        ("random", ctypes.c_int32), ("parsac_flag", ctypes.c_int32),
-    ]
 
 
 class Backend(ctypes.Structure):
@@ -49,14 +26,6 @@ PIPELINE_EXPORTS = [
     "rdvio_pipeline_window_state", "rdvio_pipeline_transform_world_cam", "rdvio_pipeline_local_map",
     "rdvio_pipeline_last_frame_keypoints", "rdvio_pipeline_counters",
 ]
-
-
-def load_pipeline_lib():
-    from rd_vio_amd import build as rbuild
-    rbuild.build()
-    lib = ctypes.CDLL(rbuild.PIPE_LIB)
-    lib.rdvio_pipeline_last_error.restype = ctypes.c_char_p
-    return lib
 
 
 def build_oracle_backend():
@@ -74,25 +43,6 @@ def build_oracle_backend():
     return ctypes.CDLL(out)
 
 
-def default_config(lib, K, w, h, extr, noise, **over):
-    cfg = PipelineConfig()
-    lib.rdvio_pipeline_config_default(ctypes.byref(cfg))
-    cfg.width, cfg.height = w, h
-    cfg.K[:] = list(np.asarray(K, dtype=np.float64).ravel())
-    cfg.q_bc[:] = list(extr[0:4])
-    cfg.p_bc[:] = list(extr[4:7])
-    cfg.q_bi[:] = list(extr[7:11])
-    cfg.p_bi[:] = list(extr[11:14])
-    cfg.keypoint_noise_cov[:] = [0.5, 0.0, 0.0, 0.5]      # configs/euroc_sensor.yaml keypoint noise
-    cfg.gyroscope_noise_cov[:] = list(noise[0:9])
-    cfg.accelerometer_noise_cov[:] = list(noise[9:18])
-    cfg.gyroscope_bias_noise_cov[:] = list(noise[18:27])
-    cfg.accelerometer_bias_noise_cov[:] = list(noise[27:36])
-    for k, v in over.items():
-        setattr(cfg, k, v)
-    return cfg
-
-
 def run_stream(lib, make_pipeline, frames, ts, imu, gt, max_kp=600):
     """make_pipeline(handle_out) -> rc creates the pipeline.  Returns dict(traj, keypoints, counters, states)."""
     h = ctypes.c_void_p()
@@ -107,16 +57,8 @@ def run_stream(lib, make_pipeline, frames, ts, imu, gt, max_kp=600):
         pose = np.zeros(7)
         st16 = np.zeros(16)
         tt = ctypes.c_double(0)
-        ii = 0
-        last_seen = 0
 
-        def snapshot():
-            nonlocal last_seen
-            cnt = np.zeros(8, dtype=np.int64)
-            lib.rdvio_pipeline_counters(h, cnt.ctypes.data_as(ctypes.c_void_p))
-            if cnt[0] == last_seen:
-                return
-            last_seen = cnt[0]
+        def snapshot(force=False):
             n = lib.rdvio_pipeline_last_frame_keypoints(h, ids.ctypes.data_as(ctypes.c_void_p), xy.ctypes.data_as(ctypes.c_void_p), max_kp)
             kps.append((ids[:n].copy(), xy[:n].copy()))
             ok = lib.rdvio_pipeline_latest_state(h, ctypes.byref(tt), pose.ctypes.data_as(ctypes.c_void_p))
@@ -125,29 +67,8 @@ def run_stream(lib, make_pipeline, frames, ts, imu, gt, max_kp=600):
             states.append(np.concatenate([[tt.value if okw else np.nan], st16.copy() if okw else np.full(16, np.nan)]))
             sys_state.append(lib.rdvio_pipeline_state(h))
 
-        def check(rc):
-            if rc != 0:
-                raise RuntimeError(lib.rdvio_pipeline_last_error(h).decode())
-
-        for k, t in enumerate(ts):
-            while ii < len(imu) and imu[ii, 0] <= t:
-                acc = np.ascontiguousarray(imu[ii, 4:7])
-                gyr = np.ascontiguousarray(imu[ii, 1:4])
-                check(lib.rdvio_pipeline_add_motion(h, ctypes.c_double(imu[ii, 0]), acc.ctypes.data_as(ctypes.c_void_p),
-                                                    gyr.ctypes.data_as(ctypes.c_void_p)))
-                snapshot()
-                ii += 1
-            img = np.ascontiguousarray(frames[k])
-            check(lib.rdvio_pipeline_add_frame(h, ctypes.c_double(t), img.ctypes.data_as(ctypes.c_void_p), img.shape[1], img.shape[0],
-                                               img.shape[1], None))
-        while ii < len(imu):   # flush: the last frame is processed when the first later IMU sample arrives
-            acc = np.ascontiguousarray(imu[ii, 4:7])
-            gyr = np.ascontiguousarray(imu[ii, 1:4])
-            check(lib.rdvio_pipeline_add_motion(h, ctypes.c_double(imu[ii, 0]), acc.ctypes.data_as(ctypes.c_void_p),
-                                                gyr.ctypes.data_as(ctypes.c_void_p)))
-            snapshot()
-            ii += 1
-        cnt = np.zeros(8, dtype=np.int64)
+        feed_stream(lib, h, frames, ts, imu, per_frame=lambda _n: snapshot(force=True))
+        cnt = np.zeros(10, dtype=np.int64)
         lib.rdvio_pipeline_counters(h, cnt.ctypes.data_as(ctypes.c_void_p))
         return dict(traj=np.array(traj), keypoints=kps, counters=cnt, states=np.array(states), sys_state=np.array(sys_state))
     finally:
