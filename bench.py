@@ -239,8 +239,8 @@ def end_to_end(cfg, ctx, n_frames, with_cpu_path):
         both = tracking & ~np.isnan(sc[:, 0]) if len(sc) == len(sg) else np.zeros(0, dtype=bool)
         out["cpu_path"] = {"fps": round(float(cnt_c[0] / spent_c), 2),
                            "feature_indices_identical": bool(same_idx),
-                           "ate_rmse_gpu_vs_cpu_path_mm": round(1e3 * pu.ate_rmse(sg[both, 5:8], sc[both, 5:8]), 6) if both.sum() >= 3 else None,
-                           "max_position_difference_mm": round(1e3 * float(np.abs(sg[both, 5:8] - sc[both, 5:8]).max()), 6) if both.sum() else None,
+                           "ate_rmse_gpu_vs_cpu_path_mm": float(f"{1e3 * pu.ate_rmse(sg[both, 5:8], sc[both, 5:8]):.3g}") if both.sum() >= 3 else None,
+                           "max_position_difference_mm": float(f"{1e3 * float(np.abs(sg[both, 5:8] - sc[both, 5:8]).max()):.3g}") if both.sum() else None,
                            "kind": "the same orchestration over the CPU oracle backend (tests/cpp/oracle_backend.c), 1 thread"}
     return out
 
