@@ -210,7 +210,7 @@ def end_to_end(cfg, ctx, n_frames, with_cpu_path):
 
         assert lib.rdvio_pipeline_set_init_states(handle, len(gt_c), gt_c.ctypes.data_as(ctypes.c_void_p)) == 0
         spent = pr.feed_stream(lib, handle, frames, ts, imu, per_frame=snap)
-        cnt = np.zeros(10, dtype=np.int64)
+        cnt = np.zeros(25, dtype=np.int64)
         lib.rdvio_pipeline_counters(handle, cnt.ctypes.data_as(ctypes.c_void_p))
         lib.rdvio_pipeline_destroy(handle)
         return np.array(states), kps, np.array(stamps), spent, cnt
@@ -219,7 +219,12 @@ def end_to_end(cfg, ctx, n_frames, with_cpu_path):
     tracking = ~np.isnan(sg[:, 0])
     out = {"frames": int(cnt[0]), "frames_tracking": int(tracking.sum()), "fps": round(float(cnt[0] / spent), 2),
            "window_solves": int(cnt[1]), "marginalizations": int(cnt[3]), "localizations": int(cnt[4]), "subwindow_solves": int(cnt[5]),
-           "largest_solve": {"frames": int(cnt[8]), "factors": int(cnt[9])},
+           "largest_solve": {"frames": int(cnt[8]), "factors": int(cnt[9])}, "solver_iterations": int(cnt[10]),
+           "backend_ms_per_frame": {name: round(float(cnt[11 + 2 * k]) / 1e3 / max(int(cnt[0]), 1), 4) for k, name in enumerate(
+               ("preprocess", "detect", "track", "preintegrate", "ba_solve", "marginalize", "image_create"))},
+           "backend_calls": {name: int(cnt[12 + 2 * k]) for k, name in enumerate(
+               ("preprocess", "detect", "track", "preintegrate", "ba_solve", "marginalize", "image_create"))},
+           "ms_per_frame": round(1e3 * spent / max(int(cnt[0]), 1), 4),
            "note": "product pipeline over the HIP backend, host buffers in/out every frame (PCIe-inclusive)"}
     if tracking.sum() >= 2:
         i0 = int(np.argmax(tracking))
@@ -276,7 +281,7 @@ def main():
     # HIP events below bracket exactly the kernels of each stage
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    ctx = rd_vio_amd.Context(max_width=cfg["width"], max_height=cfg["height"], max_features=max(1024, cfg["features"]),
+    ctx = rd_vio_amd.Context(max_width=cfg["width"], max_height=cfg["height"], max_features=max(1024, 4 * cfg["features"]),
                              max_window=cfg["window"], max_factors=20000, device=local_rank, stream=stream.cuda_stream)
     wl = build_workload(cfg, ctx, torch, dev)
     lib, h = ctx._lib, ctx._h

@@ -46,9 +46,11 @@ typedef struct rdvio_backend {
                        int has_guess, uint8_t *status);
     void (*image_release)(void *user, void *image); /* release_image_buffer */
     void (*image_destroy)(void *user, void *image);
-    /* PreIntegrator::integrate: imu n x 7 (t, gyro, acc), noise 4 x 9 (cov_w cov_a cov_bg cov_ba) */
-    int (*preintegrate)(void *user, int n, const double *imu, double t_end, const double *bg, const double *ba,
-                        const double *noise, int compute_jacobian, int compute_covariance, double *preint_out);
+    /* PreIntegrator::integrate for nseg independent segments (refine_window integrates every keyframe interval before
+     * one solve): seg_off[nseg+1] sample offsets into imu (n x 7: t, gyro, acc), t_end[nseg], bg / ba [3 nseg],
+     * noise 4 x 9 (cov_w cov_a cov_bg cov_ba), preint_out nseg x RDVIO_PREINT_SIZE */
+    int (*preintegrate)(void *user, int nseg, const int32_t *seg_off, const double *imu, const double *t_end, const double *bg,
+                        const double *ba, const double *noise, int compute_jacobian, int compute_covariance, double *preint_out);
     /* Solver::solve on the SoA problem; states_out / inv_depth_out receive the optimised values */
     int (*ba_solve)(void *user, const rdvio_ba_problem *pb, int max_iterations, double *states_out, double *inv_depth_out,
                     rdvio_ba_summary *summary);
@@ -119,8 +121,10 @@ int rdvio_pipeline_local_map(const rdvio_pipeline *p, double *xyz, int capacity)
 int rdvio_pipeline_last_frame_keypoints(const rdvio_pipeline *p, int64_t *track_ids, double *xy, int capacity);
 /* counters: [0] frames tracked, [1] window solves, [2] keyframes inserted, [3] marginalisations, [4] localisations,
  * [5] subwindow solves, [6] frame id of the newest tracked frame, [7] tracks in the window map, [8] largest number of
- * frames in one solve, [9] largest number of reprojection factors in one solve */
-int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out10);
+ * frames in one solve, [9] largest number of reprojection factors in one solve, [10] solver iterations summed over all
+ * solves, then (microseconds, calls) pairs of the time spent inside backend calls: [11,12] preprocess, [13,14] detect,
+ * [15,16] track, [17,18] preintegrate, [19,20] ba_solve, [21,22] marginalize, [23,24] image_create */
+int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out25);
 
 #ifdef __cplusplus
 }

@@ -112,6 +112,7 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
     CTX_ALLOC(ctx->pre_imu, (size_t)ctx->pre_max_samples * 7 * sizeof(double));
     CTX_ALLOC(ctx->pre_par, ((size_t)ctx->pre_max_seg * 7 + 36) * sizeof(double));
     CTX_ALLOC(ctx->pre_out, (size_t)ctx->pre_max_seg * RDVIO_PREINT_SIZE * sizeof(double));
+    CTX_ALLOC(ctx->pre_blob, ((size_t)ctx->pre_max_seg * 7 + 36 + (size_t)ctx->pre_max_samples * 7 + (size_t)ctx->pre_max_seg + 8) * sizeof(double));
     CTX_ALLOC(ctx->pre_off, (size_t)(ctx->pre_max_seg + 1) * sizeof(int32_t));
     {
         const size_t F = (size_t)max_factors, Lm = (size_t)max_factors, Nmax = 15 * (size_t)nfr, npre = (size_t)nfr + 8;
@@ -141,6 +142,7 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
         }
     }
     ctx->pinned_bytes = std::max<size_t>((size_t)ctx->harris_cand_cap * sizeof(HarrisCand), 1 << 20);
+    ctx->pinned_bytes = std::max<size_t>(ctx->pinned_bytes, ((size_t)ctx->pre_max_seg * (7 + RDVIO_PREINT_SIZE + 1) + 64 + (size_t)ctx->pre_max_samples * 7) * sizeof(double));
     if (hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
         rdvio_fail(ctx, RDVIO_ERR_HIP, "hipHostMalloc failed");
         *out = ctx;
@@ -161,7 +163,7 @@ void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
     void *bufs[] = {ctx->gray, ctx->clahe_lut, ctx->harris, ctx->harris_scalars, ctx->harris_cand, ctx->lk_curr,
                     ctx->lk_next, ctx->lk_prevf, ctx->lk_nextf, ctx->lk_status, ctx->ba_states, ctx->ba_extr,
                     ctx->ba_zref, ctx->ba_invd, ctx->ba_tangent, ctx->ba_idx, ctx->ba_r, ctx->ba_Jt, ctx->ba_Jr,
-                    ctx->ba_Jd, ctx->pre_imu, ctx->pre_par, ctx->pre_out, ctx->pre_off};
+                    ctx->ba_Jd, ctx->pre_imu, ctx->pre_par, ctx->pre_out, ctx->pre_off, ctx->pre_blob};
     for (void *b : bufs) (void)hipFree(b);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->marg.host) (void)hipHostFree(ctx->marg.host);
@@ -304,24 +306,33 @@ int rdvio_hip_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off,
         if (seg_off[i + 1] < seg_off[i]) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "seg_off must be non-decreasing");
     const int ns = seg_off[nseg];
     if (ns > ctx->pre_max_samples) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d samples exceed capacity %d", ns, ctx->pre_max_samples);
-    double *par = (double *)ctx->pinned;
+    // one pinned blob up (par | noise | samples | offsets), one kernel, one pinned blob down: a frame makes several of
+    // these calls, so the per-call fixed cost matters more than the 4 KB of payload
+    const size_t o_par = 0, o_noise = (size_t)ctx->pre_max_seg * 7, o_imu = o_noise + 36, o_off = o_imu + (size_t)ctx->pre_max_samples * 7;
+    const size_t in_doubles = o_off + ((size_t)ctx->pre_max_seg + 2) / 2 + 1, out_doubles = (size_t)nseg * RDVIO_PREINT_SIZE;
+    if ((in_doubles + out_doubles) * sizeof(double) > ctx->pinned_bytes) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "preintegration staging buffer too small");
+    double *blob = (double *)ctx->pinned;
     for (int i = 0; i < nseg; ++i) {
-        par[7 * i] = t_end[i];
+        blob[o_par + 7 * i] = t_end[i];
         for (int k = 0; k < 3; ++k) {
-            par[7 * i + 1 + k] = bg[3 * i + k];
-            par[7 * i + 4 + k] = ba[3 * i + k];
+            blob[o_par + 7 * i + 1 + k] = bg[3 * i + k];
+            blob[o_par + 7 * i + 4 + k] = ba[3 * i + k];
         }
     }
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pre_par, par, (size_t)nseg * 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pre_par + 7 * (size_t)ctx->pre_max_seg, noise, 36 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pre_off, seg_off, (size_t)(nseg + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    if (ns > 0) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pre_imu, imu, (size_t)ns * 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    // the pinned staging buffer is reused by later calls: finish the uploads that read it before returning
-    if (int rc = rdvio_launch_preintegrate(ctx, nseg, ctx->pre_off, ctx->pre_imu, ctx->pre_par,
-                                           ctx->pre_par + 7 * (size_t)ctx->pre_max_seg, cj, cc, ctx->pre_out))
+    memcpy(blob + o_noise, noise, 36 * sizeof(double));
+    if (ns > 0) memcpy(blob + o_imu, imu, (size_t)ns * 7 * sizeof(double));
+    memcpy(blob + o_off, seg_off, (size_t)(nseg + 1) * sizeof(int32_t));
+    // only the used prefix of each region travels: par, noise and the samples are contiguous up to the last sample
+    const size_t head = (o_imu + (size_t)ns * 7) * sizeof(double);
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pre_blob, blob, head, hipMemcpyHostToDevice, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pre_blob + o_off, blob + o_off, (size_t)(nseg + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = rdvio_launch_preintegrate(ctx, nseg, (const int32_t *)(ctx->pre_blob + o_off), ctx->pre_blob + o_imu, ctx->pre_blob + o_par,
+                                           ctx->pre_blob + o_noise, cj, cc, ctx->pre_out))
         return rc;
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(out, ctx->pre_out, (size_t)nseg * RDVIO_PREINT_SIZE * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    double *down = blob + in_doubles;
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, ctx->pre_out, out_doubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, down, out_doubles * sizeof(double));
     return RDVIO_OK;
 }
 

@@ -51,7 +51,7 @@ struct rdvio_hip_ctx {
     double *ba_states = nullptr, *ba_extr = nullptr, *ba_zref = nullptr, *ba_invd = nullptr, *ba_tangent = nullptr;
     int32_t *ba_idx = nullptr;  // tgt | ref | lm, each max_factors
     double *ba_r = nullptr, *ba_Jt = nullptr, *ba_Jr = nullptr, *ba_Jd = nullptr;
-    double *pre_imu = nullptr, *pre_par = nullptr, *pre_out = nullptr;
+    double *pre_imu = nullptr, *pre_par = nullptr, *pre_out = nullptr, *pre_blob = nullptr;
     int32_t *pre_off = nullptr;
     int pre_max_samples = 0, pre_max_seg = 0;
 
@@ -59,7 +59,7 @@ struct rdvio_hip_ctx {
     struct BaSlot {
         void *host = nullptr, *arena = nullptr;
         SolverWs ws{};
-        size_t in_states_off = 0, in_invd_off = 0, in_bytes = 0;
+        size_t in_states_off = 0, in_invd_off = 0, in_bytes = 0, host_bytes = 0;
         bool ready = false;
     } ba[RDVIO_BA_SLOTS];
     size_t ba_host_bytes = 0, ba_arena_bytes = 0;

@@ -60,10 +60,6 @@ int rdvio_hip_marginalize_resident(rdvio_hip_ctx *ctx, int force_eigen) {
     if (!S.ready) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "no marginalisation problem uploaded");
     SolverWs &w = S.ws;
     w.marg_force_eigen = force_eigen ? 1 : 0;
-    uint8_t *B = (uint8_t *)S.arena;
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(w.x, B + S.in_states_off, (size_t)w.nfr * 16 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    if (w.nl > 0)
-        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(w.xd, B + S.in_invd_off, (size_t)w.nl * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     rdvio_launch_marginalize(ctx->stream, w);
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
     return RDVIO_OK;
@@ -76,14 +72,20 @@ int rdvio_hip_marginalize_fetch(rdvio_hip_ctx *ctx, double *S_out, double *f_out
     const SolverWs &w = ctx->marg.ws;
     const size_t R = (size_t)15 * (w.nfr - 1);
     hipStream_t st = ctx->stream;
-    double info[4] = {0};
-    if (S_out) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(S_out, w.S_out, R * R * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (f_out) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(f_out, w.f_out, R * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (lin_out) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(lin_out, w.lin_out, (size_t)(w.nfr - 1) * 16 * sizeof(double), hipMemcpyDeviceToHost, st));
+    const rdvio_hip_ctx::BaSlot &slot = ctx->marg;
+    // S | f | lin | info in one device-to-host copy into the slot's pinned blob (behind the uploaded inputs)
+    const size_t n_out = (size_t)(w.m_info + 4 - w.S_out);
+    const size_t host_off = (slot.in_bytes + 63) & ~(size_t)63;
+    if (host_off + n_out * sizeof(double) > slot.host_bytes) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "result does not fit the pinned blob");
+    double *down = (double *)((uint8_t *)slot.host + host_off);
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, w.S_out, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
     if (Lambda_out) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(Lambda_out, w.Lambda_out, R * R * sizeof(double), hipMemcpyDeviceToHost, st));
     if (eta_out) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(eta_out, w.eta_out, R * sizeof(double), hipMemcpyDeviceToHost, st));
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(info, w.m_info, sizeof info, hipMemcpyDeviceToHost, st));
     RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (S_out) memcpy(S_out, down, R * R * sizeof(double));
+    if (f_out) memcpy(f_out, down + (w.f_out - w.S_out), R * sizeof(double));
+    if (lin_out) memcpy(lin_out, down + (w.lin_out - w.S_out), (size_t)(w.nfr - 1) * 16 * sizeof(double));
+    const double *info = down + (w.m_info - w.S_out);
     if (used_fast_path) *used_fast_path = (int)info[0];  // 1 plain Cholesky, 2 pivoted Cholesky, 0 eigen
     return RDVIO_OK;
 }

@@ -203,7 +203,9 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     Packer Sx{nullptr, cap};
     Sx.off = in_bytes;
     auto dd = [&](size_t n) { return Sx.reserve(std::max<size_t>(n, 1) * sizeof(double)); };
-    const size_t s_x = dd((size_t)nfr * 16), s_xd = dd(nl), s_xc = dd((size_t)nfr * 16), s_xdc = dd(nl), s_user = dd((size_t)nfr * 16);
+    // x | xd | summary are adjacent: the result travels back with one copy
+    const size_t s_x = dd((size_t)nfr * 16), s_xd = dd(nl), s_sum = dd(80);  // summary[0..7] + diagnostic phase stamps
+    const size_t s_xc = dd((size_t)nfr * 16), s_xdc = dd(nl), s_user = dd((size_t)nfr * 16);
     const size_t s_lfree = Sx.reserve(std::max(nl, 1));
     const size_t s_fac = dd((size_t)nf * RDVIO_FAC_STRIDE), s_prec = dd((size_t)nrec * RDVIO_REC_STRIDE), s_GP = dd((size_t)npairs * 256);
     const size_t s_PP = dd((size_t)npre * 900), s_Pg = dd((size_t)npre * 30), s_ST = dd((size_t)D * D);
@@ -214,7 +216,6 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     const size_t s_Cm = dd((size_t)(6 * nfree + 2) * (6 * nfree + 2)), s_Cg = dd((size_t)6 * nfree);
     const size_t s_lmm = dd(nl), s_lmg = dd(nl), s_lmw = dd(nl), s_A = dd((size_t)nl * (6 * nfree + 2)), s_yl = dd(nl);
     const size_t s_sigp = dd(N), s_sigl = dd(nl), s_dgp = dd(N), s_dgl = dd(nl), s_grp = dd(N), s_grl = dd(nl), s_gnp = dd(N), s_gnl = dd(nl), s_tp = dd(N), s_tl = dd(nl);
-    const size_t s_sum = dd(80);  // summary[0..7] + diagnostic phase stamps
     // marginalisation tail (victim = frame 0): R = N - 15 retained rows
     const int R = N >= 15 ? N - 15 : 0, Rb = (R + 14) / 15 * 15, Wn = std::max(R, Rb);
     size_t s_mTm = 0, s_mLr = 0, s_mer = 0, s_mWk = 0, s_mV = 0, s_mcs = 0, s_myv = 0, s_mnz = 0, s_So = 0, s_fo = 0, s_lo = 0, s_Lo = 0, s_eo = 0, s_info = 0;
@@ -222,7 +223,8 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
         s_mTm = dd((size_t)R * 15); s_mLr = dd((size_t)R * R); s_mer = dd(R); s_mWk = dd((size_t)Wn * Wn); s_mV = dd((size_t)R * R);
         s_mcs = dd((size_t)4 * (R / 2 + 2) + R); s_myv = dd(Wn);
         s_mnz = Sx.reserve((size_t)(2 * R + 2) * sizeof(int32_t));  // nz list + pivot `done` flags
-        s_So = dd((size_t)R * R); s_fo = dd(R); s_lo = dd((size_t)(nfr - 1) * 16); s_Lo = dd((size_t)R * R); s_eo = dd(R); s_info = dd(4);
+        // S | f | lin | info adjacent: the new prior travels back with one copy
+        s_So = dd((size_t)R * R); s_fo = dd(R); s_lo = dd((size_t)(nfr - 1) * 16); s_info = dd(4); s_Lo = dd((size_t)R * R); s_eo = dd(R);
     }
     if (!Sx.ok) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "BA problem does not fit the context's device arena");
 
@@ -246,6 +248,7 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     w.fcol = IP(o_fcol); w.frame_fixed = B + o_ffix; w.lm_first = IP(o_lmf); w.lm_count = IP(o_lmc);
     w.pair_fi = IP(o_pfi); w.pair_fj = IP(o_pfj); w.grp_off = IP(o_goff); w.diag_pair = IP(o_dp);
     w.gslot = IP(o_gslot); w.gflip = IP(o_gflip); w.band_src = IP(o_band); w.g_src = IP(o_gsrc); w.pcol = IP(o_pcol);
+    w.x0 = DP(o_states); w.xd0 = DP(o_invd);
     w.x = DP(s_x); w.xd = DP(s_xd); w.xc = DP(s_xc); w.xdc = DP(s_xdc); w.user = DP(s_user); w.lfree = B + s_lfree;
     w.fac = DP(s_fac); w.prec = DP(s_prec); w.GP = DP(s_GP); w.PP = DP(s_PP); w.Pg = DP(s_Pg); w.ST = DP(s_ST); w.r_r = DP(s_rr); w.Jro = DP(s_Jro);
     w.e_p = DP(s_ep); w.G = DP(s_G); w.r_p = DP(s_rp); w.c_p = DP(s_cp); w.Jp = DP(s_Jp);
@@ -266,6 +269,7 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     slot.in_states_off = o_states;
     slot.in_invd_off = o_invd;
     slot.in_bytes = in_bytes;
+    slot.host_bytes = cap;
     slot.ready = true;
     return RDVIO_OK;
 }
@@ -292,11 +296,7 @@ int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int slot, int max_iterations
     if (max_iterations < 0) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "negative iteration limit");
     SolverWs &w = S.ws;
     w.max_iter = max_iterations;
-    uint8_t *B = (uint8_t *)S.arena;
-    // (re)start from the uploaded initial values: device-to-device, no host traffic
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(w.x, B + S.in_states_off, (size_t)w.nfr * 16 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    if (w.nl > 0)
-        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(w.xd, B + S.in_invd_off, (size_t)w.nl * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    // the kernel (re)starts from the uploaded initial values (SolverWs::x0 / xd0): no host traffic, no extra copies
     rdvio_launch_ba_solve(ctx->stream, w);
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
     return RDVIO_OK;
@@ -307,11 +307,16 @@ int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double 
     rdvio_hip_ctx::BaSlot &S = ctx->ba[slot];
     if (!S.ready) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "no BA problem uploaded in slot %d", slot);
     SolverWs &w = S.ws;
-    double sum[8] = {0};
-    if (states_out) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(states_out, w.x, (size_t)w.nfr * 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (inv_depth_out && w.nl > 0) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(inv_depth_out, w.xd, (size_t)w.nl * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(sum, w.summary, sizeof sum, hipMemcpyDeviceToHost, ctx->stream));
+    // x | xd | summary[0..7] in one device-to-host copy into the slot's pinned blob (behind the uploaded inputs)
+    const size_t n_out = (size_t)(w.summary + 8 - w.x);
+    const size_t host_off = (S.in_bytes + 63) & ~(size_t)63;
+    if (host_off + n_out * sizeof(double) > S.host_bytes) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "result does not fit the pinned blob");
+    double *down = (double *)((uint8_t *)S.host + host_off);
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, w.x, n_out * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (states_out) memcpy(states_out, down, (size_t)w.nfr * 16 * sizeof(double));
+    if (inv_depth_out && w.nl > 0) memcpy(inv_depth_out, down + (w.xd - w.x), (size_t)w.nl * sizeof(double));
+    const double *sum = down + (w.summary - w.x);
     if (summary) {
         summary->iterations = (int32_t)sum[0];
         summary->successful_steps = (int32_t)sum[1];

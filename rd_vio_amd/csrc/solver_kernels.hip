@@ -155,11 +155,11 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
         }
     } else {
         const int j = t - TF;  // last wave: lanes 0..31 preintegration factors, lanes 32..63 prior frames
+        if (LIN)  // the Jacobian blocks are sparse: clear them with the whole wave (coalesced) before the per-lane evaluation
+            for (int i = j; i < w.npre * 450; i += 64) w.G[i] = 0.0;
         if (j < 32) {
             for (int k = j; k < w.npre; k += 32) {
                 double *G = w.G + 450 * k;
-                if (LIN)
-                    for (int i = 0; i < 450; ++i) G[i] = 0.0;
                 preintegration_unwhitened<LIN>(states + 16 * w.pre_i[k], states + 16 * w.pre_j[k],
                                                w.preint + (size_t)RDVIO_PREINT_SIZE * k, sh.ub + 6 * w.pre_i[k],
                                                extr, w.e_p + 15 * k, G, G + 225);
@@ -546,7 +546,12 @@ DM double grad_max_norm(const SolverWs &w, Shared &sh, int &phase) {
 DM void solver_setup(const SolverWs &w, Shared &sh) {
     const int t = threadIdx.x;
     const int nl = w.nl, nfree = w.nfree, NAs = 6 * nfree + 2;
-    for (int i = t; i < w.nfr * 16; i += T) w.user[i] = w.x[i];
+    for (int i = t; i < w.nfr * 16; i += T) {
+        const double v = w.x0[i];
+        w.x[i] = v;
+        w.user[i] = v;
+    }
+    for (int l = t; l < nl; l += T) w.xd[l] = w.xd0[l];
     for (int l = t; l < nl; l += T) w.lfree[l] = (w.lm_count[l] > 0 && !w.lm_fixed[l]) ? 1 : 0;
     for (int i = t; i < 64; i += T) {
         sh.fcol[i] = (i < w.nfr) ? w.fcol[i] : -1;

@@ -34,6 +34,7 @@ struct SolverWs {
     int nrec;
     int lds_chol, lds_bytes;             // packed LDS Cholesky when 15-blocks of S (+ inverses) fit in LDS
     // ---- state
+    const double *x0, *xd0;              // uploaded initial values (every launch restarts from them)
     double *x, *xd;                      // in/out: frame states, inverse depths
     double *xc, *xdc, *user;
     uint8_t *lfree;

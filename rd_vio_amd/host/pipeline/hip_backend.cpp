@@ -64,11 +64,9 @@ void image_destroy(void *user, void *image) {
     delete static_cast<HipImage *>(image);
 }
 
-int preintegrate(void *user, int n, const double *imu, double t_end, const double *bg, const double *ba, const double *noise, int cj, int cc,
-                 double *out) {
-    auto *b = static_cast<HipBackend *>(user);
-    const int32_t off[2] = {0, n};
-    return rdvio_hip_preintegrate(b->ctx, 1, off, imu, &t_end, bg, ba, noise, cj, cc, out);
+int preintegrate(void *user, int nseg, const int32_t *seg_off, const double *imu, const double *t_end, const double *bg, const double *ba,
+                 const double *noise, int cj, int cc, double *out) {
+    return rdvio_hip_preintegrate(static_cast<HipBackend *>(user)->ctx, nseg, seg_off, imu, t_end, bg, ba, noise, cj, cc, out);
 }
 
 int ba_solve(void *user, const rdvio_ba_problem *pb, int max_iter, double *states, double *invd, rdvio_ba_summary *sm) {

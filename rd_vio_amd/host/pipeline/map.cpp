@@ -1,6 +1,7 @@
 // Frame / Track / Map behaviour (see map.hpp for the reference file:line of each method).
 #include "map.hpp"
 
+#include <chrono>
 #include <stdexcept>
 
 namespace rdvio_pipe {
@@ -28,19 +29,45 @@ std::array<double, 9> tangent_frame(const V3 &x) {
 
 // ---------------------------------------------------------------------------------------------- PreIntegrator
 bool PreIntegrator::integrate(Backend &be, double t, const V3 &bg, const V3 &ba, bool compute_jacobian, bool compute_covariance) {
-    if (data.empty()) return false;  // preintegrator.cpp:80-81
-    std::vector<double> imu(data.size() * 7);
-    for (size_t i = 0; i < data.size(); ++i) {
-        double *d = &imu[7 * i];
-        d[0] = data[i].t;
-        d[1] = data[i].w.x; d[2] = data[i].w.y; d[3] = data[i].w.z;
-        d[4] = data[i].a.x; d[5] = data[i].a.y; d[6] = data[i].a.z;
+    return integrate_batch(be, {Job{this, t, bg, ba}}, compute_jacobian, compute_covariance)[0] != 0;
+}
+
+std::vector<char> PreIntegrator::integrate_batch(Backend &be, const std::vector<Job> &jobs, bool compute_jacobian, bool compute_covariance) {
+    std::vector<char> ok(jobs.size(), 0);
+    std::vector<int32_t> off(1, 0);
+    std::vector<double> imu, t_end, bg, ba;
+    std::vector<size_t> which;
+    for (size_t j = 0; j < jobs.size(); ++j) {
+        const std::vector<ImuData> &data = jobs[j].pre->data;
+        if (data.empty()) continue;  // preintegrator.cpp:80-81
+        ok[j] = 1;
+        which.push_back(j);
+        for (const ImuData &d : data) imu.insert(imu.end(), {d.t, d.w.x, d.w.y, d.w.z, d.a.x, d.a.y, d.a.z});
+        off.push_back((int32_t)(imu.size() / 7));
+        t_end.push_back(jobs[j].t);
+        bg.insert(bg.end(), {jobs[j].bg.x, jobs[j].bg.y, jobs[j].bg.z});
+        ba.insert(ba.end(), {jobs[j].ba.x, jobs[j].ba.y, jobs[j].ba.z});
     }
-    const double bgv[3] = {bg.x, bg.y, bg.z}, bav[3] = {ba.x, ba.y, ba.z};
-    be.check(be.fn.preintegrate(be.fn.user, (int)data.size(), imu.data(), t, bgv, bav, noise, compute_jacobian ? 1 : 0,
-                                compute_covariance ? 1 : 0, delta.data()),
-             "preintegrate");
-    return true;
+    if (which.empty()) return ok;
+    std::vector<double> out(which.size() * RDVIO_PREINT_SIZE);
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        struct Acc {
+            Backend &be;
+            std::chrono::steady_clock::time_point t0;
+            ~Acc() {
+                be.preintegrate_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                be.preintegrate_calls++;
+            }
+        } acc{be, t0};
+        be.check(be.fn.preintegrate(be.fn.user, (int)which.size(), off.data(), imu.data(), t_end.data(), bg.data(), ba.data(),
+                                    jobs[which[0]].pre->noise, compute_jacobian ? 1 : 0, compute_covariance ? 1 : 0, out.data()),
+                 "preintegrate");
+    }
+    for (size_t k = 0; k < which.size(); ++k)
+        std::copy(out.begin() + (std::ptrdiff_t)(k * RDVIO_PREINT_SIZE), out.begin() + (std::ptrdiff_t)((k + 1) * RDVIO_PREINT_SIZE),
+                  jobs[which[k]].pre->delta.begin());
+    return ok;
 }
 
 void PreIntegrator::predict(const Frame *old_frame, Frame *new_frame) const {

@@ -165,8 +165,12 @@ bool BaBuilder::solve(rdvio_ba_summary *summary_out) {
     std::vector<double> states_out(states.size()), invd_out(invd.size());
     rdvio_ba_summary sm;
     std::memset(&sm, 0, sizeof sm);
-    sh.backend.check(sh.backend.fn.ba_solve(sh.backend.fn.user, &pb, sh.cfg.solver_iteration_limit, states_out.data(), invd_out.data(), &sm),
-                     "ba_solve");
+    {
+        BackendTimer timer(sh.counters, 4);
+        sh.backend.check(sh.backend.fn.ba_solve(sh.backend.fn.user, &pb, sh.cfg.solver_iteration_limit, states_out.data(), invd_out.data(), &sm),
+                         "ba_solve");
+    }
+    sh.counters.solver_iterations += sm.iterations;
     // the reference's parameter blocks ARE the Frame / Track members (solver.cpp:88-114): copy the result back
     for (int i = 0; i < nfr; ++i)
         if (frame_fixed[i] != 1) frames[i]->set_state(&states_out[16 * (size_t)i]);
@@ -197,6 +201,7 @@ void FeatureTracker::detect_keypoints(Frame *frame) {
     }
     int n_out = 0;
     Backend &be = sh.backend;
+    BackendTimer timer(sh.counters, 1);
     be.check(be.fn.image_detect(be.fn.user, frame->image->handle, kps.data(), (int)n0, (int)(kps.size() / 2), max_points,
                                 sh.cfg.feature_tracker_min_keypoint_distance, &n_out),
              "detect_keypoints");
@@ -227,10 +232,12 @@ void FeatureTracker::track_keypoints(Frame *frame, Frame *next_frame) {
     }
     std::vector<uint8_t> status(std::max<size_t>(n, 1), 0);
     Backend &be = sh.backend;
-    if (n > 0)
+    if (n > 0) {
+        BackendTimer timer(sh.counters, 2);
         be.check(be.fn.image_track(be.fn.user, frame->image->handle, next_frame->image->handle, (int)n, curr_xy.data(), next_xy.data(),
                                    predict ? 1 : 0, status.data()),
                  "track_keypoints");
+    }
     status.resize(n);
 
     std::vector<V2> curr_h(n), next_h(n);
@@ -286,9 +293,12 @@ void FeatureTracker::run() {
     std::unique_ptr<Frame> frame = std::move(frames.front());
     frames.pop_front();
     Backend &be = sh.backend;
-    be.check(be.fn.image_preprocess(be.fn.user, frame->image->handle, sh.cfg.feature_tracker_clahe_clip_limit, sh.cfg.feature_tracker_clahe_width,
-                                    sh.cfg.feature_tracker_clahe_height),
-             "preprocess");
+    {
+        BackendTimer timer(sh.counters, 0);
+        be.check(be.fn.image_preprocess(be.fn.user, frame->image->handle, sh.cfg.feature_tracker_clahe_clip_limit, sh.cfg.feature_tracker_clahe_width,
+                                        sh.cfg.feature_tracker_clahe_height),
+                 "preprocess");
+    }
 
     auto [latest_optimized_time, latest_optimized_frame_id, latest_optimized_pose, latest_optimized_motion] = frontend->get_latest_state();
     (void)latest_optimized_time;
@@ -622,6 +632,8 @@ void SlidingWindowTracker::refine_window() {
             solver.add_reprojection_error(frame, j);
         }
     }
+    // keyframe_preintegration of every interval (:283-301); the W independent integrations go to the device as one batch
+    std::vector<PreIntegrator::Job> jobs;
     for (size_t j = 1; j < map->frame_num(); ++j) {
         Frame *frame_i = map->get_frame(j - 1), *frame_j = map->get_frame(j);
         frame_j->keyframe_preintegration = frame_j->preintegration;
@@ -630,9 +642,11 @@ void SlidingWindowTracker::refine_window() {
             for (const auto &sub : frame_i->subframes) imu_data.insert(imu_data.end(), sub->preintegration.data.begin(), sub->preintegration.data.end());
             frame_j->keyframe_preintegration.data.insert(frame_j->keyframe_preintegration.data.begin(), imu_data.begin(), imu_data.end());
         }
-        if (frame_j->keyframe_preintegration.integrate(sh.backend, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba, true, true))
-            solver.add_preintegration(frame_i, frame_j, frame_j->keyframe_preintegration, false);
+        jobs.push_back({&frame_j->keyframe_preintegration, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba});
     }
+    const std::vector<char> integrated = PreIntegrator::integrate_batch(sh.backend, jobs, true, true);
+    for (size_t j = 1; j < map->frame_num(); ++j)
+        if (integrated[j - 1]) solver.add_preintegration(map->get_frame(j - 1), map->get_frame(j), map->get_frame(j)->keyframe_preintegration, false);
     solver.solve();
     sh.counters.window_solves++;
     sh.counters.keyframes++;
@@ -744,7 +758,10 @@ void SlidingWindowTracker::marginalize_frame0() {
     pb.tangent = tangent.data();
     const size_t R = 15 * (size_t)(nfm - 1);
     std::vector<double> S(R * R), f(R), lin(16 * (size_t)(nfm - 1));
-    sh.backend.check(sh.backend.fn.marginalize(sh.backend.fn.user, &pb, S.data(), f.data(), lin.data()), "marginalize");
+    {
+        BackendTimer timer(sh.counters, 5);
+        sh.backend.check(sh.backend.fn.marginalize(sh.backend.fn.user, &pb, S.data(), f.data(), lin.data()), "marginalize");
+    }
     prior.frames.clear();
     for (int i = 1; i < nfm; ++i) prior.frames.push_back(map->get_frame(i));
     prior.S.swap(S);
@@ -754,6 +771,18 @@ void SlidingWindowTracker::marginalize_frame0() {
         if (Track *track = victim->get_track(i)) track->remove_keypoint(victim);
     map->drop_front_frame();
     sh.counters.marginalizations++;
+}
+
+// every subframe interval re-integrated with the previous frame's biases (:379-384, :416-421); the intervals are independent
+// (no state changes inside the loop), so they go to the device as one batch
+void SlidingWindowTracker::integrate_subframes(Frame *frame) {
+    std::vector<PreIntegrator::Job> jobs;
+    for (size_t i = 0; i < frame->subframes.size(); ++i) {
+        Frame *subframe = frame->subframes[i].get();
+        const Frame *prev_frame = (i == 0 ? frame : frame->subframes[i - 1].get());
+        jobs.push_back({&subframe->preintegration, subframe->image->t, prev_frame->motion.bg, prev_frame->motion.ba});
+    }
+    (void)PreIntegrator::integrate_batch(sh.backend, jobs, true, true);
 }
 
 void SlidingWindowTracker::refine_subwindow() {
@@ -778,11 +807,11 @@ void SlidingWindowTracker::refine_subwindow() {
         frame->set_tag(FT_FIX_POSE, true);
         frame->set_tag(FT_FIX_MOTION, true);
         solver.add_frame_states(frame);
+        integrate_subframes(frame);
         for (size_t i = 0; i < frame->subframes.size(); ++i) {
             Frame *subframe = frame->subframes[i].get();
             solver.add_frame_states(subframe);
             Frame *prev_frame = (i == 0 ? frame : frame->subframes[i - 1].get());
-            subframe->preintegration.integrate(sh.backend, subframe->image->t, prev_frame->motion.bg, prev_frame->motion.ba, true, true);
             solver.add_preintegration(prev_frame, subframe, subframe->preintegration, false);
         }
         Frame *last_subframe = frame->subframes.back().get();
@@ -803,11 +832,11 @@ void SlidingWindowTracker::refine_subwindow() {
         frame->set_tag(FT_FIX_POSE, true);
         frame->set_tag(FT_FIX_MOTION, true);
         solver.add_frame_states(frame);
+        integrate_subframes(frame);
         for (size_t i = 0; i < frame->subframes.size(); ++i) {
             Frame *subframe = frame->subframes[i].get();
             solver.add_frame_states(subframe);
             Frame *prev_frame = (i == 0 ? frame : frame->subframes[i - 1].get());
-            subframe->preintegration.integrate(sh.backend, subframe->image->t, prev_frame->motion.bg, prev_frame->motion.ba, true, true);
             solver.add_preintegration(prev_frame, subframe, subframe->preintegration, false);
             for (size_t k = 0; k < subframe->keypoint_num(); ++k)
                 if (Track *track = subframe->get_track(k))
@@ -1044,7 +1073,10 @@ int rdvio_pipeline_add_frame(rdvio_pipeline *p, double t, const uint8_t *gray, i
         image->t = t;
         image->width = width;
         image->height = height;
-        be.check(be.fn.image_create(be.fn.user, gray, width, height, stride, &image->handle), "image_create");
+        {
+            BackendTimer timer(p->shared.counters, 6);
+            be.check(be.fn.image_create(be.fn.user, gray, width, height, stride, &image->handle), "image_create");
+        }
         const PoseState ps = p->handler->track_camera(image);
         if (pose_out) store_pose(ps, pose_out);
     })
@@ -1161,6 +1193,12 @@ int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out) {
     out[7] = p->handler->frontend.sliding_window_tracker ? (int64_t)p->handler->frontend.sliding_window_tracker->map->track_num() : 0;
     out[8] = c.max_problem_frames;
     out[9] = c.max_problem_factors;
+    out[10] = c.solver_iterations;
+    for (int k = 0; k < 7; ++k) {
+        const bool pre = k == 3;  // microseconds and calls per backend call class
+        out[11 + 2 * k] = (int64_t)(1e6 * (pre ? p->shared.backend.preintegrate_seconds : c.backend_seconds[k]));
+        out[12 + 2 * k] = pre ? p->shared.backend.preintegrate_calls : c.backend_calls[k];
+    }
     return RDVIO_OK;
 }
 

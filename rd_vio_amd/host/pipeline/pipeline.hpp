@@ -4,6 +4,7 @@
 #pragma once
 
 #include <array>
+#include <chrono>
 #include <deque>
 #include <optional>
 #include <tuple>
@@ -14,7 +15,22 @@ namespace rdvio_pipe {
 
 struct Counters {
     int64_t frames_tracked = 0, window_solves = 0, keyframes = 0, marginalizations = 0, localizations = 0, subwindow_solves = 0;
-    int64_t max_problem_frames = 0, max_problem_factors = 0;
+    int64_t max_problem_frames = 0, max_problem_factors = 0, solver_iterations = 0;
+    // seconds spent inside backend calls: preprocess, detect, track, preintegrate, ba_solve, marginalize, image_create
+    double backend_seconds[7] = {0, 0, 0, 0, 0, 0, 0};
+    int64_t backend_calls[7] = {0, 0, 0, 0, 0, 0, 0};
+};
+
+// scope timer of one backend call class
+struct BackendTimer {
+    Counters &c;
+    int k;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    BackendTimer(Counters &c, int k) : c(c), k(k) {}
+    ~BackendTimer() {
+        c.backend_seconds[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        c.backend_calls[k]++;
+    }
 };
 
 struct Shared {  // what every stage needs
@@ -74,6 +90,7 @@ class SlidingWindowTracker {
     void refine_window();
     void slide_window();
     void refine_subwindow();
+    void integrate_subframes(Frame *frame);
     void marginalize_frame0();
     Shared &sh;
 };

@@ -73,10 +73,12 @@ static void ob_image_destroy(void *user, void *image) {
     free(im);
 }
 
-static int ob_preintegrate(void *user, int n, const double *imu, double t_end, const double *bg, const double *ba, const double *noise,
-                           int cj, int cc, double *out) {
+static int ob_preintegrate(void *user, int nseg, const int32_t *seg_off, const double *imu, const double *t_end, const double *bg,
+                           const double *ba, const double *noise, int cj, int cc, double *out) {
     (void)user;
-    ro_preintegrate(n, imu, t_end, bg, ba, noise, cj, cc, out);
+    for (int i = 0; i < nseg; ++i)
+        ro_preintegrate(seg_off[i + 1] - seg_off[i], imu + 7 * (size_t)seg_off[i], t_end[i], bg + 3 * i, ba + 3 * i, noise, cj, cc,
+                        out + (size_t)RO_PREINT_SIZE * i);
     return RDVIO_OK;
 }
 

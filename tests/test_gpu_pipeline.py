@@ -26,7 +26,7 @@ def test_hip_pipeline_reproduces_the_cpu_path():
         gpu = pu.run_stream(lib, pu.hip_pipeline_factory(lib, ctx, cfg), frames, ts, imu, gt)
     finally:
         ctx.close()
-    assert (gpu["counters"] == cpu["counters"]).all(), (gpu["counters"], cpu["counters"])
+    assert (gpu["counters"][:11] == cpu["counters"][:11]).all(), (gpu["counters"], cpu["counters"])   # [11:] are timers
     assert (gpu["sys_state"] == cpu["sys_state"]).all() and gpu["sys_state"][-1] == 1
     # metric (3): tracked-feature index sets (and their pixel positions) per frame are identical
     assert len(gpu["keypoints"]) == len(cpu["keypoints"]) == len(ts)
