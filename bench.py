@@ -67,6 +67,20 @@ def ba_algorithmic_flops(pb, iterations, successful_steps):
     return (successful_steps + 1) * lin + iterations * cost
 
 
+def pmc_traffic_bytes():
+    """HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate
+    runs of this script; profiles/r01_c_pmc_fetch_write.csv).  FETCH_SIZE + WRITE_SIZE in KB, RAW: the gfx950 x2
+    FETCH_SIZE correction of MI355X_MICROARCH.md is calibrated for 16-B-per-lane streaming reads only, these kernels
+    read bytes / shorts / scattered doubles, so no correction is applied (the guide calls such widths uncalibrated)."""
+    path = os.path.join(ROOT, "profiles", "r01_c_pmc_fetch_write.csv")
+    out = {}
+    if os.path.exists(path):
+        for line in open(path).read().strip().splitlines()[1:]:
+            k, _n, f, w = line.split(",")
+            out[k] = int((float(f) + float(w)) * 1024)
+    return out
+
+
 def build_workload(cfg, ctx, torch, dev, seed=648):
     import rd_vio_amd
     from rd_vio_amd import synth
@@ -354,8 +368,10 @@ def main():
               + ba_algorithmic_flops(wl["localize_pb"], sm_loc.iterations, sm_loc.successful_steps))
         ba_ms = stage_ms[4] + stage_ms[5]
         tfl = fl / (ba_ms * 1e-3) / 1e12
+        pmc = pmc_traffic_bytes() if args.config == "euroc_v101" else {}
         roof = dict(kernel="ba_solve_kernel", bound="mfma", achieved=round(tfl, 5), peak=FP64_PEAK_TFLOPS,
-                    unit="TFLOP/s", frac=round(tfl / FP64_PEAK_TFLOPS, 7), traffic=None,
+                    unit="TFLOP/s", frac=round(tfl / FP64_PEAK_TFLOPS, 7), traffic=pmc.get("ba_solve_kernel"),
+                    traffic_unit="bytes per launch, FETCH_SIZE + WRITE_SIZE raw (profiles/r01_c_pmc_fetch_write.csv)",
                     algorithmic_flops_per_launch=int(fl / 2), avg_launch_us=round(float(ba_ms) * 1e3 / 2, 2),
                     launches_per_frame=2, dominant_stage=stage_names[dom],
                     note="single-workgroup latency-bound trust-region loop; see DESIGN.md section 4 for the phase table")
@@ -364,6 +380,10 @@ def main():
         image_roof = [hbm_row("clahe_lut_kernel+pyr_level_kernel", preprocess_algorithmic_bytes(wl["L"]), stage_ms[0]),
                       hbm_row("lk_track_kernel", lk_algorithmic_bytes(nfeat), stage_ms[1]),
                       hbm_row("harris_kernel+harris_candidates_kernel (+host selection)", 9 * P0, stage_ms[2])]
+        if pmc:
+            image_roof[0]["traffic"] = pmc.get("clahe_lut_kernel", 0) + pmc.get("pyr_level_kernel<true>", 0) + 3 * pmc.get("pyr_level_kernel<false>", 0)
+            image_roof[1]["traffic"] = pmc.get("lk_track_kernel")
+            image_roof[2]["traffic"] = pmc.get("harris_kernel", 0) + pmc.get("harris_candidates_kernel", 0)
         out = {
             "metric": "VIO frames/sec per GPU (hot path: LK tracker + sliding-window BA), synthetic EuRoC-shaped stream",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
