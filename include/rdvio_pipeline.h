@@ -123,8 +123,9 @@ int rdvio_pipeline_last_frame_keypoints(const rdvio_pipeline *p, int64_t *track_
  * [5] subwindow solves, [6] frame id of the newest tracked frame, [7] tracks in the window map, [8] largest number of
  * frames in one solve, [9] largest number of reprojection factors in one solve, [10] solver iterations summed over all
  * solves, then (microseconds, calls) pairs of the time spent inside backend calls: [11,12] preprocess, [13,14] detect,
- * [15,16] track, [17,18] preintegrate, [19,20] ba_solve, [21,22] marginalize, [23,24] image_create */
-int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out25);
+ * [15,16] track, [17,18] preintegrate, [19,20] ba_solve, [21,22] marginalize, [23,24] image_create; [25] frames tagged
+ * FT_NO_TRANSLATION, [26] rotation-prior factors summed over all solves */
+int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out27);
 
 #ifdef __cplusplus
 }

@@ -162,6 +162,7 @@ bool BaBuilder::solve(rdvio_ba_summary *summary_out) {
     }
     sh.counters.max_problem_frames = std::max<int64_t>(sh.counters.max_problem_frames, nfr);
     sh.counters.max_problem_factors = std::max<int64_t>(sh.counters.max_problem_factors, nf);
+    sh.counters.rotation_prior_factors += nrot;
     std::vector<double> states_out(states.size()), invd_out(invd.size());
     rdvio_ba_summary sm;
     std::memset(&sm, 0, sizeof sm);
@@ -260,7 +261,10 @@ void FeatureTracker::track_keypoints(Frame *frame, Frame *next_frame) {
         if (mask[i]) angles.push_back(std::acos(dot(R * frame->bearings[i], next_bearings[i])) * 180 / M_PI);
     std::sort(angles.begin(), angles.end());
     const double misalignment = angles.size() > 0 ? angles[angles.size() * 7 / 10] : 0;
-    if (misalignment < sh.cfg.rotation_misalignment_threshold) next_frame->set_tag(FT_NO_TRANSLATION, true);
+    if (misalignment < sh.cfg.rotation_misalignment_threshold) {
+        next_frame->set_tag(FT_NO_TRANSLATION, true);
+        sh.counters.no_translation_frames++;
+    }
 
     // longest tracks first, Poisson-disk thinning in the next image (frame.cpp:134-161)
     std::vector<std::pair<size_t, size_t>> by_length;
@@ -1194,6 +1198,8 @@ int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out) {
     out[8] = c.max_problem_frames;
     out[9] = c.max_problem_factors;
     out[10] = c.solver_iterations;
+    out[25] = c.no_translation_frames;
+    out[26] = c.rotation_prior_factors;
     for (int k = 0; k < 7; ++k) {
         const bool pre = k == 3;  // microseconds and calls per backend call class
         out[11 + 2 * k] = (int64_t)(1e6 * (pre ? p->shared.backend.preintegrate_seconds : c.backend_seconds[k]));

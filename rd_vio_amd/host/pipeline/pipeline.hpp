@@ -16,6 +16,7 @@ namespace rdvio_pipe {
 struct Counters {
     int64_t frames_tracked = 0, window_solves = 0, keyframes = 0, marginalizations = 0, localizations = 0, subwindow_solves = 0;
     int64_t max_problem_frames = 0, max_problem_factors = 0, solver_iterations = 0;
+    int64_t no_translation_frames = 0, rotation_prior_factors = 0;
     // seconds spent inside backend calls: preprocess, detect, track, preintegrate, ba_solve, marginalize, image_create
     double backend_seconds[7] = {0, 0, 0, 0, 0, 0, 0};
     int64_t backend_calls[7] = {0, 0, 0, 0, 0, 0, 0};

@@ -71,7 +71,7 @@ def create_hip_pipeline(lib, ctx, cfg):
 def feed_stream(lib, handle, frames, ts, imu, per_frame=None):
     """Push IMU samples and frames in timestamp order.  per_frame(k_processed) is called whenever the feature tracker has
     consumed another frame.  Returns wall-clock seconds spent inside the pipeline calls."""
-    cnt = np.zeros(25, dtype=np.int64)
+    cnt = np.zeros(27, dtype=np.int64)
     seen = 0
     spent = 0.0
     ii = 0

@@ -81,18 +81,29 @@ def traj_pose(t):
     return q, p
 
 
-def traj_vel(t, h=1e-5):
-    return (traj_pose(t + h)[1] - traj_pose(t - h)[1]) / (2 * h)
-
-
-def traj_imu(t, h=1e-4):
-    """analytic-derivative IMU sample (body frame): gyro, specific force."""
+def traj_pose_rotation_phase(t, t_stop=2.2, tau=0.25):
+    """the same trajectory whose translation smoothly comes to rest after t_stop while the rotation continues: a
+    pure-rotation phase (FT_NO_TRANSLATION frames, rotation-prior factors, keyframe lifting in manage_keyframe)."""
+    s = t if t <= t_stop else t_stop + tau * np.tanh((t - t_stop) / tau)
+    _, p = traj_pose(s)
     q, _ = traj_pose(t)
-    qp, _ = traj_pose(t + h)
-    qm, _ = traj_pose(t - h)
+    return q, p
+
+
+def traj_vel(t, h=1e-5, pose_fn=None):
+    pose_fn = pose_fn or traj_pose
+    return (pose_fn(t + h)[1] - pose_fn(t - h)[1]) / (2 * h)
+
+
+def traj_imu(t, h=1e-4, pose_fn=None):
+    """analytic-derivative IMU sample (body frame): gyro, specific force."""
+    pose_fn = pose_fn or traj_pose
+    q, _ = pose_fn(t)
+    qp, _ = pose_fn(t + h)
+    qm, _ = pose_fn(t - h)
     dq = q_mul(q_conj(qm), qp)
     w = 2.0 * dq[:3] / (2 * h)
-    acc_w = (traj_pose(t + h)[1] - 2 * traj_pose(t)[1] + traj_pose(t - h)[1]) / (h * h)
+    acc_w = (pose_fn(t + h)[1] - 2 * pose_fn(t)[1] + pose_fn(t - h)[1]) / (h * h)
     a = q_to_mat(q).T @ (acc_w - np.array([0, 0, -GRAVITY]))
     return w, a
 
@@ -101,12 +112,12 @@ TRUE_BG = np.array([1e-3, -2e-3, 5e-4])
 TRUE_BA = np.array([0.02, -0.01, 0.03])
 
 
-def make_imu_segment(t0, t1, rate=200.0, rng=None, noise=True, bg=None, ba=None):
+def make_imu_segment(t0, t1, rate=200.0, rng=None, noise=True, bg=None, ba=None, pose_fn=None):
     """IMU samples in [t0, t1) as n x 7 (t, w, a); optional constant sensor biases are added."""
     ts = np.arange(t0, t1 - 1e-9, 1.0 / rate)
     out = np.zeros((len(ts), 7))
     for i, t in enumerate(ts):
-        w, a = traj_imu(t)
+        w, a = traj_imu(t, pose_fn=pose_fn)
         if noise and rng is not None:
             w = w + rng.normal(0, np.sqrt(2.8791302399999997e-08 * rate), 3)
             a = a + rng.normal(0, np.sqrt(4.0e-6 * rate), 3)
@@ -385,17 +396,18 @@ def render_room(q_wb, p_wb, K, w, h, extr=EUROC_EXTR, seed=648):
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
-def make_stream(n_frames, w=752, h=480, K=EUROC_K, t0=1.0, cam_rate=20.0, imu_rate=200.0, seed=648, imu_noise=True):
+def make_stream(n_frames, w=752, h=480, K=EUROC_K, t0=1.0, cam_rate=20.0, imu_rate=200.0, seed=648, imu_noise=True, pose_fn=None):
     """A synthetic EuRoC-shaped stream on the SURVEY.md 8d trajectory: images (n_frames x h x w u8), frame times, IMU rows
     (t, gyro, acc) covering the frames with the constant biases TRUE_BG / TRUE_BA added, and the ground-truth body
     states at the frame times as rows (t, q, p, v, bg, ba)."""
     rng = np.random.default_rng(seed + 1)
     ts = t0 + np.arange(n_frames) / cam_rate
-    frames = np.stack([render_room(*traj_pose(t), K, w, h, seed=seed) for t in ts])
+    pose_fn = pose_fn or traj_pose
+    frames = np.stack([render_room(*pose_fn(t), K, w, h, seed=seed) for t in ts])
     imu = make_imu_segment(t0 - 0.5 / imu_rate - 2.0 / imu_rate, ts[-1] + 3.0 / imu_rate, rate=imu_rate, rng=rng if imu_noise else None,
-                           noise=imu_noise, bg=TRUE_BG, ba=TRUE_BA)
+                           noise=imu_noise, bg=TRUE_BG, ba=TRUE_BA, pose_fn=pose_fn)
     gt = np.zeros((n_frames, 17))
     for i, t in enumerate(ts):
-        q, p = traj_pose(t)
-        gt[i] = np.concatenate([[t], q, p, traj_vel(t), TRUE_BG, TRUE_BA])
+        q, p = pose_fn(t)
+        gt[i] = np.concatenate([[t], q, p, traj_vel(t, pose_fn=pose_fn), TRUE_BG, TRUE_BA])
     return frames, ts, imu, gt

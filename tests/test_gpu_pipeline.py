@@ -8,16 +8,26 @@ import pipeline_util as pu
 import rd_vio_amd
 from rd_vio_amd import synth
 
-W, H = 752, 480
-K = synth.EUROC_K
 OVER = dict(sliding_window_size=8, feature_tracker_max_keypoint_detection=150, feature_tracker_min_keypoint_distance=10.0,
             solver_iteration_limit=30, initializer_keyframe_gap=2, feature_tracker_max_frames=20,
             sliding_window_force_keyframe_landmarks=50, sliding_window_subframe_size=3, rotation_misalignment_threshold=0.02)
 
 
 @pytest.mark.gpu
-def test_hip_pipeline_reproduces_the_cpu_path():
-    frames, ts, imu, gt = synth.make_stream(36, W, H, K)
+@pytest.mark.parametrize("case", ["translation_full_res", "rotation_phase_half_res"])
+def test_hip_pipeline_reproduces_the_cpu_path(case):
+    if case == "translation_full_res":
+        W, H, K = 752, 480, synth.EUROC_K
+        frames, ts, imu, gt = synth.make_stream(36, W, H, K)
+        pose_fn = synth.traj_pose
+    else:
+        # translation comes to rest after 1.2 s while the rotation continues: FT_NO_TRANSLATION frames, keyframe lifting
+        # and rotation-only subwindows (manage_keyframe / refine_subwindow, sliding_window_tracker.cpp:127-204, 349-400)
+        W, H = 376, 240
+        K = synth.EUROC_K.copy()
+        K[:2] *= 0.5
+        pose_fn = synth.traj_pose_rotation_phase
+        frames, ts, imu, gt = synth.make_stream(80, W, H, K, pose_fn=pose_fn)
     lib, shim = pu.load_pipeline_lib(), pu.build_oracle_backend()
     cfg = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **OVER)
     cpu = pu.run_stream(lib, pu.oracle_pipeline_factory(lib, shim, cfg), frames, ts, imu, gt)
@@ -41,5 +51,7 @@ def test_hip_pipeline_reproduces_the_cpu_path():
     assert pu.ate_rmse(sg[ok, 5:8], sc[ok, 5:8]) < 1e-3
     assert np.abs(sg[ok, 1:5] - sc[ok, 1:5]).max() < 1e-3     # orientation (quaternion components)
     # and both stay on the ground truth
-    p_gt = np.array([synth.traj_pose(t)[1] for t in sc[ok, 0]])
+    p_gt = np.array([pose_fn(t)[1] for t in sc[ok, 0]])
+    if case != "translation_full_res":
+        assert cpu["counters"][25] >= 10                        # the rotation-only branch was really exercised
     assert np.linalg.norm(sg[ok, 5:8] - p_gt, axis=1).max() < 0.15

@@ -98,3 +98,18 @@ def test_pipeline_stays_initialising_without_bootstrap_states(libs, stream):
     res = pu.run_stream(lib, pu.oracle_pipeline_factory(lib, shim, cfg), frames[:24], ts[:24], imu, gt[:0])
     assert (res["sys_state"] == 0).all() and np.isnan(res["states"][:, 0]).all()
     assert np.isnan(res["traj"][:, 0]).all()                    # no pose before the first optimised state
+
+
+def test_rotation_only_phase_is_handled(libs):
+    # the translation comes to rest while the rotation continues: frames get FT_NO_TRANSLATION, manage_keyframe lifts
+    # subframes to keyframes, refine_subwindow takes its rotation-only branch (sliding_window_tracker.cpp:127-204, 349-400)
+    lib, shim = libs
+    pose_fn = synth.traj_pose_rotation_phase
+    frames, ts, imu, gt = synth.make_stream(70, W, H, K, pose_fn=pose_fn)
+    cfg = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **OVER)
+    res = pu.run_stream(lib, pu.oracle_pipeline_factory(lib, shim, cfg), frames, ts, imu, gt)
+    assert res["counters"][25] >= 10 and res["sys_state"][-1] == 1
+    st = res["states"]
+    ok = ~np.isnan(st[:, 0])
+    p_gt = np.array([pose_fn(t)[1] for t in st[ok, 0]])
+    assert np.linalg.norm(st[ok, 5:8] - p_gt, axis=1).max() < 0.15
