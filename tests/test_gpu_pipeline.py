@@ -55,3 +55,29 @@ def test_hip_pipeline_reproduces_the_cpu_path(case):
     if case != "translation_full_res":
         assert cpu["counters"][25] >= 10                        # the rotation-only branch was really exercised
     assert np.linalg.norm(sg[ok, 5:8] - p_gt, axis=1).max() < 0.15
+
+
+@pytest.mark.gpu
+def test_run_euroc_script_on_a_synthetic_mav0(tmp_path):
+    """scripts/run_euroc.py (the headless test_euroc) over a synthetic stream written in the EuRoC layout."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from rd_vio_amd import euroc
+    from test_euroc_harness import SENSOR_YAML, SETTING_YAML, W, H, K as Kh
+
+    frames, ts, imu, gt = synth.make_stream(40, W, H, Kh)
+    d = tmp_path / "mav0"
+    euroc.write_mav0(str(d), frames, ts, imu, gt, Kh)
+    (tmp_path / "sensor.yaml").write_text(SENSOR_YAML)
+    (tmp_path / "setting.yaml").write_text(SETTING_YAML)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "run_euroc.py"), str(d), "--sensor", str(tmp_path / "sensor.yaml"),
+                          "--setting", str(tmp_path / "setting.yaml"), "--out", str(tmp_path / "traj.txt")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rep["poses"] >= 15 and rep["ate_rmse_m"] < 0.05
+    assert np.loadtxt(str(tmp_path / "traj.txt")).shape == (rep["poses"], 8)
