@@ -18,9 +18,9 @@
  * that the test-suite can run the SAME orchestration over the CPU oracle and compare trajectories and feature index
  * sets (SURVEY.md 8d metrics 2 and 3); the product never constructs a non-HIP backend.
  *
- * Not built in this round: the SfM/IMU initializer (N4) -- the window is bootstrapped from externally
- * supplied states of the first keyframes (rdvio_pipeline_set_init_states), every later pose comes from the pipeline;
- * the RD dynamic-outlier path (N2, parsac_flag) is rejected at create time.
+ * Initialisation: Initializer::initialize (src/rdvio/src/initializer.cpp:72-560: two-view SfM + IMU alignment + BA) runs
+ * unless bootstrap states were supplied with rdvio_pipeline_set_init_states, which then replace its SfM / alignment
+ * stages.  Not built: the RD dynamic-outlier path (parsac_flag), rejected at create time.
  */
 #ifndef RDVIO_PIPELINE_H
 #define RDVIO_PIPELINE_H
@@ -76,6 +76,8 @@ typedef struct rdvio_pipeline_config {
     double feature_tracker_clahe_clip_limit;
     int32_t feature_tracker_clahe_width, feature_tracker_clahe_height, feature_tracker_predict_keypoints;
     int32_t initializer_keyframe_num, initializer_keyframe_gap;
+    int32_t initializer_min_matches, initializer_min_triangulation, initializer_min_landmarks;
+    double initializer_min_parallax;
     int32_t solver_iteration_limit;
     double rotation_misalignment_threshold, rotation_ransac_threshold;
     int32_t random;
@@ -93,8 +95,9 @@ int rdvio_pipeline_create(rdvio_pipeline **out, const rdvio_pipeline_config *cfg
 void rdvio_pipeline_destroy(rdvio_pipeline *p);
 const char *rdvio_pipeline_last_error(const rdvio_pipeline *p);
 
-/* Bootstrap states of the first keyframes: n rows of (t, q(4), p(3), v(3), bg(3), ba(3)) = 17 doubles, body frame in
- * the world frame with gravity along -z.  A keyframe whose timestamp matches a row within 1e-6 s takes that state. */
+/* OPTIONAL bootstrap states of the first keyframes: n rows of (t, q(4), p(3), v(3), bg(3), ba(3)) = 17 doubles, body
+ * frame in the world frame with gravity along -z.  A keyframe whose timestamp matches a row within 1e-6 s takes that
+ * state and the SfM / IMU-alignment stages of the initializer are skipped; n = 0 restores the full initializer. */
 int rdvio_pipeline_set_init_states(rdvio_pipeline *p, int n, const double *rows17);
 
 /* Odometry::addFrame (rdvio.hpp:41-56): gray u8 image; pose_out (may be NULL) = predicted output pose q(4) p(3), all

@@ -25,7 +25,7 @@ def needs_build():
 
 PIPE_DIR = os.path.join(HERE, "host", "pipeline")
 PIPE_LIB = os.path.join(HERE, "librdvio_pipeline.so")
-PIPE_SOURCES = ["map.cpp", "pipeline.cpp", "hip_backend.cpp"]
+PIPE_SOURCES = ["map.cpp", "pipeline.cpp", "initializer.cpp", "hip_backend.cpp"]
 
 
 def build_pipeline(force=False, verbose=False):

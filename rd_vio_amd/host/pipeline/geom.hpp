@@ -684,4 +684,217 @@ class PoissonDisk2 {
     std::unordered_map<int64_t, size_t> grid_;
 };
 
+// ------------------------------------------------------------------------------------------------------------------
+// pieces used by the SfM / IMU initializer (initializer.cpp)
+// ------------------------------------------------------------------------------------------------------------------
+// lie_algebra.h:18-21: Eigen::AngleAxis(q) -> angle * axis
+inline V3 logmap(const Q4 &q) {
+    double n = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
+    if (n == 0.0) return {0, 0, 0};
+    const double angle = 2.0 * std::atan2(n, std::fabs(q.w));
+    if (q.w < 0) n = -n;
+    return {angle * q.x / n, angle * q.y / n, angle * q.z / n};
+}
+inline M3 inverse3(const M3 &A) {
+    const double d = det(A);
+    M3 I;
+    I.m[0] = (A.m[4] * A.m[8] - A.m[5] * A.m[7]) / d; I.m[1] = (A.m[2] * A.m[7] - A.m[1] * A.m[8]) / d; I.m[2] = (A.m[1] * A.m[5] - A.m[2] * A.m[4]) / d;
+    I.m[3] = (A.m[5] * A.m[6] - A.m[3] * A.m[8]) / d; I.m[4] = (A.m[0] * A.m[8] - A.m[2] * A.m[6]) / d; I.m[5] = (A.m[2] * A.m[3] - A.m[0] * A.m[5]) / d;
+    I.m[6] = (A.m[3] * A.m[7] - A.m[4] * A.m[6]) / d; I.m[7] = (A.m[1] * A.m[6] - A.m[0] * A.m[7]) / d; I.m[8] = (A.m[0] * A.m[4] - A.m[1] * A.m[3]) / d;
+    return I;
+}
+// quaternion of a rotation matrix (Eigen's Quaternion(Matrix3) recipe)
+inline Q4 from_mat(const M3 &R) {
+    const double t = R.m[0] + R.m[4] + R.m[8];
+    Q4 q;
+    if (t > 0) {
+        double s = std::sqrt(t + 1.0);
+        q.w = 0.5 * s;
+        s = 0.5 / s;
+        q.x = (R.m[7] - R.m[5]) * s; q.y = (R.m[2] - R.m[6]) * s; q.z = (R.m[3] - R.m[1]) * s;
+    } else {
+        int i = 0;
+        if (R.m[4] > R.m[0]) i = 1;
+        if (R.m[8] > R.m[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        double s = std::sqrt(R.m[4 * i] - R.m[4 * j] - R.m[4 * k] + 1.0);
+        double v[3];
+        v[i] = 0.5 * s;
+        s = 0.5 / s;
+        q.w = (R.m[3 * k + j] - R.m[3 * j + k]) * s;
+        v[j] = (R.m[3 * j + i] + R.m[3 * i + j]) * s;
+        v[k] = (R.m[3 * k + i] + R.m[3 * i + k]) * s;
+        q.x = v[0]; q.y = v[1]; q.z = v[2];
+    }
+    return q;
+}
+// Eigen::Quaternion::FromTwoVectors
+inline Q4 from_two_vectors(const V3 &a, const V3 &b) {
+    const V3 v0 = normalized(a), v1 = normalized(b);
+    const double c = dot(v1, v0);
+    if (c < -1.0 + 1e-12) {  // nearly opposite: any axis orthogonal to v0
+        V3 axis = cross(v0, std::fabs(v0.x) < 0.9 ? V3{1, 0, 0} : V3{0, 1, 0});
+        axis = normalized(axis);
+        return {axis.x, axis.y, axis.z, 0.0};
+    }
+    const V3 axis = cross(v0, v1);
+    const double s = std::sqrt((1.0 + c) * 2.0), invs = 1.0 / s;
+    return {axis.x * invs, axis.y * invs, axis.z * invs, s * 0.5};
+}
+
+// minimum-norm least squares x = argmin |A x - b| (rows x cols, row-major) through the eigen-decomposition of A^T A
+// (stands in for fullPivHouseholderQr().solve / JacobiSVD::solve)
+inline std::vector<double> least_squares(int rows, int cols, const std::vector<double> &A, const std::vector<double> &b) {
+    std::vector<double> AtA((size_t)cols * cols, 0.0), Atb(cols, 0.0), V((size_t)cols * cols), lam(cols);
+    for (int r = 0; r < rows; ++r)
+        for (int i = 0; i < cols; ++i) {
+            const double ai = A[(size_t)r * cols + i];
+            if (ai == 0.0) continue;
+            Atb[i] += ai * b[r];
+            for (int j = 0; j < cols; ++j) AtA[(size_t)i * cols + j] += ai * A[(size_t)r * cols + j];
+        }
+    sym_eigen(cols, AtA.data(), V.data(), lam.data());
+    double lmax = 0.0;
+    for (double l : lam) lmax = std::max(lmax, l);
+    std::vector<double> x(cols, 0.0);
+    for (int k = 0; k < cols; ++k) {
+        if (!(lam[k] > 1e-13 * lmax)) continue;
+        double c = 0.0;
+        for (int i = 0; i < cols; ++i) c += V[(size_t)i * cols + k] * Atb[i];
+        c /= lam[k];
+        for (int i = 0; i < cols; ++i) x[i] += c * V[(size_t)i * cols + k];
+    }
+    return x;
+}
+
+// homography.h:16-20
+inline double homography_geometric_error(const M3 &H, const V2 &p1, const V2 &p2) {
+    const V3 q = H * V3{p1.x, p1.y, 1.0};
+    return sqnorm(p2 - V2{q.x / q.z, q.y / q.z});
+}
+
+// homography.cpp:89-158: normalised 4-point DLT
+inline M3 solve_homography_4pt(const std::array<V2, 4> &p1, const std::array<V2, 4> &p2) {
+    const double sqrt2 = std::sqrt(2.0);
+    V2 ma{0, 0}, mb{0, 0};
+    for (int i = 0; i < 4; ++i) { ma.x += p1[i].x; ma.y += p1[i].y; mb.x += p2[i].x; mb.y += p2[i].y; }
+    ma.x /= 4; ma.y /= 4; mb.x /= 4; mb.y /= 4;
+    double sa = 0, sb = 0;
+    for (int i = 0; i < 4; ++i) { sa += norm(p1[i] - ma); sb += norm(p2[i] - mb); }
+    sa = 1.0 / (sqrt2 * sa);
+    sb = 1.0 / (sqrt2 * sb);
+    double A[8][9] = {{0}};
+    for (int i = 0; i < 4; ++i) {
+        const V2 a{(p1[i].x - ma.x) * sa, (p1[i].y - ma.y) * sa}, b{(p2[i].x - mb.x) * sb, (p2[i].y - mb.y) * sb};
+        A[2 * i][1] = -a.x; A[2 * i][2] = a.x * b.y; A[2 * i][4] = -a.y; A[2 * i][5] = a.y * b.y; A[2 * i][7] = -1; A[2 * i][8] = b.y;
+        A[2 * i + 1][0] = a.x; A[2 * i + 1][2] = -a.x * b.x; A[2 * i + 1][3] = a.y; A[2 * i + 1][5] = -a.y * b.x; A[2 * i + 1][6] = 1; A[2 * i + 1][8] = -b.x;
+    }
+    double AtA[81], V[81], lam[9];
+    for (int i = 0; i < 9; ++i)
+        for (int j = 0; j < 9; ++j) {
+            double s = 0;
+            for (int k = 0; k < 8; ++k) s += A[k][i] * A[k][j];
+            AtA[9 * i + j] = s;
+        }
+    sym_eigen(9, AtA, V, lam);
+    const int kmin = ascending_order(9, lam)[0];
+    M3 NH;  // to_matrix: column c = segment c
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) NH.m[3 * r + c] = V[9 * (3 * c + r) + kmin];
+    const M3 Nb{{1 / sb, 0, mb.x, 0, 1 / sb, mb.y, 0, 0, 1}}, Na{{sa, 0, -sa * ma.x, 0, sa, -sa * ma.y, 0, 0, 1}};
+    return Nb * NH * Na;
+}
+
+// stereo.cpp:93-120
+inline M3 find_homography_matrix(const std::vector<V2> &p1, const std::vector<V2> &p2, std::vector<char> &mask, double threshold, double confidence,
+                                 size_t max_iteration, int seed) {
+    const double t2 = 5.99;
+    auto solve = [&](const std::array<size_t, 4> &s) {
+        return std::vector<M3>{solve_homography_4pt({p1[s[0]], p1[s[1]], p1[s[2]], p1[s[3]]}, {p2[s[0]], p2[s[1]], p2[s[2]], p2[s[3]]})};
+    };
+    auto err = [&](const M3 &H, size_t i) { return homography_geometric_error(H, p1[i], p2[i]) + homography_geometric_error(inverse3(H), p2[i], p1[i]); };
+    return ransac<4, M3>(p1.size(), 2.0 * t2 * threshold * threshold, confidence, max_iteration, seed, solve, err, mask);
+}
+
+// homography.cpp:5-87.  Returns false for a pure rotation.
+inline bool decompose_homography(const M3 &H, M3 &R1, M3 &R2, V3 &T1, V3 &T2, V3 &n1, V3 &n2) {
+    M3 U, V;
+    double sv[3];
+    svd3(H, U, sv, V);
+    M3 Hn;
+    for (int i = 0; i < 9; ++i) Hn.m[i] = H.m[i] / sv[1];
+    M3 S = transpose(Hn) * Hn;
+    S.m[0] -= 1; S.m[4] -= 1; S.m[8] -= 1;
+    bool pure_rotation = true;
+    for (int i = 0; i < 9 && pure_rotation; ++i)
+        if (std::fabs(S.m[i]) > 1e-3) pure_rotation = false;
+    auto Sx = [&](int i, int j) { return S.m[3 * i + j]; };
+    if (pure_rotation) {
+        R1 = U * transpose(V);
+        if (det(R1) < 0)
+            for (double &v : R1.m) v = -v;
+        R2 = R1;
+        T1 = T2 = n1 = n2 = V3{0, 0, 0};
+        return false;
+    }
+    const double Ms00 = Sx(1, 2) * Sx(1, 2) - Sx(1, 1) * Sx(2, 2), Ms11 = Sx(0, 2) * Sx(0, 2) - Sx(0, 0) * Sx(2, 2),
+                 Ms22 = Sx(0, 1) * Sx(0, 1) - Sx(0, 0) * Sx(1, 1);
+    const double r00 = std::sqrt(Ms00), r11 = std::sqrt(Ms11), r22 = std::sqrt(Ms22);
+    const double tr = Sx(0, 0) + Sx(1, 1) + Sx(2, 2);
+    const double nu = 2.0 * std::sqrt(1 + tr - Ms00 - Ms11 - Ms22);
+    const double tenormsq = 2 + tr - nu;
+    V3 ts1, ts2;
+    if (Sx(0, 0) > Sx(1, 1) && Sx(0, 0) > Sx(2, 2)) {
+        const double e = ((Sx(0, 1) * Sx(0, 2) - Sx(0, 0) * Sx(1, 2)) < 0) ? -1 : 1;
+        n1 = {Sx(0, 0), Sx(0, 1) + r22, Sx(0, 2) + e * r11};
+        n2 = {Sx(0, 0), Sx(0, 1) - r22, Sx(0, 2) - e * r11};
+        ts1 = norm(n1) * n2 / Sx(0, 0);
+        ts2 = norm(n2) * n1 / Sx(0, 0);
+    } else if (Sx(1, 1) > Sx(0, 0) && Sx(1, 1) > Sx(2, 2)) {
+        const double e = ((Sx(1, 1) * Sx(0, 2) - Sx(0, 1) * Sx(1, 2)) < 0) ? -1 : 1;
+        n1 = {Sx(0, 1) + r22, Sx(1, 1), Sx(1, 2) - e * r00};
+        n2 = {Sx(0, 1) - r22, Sx(1, 1), Sx(1, 2) + e * r00};
+        ts2 = norm(n2) * n1 / Sx(1, 1);
+        ts1 = norm(n1) * n2 / Sx(1, 1);
+    } else {
+        const double e = ((Sx(1, 2) * Sx(0, 2) - Sx(0, 1) * Sx(2, 2)) < 0) ? -1 : 1;
+        n1 = {Sx(0, 2) + e * r11, Sx(1, 2) + r00, Sx(2, 2)};
+        n2 = {Sx(0, 2) - e * r11, Sx(1, 2) - r00, Sx(2, 2)};
+        ts1 = norm(n1) * n2 / Sx(2, 2);
+        ts2 = norm(n2) * n1 / Sx(2, 2);
+    }
+    n1 = normalized(n1);
+    n2 = normalized(n2);
+    ts1 = ts1 - tenormsq * n1;
+    ts2 = ts2 - tenormsq * n2;
+    auto outer_sub = [&](const V3 &t, const V3 &n) {  // I - (t / nu) n^T
+        M3 M;
+        const double tv[3] = {t.x / nu, t.y / nu, t.z / nu}, nv[3] = {n.x, n.y, n.z};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) M.m[3 * i + j] = (i == j ? 1.0 : 0.0) - tv[i] * nv[j];
+        return M;
+    };
+    R1 = Hn * outer_sub(ts1, n1);
+    R2 = Hn * outer_sub(ts2, n2);
+    T1 = R1 * (0.5 * ts1);
+    T2 = R2 * (0.5 * ts2);
+    return true;
+}
+
+// essential.cpp:266-284 (JacobiSVD branch)
+inline void decompose_essential(const M3 &E, M3 &R1, M3 &R2, V3 &T) {
+    M3 U, V;
+    double sv[3];
+    svd3(E, U, sv, V);
+    M3 VT = transpose(V);
+    if (det(U) < 0)
+        for (double &v : U.m) v = -v;
+    if (det(VT) < 0)
+        for (double &v : VT.m) v = -v;
+    const M3 W{{0, 1, 0, -1, 0, 0, 0, 0, 1}};
+    R1 = U * W * VT;
+    R2 = U * transpose(W) * VT;
+    T = {U.m[2], U.m[5], U.m[8]};
+}
+
 }  // namespace rdvio_pipe

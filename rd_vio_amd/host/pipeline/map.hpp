@@ -25,7 +25,7 @@ namespace rdvio_pipe {
 constexpr double GRAVITY_NOMINAL = 9.80665;
 constexpr size_t nil = size_t(-1);
 // layout of a preintegration record (include/rdvio_hip.h: RDVIO_PREINT_SIZE)
-constexpr int PRE_T = 0, PRE_Q = 1, PRE_P = 5, PRE_V = 8;
+constexpr int PRE_T = 0, PRE_Q = 1, PRE_P = 5, PRE_V = 8, PRE_JAC = 461;
 
 struct ImuData {
     double t;

@@ -21,11 +21,14 @@ int BaBuilder::frame_index(Frame *frame) const {
     return it == fidx.end() ? -1 : it->second;
 }
 
-int BaBuilder::add_frame_states(Frame *frame) {
+int BaBuilder::add_frame_states(Frame *frame, bool with_motion) {
     if (int i = frame_index(frame); i >= 0) return i;
-    // FT_FIX_POSE & FT_FIX_MOTION -> constant; FT_FIX_POSE alone -> pose constant, motion free (solver.cpp:92-113)
+    // FT_FIX_POSE & FT_FIX_MOTION -> constant; FT_FIX_POSE alone -> pose constant, motion free (solver.cpp:92-113).
+    // with_motion = false (the SfM bundle adjustment, initializer.cpp:321): the motion blocks are not parameters; no factor
+    // of such a solve touches them, so their columns stay empty (zero gradient, zero step) -- a pose-constant frame is
+    // then entirely constant.
     uint8_t fixed = 0;
-    if (frame->tag(FT_FIX_POSE)) fixed = frame->tag(FT_FIX_MOTION) ? 1 : 2;
+    if (frame->tag(FT_FIX_POSE)) fixed = (frame->tag(FT_FIX_MOTION) || !with_motion) ? 1 : 2;
     fidx[frame] = (int)frames.size();
     frames.push_back(frame);
     frame_fixed.push_back(fixed);
@@ -386,91 +389,6 @@ void Frontend::run() {
             sliding_window_tracker.reset();
         }
     }
-}
-
-// =====================================================================================================================
-// Bootstrap (initializer.cpp:20-140 without init_sfm / init_imu)
-// =====================================================================================================================
-void Initializer::mirror_keyframe_map(Map *ftmap, size_t init_frame_id) {
-    const size_t last = ftmap->frame_index_by_id(init_frame_id);
-    const size_t gap = (size_t)sh.cfg.initializer_keyframe_gap;
-    const size_t distance = gap * ((size_t)sh.cfg.initializer_keyframe_num - 1);
-    if (last == nil || last < distance) {
-        map.reset();
-        return;
-    }
-    const size_t first = last - distance;
-    std::vector<size_t> indices;
-    for (size_t i = 0; i < (size_t)sh.cfg.initializer_keyframe_num; ++i) indices.push_back(first + i * gap);
-    map = std::make_unique<Map>(sh.ids);
-    for (size_t index : indices) map->attach_frame(ftmap->get_frame(index)->clone());
-    for (size_t j = 1; j < map->frame_num(); ++j) {
-        Frame *old_i = ftmap->get_frame(indices[j - 1]), *old_j = ftmap->get_frame(indices[j]);
-        Frame *new_i = map->get_frame(j - 1), *new_j = map->get_frame(j);
-        for (size_t ki = 0; ki < old_i->keypoint_num(); ++ki)
-            if (Track *track = old_i->get_track(ki))
-                if (size_t kj = track->get_keypoint_index(old_j); kj != nil) new_i->get_track(ki, nullptr)->add_keypoint(new_j, kj);
-        new_j->preintegration.data.clear();
-        for (size_t f = indices[j - 1]; f < indices[j]; ++f) {
-            const std::vector<ImuData> &old_data = ftmap->get_frame(f + 1)->preintegration.data;
-            new_j->preintegration.data.insert(new_j->preintegration.data.end(), old_data.begin(), old_data.end());
-        }
-    }
-}
-
-std::unique_ptr<SlidingWindowTracker> Initializer::initialize() {
-    if (!map) return nullptr;
-    // externally supplied states replace init_sfm / init_imu (initializer.cpp:142-420)
-    for (size_t i = 0; i < map->frame_num(); ++i) {
-        Frame *frame = map->get_frame(i);
-        const std::array<double, 17> *row = nullptr;
-        for (const auto &r : sh.init_states)
-            if (std::fabs(r[0] - frame->image->t) < 1.0e-6) { row = &r; break; }
-        if (!row) return nullptr;
-        frame->set_state(row->data() + 1);
-    }
-    // triangulate every track of the keyframe map (initializer.cpp:305-315), drop the failures (:361-364)
-    for (size_t i = 0; i < map->track_num(); ++i) {
-        Track *track = map->get_track(i);
-        if (track->tag(TT_VALID)) continue;
-        if (auto p = track->triangulate()) {
-            track->set_landmark_point(p.value());
-            track->set_tag(TT_VALID, true);
-            track->set_tag(TT_TRIANGULATED, true);
-        }
-    }
-    map->prune_tracks([](const Track *track) { return !track->tag(TT_VALID); });
-
-    // closing visual-inertial BA (initializer.cpp:82-127)
-    map->get_frame(0)->set_tag(FT_FIX_POSE, true);
-    BaBuilder solver(sh);
-    for (size_t i = 0; i < map->frame_num(); ++i) solver.add_frame_states(map->get_frame(i));
-    std::unordered_set<Track *> visited;
-    for (size_t i = 0; i < map->frame_num(); ++i) {
-        Frame *frame = map->get_frame(i);
-        for (size_t j = 0; j < frame->keypoint_num(); ++j) {
-            Track *track = frame->get_track(j);
-            if (!track || !track->tag(TT_VALID) || visited.count(track)) continue;
-            visited.insert(track);
-            solver.add_track_states(track, false);
-        }
-    }
-    for (size_t i = 0; i < map->frame_num(); ++i) {
-        Frame *frame = map->get_frame(i);
-        for (size_t j = 0; j < frame->keypoint_num(); ++j) {
-            Track *track = frame->get_track(j);
-            if (!track || !track->all_tagged({TT_VALID, TT_TRIANGULATED}) || frame == track->first_frame()) continue;
-            solver.add_reprojection_error(frame, j);
-        }
-    }
-    for (size_t j = 1; j < map->frame_num(); ++j) {
-        Frame *frame_i = map->get_frame(j - 1), *frame_j = map->get_frame(j);
-        if (frame_j->preintegration.integrate(sh.backend, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba, true, true))
-            solver.add_preintegration(frame_i, frame_j, frame_j->preintegration, false);
-    }
-    solver.solve();
-    for (size_t i = 0; i < map->frame_num(); ++i) map->get_frame(i)->set_tag(FT_KEYFRAME, true);
-    return std::make_unique<SlidingWindowTracker>(std::move(map), sh);
 }
 
 // =====================================================================================================================
@@ -1016,6 +934,10 @@ void rdvio_pipeline_config_default(rdvio_pipeline_config *c) {
     c->feature_tracker_predict_keypoints = 1;
     c->initializer_keyframe_num = 8;
     c->initializer_keyframe_gap = 5;
+    c->initializer_min_matches = 50;
+    c->initializer_min_parallax = 10;
+    c->initializer_min_triangulation = 50;
+    c->initializer_min_landmarks = 30;
     c->solver_iteration_limit = 10;
     c->rotation_misalignment_threshold = 0.1;
     c->rotation_ransac_threshold = 10;

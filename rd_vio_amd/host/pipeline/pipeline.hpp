@@ -47,7 +47,7 @@ class BaBuilder {
   public:
     explicit BaBuilder(Shared &sh) : sh(sh) {}
     // Solver::add_frame_states: constancy from the frame's FT_FIX_POSE / FT_FIX_MOTION tags (solver.cpp:88-114)
-    int add_frame_states(Frame *frame);
+    int add_frame_states(Frame *frame, bool with_motion = true);
     // a frame whose values are read by a factor but which is not a parameter of this solve
     int add_constant_frame(Frame *frame);
     int add_track_states(Track *track, bool constant);
@@ -105,8 +105,20 @@ class Initializer {
     std::unique_ptr<SlidingWindowTracker> initialize();
 
   private:
+    bool bootstrap_from_supplied_states();   // rdvio_pipeline_set_init_states path
+    bool init_sfm();                          // initializer.cpp:142-366
+    bool init_imu();                          // :368-381
+    void solve_gyro_bias();                   // :383-409
+    void solve_gravity_scale_velocity();      // :411-447
+    void refine_scale_velocity_via_gravity(); // :449-503
+    void reset_states();
+    void preintegrate();
+    bool apply_init(bool apply_ba = false, bool apply_velocity = true);  // :522-560
     Shared &sh;
     std::unique_ptr<Map> map;
+    V3 bg, ba, gravity;
+    double scale = 1.0;
+    std::vector<V3> velocities;
 };
 
 class FeatureTracker;

@@ -26,6 +26,8 @@ class PipelineConfig(ctypes.Structure):
         ("feature_tracker_clahe_width", ctypes.c_int32), ("feature_tracker_clahe_height", ctypes.c_int32),
         ("feature_tracker_predict_keypoints", ctypes.c_int32),
         ("initializer_keyframe_num", ctypes.c_int32), ("initializer_keyframe_gap", ctypes.c_int32),
+        ("initializer_min_matches", ctypes.c_int32), ("initializer_min_triangulation", ctypes.c_int32),
+        ("initializer_min_landmarks", ctypes.c_int32), ("initializer_min_parallax", ctypes.c_double),
         ("solver_iteration_limit", ctypes.c_int32),
         ("rotation_misalignment_threshold", ctypes.c_double), ("rotation_ransac_threshold", ctypes.c_double),
         ("random", ctypes.c_int32), ("parsac_flag", ctypes.c_int32),

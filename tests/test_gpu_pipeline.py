@@ -14,12 +14,20 @@ OVER = dict(sliding_window_size=8, feature_tracker_max_keypoint_detection=150, f
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["translation_full_res", "rotation_phase_half_res"])
+@pytest.mark.parametrize("case", ["translation_full_res", "rotation_phase_half_res", "full_initializer_half_res"])
 def test_hip_pipeline_reproduces_the_cpu_path(case):
     if case == "translation_full_res":
         W, H, K = 752, 480, synth.EUROC_K
         frames, ts, imu, gt = synth.make_stream(36, W, H, K)
         pose_fn = synth.traj_pose
+    elif case == "full_initializer_half_res":
+        # no bootstrap states: Initializer::initialize (SfM + IMU alignment) runs on both paths
+        W, H = 376, 240
+        K = synth.EUROC_K.copy()
+        K[:2] *= 0.5
+        pose_fn = synth.traj_pose
+        frames, ts, imu, gt = synth.make_stream(70, W, H, K)
+        gt = gt[:0]
     else:
         # translation comes to rest after 1.2 s while the rotation continues: FT_NO_TRANSLATION frames, keyframe lifting
         # and rotation-only subwindows (manage_keyframe / refine_subwindow, sliding_window_tracker.cpp:127-204, 349-400)
@@ -29,7 +37,8 @@ def test_hip_pipeline_reproduces_the_cpu_path(case):
         pose_fn = synth.traj_pose_rotation_phase
         frames, ts, imu, gt = synth.make_stream(80, W, H, K, pose_fn=pose_fn)
     lib, shim = pu.load_pipeline_lib(), pu.build_oracle_backend()
-    cfg = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **OVER)
+    over = dict(OVER, initializer_keyframe_gap=3, initializer_min_parallax=5.0, initializer_min_triangulation=20) if case == "full_initializer_half_res" else OVER
+    cfg = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **over)
     cpu = pu.run_stream(lib, pu.oracle_pipeline_factory(lib, shim, cfg), frames, ts, imu, gt)
     ctx = rd_vio_amd.Context(max_width=W, max_height=H, max_features=1024, max_window=16, max_factors=20000)
     try:
@@ -52,8 +61,11 @@ def test_hip_pipeline_reproduces_the_cpu_path(case):
     assert np.abs(sg[ok, 1:5] - sc[ok, 1:5]).max() < 1e-3     # orientation (quaternion components)
     # and both stay on the ground truth
     p_gt = np.array([pose_fn(t)[1] for t in sc[ok, 0]])
-    if case != "translation_full_res":
+    if case == "rotation_phase_half_res":
         assert cpu["counters"][25] >= 10                        # the rotation-only branch was really exercised
+    if case == "full_initializer_half_res":                    # own world frame: compare after a rigid alignment
+        assert pu.ate_rmse(sg[ok, 5:8], p_gt) < 0.06
+        return
     assert np.linalg.norm(sg[ok, 5:8] - p_gt, axis=1).max() < 0.15
 
 
