@@ -87,7 +87,7 @@ def test_run_euroc_script_on_a_synthetic_mav0(tmp_path):
     (tmp_path / "setting.yaml").write_text(SETTING_YAML)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "run_euroc.py"), str(d), "--sensor", str(tmp_path / "sensor.yaml"),
-                          "--setting", str(tmp_path / "setting.yaml"), "--out", str(tmp_path / "traj.txt")],
+                          "--setting", str(tmp_path / "setting.yaml"), "--out", str(tmp_path / "traj.txt"), "--bootstrap-from-groundtruth"],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     rep = json.loads(out.stdout.strip().splitlines()[-1])
