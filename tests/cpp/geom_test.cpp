@@ -131,6 +131,67 @@ int main() {
         }
     }
     {
+        // points on a plane n.X = d seen from two poses: H = R + t n^T / d (normalised coordinates)
+        const V3 n = normalized(V3{0.1, -0.2, 1.0});
+        const double d = 4.0;
+        std::vector<V2> a, b;
+        for (int i = 0; i < 40; ++i) {
+            const double x = 2.0 * U(rng), y = 1.5 * U(rng);
+            const double z = (d - n.x * x - n.y * y) / n.z;
+            const V3 X{x, y, z}, Y = R * X + t;
+            a.push_back(hnormalized(X));
+            b.push_back(hnormalized(Y));
+        }
+        std::vector<char> mask;
+        const M3 H = find_homography_matrix(a, b, mask, 1e-3, 0.999, 1000, 648);
+        size_t inl = 0;
+        for (char c : mask) inl += c;
+        CHECK(inl == a.size(), "homography inliers %zu of %zu", inl, a.size());
+        for (size_t i = 0; i < a.size(); ++i) CHECK(homography_geometric_error(H, a[i], b[i]) < 1e-16, "homography transfer error");
+        M3 R1, R2;
+        V3 T1, T2, n1, n2;
+        CHECK(decompose_homography(H, R1, R2, T1, T2, n1, n2), "plane-induced homography reported as pure rotation");
+        double best = 1e9;
+        for (const M3 *Rc : {&R1, &R2}) {
+            double e = 0;
+            for (int i = 0; i < 9; ++i) e = std::max(e, std::fabs(Rc->m[i] - R.m[i]));
+            best = std::min(best, e);
+        }
+        CHECK(best < 1e-8, "homography decomposition: rotation error %g", best);
+        const V3 tn = normalized(t);
+        const double cs = std::max(std::fabs(dot(normalized(T1), tn)), std::fabs(dot(normalized(T2), tn)));
+        CHECK(cs > 1.0 - 1e-8, "homography decomposition: translation direction cos %g", cs);
+        // a rotation-only homography is recognised
+        M3 Ra, Rb;
+        CHECK(!decompose_homography(R, Ra, Rb, T1, T2, n1, n2), "pure rotation not recognised");
+        // essential decomposition contains the true rotation and +-t
+        const M3 tx{{0, -t.z, t.y, t.z, 0, -t.x, -t.y, t.x, 0}};
+        M3 E1, E2;
+        V3 TE;
+        decompose_essential(tx * R, E1, E2, TE);
+        double be = 1e9;
+        for (const M3 *Rc : {&E1, &E2}) {
+            double e = 0;
+            for (int i = 0; i < 9; ++i) e = std::max(e, std::fabs(Rc->m[i] - R.m[i]));
+            be = std::min(be, e);
+        }
+        CHECK(be < 1e-9 && std::fabs(std::fabs(dot(TE, tn)) - 1.0) < 1e-9, "essential decomposition error %g", be);
+        // least squares: exact solution of a consistent overdetermined system; quaternion helpers
+        std::vector<double> A(12 * 4), xs{1.5, -2.0, 0.25, 3.0}, rhs(12, 0.0);
+        for (double &v : A) v = U(rng);
+        for (int r = 0; r < 12; ++r)
+            for (int c = 0; c < 4; ++c) rhs[r] += A[r * 4 + c] * xs[c];
+        const std::vector<double> xr = least_squares(12, 4, A, rhs);
+        for (int c = 0; c < 4; ++c) CHECK(std::fabs(xr[c] - xs[c]) < 1e-9, "least squares x[%d] = %g", c, xr[c]);
+        const Q4 qr = from_mat(R);
+        CHECK(std::fabs(std::fabs(qr.x * q.x + qr.y * q.y + qr.z * q.z + qr.w * q.w) - 1.0) < 1e-12, "from_mat");
+        const V3 w{0.3, -0.2, 0.5};
+        const V3 wl = logmap(expmap(w));
+        CHECK(norm(wl - w) < 1e-12, "logmap(expmap(w))");
+        const V3 va = normalized(V3{0.2, -1.0, 0.4}), vb = normalized(V3{-0.5, 0.1, 0.9});
+        CHECK(norm(rot(from_two_vectors(va, vb), va) - vb) < 1e-12, "from_two_vectors");
+    }
+    {
         // LotBox draws are a permutation prefix
         LotBox box(10);
         box.seed(0);
