@@ -57,6 +57,7 @@ typedef struct rdvio_backend {
     /* MarginalizationFactor::marginalize(0) */
     int (*marginalize)(void *user, const rdvio_marg_problem *pb, double *S_out, double *f_out, double *lin_out);
     const char *(*last_error)(void *user);
+    void (*destroy)(void *user); /* optional: called by rdvio_pipeline_destroy */
 } rdvio_backend;
 
 /* rdvio::Config (types.h:85-151) with the defaults of src/rdvio/src/config.cpp; rdvio_pipeline_config_default fills

@@ -394,6 +394,7 @@ __device__ __attribute__((noinline)) void build_normal_equations(const SolverWs 
         block_store(blk, v0);
         if (two) block_store(blk + NW, v1);
     }
+    STAMP(27);
     for (int o = t; o < N; o += T) {
         const int c = o / 15, a = o - 15 * c;
         double acc = 0.0;
@@ -543,7 +544,7 @@ DM double grad_max_norm(const SolverWs &w, Shared &sh, int &phase) {
 
 // per-launch setup shared by the solver and the marginalisation kernel: user state, free-landmark flags, LDS index
 // tables, zeroed coupling rows, and the constant parts of the prior (S^T, Lambda = S^T S, eta0 = S^T f)
-DM void solver_setup(const SolverWs &w, Shared &sh) {
+DM void solver_setup(const SolverWs &w, Shared &sh, double *lds, size_t lds_cap, unsigned long long &prof_last) {
     const int t = threadIdx.x;
     const int nl = w.nl, nfree = w.nfree, NAs = 6 * nfree + 2;
     for (int i = t; i < w.nfr * 16; i += T) {
@@ -568,15 +569,33 @@ DM void solver_setup(const SolverWs &w, Shared &sh) {
     for (size_t i = t; i < (size_t)nl * NAs; i += T) w.A[i] = 0.0;  // slots of frames that do not observe a landmark stay zero
     for (int i = t; i < nfree * 6; i += T) sh.band_src[i] = w.band_src[i];
     for (int i = t; i < nfree * 2; i += T) sh.g_src[i] = w.g_src[i];
+    STAMP(23);
     if (w.np > 0) {
-        for (int o = t; o < w.D * w.D; o += T) w.ST[o] = w.S[(size_t)(o % w.D) * w.D + o / w.D];
-        // Lambda = S^T S (MFMA tiles), eta0 = S^T f: constant during the solve
-        block_gemm_tn<T>(w.Lam, w.D, w.S, w.D, w.S, w.D, nullptr, w.D, w.D, w.D, false);
-        for (int a = t; a < w.D; a += T) {
+        const int D = w.D;
+        // constant parts of the prior: S^T (coalesced S e), Lambda = S^T S (MFMA tiles), eta0 = S^T f.  S is staged in LDS
+        // first (one batch of coalesced loads): the K-loops of the GEMM and of S^T f then run at LDS latency.
+        const double *Sp = w.S;
+        if ((size_t)D * D <= lds_cap) {
+            for (int o = t; o < D * D; o += T) lds[o] = w.S[o];
+            __syncthreads();
+            Sp = lds;
+        }
+        for (int o = t; o < D * D; o += T) w.ST[o] = Sp[(size_t)(o % D) * D + o / D];
+        STAMP(24);
+        block_gemm_tn<T>(w.Lam, D, Sp, D, Sp, D, nullptr, D, D, D, true);
+        STAMP(25);
+        for (int a = t; a < D; a += T) {
             double acc = 0.0;
-            for (int q = 0; q < w.D; ++q) acc += w.S[(size_t)q * w.D + a] * w.f[q];
+            for (int q = 0; q < D; ++q) acc += Sp[(size_t)q * D + a] * w.f[q];
             w.eta0[a] = acc;
         }
+        __syncthreads();
+        // mirror the lower tiles (the assembly reads Lambda as a full symmetric matrix)
+        for (int o = t; o < D * D; o += T) {
+            const int r = o / D, c = o - r * D;
+            if ((c >> 4) > (r >> 4)) w.Lam[o] = w.Lam[(size_t)c * D + r];
+        }
+        STAMP(26);
     }
     __syncthreads();
 }
@@ -598,7 +617,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     if (t == 0) for (int i = 8; i < 72; ++i) w.summary[i] = 0.0;
 #endif
 
-    solver_setup(w, sh);
+    solver_setup(w, sh, lds_chol_buf, LDS_CAP, prof_last);
 
     double radius = 1e4, mu = 1e-8, alpha = 0.0, dogleg_step_norm = 0.0;
     double gnorm = 0.0, gn_norm = 0.0, gdotgn = 0.0, gsq_keep = 0.0;
@@ -684,6 +703,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                         }
                     }
                     __syncthreads();
+                    STAMP(29);
                     // S = Sigma (H - C) Sigma + mu D^2   (lower triangle); one wave per 15 x 15 block, 4 passes in flight
                     for (int i = t; i < N; i += T) sh.xv[i] = w.sig_p[i];
                     __syncthreads();
@@ -896,7 +916,7 @@ __global__ __launch_bounds__(T) void marginalize_kernel(SolverWs w) {
     prof_last = wall_clock64();
     if (threadIdx.x == 0) for (int i = 8; i < 72; ++i) w.summary[i] = 0.0;
 #endif
-    solver_setup(w, sh);
+    solver_setup(w, sh, lds_buf, sizeof(lds_buf) / sizeof(double), prof_last);
     STAMP(0);
     (void)evaluate<true>(w, sh, phase, w.x, w.xd, prof_last);
     STAMP(1);

@@ -79,11 +79,12 @@ int marginalize(void *user, const rdvio_marg_problem *pb, double *S, double *f, 
 
 const char *last_error(void *user) { return rdvio_hip_last_error(static_cast<HipBackend *>(user)->ctx); }
 
+void destroy(void *user) { delete static_cast<HipBackend *>(user); }
+
 }  // namespace
 
 extern "C" int rdvio_pipeline_create_hip(rdvio_pipeline **out, const rdvio_pipeline_config *cfg, rdvio_hip_ctx *ctx) {
     if (!out || !cfg || !ctx) return RDVIO_ERR_INVALID;
-    // the backend record lives as long as the process-wide context it wraps (one Odometry per process)
     auto *b = new HipBackend{ctx};
     rdvio_backend fn;
     fn.user = b;
@@ -97,6 +98,7 @@ extern "C" int rdvio_pipeline_create_hip(rdvio_pipeline **out, const rdvio_pipel
     fn.ba_solve = ba_solve;
     fn.marginalize = marginalize;
     fn.last_error = last_error;
+    fn.destroy = destroy;
     const int rc = rdvio_pipeline_create(out, cfg, &fn);
     if (rc != RDVIO_OK) delete b;
     return rc;

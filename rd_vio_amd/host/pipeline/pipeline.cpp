@@ -963,7 +963,13 @@ int rdvio_pipeline_create(rdvio_pipeline **out, const rdvio_pipeline_config *cfg
     return RDVIO_OK;
 }
 
-void rdvio_pipeline_destroy(rdvio_pipeline *p) { delete p; }
+void rdvio_pipeline_destroy(rdvio_pipeline *p) {
+    if (!p) return;
+    const rdvio_backend fn = p->shared.backend.fn;
+    p->handler.reset();  // frames release their images through the backend first
+    delete p;
+    if (fn.destroy) fn.destroy(fn.user);
+}
 
 const char *rdvio_pipeline_last_error(const rdvio_pipeline *p) { return p ? p->error.c_str() : "null pipeline"; }
 

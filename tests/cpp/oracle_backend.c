@@ -134,4 +134,5 @@ void rdvio_oracle_backend_fill(rdvio_backend *b) {
     b->ba_solve = ob_ba_solve;
     b->marginalize = ob_marginalize;
     b->last_error = ob_last_error;
+    b->destroy = NULL;
 }
