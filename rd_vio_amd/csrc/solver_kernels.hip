@@ -75,7 +75,25 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
     constexpr int TF = T - 64;
     if (t < TF) {
         // reprojection factors, CauchyLoss(1): cost 0.5 log(1+s); Corrector with rho'' < 0 => scale r, J by sqrt(rho')
-        for (int k = t; k < w.nf; k += TF) {
+        if (!LIN) {
+            // cost-only evaluation: two independent factors per trip so that their FP64 dependency chains interleave
+            // (a single workgroup has only two wavefronts per SIMD to hide latency with); same summation order
+            for (int k = t; k < w.nf; k += 2 * TF) {
+                const int k2 = k + TF;
+                const bool has2 = k2 < w.nf;
+                const int kb = has2 ? k2 : k;
+                double ra[2], rb[2];
+                const int la = w.lm[k], lb = w.lm[kb];
+                reprojection_factor<false>(states + 16 * w.tgt[k], states + 16 * w.ref[k], w.tangent + 9 * (size_t)k, w.z_ref + 3 * (size_t)la,
+                                           invd[la], extr, W, ra, nullptr, nullptr, nullptr);
+                reprojection_factor<false>(states + 16 * w.tgt[kb], states + 16 * w.ref[kb], w.tangent + 9 * (size_t)kb, w.z_ref + 3 * (size_t)lb,
+                                           invd[lb], extr, W, rb, nullptr, nullptr, nullptr);
+                const double sa = ra[0] * ra[0] + ra[1] * ra[1], sb = rb[0] * rb[0] + rb[1] * rb[1];
+                cost += w.no_loss ? 0.5 * sa : 0.5 * log(1.0 + sa);
+                if (has2) cost += w.no_loss ? 0.5 * sb : 0.5 * log(1.0 + sb);
+            }
+        }
+        for (int k = t; LIN && k < w.nf; k += TF) {
             double r[2], Jt[12], Jr[12], Jd[2];
             const int l = w.lm[k];
             reprojection_factor<LIN>(states + 16 * w.tgt[k], states + 16 * w.ref[k], w.tangent + 9 * (size_t)k,
@@ -359,10 +377,18 @@ __device__ __attribute__((noinline)) void build_normal_equations(const SolverWs 
                 if (src1 >= 0) acc += w.PP[900 * (size_t)(src1 >> 2) + 30 * (15 * ((src1 >> 1) & 1) + a) + 15 * (src1 & 1) + b];
                 if (a < 6 && b < 6) {
                     if (fi == fj) {
-                        for (int f2 = 0; f2 < nfree; ++f2) {
-                            const int lo = f2 < fi ? f2 : fi, hi = f2 < fi ? fi : f2;
-                            const int off = (fi == lo) ? 0 : 6;  // quadrant (lo,lo) or (hi,hi); the single group (f,f) uses (lo,lo)
-                            acc += w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + off + b];
+                        // the nfree group tiles that touch this frame, four loads in flight (summed in f2 order)
+                        for (int f0 = 0; f0 < nfree; f0 += 4) {
+                            double gv[4];
+#pragma unroll
+                            for (int u4 = 0; u4 < 4; ++u4) {
+                                const int f2 = f0 + u4;
+                                const int lo = f2 < fi ? f2 : fi, hi = f2 < fi ? fi : f2;
+                                const int off = (fi == lo) ? 0 : 6;  // quadrant (lo,lo) or (hi,hi); the single group (f,f) uses (lo,lo)
+                                gv[u4] = f2 < nfree ? w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + off + b] : 0.0;
+                            }
+#pragma unroll
+                            for (int u4 = 0; u4 < 4; ++u4) acc += gv[u4];
                         }
                         if (a < 3 && b < 3)
                             for (int k = 0; k < w.nrot; ++k)
@@ -399,10 +425,17 @@ __device__ __attribute__((noinline)) void build_normal_equations(const SolverWs 
         const int c = o / 15, a = o - 15 * c;
         double acc = 0.0;
         if (a < 6) {
-            for (int f2 = 0; f2 < nfree; ++f2) {
-                const int lo = f2 < c ? f2 : c, hi = f2 < c ? c : f2;
-                const int off = (c == lo) ? 0 : 6;
-                acc += w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + 12];
+            for (int f0 = 0; f0 < nfree; f0 += 4) {
+                double gv[4];
+#pragma unroll
+                for (int u4 = 0; u4 < 4; ++u4) {
+                    const int f2 = f0 + u4;
+                    const int lo = f2 < c ? f2 : c, hi = f2 < c ? c : f2;
+                    const int off = (c == lo) ? 0 : 6;
+                    gv[u4] = f2 < nfree ? w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + 12] : 0.0;
+                }
+#pragma unroll
+                for (int u4 = 0; u4 < 4; ++u4) acc += gv[u4];
             }
             if (a < 3)
                 for (int k = 0; k < w.nrot; ++k)
