@@ -31,3 +31,27 @@ def test_host_mirror_runs_on_gpu():
     out = subprocess.run([EXE], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.startswith("OK")
+
+
+ODO_SRC = os.path.join(ROOT, "tests", "cpp", "odometry_mirror_test.cpp")
+ODO_EXE = os.path.join(ROOT, "tests", "cpp", "odometry_mirror_test.bin")
+
+
+def _compile_odometry():
+    rbuild.build()
+    libdir = os.path.join(ROOT, "rd_vio_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-o", ODO_EXE, ODO_SRC, "-L", libdir, "-lrdvio_pipeline", "-lrdvio_hip",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
+
+
+def test_odometry_mirror_compiles_and_links():
+    _compile_odometry()
+    assert os.path.exists(ODO_EXE)
+
+
+@pytest.mark.gpu
+def test_odometry_mirror_runs_on_gpu():
+    _compile_odometry()
+    out = subprocess.run([ODO_EXE], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith("OK")
