@@ -224,7 +224,7 @@ def end_to_end(cfg, ctx, n_frames, with_cpu_path):
 
         assert lib.rdvio_pipeline_set_init_states(handle, len(gt_c), gt_c.ctypes.data_as(ctypes.c_void_p)) == 0
         spent = pr.feed_stream(lib, handle, frames, ts, imu, per_frame=snap)
-        cnt = np.zeros(27, dtype=np.int64)
+        cnt = np.zeros(29, dtype=np.int64)
         lib.rdvio_pipeline_counters(handle, cnt.ctypes.data_as(ctypes.c_void_p))
         lib.rdvio_pipeline_destroy(handle)
         return np.array(states), kps, np.array(stamps), spent, cnt

@@ -20,7 +20,7 @@
  *
  * Initialisation: Initializer::initialize (src/rdvio/src/initializer.cpp:72-560: two-view SfM + IMU alignment + BA) runs
  * unless bootstrap states were supplied with rdvio_pipeline_set_init_states, which then replace its SfM / alignment
- * stages.  Not built: the RD dynamic-outlier path (parsac_flag), rejected at create time.
+ * stages.  parsac_flag enables the RD dynamic-outlier path (IMU-PARSAC over EPnP hypotheses, PARSAC essential checks).
  */
 #ifndef RDVIO_PIPELINE_H
 #define RDVIO_PIPELINE_H
@@ -82,7 +82,8 @@ typedef struct rdvio_pipeline_config {
     int32_t solver_iteration_limit;
     double rotation_misalignment_threshold, rotation_ransac_threshold;
     int32_t random;
-    int32_t parsac_flag; /* must be 0 in this round */
+    int32_t parsac_flag; /* RD dynamic-outlier handling (judge_track_status / update_track_status) */
+    int32_t parsac_keyframe_check_size;
 } rdvio_pipeline_config;
 
 void rdvio_pipeline_config_default(rdvio_pipeline_config *cfg);
@@ -128,8 +129,9 @@ int rdvio_pipeline_last_frame_keypoints(const rdvio_pipeline *p, int64_t *track_
  * frames in one solve, [9] largest number of reprojection factors in one solve, [10] solver iterations summed over all
  * solves, then (microseconds, calls) pairs of the time spent inside backend calls: [11,12] preprocess, [13,14] detect,
  * [15,16] track, [17,18] preintegrate, [19,20] ba_solve, [21,22] marginalize, [23,24] image_create; [25] frames tagged
- * FT_NO_TRANSLATION, [26] rotation-prior factors summed over all solves */
-int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out27);
+ * FT_NO_TRANSLATION, [26] rotation-prior factors summed over all solves, [27] IMU-PARSAC judgements run, [28] tracks
+ * switched to non-static by update_track_status */
+int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out29);
 
 #ifdef __cplusplus
 }

@@ -56,7 +56,7 @@ def config_overrides(sensor_yaml, setting_yaml=None):
             ("initializer", "min_triangulation"): "initializer_min_triangulation", ("initializer", "min_landmarks"): "initializer_min_landmarks",
             ("solver", "iteration_limit"): "solver_iteration_limit",
             ("rotation", "misalignment_threshold"): "rotation_misalignment_threshold", ("rotation", "ransac_threshold"): "rotation_ransac_threshold",
-            ("parsac", "parsac_flag"): "parsac_flag",
+            ("parsac", "parsac_flag"): "parsac_flag", ("parsac", "keyframe_check_size"): "parsac_keyframe_check_size",
         }
         for (sec, key), field in names.items():
             if sec in t and key in t[sec]:
@@ -211,7 +211,7 @@ def replay(lib, handle, dataset, max_frames=None):
     traj, spent, n_img = [], 0.0, 0
     pose = np.zeros(7)
     tt = ctypes.c_double(0)
-    cnt = np.zeros(27, dtype=np.int64)
+    cnt = np.zeros(29, dtype=np.int64)
     seen = 0
     for clip in dataset.clips:
         if "gyro" in clip:

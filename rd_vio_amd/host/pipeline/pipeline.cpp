@@ -1,8 +1,11 @@
 // Per-frame orchestration around the HIP hot path.  Each block cites the reference code whose behaviour it keeps;
 // everything data-parallel is a call through the backend table (include/rdvio_pipeline.h).
 #include "pipeline.hpp"
+#include "parsac.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <unordered_set>
@@ -372,6 +375,7 @@ void Frontend::run() {
         pending_frame_ids.clear();
         initializer->mirror_keyframe_map(feature_tracker->map.get(), pending_frame_id);
         if ((sliding_window_tracker = initializer->initialize())) {
+            sliding_window_tracker->feature_tracking_map = feature_tracker->map.get();
             auto [t, pose, motion] = sliding_window_tracker->get_latest_state();
             latest_state = std::make_tuple(t, pending_frame_id, pose, motion);
             initializer.reset();
@@ -429,7 +433,9 @@ void SlidingWindowTracker::mirror_frame(Map *ftmap, size_t frame_id) {
 }
 
 bool SlidingWindowTracker::track() {
-    // parsac_flag (judge_track_status / update_track_status, :557-769) is rejected at create time
+    if (sh.cfg.parsac_flag) {
+        if (judge_track_status()) update_track_status();
+    }
     localize_newframe();
     if (manage_keyframe()) {
         track_landmark();
@@ -487,6 +493,7 @@ bool SlidingWindowTracker::manage_keyframe() {
     for (size_t k = 0; k < newframe_j->keypoint_num(); ++k)
         if (Track *track = newframe_j->get_track(k))
             if (track->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) mapped_landmark_count++;
+    if (std::getenv("RDVIO_PIPE_DEBUG")) std::fprintf(stderr, "manage: kp %zu mapped %zu tracks %zu\n", newframe_j->keypoint_num(), mapped_landmark_count, map->track_num());
     const bool is_keyframe = mapped_landmark_count < (size_t)sh.cfg.sliding_window_force_keyframe_landmarks;
     if (is_keyframe) {
         newframe_j->set_tag(FT_KEYFRAME, true);
@@ -776,6 +783,157 @@ void SlidingWindowTracker::refine_subwindow() {
     sh.counters.subwindow_solves++;
 }
 
+
+// =====================================================================================================================
+// RD dynamic-outlier handling (sliding_window_tracker.cpp:461-769), parsac_flag only
+// =====================================================================================================================
+namespace {
+// :557-583: relative camera motion between two frames
+void predict_RT(const Frame *frame_i, const Frame *frame_j, M3 &R, V3 &t) {
+    // P = Pwc^-1 PwI Pji PwI^-1 Pwc with Pji = Pwj^-1 Pwi (4 x 4 rigid transforms)
+    struct T4 { M3 R; V3 t; };
+    auto mul = [](const T4 &a, const T4 &b) { return T4{a.R * b.R, a.R * b.t + a.t}; };
+    auto inv = [](const T4 &a) { const M3 Rt = transpose(a.R); return T4{Rt, -(Rt * a.t)}; };
+    const T4 Pwc{to_mat(frame_i->camera.q_cs), frame_i->camera.p_cs}, PwI{to_mat(frame_i->imu.q_cs), frame_i->imu.p_cs};
+    const T4 Pwi{to_mat(frame_i->pose.q), frame_i->pose.p}, Pwj{to_mat(frame_j->pose.q), frame_j->pose.p};
+    const T4 Pji = mul(inv(Pwj), Pwi);
+    const T4 P = mul(mul(mul(mul(inv(Pwc), PwI), Pji), inv(PwI)), Pwc);
+    R = P.R;
+    t = P.t;
+}
+// :469-474
+double epipolar_dist(const M3 &F, const V2 &pt1, const V2 &pt2) {
+    const V3 l = F * V3{pt1.x, pt1.y, 1.0};
+    return std::fabs(pt2.x * l.x + pt2.y * l.y + l.z) / std::sqrt(l.x * l.x + l.y * l.y);
+}
+M3 k_matrix(const double *K) {
+    M3 M;
+    for (int i = 0; i < 9; ++i) M.m[i] = K[i];
+    return M;
+}
+}  // namespace
+
+bool SlidingWindowTracker::filter_parsac_2d2d(Frame *frame_i, Frame *frame_j, std::vector<char> &mask, std::vector<size_t> &pts_to_index) {
+    std::vector<V2> pts1, pts2;
+    for (size_t ki = 0; ki < frame_i->keypoint_num(); ++ki)
+        if (Track *track = frame_i->get_track(ki)) {
+            const size_t kj = track->get_keypoint_index(frame_j);
+            // (`if (size_t kj = ...)` in the reference: an observation at keypoint index 0 is skipped, :506)
+            if (kj != 0 && kj != nil) {
+                pts1.push_back(hnormalized(frame_i->get_keypoint(ki)));
+                pts2.push_back(hnormalized(frame_j->get_keypoint(kj)));
+                pts_to_index.push_back(kj);
+            }
+        }
+    if (pts1.size() < 10) return false;
+    (void)find_essential_matrix_parsac(pts1, pts2, mask, sh.essential_bin_confidences, m_th / frame_i->K[0]);
+    return true;
+}
+
+bool SlidingWindowTracker::judge_track_status() {
+    Frame *curr_frame = map->get_frame(map->frame_num() - 1);
+    Frame *keyframe = map->get_frame(map->frame_num() - 2);
+    Frame *last_frame = keyframe;
+    if (!keyframe->subframes.empty()) last_frame = keyframe->subframes.back().get();
+    curr_frame->preintegration.integrate(sh.backend, curr_frame->image->t, last_frame->motion.bg, last_frame->motion.ba, true, true);
+    curr_frame->preintegration.predict(last_frame, curr_frame);
+
+    std::vector<V2> P2D;
+    std::vector<V3> P3D;
+    std::vector<size_t> lens;
+    std::vector<int> indices_map(curr_frame->keypoint_num(), -1);
+    for (size_t k = 0; k < curr_frame->keypoint_num(); ++k)
+        if (Track *track = curr_frame->get_track(k))
+            if (track->all_tagged({TT_VALID, TT_TRIANGULATED})) {
+                P2D.push_back(hnormalized(curr_frame->get_keypoint(k)));
+                P3D.push_back(track->get_landmark_point());
+                lens.push_back(track->m_life);
+                indices_map[k] = (int)P3D.size() - 1;
+            }
+    if (P2D.size() < 20) return false;
+    const PoseState pose = curr_frame->get_pose(curr_frame->camera);
+    std::vector<char> mask;
+    const M3 Rcw = to_mat(conj(pose.q));
+    const V3 tcw = -(Rcw * pose.p);
+    (void)find_pnp_matrix_parsac_imu(P3D, P2D, lens, Rcw, tcw, 0.20, 1.0, mask, sh.pnp_bin_confidences, 1.0 / curr_frame->K[0]);
+    mask.resize(P2D.size(), 0);
+    sh.counters.parsac_judgements++;
+
+    M3 R;
+    V3 t;
+    predict_RT(keyframe, curr_frame, R, t);
+    // E = [t]x R, F = K^-T E K^-1 (:461-468, :617-619)
+    const M3 tx{{0, -t.z, t.y, t.z, 0, -t.x, -t.y, t.x, 0}};
+    const M3 E = tx * R;
+    const M3 F = inverse3(transpose(k_matrix(keyframe->K))) * E * inverse3(k_matrix(curr_frame->K));
+    std::vector<double> inliers_dist, outliers_dist;
+    for (size_t i = 0; i < curr_frame->keypoint_num(); ++i) {
+        if (indices_map[i] == -1) continue;
+        const size_t j = curr_frame->get_track(i)->get_keypoint_index(keyframe);
+        if (j == 0 || j == nil) continue;  // (`if (size_t j = ...; j != nil())` with the same index-0 quirk, :626-628)
+        const V2 p1 = apply_k(keyframe->get_keypoint(j), keyframe->K), p2 = apply_k(curr_frame->get_keypoint(i), curr_frame->K);
+        const double err = epipolar_dist(F, p1, p2) + epipolar_dist(transpose(F), p2, p1);
+        (mask[(size_t)indices_map[i]] ? inliers_dist : outliers_dist).push_back(err);
+    }
+    const size_t min_num = 20;
+    if (std::getenv("RDVIO_PIPE_DEBUG")) {
+        size_t inl = 0;
+        for (char c : mask) inl += c;
+        std::fprintf(stderr, "judge: P2D %zu pnp-inliers %zu dist-in %zu dist-out %zu\n", P2D.size(), inl, inliers_dist.size(), outliers_dist.size());
+    }
+    if (inliers_dist.size() < min_num || outliers_dist.size() < min_num) return false;
+    std::sort(inliers_dist.begin(), inliers_dist.end());
+    std::sort(outliers_dist.begin(), outliers_dist.end());
+    const double th1 = inliers_dist[(size_t)(inliers_dist.size() * 0.5)], th2 = outliers_dist[(size_t)(outliers_dist.size() * 0.5)];
+    if (th2 < th1 * 2) return false;  // ambiguous
+    m_th = (th1 + th2) / 2;
+    for (size_t k = 0; k < curr_frame->keypoint_num(); ++k)
+        if (Track *track = curr_frame->get_track(k))
+            if (indices_map[k] != -1) {
+                const bool inlier = mask[(size_t)indices_map[k]] != 0;
+                track->set_tag(TT_OUTLIER, !inlier);
+                track->set_tag(TT_STATIC, inlier);
+            }
+    return true;
+}
+
+void SlidingWindowTracker::update_track_status() {
+    Frame *curr_frame = map->get_frame(map->frame_num() - 1);
+    if (!feature_tracking_map) return;
+    const size_t frame_id = feature_tracking_map->frame_index_by_id(curr_frame->id());
+    if (frame_id == nil) return;
+    Frame *old_frame = feature_tracking_map->get_frame(frame_id);
+    std::vector<size_t> outlier_cnts(curr_frame->keypoint_num(), 0), matches_cnts(curr_frame->keypoint_num(), 0);
+    const size_t last = map->frame_num() - 1;
+    // std::min(last, std::max(last - check_size, size_t(0))) with unsigned wrap-around, as written (:706-709)
+    const size_t start_idx = std::min(last, std::max(last - (size_t)sh.cfg.parsac_keyframe_check_size, size_t(0)));
+    for (size_t i = start_idx; i < last; i++) {
+        std::vector<char> mask;
+        std::vector<size_t> pts_to_index;
+        if (filter_parsac_2d2d(map->get_frame(i), curr_frame, mask, pts_to_index)) {
+            mask.resize(pts_to_index.size(), 0);
+            for (size_t j = 0; j < mask.size(); j++) {
+                if (!mask[j]) outlier_cnts[pts_to_index[j]] += 1;
+                matches_cnts[pts_to_index[j]] += 1;
+            }
+        }
+    }
+    for (size_t i = 0; i < curr_frame->keypoint_num(); i++)
+        if (Track *curr_track = curr_frame->get_track(i)) {
+            // the lookup goes through the frame id (compare<Frame *>), so the feature-tracker's frame finds the window's clone
+            const size_t j = curr_track->get_keypoint_index(old_frame);
+            if (j == 0 || j == nil) continue;  // (`if (size_t j = ...)` index-0 quirk, :727)
+            Track *old_track = old_frame->get_track(j);
+            const size_t outlier_th = map->frame_num() / 2;
+            if (outlier_cnts[i] > outlier_th / 2 && outlier_cnts[i] > 0.8 * matches_cnts[i]) curr_track->set_tag(TT_STATIC, false);
+            if (old_track && (!old_track->tag(TT_STATIC) || !curr_track->tag(TT_STATIC))) {
+                if (curr_track->tag(TT_STATIC) || old_track->tag(TT_STATIC)) sh.counters.tracks_marked_dynamic++;
+                curr_track->set_tag(TT_STATIC, false);
+                old_track->set_tag(TT_STATIC, false);
+            }
+        }
+}
+
 std::tuple<double, PoseState, MotionState> SlidingWindowTracker::get_latest_state() const {
     const Frame *frame = map->get_frame(map->frame_num() - 1);
     if (!frame->subframes.empty()) frame = frame->subframes.back().get();
@@ -943,6 +1101,7 @@ void rdvio_pipeline_config_default(rdvio_pipeline_config *c) {
     c->rotation_ransac_threshold = 10;
     c->random = 648;
     c->parsac_flag = 0;
+    c->parsac_keyframe_check_size = 3;
 }
 
 int rdvio_pipeline_create(rdvio_pipeline **out, const rdvio_pipeline_config *cfg, const rdvio_backend *backend) {
@@ -951,7 +1110,6 @@ int rdvio_pipeline_create(rdvio_pipeline **out, const rdvio_pipeline_config *cfg
     if (!backend->image_create || !backend->image_preprocess || !backend->image_detect || !backend->image_track || !backend->image_release ||
         !backend->image_destroy || !backend->preintegrate || !backend->ba_solve || !backend->marginalize)
         return RDVIO_ERR_INVALID;
-    if (cfg->parsac_flag) return RDVIO_ERR_INVALID;  // RD dynamic-outlier path: SURVEY.md 8f N2
     if (cfg->width <= 0 || cfg->height <= 0 || cfg->sliding_window_size < 2 || cfg->sliding_window_tracker_frequent < 1 ||
         cfg->initializer_keyframe_num < 2 || cfg->initializer_keyframe_gap < 1 || cfg->feature_tracker_max_keypoint_detection < 1)
         return RDVIO_ERR_INVALID;
@@ -1128,6 +1286,8 @@ int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out) {
     out[10] = c.solver_iterations;
     out[25] = c.no_translation_frames;
     out[26] = c.rotation_prior_factors;
+    out[27] = c.parsac_judgements;
+    out[28] = c.tracks_marked_dynamic;
     for (int k = 0; k < 7; ++k) {
         const bool pre = k == 3;  // microseconds and calls per backend call class
         out[11 + 2 * k] = (int64_t)(1e6 * (pre ? p->shared.backend.preintegrate_seconds : c.backend_seconds[k]));

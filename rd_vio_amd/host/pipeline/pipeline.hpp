@@ -16,7 +16,7 @@ namespace rdvio_pipe {
 struct Counters {
     int64_t frames_tracked = 0, window_solves = 0, keyframes = 0, marginalizations = 0, localizations = 0, subwindow_solves = 0;
     int64_t max_problem_frames = 0, max_problem_factors = 0, solver_iterations = 0;
-    int64_t no_translation_frames = 0, rotation_prior_factors = 0;
+    int64_t no_translation_frames = 0, rotation_prior_factors = 0, parsac_judgements = 0, tracks_marked_dynamic = 0;
     // seconds spent inside backend calls: preprocess, detect, track, preintegrate, ba_solve, marginalize, image_create
     double backend_seconds[7] = {0, 0, 0, 0, 0, 0, 0};
     int64_t backend_calls[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -40,6 +40,8 @@ struct Shared {  // what every stage needs
     IdGenerator ids;
     Counters counters;
     std::vector<std::array<double, 17>> init_states;
+    // bin confidences of the two PARSAC call sites (function-local statics in the reference: pnp.h:195, stereo.cpp:147)
+    std::vector<float> pnp_bin_confidences = std::vector<float>(400, 0.5f), essential_bin_confidences = std::vector<float>(400, 0.5f);
 };
 
 // SoA export of one Solver problem (row A16): frames / landmarks / factors by index, ordered by landmark
@@ -93,7 +95,15 @@ class SlidingWindowTracker {
     void refine_subwindow();
     void integrate_subframes(Frame *frame);
     void marginalize_frame0();
+    // RD dynamic-outlier path (parsac_flag; sliding_window_tracker.cpp:487-769)
+    bool judge_track_status();
+    void update_track_status();
+    bool filter_parsac_2d2d(Frame *frame_i, Frame *frame_j, std::vector<char> &mask, std::vector<size_t> &pts_to_index);
     Shared &sh;
+    double m_th = 0.0;
+
+  public:
+    Map *feature_tracking_map = nullptr;  // frontend.cpp:37-38
 };
 
 // Bootstrap of the window from externally supplied keyframe states (the reference's Initializer without its SfM /

@@ -30,7 +30,7 @@ class PipelineConfig(ctypes.Structure):
         ("initializer_min_landmarks", ctypes.c_int32), ("initializer_min_parallax", ctypes.c_double),
         ("solver_iteration_limit", ctypes.c_int32),
         ("rotation_misalignment_threshold", ctypes.c_double), ("rotation_ransac_threshold", ctypes.c_double),
-        ("random", ctypes.c_int32), ("parsac_flag", ctypes.c_int32),
+        ("random", ctypes.c_int32), ("parsac_flag", ctypes.c_int32), ("parsac_keyframe_check_size", ctypes.c_int32),
     ]
 
 
@@ -73,7 +73,7 @@ def create_hip_pipeline(lib, ctx, cfg):
 def feed_stream(lib, handle, frames, ts, imu, per_frame=None):
     """Push IMU samples and frames in timestamp order.  per_frame(k_processed) is called whenever the feature tracker has
     consumed another frame.  Returns wall-clock seconds spent inside the pipeline calls."""
-    cnt = np.zeros(27, dtype=np.int64)
+    cnt = np.zeros(29, dtype=np.int64)
     seen = 0
     spent = 0.0
     ii = 0

@@ -367,9 +367,21 @@ def _wall_texture(u, v, seed):
     return img
 
 
-def render_room(q_wb, p_wb, K, w, h, extr=EUROC_EXTR, seed=648):
+MOVER_START = 2.6   # [s] the billboard rests until then (its points get mapped), then moves on its own
+
+
+def mover_center(t):
+    """centre of the billboard of render_room(..., mover_t=t): a 0.8 m textured square at height 1.6 m that is part of the
+    static scene until MOVER_START and then drifts sideways at 0.3 m/s -- an independently moving rigid object whose
+    landmarks are already in the map (the dynamic-outlier scenario of the RD path)."""
+    dt = max(0.0, t - MOVER_START)
+    return np.array([1.1 - 0.25 * dt, 0.8 - 0.2 * dt, 1.6])
+
+
+def render_room(q_wb, p_wb, K, w, h, extr=EUROC_EXTR, seed=648, mover_t=None):
     """u8 image seen by the camera of a body at pose (q_wb, p_wb) inside the textured box room: per-pixel ray cast
-    against the six walls (geometrically consistent across frames: true parallax and perspective)."""
+    against the six walls (geometrically consistent across frames: true parallax and perspective).  mover_t adds a
+    horizontal textured square at mover_center(mover_t) in front of the ceiling."""
     q_wc = q_mul(q_wb, extr[0:4])
     R = q_to_mat(q_wc)
     c = p_wb + q_to_mat(q_wb) @ extr[4:7]
@@ -393,17 +405,29 @@ def render_room(q_wb, p_wb, K, w, h, extr=EUROC_EXTR, seed=648):
             tex = _wall_texture(hit[..., a1][ok], hit[..., a2][ok], seed + 100 * plane)
             img[ok] = tex
             best_t[ok] = t[ok]
+    if mover_t is not None:
+        mc = mover_center(mover_t)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (mc[2] - c[2]) / d[..., 2]
+        hit = c[None, None, :] + t[..., None] * d
+        u, v = hit[..., 0] - mc[0], hit[..., 1] - mc[1]
+        ok = (t > 1e-6) & (t < best_t) & (np.abs(u) <= 0.4) & (np.abs(v) <= 0.4)
+        if ok.any():
+            # feathered border: a hard step edge would own GFTT's quality threshold (1e-3 of the strongest corner)
+            alpha = np.clip((0.4 - np.maximum(np.abs(u[ok]), np.abs(v[ok]))) / 0.08, 0.0, 1.0)
+            img[ok] = alpha * _wall_texture(u[ok], v[ok], seed + 4242) + (1.0 - alpha) * img[ok]   # the texture travels with the object
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
-def make_stream(n_frames, w=752, h=480, K=EUROC_K, t0=1.0, cam_rate=20.0, imu_rate=200.0, seed=648, imu_noise=True, pose_fn=None):
+def make_stream(n_frames, w=752, h=480, K=EUROC_K, t0=1.0, cam_rate=20.0, imu_rate=200.0, seed=648, imu_noise=True, pose_fn=None,
+                mover=False):
     """A synthetic EuRoC-shaped stream on the SURVEY.md 8d trajectory: images (n_frames x h x w u8), frame times, IMU rows
     (t, gyro, acc) covering the frames with the constant biases TRUE_BG / TRUE_BA added, and the ground-truth body
     states at the frame times as rows (t, q, p, v, bg, ba)."""
     rng = np.random.default_rng(seed + 1)
     ts = t0 + np.arange(n_frames) / cam_rate
     pose_fn = pose_fn or traj_pose
-    frames = np.stack([render_room(*pose_fn(t), K, w, h, seed=seed) for t in ts])
+    frames = np.stack([render_room(*pose_fn(t), K, w, h, seed=seed, mover_t=(t if mover else None)) for t in ts])
     imu = make_imu_segment(t0 - 0.5 / imu_rate - 2.0 / imu_rate, ts[-1] + 3.0 / imu_rate, rate=imu_rate, rng=rng if imu_noise else None,
                            noise=imu_noise, bg=TRUE_BG, ba=TRUE_BA, pose_fn=pose_fn)
     gt = np.zeros((n_frames, 17))

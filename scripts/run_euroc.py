@@ -30,9 +30,6 @@ def main():
     from rd_vio_amd import pipeline_run as pr
 
     K, w, h, extr, noise, over = euroc.config_overrides(args.sensor, args.setting)
-    if over.get("parsac_flag"):
-        print("note: parsac_flag is set in the settings; the RD dynamic-outlier path is not built, running without it", file=sys.stderr)
-        over["parsac_flag"] = 0
     ds = euroc.EurocDataset(args.mav_dir)
     if args.bootstrap_from_groundtruth and ds.groundtruth is None:
         raise SystemExit("--bootstrap-from-groundtruth needs mav0/state_groundtruth_estimate0/data.csv")

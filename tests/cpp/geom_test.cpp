@@ -5,6 +5,7 @@
 #include <random>
 
 #include "../../rd_vio_amd/host/pipeline/geom.hpp"
+#include "../../rd_vio_amd/host/pipeline/parsac.hpp"
 
 using namespace rdvio_pipe;
 
@@ -190,6 +191,57 @@ int main() {
         CHECK(norm(wl - w) < 1e-12, "logmap(expmap(w))");
         const V3 va = normalized(V3{0.2, -1.0, 0.4}), vb = normalized(V3{-0.5, 0.1, 0.9});
         CHECK(norm(rot(from_two_vectors(va, vb), va) - vb) < 1e-12, "from_two_vectors");
+    }
+    {
+        // EPnP: six points, known pose; the float32 round trips of pnp.h:11-48 bound the accuracy
+        std::array<V3, 6> Xs;
+        std::array<V2, 6> xs;
+        for (int i = 0; i < 6; ++i) {
+            Xs[i] = V3{2.0 * U(rng), 1.5 * U(rng), 4.0 + U(rng)};
+            xs[i] = hnormalized(R * Xs[i] + t);
+        }
+        const std::vector<Pose4> sol = solve_pnp_6pt(Xs, xs);
+        CHECK(sol.size() == 1, "solve_pnp_6pt returned %zu poses", sol.size());
+        double er = 0;
+        for (int i = 0; i < 9; ++i) er = std::max(er, std::fabs(sol[0].R.m[i] - R.m[i]));
+        CHECK(er < 1e-4 && norm(sol[0].t - t) < 1e-3, "EPnP pose error: R %g t %g", er, norm(sol[0].t - t));
+        // IMU-PARSAC: 70 static points + 30 points on an object that moved by 0.4 m between mapping and observation;
+        // the prior is the true pose.  Inliers = the static set.
+        std::vector<V3> P3;
+        std::vector<V2> p2;
+        std::vector<size_t> lens;
+        for (int i = 0; i < 100; ++i) {
+            const V3 X{2.4 * U(rng), 1.6 * U(rng), 4.0 + U(rng)};
+            const V3 Xobs = i < 70 ? X : X + V3{0.4, -0.25, 0.0};
+            P3.push_back(X);
+            p2.push_back(hnormalized(R * Xobs + t));
+            lens.push_back(5 + (size_t)(i % 7));
+        }
+        std::vector<char> mask;
+        std::vector<float> bins(400, 0.5f);
+        const Pose4 T = find_pnp_matrix_parsac_imu(P3, p2, lens, R, t, 0.20, 1.0, mask, bins, 1.0 / 458.0);
+        size_t good = 0, bad = 0;
+        for (int i = 0; i < 100; ++i) (i < 70 ? good : bad) += (mask[(size_t)i] != 0);
+        CHECK(good >= 66 && bad <= 2, "IMU-PARSAC: %zu of 70 static kept, %zu of 30 dynamic kept", good, bad);
+        double eT = 0;
+        for (int i = 0; i < 9; ++i) eT = std::max(eT, std::fabs(T.R.m[i] - R.m[i]));
+        CHECK(eT < 5e-3, "IMU-PARSAC pose rotation error %g", eT);
+        // PARSAC essential: the same split seen in two views
+        std::vector<V2> a, b;
+        for (int i = 0; i < 100; ++i) {
+            const V3 X = P3[(size_t)i];
+            a.push_back(hnormalized(X));
+            b.push_back(p2[(size_t)i]);
+        }
+        std::vector<float> ebins(400, 0.5f);
+        std::vector<char> emask;
+        (void)find_essential_matrix_parsac(a, b, emask, ebins, 1.0 / 458.0);
+        good = bad = 0;
+        for (int i = 0; i < 100; ++i) (i < 70 ? good : bad) += (emask[(size_t)i] != 0);
+        CHECK(good >= 60 && bad <= 6, "PARSAC essential: %zu of 70 static kept, %zu of 30 dynamic kept", good, bad);
+        float mx = 0;
+        for (float c : ebins) mx = std::max(mx, c);
+        CHECK(mx > 0.5f && mx <= 1.0f, "bin confidences not updated (max %g)", (double)mx);
     }
     {
         // LotBox draws are a permutation prefix

@@ -68,7 +68,7 @@ def run_stream(lib, make_pipeline, frames, ts, imu, gt, max_kp=600):
             sys_state.append(lib.rdvio_pipeline_state(h))
 
         feed_stream(lib, h, frames, ts, imu, per_frame=lambda _n: snapshot(force=True))
-        cnt = np.zeros(27, dtype=np.int64)
+        cnt = np.zeros(29, dtype=np.int64)
         lib.rdvio_pipeline_counters(h, cnt.ctypes.data_as(ctypes.c_void_p))
         return dict(traj=np.array(traj), keypoints=kps, counters=cnt, states=np.array(states), sys_state=np.array(sys_state))
     finally:

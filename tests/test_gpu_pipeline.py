@@ -14,12 +14,18 @@ OVER = dict(sliding_window_size=8, feature_tracker_max_keypoint_detection=150, f
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["translation_full_res", "rotation_phase_half_res", "full_initializer_half_res"])
+@pytest.mark.parametrize("case", ["translation_full_res", "rotation_phase_half_res", "full_initializer_half_res", "dynamic_object_parsac"])
 def test_hip_pipeline_reproduces_the_cpu_path(case):
     if case == "translation_full_res":
         W, H, K = 752, 480, synth.EUROC_K
         frames, ts, imu, gt = synth.make_stream(36, W, H, K)
         pose_fn = synth.traj_pose
+    elif case == "dynamic_object_parsac":
+        # row A19: a mapped object starts to move at t = 2.6 s; parsac_flag enables judge_track_status / update_track_status
+        # (IMU-PARSAC over EPnP hypotheses, PARSAC essential checks)
+        W, H, K = 752, 480, synth.EUROC_K
+        pose_fn = synth.traj_pose
+        frames, ts, imu, gt = synth.make_stream(80, W, H, K, mover=True)
     elif case == "full_initializer_half_res":
         # no bootstrap states: Initializer::initialize (SfM + IMU alignment) runs on both paths
         W, H = 376, 240
@@ -38,6 +44,8 @@ def test_hip_pipeline_reproduces_the_cpu_path(case):
         frames, ts, imu, gt = synth.make_stream(80, W, H, K, pose_fn=pose_fn)
     lib, shim = pu.load_pipeline_lib(), pu.build_oracle_backend()
     over = dict(OVER, initializer_keyframe_gap=3, initializer_min_parallax=5.0, initializer_min_triangulation=20) if case == "full_initializer_half_res" else OVER
+    if case == "dynamic_object_parsac":
+        over = dict(OVER, parsac_flag=1, parsac_keyframe_check_size=1)
     cfg = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **over)
     cpu = pu.run_stream(lib, pu.oracle_pipeline_factory(lib, shim, cfg), frames, ts, imu, gt)
     ctx = rd_vio_amd.Context(max_width=W, max_height=H, max_features=1024, max_window=16, max_factors=20000)
@@ -63,6 +71,17 @@ def test_hip_pipeline_reproduces_the_cpu_path(case):
     p_gt = np.array([pose_fn(t)[1] for t in sc[ok, 0]])
     if case == "rotation_phase_half_res":
         assert cpu["counters"][25] >= 10                        # the rotation-only branch was really exercised
+    if case == "dynamic_object_parsac":
+        assert cpu["counters"][27] >= 30 and cpu["counters"][28] >= 20   # judgements ran, tracks were switched to non-static
+        off = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **dict(over, parsac_flag=0))
+        ref = pu.run_stream(lib, pu.oracle_pipeline_factory(lib, shim, off), frames, ts, imu, gt)
+        so = ref["states"]
+        oo = ~np.isnan(so[:, 0])
+        e_on = np.linalg.norm(sc[ok, 5:8] - p_gt, axis=1).mean()
+        e_off = np.linalg.norm(so[oo, 5:8] - np.array([pose_fn(t)[1] for t in so[oo, 0]]), axis=1).mean()
+        assert e_on < e_off                                     # rejecting the moving object's tracks helps
+        assert np.linalg.norm(sg[ok, 5:8] - p_gt, axis=1).max() < 0.25
+        return
     if case == "full_initializer_half_res":                    # own world frame: compare after a rigid alignment
         assert pu.ate_rmse(sg[ok, 5:8], p_gt) < 0.06
         return

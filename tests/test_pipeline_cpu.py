@@ -52,10 +52,11 @@ def test_pipeline_library_exports_every_declared_symbol(libs):
 def test_pipeline_rejects_unsupported_configs(libs):
     lib, shim = libs
     cfg = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **OVER)
-    cfg.parsac_flag = 1     # RD dynamic-outlier path: not built -> refused loudly
+    cfg.sliding_window_size = 1      # meaningless window -> refused loudly
     h = ctypes.c_void_p()
     assert pu.oracle_pipeline_factory(lib, shim, cfg)(ctypes.byref(h)) != 0
-    cfg.parsac_flag = 0
+    cfg.sliding_window_size = 8
+    cfg.parsac_flag = 1              # the RD dynamic-outlier path is a supported configuration
     assert pu.oracle_pipeline_factory(lib, shim, cfg)(ctypes.byref(h)) == 0
     img = np.zeros((H + 1, W), dtype=np.uint8)   # wrong shape
     assert lib.rdvio_pipeline_add_frame(h, ctypes.c_double(0.0), img.ctypes.data_as(ctypes.c_void_p), W, H + 1, W, None) != 0
