@@ -27,6 +27,10 @@ CONFIGS = {
     # BASELINE.json configs[1]: EuRoC V1_01_easy shape, 150 features, window 8
     "euroc_v101": dict(width=752, height=480, features=150, window=8, landmarks=150, iters=30,
                        name="EuRoC V1_01_easy-shaped synthetic stream 752x480, 150 features, window 8, LK + BA on GPU"),
+    # configs[2]: MH_03_medium shape, 300 features, window 10, RD dynamic-outlier path on (end-to-end leg: a mapped object
+    # starts to move, parsac_flag = 1)
+    "euroc_mh03_rd": dict(width=752, height=480, features=300, window=10, landmarks=300, iters=30, parsac=True,
+                          name="EuRoC MH_03_medium-shaped synthetic stream 752x480, 300 features, window 10, RD path"),
     # configs[4]: roofline run
     "synthetic_720p": dict(width=1280, height=720, features=1000, window=16, landmarks=1000, iters=30,
                            name="synthetic 1280x720 stream, 1000 features, window 16"),
@@ -198,13 +202,13 @@ def end_to_end(cfg, ctx, n_frames, with_cpu_path):
     K = synth.EUROC_K.copy()
     if (w, h) != (752, 480):
         K = np.array([[900.0, 0, w / 2.0], [0, 900.0, h / 2.0], [0, 0, 1.0]])
-    frames, ts, imu, gt = synth.make_stream(n_frames, w, h, K)
+    frames, ts, imu, gt = synth.make_stream(n_frames, w, h, K, mover=bool(cfg.get("parsac")))
     lib = pr.load_pipeline_lib()
     pcfg = pr.default_config(lib, K, w, h, synth.EUROC_EXTR, synth.EUROC_NOISE, sliding_window_size=cfg["window"],
                              feature_tracker_max_keypoint_detection=cfg["features"], feature_tracker_min_keypoint_distance=10.0,
                              solver_iteration_limit=cfg["iters"], feature_tracker_max_frames=20,
                              sliding_window_force_keyframe_landmarks=50, sliding_window_subframe_size=3,
-                             rotation_misalignment_threshold=0.02)
+                             rotation_misalignment_threshold=0.02, parsac_flag=1 if cfg.get("parsac") else 0, parsac_keyframe_check_size=1)
     gt_c = np.ascontiguousarray(gt)
 
     def run(handle):
@@ -234,6 +238,7 @@ def end_to_end(cfg, ctx, n_frames, with_cpu_path):
     out = {"frames": int(cnt[0]), "frames_tracking": int(tracking.sum()), "fps": round(float(cnt[0] / spent), 2),
            "window_solves": int(cnt[1]), "marginalizations": int(cnt[3]), "localizations": int(cnt[4]), "subwindow_solves": int(cnt[5]),
            "largest_solve": {"frames": int(cnt[8]), "factors": int(cnt[9])}, "solver_iterations": int(cnt[10]),
+           "rd_path": {"imu_parsac_judgements": int(cnt[27]), "tracks_marked_dynamic": int(cnt[28])},
            "backend_ms_per_frame": {name: round(float(cnt[11 + 2 * k]) / 1e3 / max(int(cnt[0]), 1), 4) for k, name in enumerate(
                ("preprocess", "detect", "track", "preintegrate", "ba_solve", "marginalize", "image_create"))},
            "backend_calls": {name: int(cnt[12 + 2 * k]) for k, name in enumerate(
