@@ -109,11 +109,8 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
     CTX_ALLOC(ctx->ba_Jd, (size_t)max_factors * 2 * sizeof(double));
     ctx->pre_max_seg = nfr + 8;
     ctx->pre_max_samples = ctx->pre_max_seg * 256;
-    CTX_ALLOC(ctx->pre_imu, (size_t)ctx->pre_max_samples * 7 * sizeof(double));
-    CTX_ALLOC(ctx->pre_par, ((size_t)ctx->pre_max_seg * 7 + 36) * sizeof(double));
     CTX_ALLOC(ctx->pre_out, (size_t)ctx->pre_max_seg * RDVIO_PREINT_SIZE * sizeof(double));
     CTX_ALLOC(ctx->pre_blob, ((size_t)ctx->pre_max_seg * 7 + 36 + (size_t)ctx->pre_max_samples * 7 + (size_t)ctx->pre_max_seg + 8) * sizeof(double));
-    CTX_ALLOC(ctx->pre_off, (size_t)(ctx->pre_max_seg + 1) * sizeof(int32_t));
     {
         const size_t F = (size_t)max_factors, Lm = (size_t)max_factors, Nmax = 15 * (size_t)nfr, npre = (size_t)nfr + 8;
         size_t bytes = (1 << 16) + F * (520 + 3 * 26 * 8 + 12) + Lm * (192 + 48 * (size_t)nfr) + Nmax * Nmax * 8 * 7 + npre * 930 * 8 +
@@ -163,7 +160,7 @@ void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
     void *bufs[] = {ctx->gray, ctx->clahe_lut, ctx->harris, ctx->harris_scalars, ctx->harris_cand, ctx->lk_curr,
                     ctx->lk_next, ctx->lk_prevf, ctx->lk_nextf, ctx->lk_status, ctx->ba_states, ctx->ba_extr,
                     ctx->ba_zref, ctx->ba_invd, ctx->ba_tangent, ctx->ba_idx, ctx->ba_r, ctx->ba_Jt, ctx->ba_Jr,
-                    ctx->ba_Jd, ctx->pre_imu, ctx->pre_par, ctx->pre_out, ctx->pre_off, ctx->pre_blob};
+                    ctx->ba_Jd, ctx->pre_out, ctx->pre_blob};
     for (void *b : bufs) (void)hipFree(b);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->marg.host) (void)hipHostFree(ctx->marg.host);

@@ -51,8 +51,7 @@ struct rdvio_hip_ctx {
     double *ba_states = nullptr, *ba_extr = nullptr, *ba_zref = nullptr, *ba_invd = nullptr, *ba_tangent = nullptr;
     int32_t *ba_idx = nullptr;  // tgt | ref | lm, each max_factors
     double *ba_r = nullptr, *ba_Jt = nullptr, *ba_Jr = nullptr, *ba_Jd = nullptr;
-    double *pre_imu = nullptr, *pre_par = nullptr, *pre_out = nullptr, *pre_blob = nullptr;
-    int32_t *pre_off = nullptr;
+    double *pre_out = nullptr, *pre_blob = nullptr;  // results; one staging blob (par | noise | samples | offsets)
     int pre_max_samples = 0, pre_max_seg = 0;
 
     // BA solver: pinned input blob, device arena (inputs + scratch), workspace descriptor

@@ -48,7 +48,7 @@ struct SolverWs {
     double *e_p, *G, *r_p, *c_p, *Jp;    // Jp: per factor [Ji 225 | Jj 225]
     double *e_m, *r_m, *c_m, *Jri, *Lam, *eta0, *le, *Ex;
     // ---- normal equations / step
-    double *H, *Sm, *g, *yp, *Cm, *Cg;   // Cm: (6 nfree)^2 landmark Schur term, Cg: its gradient part
+    double *H, *Sm, *g, *yp, *Cm;        // Cm: (6 nfree + 2)^2 landmark Schur term A^T W [A | g] (gradient part in column 6 nfree)
     double *lm_m, *lm_g, *lm_w, *A, *yl;
     double *sig_p, *sig_l, *diag_p, *diag_l, *grad_p, *grad_l, *gn_p, *gn_l, *tp, *tl;
     double *summary;

@@ -493,7 +493,6 @@ bool SlidingWindowTracker::manage_keyframe() {
     for (size_t k = 0; k < newframe_j->keypoint_num(); ++k)
         if (Track *track = newframe_j->get_track(k))
             if (track->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) mapped_landmark_count++;
-    if (std::getenv("RDVIO_PIPE_DEBUG")) std::fprintf(stderr, "manage: kp %zu mapped %zu tracks %zu\n", newframe_j->keypoint_num(), mapped_landmark_count, map->track_num());
     const bool is_keyframe = mapped_landmark_count < (size_t)sh.cfg.sliding_window_force_keyframe_landmarks;
     if (is_keyframe) {
         newframe_j->set_tag(FT_KEYFRAME, true);
@@ -876,11 +875,6 @@ bool SlidingWindowTracker::judge_track_status() {
         (mask[(size_t)indices_map[i]] ? inliers_dist : outliers_dist).push_back(err);
     }
     const size_t min_num = 20;
-    if (std::getenv("RDVIO_PIPE_DEBUG")) {
-        size_t inl = 0;
-        for (char c : mask) inl += c;
-        std::fprintf(stderr, "judge: P2D %zu pnp-inliers %zu dist-in %zu dist-out %zu\n", P2D.size(), inl, inliers_dist.size(), outliers_dist.size());
-    }
     if (inliers_dist.size() < min_num || outliers_dist.size() < min_num) return false;
     std::sort(inliers_dist.begin(), inliers_dist.end());
     std::sort(outliers_dist.begin(), outliers_dist.end());
