@@ -16,6 +16,7 @@ struct BlockShared {
     double vec[16];
     int flag;
     int red_phase;
+    int seq;  // command sequence number of the helper-workgroup protocol (solver)
     // small per-problem index tables (solver): frame -> free column block, column block -> prior frame, preintegration sources
     // per frame (up to RDVIO_SOLVER_MAX_FRAMES = 64, most of them constant anchors) / per free column block (<= 32)
     int fcol[64], pcol[32], band_src[32 * 6], g_src[32 * 2];

@@ -32,6 +32,7 @@ struct rdvio_hip_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int max_w = 0, max_h = 0, max_feat = 0, max_window = 0, max_factors = 0;
+    int solver_wgs = 8;  // workgroups per solver launch for problems with >= RDVIO_HELPER_MIN_FACTORS factors (env RDVIO_SOLVER_WGS)
     rdvio_pyr_layout maxL{};
 
     ImageSlot slots[RDVIO_NUM_SLOTS];

@@ -205,6 +205,7 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     auto dd = [&](size_t n) { return Sx.reserve(std::max<size_t>(n, 1) * sizeof(double)); };
     // x | xd | summary are adjacent: the result travels back with one copy
     const size_t s_x = dd((size_t)nfr * 16), s_xd = dd(nl), s_sum = dd(80);  // summary[0..7] + diagnostic phase stamps
+    const size_t s_sync = dd(8), s_partial = dd(RDVIO_MAX_SOLVER_WGS);
     const size_t s_xc = dd((size_t)nfr * 16), s_xdc = dd(nl), s_user = dd((size_t)nfr * 16);
     const size_t s_lfree = Sx.reserve(std::max(nl, 1));
     const size_t s_fac = dd((size_t)nf * RDVIO_FAC_STRIDE), s_prec = dd((size_t)nrec * RDVIO_REC_STRIDE), s_GP = dd((size_t)npairs * 256);
@@ -258,6 +259,11 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     w.sig_p = DP(s_sigp); w.sig_l = DP(s_sigl); w.diag_p = DP(s_dgp); w.diag_l = DP(s_dgl); w.grad_p = DP(s_grp); w.grad_l = DP(s_grl);
     w.gn_p = DP(s_gnp); w.gn_l = DP(s_gnl); w.tp = DP(s_tp); w.tl = DP(s_tl);
     w.summary = DP(s_sum);
+    w.sync = (unsigned *)(B + s_sync); w.partial = DP(s_partial);
+    // helper workgroups: a command round trip costs ~8 us (L2 atomics, barriers, re-staging the states), one evaluation
+    // of F factors on the leader alone ~F / 90 us -- measured break-even near 2000 factors; the marginalisation kernel
+    // (a single linearisation) never uses them
+    w.n_wg = (!with_marg_tail && nf >= RDVIO_HELPER_MIN_FACTORS && ctx->solver_wgs > 1) ? ctx->solver_wgs : 1;
     if (with_marg_tail) {
         w.no_loss = 1;
         w.m_Tm = DP(s_mTm); w.m_Lr = DP(s_mLr); w.m_er = DP(s_mer); w.m_Wk = DP(s_mWk); w.m_V = DP(s_mV); w.m_cs = DP(s_mcs);
@@ -297,6 +303,7 @@ int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int slot, int max_iterations
     SolverWs &w = S.ws;
     w.max_iter = max_iterations;
     // the kernel (re)starts from the uploaded initial values (SolverWs::x0 / xd0): no host traffic, no extra copies
+    if (w.n_wg > 1) RDVIO_HIP_CHECK(ctx, hipMemsetAsync(w.sync, 0, 8 * sizeof(double), ctx->stream));
     rdvio_launch_ba_solve(ctx->stream, w);
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
     return RDVIO_OK;

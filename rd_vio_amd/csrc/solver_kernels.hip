@@ -57,6 +57,216 @@ DM double prior_E(const Shared &sh, int i, int a, int b) {
     return a == b ? 1.0 : 0.0;
 }
 
+// one reprojection factor of the stored linearisation (robustified residual + Jacobians, per-factor landmark products,
+// the target slot of the coupling row, the group-ordered record); returns the factor's cost
+DM double linearize_factor(const SolverWs &w, Shared &sh, int k, const double *states, const double *invd, const double *extr, const double *W) {
+    double cost = 0.0;
+    double r[2], Jt[12], Jr[12], Jd[2];
+    const int l = w.lm[k];
+    reprojection_factor<true>(states + 16 * w.tgt[k], states + 16 * w.ref[k], w.tangent + 9 * (size_t)k,
+                             w.z_ref + 3 * (size_t)l, invd[l], extr, W, r, Jt, Jr, Jd);
+    const double s = r[0] * r[0] + r[1] * r[1];
+    const double sum = 1.0 + s;
+    cost += w.no_loss ? 0.5 * s : 0.5 * log(sum);
+    if (true) {
+        const double sc = w.no_loss ? 1.0 : sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
+        r[0] *= sc;
+        r[1] *= sc;
+        Jd[0] *= sc;
+        Jd[1] *= sc;
+        double *o = w.fac + RDVIO_FAC_STRIDE * (size_t)k;
+        // pose-constant frames (frame_fixed == 2) keep their columns, with zero pose Jacobians
+        const double zt = sh.pfix[w.tgt[k]] ? 0.0 : sc, zr = sh.pfix[w.ref[k]] ? 0.0 : sc;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            Jt[i] *= zt;
+            Jr[i] *= zr;
+            o[i] = Jt[i];
+            o[12 + i] = Jr[i];
+        }
+        o[24] = Jd[0];
+        o[25] = Jd[1];
+        o[26] = r[0];
+        o[27] = r[1];
+        // per-factor landmark products: ht = Jd^T Jt, hr = Jd^T Jr, m = Jd^T Jd, g = Jd^T r
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            o[28 + a] = Jd[0] * Jt[a] + Jd[1] * Jt[6 + a];
+            o[34 + a] = Jd[0] * Jr[a] + Jd[1] * Jr[6 + a];
+        }
+        o[40] = Jd[0] * Jd[0] + Jd[1] * Jd[1];
+        o[41] = Jd[0] * r[0] + Jd[1] * r[1];
+        // coupling row of the landmark: the target frame's slot belongs to this factor alone (one observation per
+        // (track, frame)), so it is a plain store; the anchor slot is summed in the landmark pass
+        {
+            const int ctc = sh.fcol[w.tgt[k]];
+            if (ctc >= 0 && w.lfree[l]) {
+                double *Arow = w.A + (size_t)l * (6 * w.nfree + 2) + 6 * ctc;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) Arow[a] = o[28 + a];
+            }
+        }
+        // group-ordered record [J_lo | J_hi | r]: the assembly streams these with no indirection
+        const int gs = w.gslot[k];
+        if (gs >= 0) {
+            double *q = w.prec + RDVIO_REC_STRIDE * (size_t)gs;
+            const bool flip = w.gflip[k] != 0;          // first slot holds Jr
+            const bool both = sh.fcol[w.tgt[k]] >= 0 && sh.fcol[w.ref[k]] >= 0;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                q[i] = flip ? Jr[i] : Jt[i];
+                q[12 + i] = both ? (flip ? Jt[i] : Jr[i]) : 0.0;
+            }
+            q[24] = r[0];
+            q[25] = r[1];
+        }
+    }
+    return cost;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Helper workgroups.  The factor evaluation is issue-bound on one CU, so a solve may be launched
+// with n_wg > 1 workgroups: workgroup 0 runs the trust-region loop, the others wait for "evaluate your share of the
+// factors" commands.  Protocol (all words in w.sync, agent-scope atomics):
+//   sync[0] (sequence number << 12) | command   (release-stored by the leader, acquire-polled by the helpers);
+//           command: bit 0 = with linearisation, bit 1 = candidate states (xc / xdc), 0x100 = exit
+//   sync[1] completion counter                  (release-incremented by each helper, acquire-polled by the leader)
+// partial[g] is written with a plain store before the helper's release-increment and read with an atomic load (never
+// through the scalar cache).
+// Every wait is bounded (RDVIO_SPIN_LIMIT polls of ~0.2 us): a helper that never hears from the leader exits, a leader
+// that never hears from a helper reports failure -- the grid always drains.  The launch assumes the workgroups are
+// co-resident (one per CU on an otherwise idle stream), which is what a <= 16-workgroup grid on 256 CUs gets.
+// ---------------------------------------------------------------------------------------------
+#define RDVIO_SPIN_LIMIT 1000000
+enum { CMD_LIN = 1, CMD_CAND = 2, CMD_EXIT = 0x100 };
+
+DM unsigned sync_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+DM void sync_store(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+// leader: publish a command (all earlier global writes of the workgroup become visible to the helpers)
+DM void post_command(const SolverWs &w, Shared &sh, unsigned cmd) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(w.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh.seq += 1;
+        sync_store(w.sync, ((unsigned)sh.seq << 12) | cmd);
+    }
+}
+// leader: wait for all helpers; returns the sum of their partial costs in workgroup order (NaN on timeout)
+DM double collect_partials(const SolverWs &w, Shared &sh) {
+    const int G = w.n_wg - 1;
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while (sync_load(w.sync + 1) != (unsigned)G && ++spins < RDVIO_SPIN_LIMIT) __builtin_amdgcn_s_sleep(4);
+        sh.flag = spins < RDVIO_SPIN_LIMIT ? 1 : 0;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    double extra = 0.0;
+    if (threadIdx.x == 0) {
+        if (!sh.flag) extra = __builtin_nan("");
+        else
+            for (int g = 1; g <= G; ++g)
+                extra += __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(w.partial + g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    return extra;
+}
+
+// cost-only pass over the factors gid, gid + P, ...: two independent factors per trip so that their FP64 dependency
+// chains interleave (a workgroup has only two wavefronts per SIMD to hide latency with); fixed summation order
+DM double cost_factors(const SolverWs &w, const double *states, const double *invd, const double *extr, const double *W, int gid, int P) {
+    double cost = 0.0;
+    for (int k = gid; k < w.nf; k += 2 * P) {
+        const int k2 = k + P;
+        const bool has2 = k2 < w.nf;
+        const int kb = has2 ? k2 : k;
+        double ra[2], rb[2];
+        const int la = w.lm[k], lb = w.lm[kb];
+        reprojection_factor<false>(states + 16 * w.tgt[k], states + 16 * w.ref[k], w.tangent + 9 * (size_t)k, w.z_ref + 3 * (size_t)la, invd[la],
+                                   extr, W, ra, nullptr, nullptr, nullptr);
+        reprojection_factor<false>(states + 16 * w.tgt[kb], states + 16 * w.ref[kb], w.tangent + 9 * (size_t)kb, w.z_ref + 3 * (size_t)lb, invd[lb],
+                                   extr, W, rb, nullptr, nullptr, nullptr);
+        const double sa = ra[0] * ra[0] + ra[1] * ra[1], sb = rb[0] * rb[0] + rb[1] * rb[1];
+        cost += w.no_loss ? 0.5 * sa : 0.5 * log(1.0 + sa);
+        if (has2) cost += w.no_loss ? 0.5 * sb : 0.5 * log(1.0 + sb);
+    }
+    return cost;
+}
+
+// rotation-prior factors gid, gid + P, ...
+template <bool LIN>
+DM double rotation_factors(const SolverWs &w, Shared &sh, const double *states, const double *extr, const double *W, int gid, int P) {
+    double cost = 0.0;
+    for (int k = gid; k < w.nrot; k += P) {
+        double r[2], J[6];
+        rotation_prior_factor<LIN>(states + 16 * w.rot_tgt[k], states + 16 * w.rot_ref[k], w.rot_zref + 3 * k, w.rot_tangent + 9 * k, extr, W, r, J);
+        const double s = r[0] * r[0] + r[1] * r[1];
+        const double sum = 1.0 + s;
+        cost += 0.5 * log(sum);
+        if (LIN) {
+            const double sc = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
+            w.r_r[2 * k] = r[0] * sc;
+            w.r_r[2 * k + 1] = r[1] * sc;
+            const double zs = sh.pfix[w.rot_tgt[k]] ? 0.0 : sc;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w.Jro[6 * k + i] = J[i] * zs;
+        }
+    }
+    return cost;
+}
+
+// the helpers' side: serve evaluation commands until told to exit (or until the leader goes silent)
+__device__ __attribute__((noinline)) void helper_loop(const SolverWs &w, Shared &sh) {
+    const int t = threadIdx.x;
+    constexpr int TFm = T - 64;
+    const int P = TFm + (w.n_wg - 1) * T, gid = TFm + ((int)blockIdx.x - 1) * T + t;
+    int phase = 0;
+    unsigned seen = 0;
+    for (;;) {
+        if (t == 0) {
+            int spins = 0;
+            unsigned s;
+            while ((s = sync_load(w.sync)) == seen && ++spins < RDVIO_SPIN_LIMIT) __builtin_amdgcn_s_sleep(4);
+            sh.flag = (s == seen) ? -1 : (int)s;
+        }
+        __syncthreads();
+        const int s = sh.flag;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (s < 0) return;  // the leader went silent
+        seen = (unsigned)s;
+        const unsigned cmd = seen & 0xfffu;
+        if (cmd & CMD_EXIT) return;
+        const double *states = (cmd & CMD_CAND) ? w.xc : w.x, *invd = (cmd & CMD_CAND) ? w.xdc : w.xd;
+        if ((seen >> 12) == 1) {  // first command: the leader's setup is complete, mirror the small tables
+            for (int i = t; i < 64; i += T) {
+                sh.fcol[i] = (i < w.nfr) ? w.fcol[i] : -1;
+                sh.pfix[i] = (i < w.nfr && w.frame_fixed[i] == 2) ? 1 : 0;
+            }
+            for (int i = t; i < 18; i += T) sh.ext[i] = w.extr[i];
+        }
+        for (int i = t; i < w.nfr * 16; i += T) sh.st[i] = states[i];
+        __syncthreads();
+        const double *W = sh.ext + 14, *extr = sh.ext;
+        double cost = 0.0;
+        if (cmd & CMD_LIN) {
+            for (int k = gid; k < w.nf; k += P) cost += linearize_factor(w, sh, k, sh.st, invd, extr, W);
+            cost += rotation_factors<true>(w, sh, sh.st, extr, W, gid, P);
+        } else {
+            cost += cost_factors(w, sh.st, invd, extr, W, gid, P);
+            cost += rotation_factors<false>(w, sh, sh.st, extr, W, gid, P);
+        }
+        cost = block_sum(sh, cost, phase);
+        __threadfence();
+        __syncthreads();
+        if (t == 0) {
+            w.partial[blockIdx.x] = cost;
+            __threadfence();
+            __hip_atomic_fetch_add(w.sync + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // cost (and optionally the stored, robustified linearisation) at (states, invd).
 // Waves 0..NW-2 evaluate reprojection factors while the last wave evaluates the (long, serial) preintegration
@@ -73,104 +283,14 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
     const double *W = sh.ext + 14, *extr = sh.ext;
     double cost = 0.0;
     constexpr int TF = T - 64;
+    // threads that evaluate reprojection factors: TF of this workgroup + every thread of the helper workgroups
+    const int P = TF + (w.n_wg - 1) * T, gid = t;
+    if (w.n_wg > 1) post_command(w, sh, (LIN ? CMD_LIN : 0u) | ((invd == w.xdc) ? CMD_CAND : 0u));
     if (t < TF) {
         // reprojection factors, CauchyLoss(1): cost 0.5 log(1+s); Corrector with rho'' < 0 => scale r, J by sqrt(rho')
-        if (!LIN) {
-            // cost-only evaluation: two independent factors per trip so that their FP64 dependency chains interleave
-            // (a single workgroup has only two wavefronts per SIMD to hide latency with); same summation order
-            for (int k = t; k < w.nf; k += 2 * TF) {
-                const int k2 = k + TF;
-                const bool has2 = k2 < w.nf;
-                const int kb = has2 ? k2 : k;
-                double ra[2], rb[2];
-                const int la = w.lm[k], lb = w.lm[kb];
-                reprojection_factor<false>(states + 16 * w.tgt[k], states + 16 * w.ref[k], w.tangent + 9 * (size_t)k, w.z_ref + 3 * (size_t)la,
-                                           invd[la], extr, W, ra, nullptr, nullptr, nullptr);
-                reprojection_factor<false>(states + 16 * w.tgt[kb], states + 16 * w.ref[kb], w.tangent + 9 * (size_t)kb, w.z_ref + 3 * (size_t)lb,
-                                           invd[lb], extr, W, rb, nullptr, nullptr, nullptr);
-                const double sa = ra[0] * ra[0] + ra[1] * ra[1], sb = rb[0] * rb[0] + rb[1] * rb[1];
-                cost += w.no_loss ? 0.5 * sa : 0.5 * log(1.0 + sa);
-                if (has2) cost += w.no_loss ? 0.5 * sb : 0.5 * log(1.0 + sb);
-            }
-        }
-        for (int k = t; LIN && k < w.nf; k += TF) {
-            double r[2], Jt[12], Jr[12], Jd[2];
-            const int l = w.lm[k];
-            reprojection_factor<LIN>(states + 16 * w.tgt[k], states + 16 * w.ref[k], w.tangent + 9 * (size_t)k,
-                                     w.z_ref + 3 * (size_t)l, invd[l], extr, W, r, Jt, Jr, Jd);
-            const double s = r[0] * r[0] + r[1] * r[1];
-            const double sum = 1.0 + s;
-            cost += w.no_loss ? 0.5 * s : 0.5 * log(sum);
-            if (LIN) {
-                const double sc = w.no_loss ? 1.0 : sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
-                r[0] *= sc;
-                r[1] *= sc;
-                Jd[0] *= sc;
-                Jd[1] *= sc;
-                double *o = w.fac + RDVIO_FAC_STRIDE * (size_t)k;
-                // pose-constant frames (frame_fixed == 2) keep their columns, with zero pose Jacobians
-                const double zt = sh.pfix[w.tgt[k]] ? 0.0 : sc, zr = sh.pfix[w.ref[k]] ? 0.0 : sc;
-#pragma unroll
-                for (int i = 0; i < 12; ++i) {
-                    Jt[i] *= zt;
-                    Jr[i] *= zr;
-                    o[i] = Jt[i];
-                    o[12 + i] = Jr[i];
-                }
-                o[24] = Jd[0];
-                o[25] = Jd[1];
-                o[26] = r[0];
-                o[27] = r[1];
-                // per-factor landmark products: ht = Jd^T Jt, hr = Jd^T Jr, m = Jd^T Jd, g = Jd^T r
-#pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    o[28 + a] = Jd[0] * Jt[a] + Jd[1] * Jt[6 + a];
-                    o[34 + a] = Jd[0] * Jr[a] + Jd[1] * Jr[6 + a];
-                }
-                o[40] = Jd[0] * Jd[0] + Jd[1] * Jd[1];
-                o[41] = Jd[0] * r[0] + Jd[1] * r[1];
-                // coupling row of the landmark: the target frame's slot belongs to this factor alone (one observation per
-                // (track, frame)), so it is a plain store; the anchor slot is summed in the landmark pass
-                {
-                    const int ctc = sh.fcol[w.tgt[k]];
-                    if (ctc >= 0 && w.lfree[l]) {
-                        double *Arow = w.A + (size_t)l * (6 * w.nfree + 2) + 6 * ctc;
-#pragma unroll
-                        for (int a = 0; a < 6; ++a) Arow[a] = o[28 + a];
-                    }
-                }
-                // group-ordered record [J_lo | J_hi | r]: the assembly streams these with no indirection
-                const int gs = w.gslot[k];
-                if (gs >= 0) {
-                    double *q = w.prec + RDVIO_REC_STRIDE * (size_t)gs;
-                    const bool flip = w.gflip[k] != 0;          // first slot holds Jr
-                    const bool both = sh.fcol[w.tgt[k]] >= 0 && sh.fcol[w.ref[k]] >= 0;
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) {
-                        q[i] = flip ? Jr[i] : Jt[i];
-                        q[12 + i] = both ? (flip ? Jt[i] : Jr[i]) : 0.0;
-                    }
-                    q[24] = r[0];
-                    q[25] = r[1];
-                }
-            }
-        }
-        for (int k = t; k < w.nrot; k += TF) {
-            double r[2], J[6];
-            rotation_prior_factor<LIN>(states + 16 * w.rot_tgt[k], states + 16 * w.rot_ref[k], w.rot_zref + 3 * k,
-                                       w.rot_tangent + 9 * k, extr, W, r, J);
-            const double s = r[0] * r[0] + r[1] * r[1];
-            const double sum = 1.0 + s;
-            cost += 0.5 * log(sum);
-            if (LIN) {
-                const double sc = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
-                w.r_r[2 * k] = r[0] * sc;
-                w.r_r[2 * k + 1] = r[1] * sc;
-                const double zs = sh.pfix[w.rot_tgt[k]] ? 0.0 : sc;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) w.Jro[6 * k + i] = J[i] * zs;
-            }
-        }
+        if (!LIN) cost += cost_factors(w, states, invd, extr, W, gid, P);
+        for (int k = gid; LIN && k < w.nf; k += P) cost += linearize_factor(w, sh, k, states, invd, extr, W);
+        cost += rotation_factors<LIN>(w, sh, states, extr, W, gid, P);
     } else {
         const int j = t - TF;  // last wave: lanes 0..31 preintegration factors, lanes 32..63 prior frames
         if (LIN)  // the Jacobian blocks are sparse: clear them with the whole wave (coalesced) before the per-lane evaluation
@@ -243,6 +363,7 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
             }
         }
     }
+    if (w.n_wg > 1) cost += collect_partials(w, sh);  // (thread 0 carries the helpers' partial sums into the reduction)
     return block_sum(sh, cost, phase);
 }
 
@@ -580,6 +701,7 @@ DM double grad_max_norm(const SolverWs &w, Shared &sh, int &phase) {
 DM void solver_setup(const SolverWs &w, Shared &sh, double *lds, size_t lds_cap, unsigned long long &prof_last) {
     const int t = threadIdx.x;
     const int nl = w.nl, nfree = w.nfree, NAs = 6 * nfree + 2;
+    if (t == 0) sh.seq = 0;
     for (int i = t; i < w.nfr * 16; i += T) {
         const double v = w.x0[i];
         w.x[i] = v;
@@ -642,6 +764,10 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     __shared__ __attribute__((aligned(16))) double lds_chol_buf[LDS_CAP];
     double *Sl = lds_chol_buf, *Dinv = lds_chol_buf + w.N * (w.N + 1) / 2;
     const int t = threadIdx.x;
+    if (blockIdx.x > 0) {  // helper workgroup: factor evaluation on request
+        helper_loop(w, sh);
+        return;
+    }
     const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
     int phase = 0;
     unsigned long long prof_last = 0;
@@ -927,6 +1053,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                 reuse = 1;
             }
         }
+    if (w.n_wg > 1) post_command(w, sh, CMD_EXIT);
     if (t == 0) {
         w.summary[0] = (double)iteration;
         w.summary[1] = (double)n_success;
@@ -966,5 +1093,5 @@ void rdvio_launch_marginalize(hipStream_t stream, const SolverWs &w) {
 }
 
 void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w) {
-    hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(T), 0, stream, w);
+    hipLaunchKernelGGL(ba_solve_kernel, dim3(w.n_wg > 1 ? w.n_wg : 1), dim3(T), 0, stream, w);
 }

@@ -7,6 +7,8 @@
 #define RDVIO_FAC_STRIDE 42
 #define RDVIO_REC_STRIDE 26
 #define RDVIO_LDS_CHOL_MAX_FRAMES 11
+#define RDVIO_MAX_SOLVER_WGS 16
+#define RDVIO_HELPER_MIN_FACTORS 4096
 
 struct SolverWs {
     // ---- problem (read-only on the device)
@@ -33,6 +35,9 @@ struct SolverWs {
     const int32_t *pcol;                 // nfree: prior frame index of a free column block or -1
     int nrec;
     int lds_chol, lds_bytes;             // packed LDS Cholesky when 15-blocks of S (+ inverses) fit in LDS
+    int n_wg;                            // workgroups of the launch: 1 leader + helpers for the factor evaluation
+    unsigned *sync;                      // [0] command sequence, [1] completion counter, [2] command (zeroed before each launch)
+    double *partial;                     // per-workgroup partial costs
     // ---- state
     const double *x0, *xd0;              // uploaded initial values (every launch restarts from them)
     double *x, *xd;                      // in/out: frame states, inverse depths

@@ -217,3 +217,19 @@ def test_marginalize_chain_feeds_solver(ctx, oracle):
     s_ref, d_ref, sm_ref = oracle.ba_solve(sub(So, fo, lino), 10)
     assert abs(sm_gpu.initial_cost - sm_ref.initial_cost) <= 1e-6 * sm_ref.initial_cost
     assert np.abs(s_gpu - s_ref).max() < 1e-5
+
+
+def test_ba_solve_large_problem_uses_helper_workgroups(ctx, oracle):
+    # config-5 shape (1000 landmarks, window 16, > 4096 factors): the launch has 8 workgroups, the helpers evaluate
+    # their share of the factors on request (solver_kernels.hip "Helper workgroups"); same accept / reject path and
+    # states as the single-threaded oracle
+    pb = synth.make_window_problem(17, 1000, 655, preintegrate=_oracle_pre(oracle))
+    assert len(pb["tgt"]) >= 4096
+    ref_s, ref_d, ref_sm = oracle.ba_solve(pb, 6)
+    got_s, got_d, got_sm = ctx.ba_solve(pb, 6)
+    assert (got_sm.iterations, got_sm.successful_steps, got_sm.termination) == (ref_sm.iterations, ref_sm.successful_steps, ref_sm.termination)
+    assert abs(got_sm.initial_cost - ref_sm.initial_cost) <= 1e-9 * abs(ref_sm.initial_cost)
+    assert abs(got_sm.final_cost - ref_sm.final_cost) <= 1e-6 * abs(ref_sm.final_cost)
+    assert np.abs(got_s - ref_s).max() < 1e-6 and np.abs(got_d - ref_d).max() < 1e-6
+    again_s, again_d, _ = ctx.ba_solve(pb, 6)
+    assert (again_s == got_s).all() and (again_d == got_d).all()     # fixed reduction order across workgroups: reproducible
