@@ -769,6 +769,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
         return;
     }
     const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
+    const bool has_lm = nl > 0 && w.n_lfree_hint > 0;  // no free landmark (localize_newframe, prior-only solves): no Schur term
     int phase = 0;
     unsigned long long prof_last = 0;
 #ifdef RDVIO_PROF
@@ -850,7 +851,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     // [C | Cg] = A^T W [A | g] (lower tiles + the gradient column) on the matrix cores.  The operand is
                     // first staged into the (currently idle) LDS Cholesky buffer with one batch of coalesced loads: a
                     // K-loop over global memory is a chain of ~nl/16 dependent L2 round trips per tile.
-                    if (NA > 0 && nl > 0) {
+                    if (NA > 0 && has_lm) {
                         if (w.lds_chol && (size_t)nl * NAs + nl <= LDS_CAP) {
                             double *As = lds_chol_buf, *ws = lds_chol_buf + (size_t)nl * NAs;
                             for (int i = t; i < nl * NAs; i += T) As[i] = w.A[i];
@@ -877,7 +878,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                             if (e < 225 && (fi != fj || b <= a)) {
                                 const int i = 15 * fi + a, j = 15 * fj + b;
                                 v = w.H[(size_t)i * N + j];
-                                if (a < 6 && b < 6 && nl > 0) v -= w.Cm[(size_t)(6 * fi + a) * NAs + 6 * fj + b];
+                                if (a < 6 && b < 6 && has_lm) v -= w.Cm[(size_t)(6 * fi + a) * NAs + 6 * fj + b];
                                 v *= sh.xv[i] * sh.xv[j];
                                 if (i == j) v += mu * w.diag_p[i] * w.diag_p[i];
                             }
@@ -896,7 +897,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     for (int i = t; i < N; i += T) {
                         const int fi = i / 15, a = i - 15 * fi;
                         double v = w.g[i];
-                        if (a < 6 && nl > 0) v -= w.Cm[(size_t)(6 * fi + a) * NAs + NA];
+                        if (a < 6 && has_lm) v -= w.Cm[(size_t)(6 * fi + a) * NAs + NA];
                         w.yp[i] = v * w.sig_p[i];
                     }
                     __syncthreads();
