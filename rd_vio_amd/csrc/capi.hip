@@ -92,7 +92,7 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
     CTX_ALLOC(ctx->harris_scalars, 4 * sizeof(uint32_t));
     ctx->harris_cand_cap = (max_w * max_h) / 4 + 1024;  // 3x3 strict local maxima cannot exceed 1/4 of the pixels
     CTX_ALLOC(ctx->harris_cand, (size_t)ctx->harris_cand_cap * sizeof(HarrisCand));
-    CTX_ALLOC(ctx->lk_curr, (size_t)max_feat * 2 * sizeof(double));
+    CTX_ALLOC(ctx->lk_curr, (size_t)max_feat * (4 * sizeof(double) + 1) + 64);  // curr | next | status for the host entry point
     CTX_ALLOC(ctx->lk_next, (size_t)max_feat * 2 * sizeof(double));
     CTX_ALLOC(ctx->lk_prevf, (size_t)max_feat * 2 * sizeof(float));
     CTX_ALLOC(ctx->lk_nextf, (size_t)max_feat * 2 * sizeof(float));
@@ -141,7 +141,7 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
             return RDVIO_ERR_HIP;
         }
     }
-    ctx->pinned_bytes = std::max<size_t>((size_t)ctx->harris_cand_cap * sizeof(HarrisCand), 1 << 20);
+    ctx->pinned_bytes = std::max<size_t>((size_t)ctx->harris_cand_cap * sizeof(HarrisCand) + 64, 1 << 20);
     ctx->pinned_bytes = std::max<size_t>(ctx->pinned_bytes, ((size_t)ctx->pre_max_seg * (7 + RDVIO_PREINT_SIZE + 1) + 64 + (size_t)ctx->pre_max_samples * 7) * sizeof(double));
     if (hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
         rdvio_fail(ctx, RDVIO_ERR_HIP, "hipHostMalloc failed");
@@ -235,13 +235,21 @@ int rdvio_hip_track_keypoints(rdvio_hip_ctx *ctx, int slot_curr, int slot_next, 
     if (!ctx || n < 0 || (n > 0 && (!curr_xy || !next_xy || !status))) return RDVIO_ERR_INVALID;
     if (n > ctx->max_feat) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d features exceed context capacity %d", n, ctx->max_feat);
     if (n == 0) return RDVIO_OK;
-    const size_t bytes = (size_t)n * 2 * sizeof(double);
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lk_curr, curr_xy, bytes, hipMemcpyHostToDevice, ctx->stream));
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lk_next, next_xy, bytes, hipMemcpyHostToDevice, ctx->stream));
-    if (int rc = rdvio_launch_track(ctx, slot_curr, slot_next, n, ctx->lk_curr, ctx->lk_next, has_guess, ctx->lk_status)) return rc;
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(next_xy, ctx->lk_next, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(status, ctx->lk_status, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    // one pinned blob up (curr | guess), one kernel, one pinned blob down (next | status): lk_curr / lk_next / lk_status are
+    // carved from one allocation, so both directions are single copies
+    const size_t nd = (size_t)n * 2;
+    double *up = (double *)ctx->pinned;
+    memcpy(up, curr_xy, nd * sizeof(double));
+    memcpy(up + nd, next_xy, nd * sizeof(double));
+    double *d_curr = ctx->lk_curr, *d_next = ctx->lk_curr + nd;
+    uint8_t *d_status = (uint8_t *)(ctx->lk_curr + 2 * nd);
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(d_curr, up, 2 * nd * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = rdvio_launch_track(ctx, slot_curr, slot_next, n, d_curr, d_next, has_guess, d_status)) return rc;
+    uint8_t *down = (uint8_t *)(up + 2 * nd);
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, d_next, nd * sizeof(double) + (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(next_xy, down, nd * sizeof(double));
+    memcpy(status, down + nd * sizeof(double), (size_t)n);
     return RDVIO_OK;
 }
 
@@ -280,13 +288,18 @@ int rdvio_hip_detect_keypoints(rdvio_hip_ctx *ctx, int slot, double *keypoints, 
     // GFTTDetector::create(max_points, 1.0e-3, 20, 3, true): opencv_image.cpp:184-188
     if (int rc = rdvio_launch_harris(ctx, slot)) return rc;
     if (int rc = rdvio_launch_harris_candidates(ctx, slot, 1.0e-3)) return rc;
-    uint32_t scalars[2];
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(scalars, ctx->harris_scalars, sizeof scalars, hipMemcpyDeviceToHost, ctx->stream));
+    // one round trip in the common case: the counters and a 4096-candidate prefix travel together into pinned memory
+    // (a second copy only if the image produced more local maxima than that)
+    uint32_t *scalars = (uint32_t *)ctx->pinned;
+    HarrisCand *cand = (HarrisCand *)((uint8_t *)ctx->pinned + 64);
+    const int prefix = std::min(ctx->harris_cand_cap, 4096);
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(scalars, ctx->harris_scalars, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(cand, ctx->harris_cand, (size_t)prefix * sizeof(HarrisCand), hipMemcpyDeviceToHost, ctx->stream));
     RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    int nc = (int)std::min<uint32_t>(scalars[1], (uint32_t)ctx->harris_cand_cap);
-    HarrisCand *cand = (HarrisCand *)ctx->pinned;
-    if (nc > 0) {
-        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(cand, ctx->harris_cand, (size_t)nc * sizeof(HarrisCand), hipMemcpyDeviceToHost, ctx->stream));
+    const int nc = (int)std::min<uint32_t>(scalars[1], (uint32_t)ctx->harris_cand_cap);
+    if (nc > prefix) {
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(cand + prefix, ctx->harris_cand + prefix, (size_t)(nc - prefix) * sizeof(HarrisCand), hipMemcpyDeviceToHost,
+                                            ctx->stream));
         RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     }
     int total = rdvio_host_select_keypoints(cand, nc, S.w, S.h, max_points, 20.0, min_distance, keypoints, n_existing, capacity);
