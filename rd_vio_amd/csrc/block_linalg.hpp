@@ -26,6 +26,7 @@ struct BlockShared {
     double st[64 * 16];  // frame states being evaluated (x or the candidate)
     double ub[64 * 6];   // user-state biases (bias linearisation of the preintegration factors)
     double ext[18];      // extrinsics (14) + sqrt_inv_cov (4)
+    double cam[64 * 12]; // per frame: camera-to-world rotation (row-major 3x3) and camera centre of the states being evaluated
 };
 
 // sum_i a[i * sa] * x[i * sx] with the loads of U iterations issued together (memory-level parallelism: a single

@@ -175,7 +175,7 @@ DM double collect_partials(const SolverWs &w, Shared &sh) {
 
 // cost-only pass over the factors gid, gid + P, ...: two independent factors per trip so that their FP64 dependency
 // chains interleave (a workgroup has only two wavefronts per SIMD to hide latency with); fixed summation order
-DM double cost_factors(const SolverWs &w, const double *states, const double *invd, const double *extr, const double *W, int gid, int P) {
+DM double cost_factors(const SolverWs &w, const Shared &sh, const double *invd, const double *W, int gid, int P) {
     double cost = 0.0;
     for (int k = gid; k < w.nf; k += 2 * P) {
         const int k2 = k + P;
@@ -183,10 +183,8 @@ DM double cost_factors(const SolverWs &w, const double *states, const double *in
         const int kb = has2 ? k2 : k;
         double ra[2], rb[2];
         const int la = w.lm[k], lb = w.lm[kb];
-        reprojection_factor<false>(states + 16 * w.tgt[k], states + 16 * w.ref[k], w.tangent + 9 * (size_t)k, w.z_ref + 3 * (size_t)la, invd[la],
-                                   extr, W, ra, nullptr, nullptr, nullptr);
-        reprojection_factor<false>(states + 16 * w.tgt[kb], states + 16 * w.ref[kb], w.tangent + 9 * (size_t)kb, w.z_ref + 3 * (size_t)lb, invd[lb],
-                                   extr, W, rb, nullptr, nullptr, nullptr);
+        reprojection_residual(sh.cam + 12 * w.tgt[k], sh.cam + 12 * w.ref[k], w.tangent + 9 * (size_t)k, w.z_ref + 3 * (size_t)la, invd[la], W, ra);
+        reprojection_residual(sh.cam + 12 * w.tgt[kb], sh.cam + 12 * w.ref[kb], w.tangent + 9 * (size_t)kb, w.z_ref + 3 * (size_t)lb, invd[lb], W, rb);
         const double sa = ra[0] * ra[0] + ra[1] * ra[1], sb = rb[0] * rb[0] + rb[1] * rb[1];
         cost += w.no_loss ? 0.5 * sa : 0.5 * log(1.0 + sa);
         if (has2) cost += w.no_loss ? 0.5 * sb : 0.5 * log(1.0 + sb);
@@ -246,6 +244,8 @@ __device__ __attribute__((noinline)) void helper_loop(const SolverWs &w, Shared 
             for (int i = t; i < 18; i += T) sh.ext[i] = w.extr[i];
         }
         for (int i = t; i < w.nfr * 16; i += T) sh.st[i] = states[i];
+        if (!(cmd & CMD_LIN))
+            for (int i = t; i < w.nfr; i += T) camera_pose_of(states + 16 * i, w.extr, sh.cam + 12 * i);
         __syncthreads();
         const double *W = sh.ext + 14, *extr = sh.ext;
         double cost = 0.0;
@@ -253,7 +253,7 @@ __device__ __attribute__((noinline)) void helper_loop(const SolverWs &w, Shared 
             for (int k = gid; k < w.nf; k += P) cost += linearize_factor(w, sh, k, sh.st, invd, extr, W);
             cost += rotation_factors<true>(w, sh, sh.st, extr, W, gid, P);
         } else {
-            cost += cost_factors(w, sh.st, invd, extr, W, gid, P);
+            cost += cost_factors(w, sh, invd, W, gid, P);
             cost += rotation_factors<false>(w, sh, sh.st, extr, W, gid, P);
         }
         cost = block_sum(sh, cost, phase);
@@ -278,6 +278,8 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
     // small hot data in LDS: every factor reads two frame states; L2 round trips would dominate the evaluation
     for (int i = t; i < w.nfr * 16; i += T) sh.st[i] = states[i];
     for (int i = t; i < w.nfr * 6; i += T) sh.ub[i] = w.user[16 * (i / 6) + ST_BG + (i % 6)];
+    if (!LIN)  // camera poses for the cost-only residuals (the last wave is idle here: its work starts after the barrier)
+        for (int i = T - 1 - t; i < w.nfr; i += T) camera_pose_of(states + 16 * i, w.extr, sh.cam + 12 * i);
     __syncthreads();
     states = sh.st;
     const double *W = sh.ext + 14, *extr = sh.ext;
@@ -288,7 +290,7 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
     if (w.n_wg > 1) post_command(w, sh, (LIN ? CMD_LIN : 0u) | ((invd == w.xdc) ? CMD_CAND : 0u));
     if (t < TF) {
         // reprojection factors, CauchyLoss(1): cost 0.5 log(1+s); Corrector with rho'' < 0 => scale r, J by sqrt(rho')
-        if (!LIN) cost += cost_factors(w, states, invd, extr, W, gid, P);
+        if (!LIN) cost += cost_factors(w, sh, invd, W, gid, P);
         for (int k = gid; LIN && k < w.nf; k += P) cost += linearize_factor(w, sh, k, states, invd, extr, W);
         cost += rotation_factors<LIN>(w, sh, states, extr, W, gid, P);
     } else {
