@@ -54,6 +54,16 @@ DM double dot_strided(const double *__restrict__ a, long sa, const double *__res
 DM double quad_col_dot(const double *__restrict__ M, long ld, const double *__restrict__ x, int C, int r, int part) {
     double acc = 0.0;
     int c = part;
+    for (; c + 60 < C; c += 64) {  // 16 loads in flight per lane: two L2 round trips cover 128 columns
+        double mv[16], xv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            mv[u] = M[(long)(c + 4 * u) * ld + r];
+            xv[u] = x[c + 4 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += mv[u] * xv[u];
+    }
     for (; c + 28 < C; c += 32) {
         double mv[8], xv[8];
 #pragma unroll

@@ -272,15 +272,56 @@ __device__ __attribute__((noinline)) void helper_loop(const SolverWs &w, Shared 
 // Waves 0..NW-2 evaluate reprojection factors while the last wave evaluates the (long, serial) preintegration
 // factors and the prior's per-frame errors, so the two overlap.
 // ---------------------------------------------------------------------------------------------
-template <bool LIN>
-__device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &sh, int &phase, const double *states, const double *invd, unsigned long long &prof_last) {
+// CAND (cost-only): the candidate Plus(x, delta) is formed HERE -- straight into LDS, with the camera poses and the
+// squared ambient step norm -- instead of being written to global memory, fenced and read back (a rejected trust-region
+// iteration is a chain of such 1-5 us phases); *sn2_out receives the step norm squared.
+template <bool LIN, bool CAND = false>
+__device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &sh, int &phase, const double *states, const double *invd, unsigned long long &prof_last,
+                                                     double *sn2_out = nullptr, double ca = 0.0, double cb = 0.0) {
     const int t = threadIdx.x;
+    double sn2 = 0.0;
     // small hot data in LDS: every factor reads two frame states; L2 round trips would dominate the evaluation
-    for (int i = t; i < w.nfr * 16; i += T) sh.st[i] = states[i];
+    if (CAND) {
+        for (int i = T - 1 - t; i < w.nfr; i += T) {  // (from the top: the last wave has no factor work)
+            const int c = sh.fcol[i];
+            double o[16];
+            if (c < 0) {
+#pragma unroll
+                for (int a = 0; a < 16; ++a) o[a] = w.x[16 * i + a];
+            } else {
+                // delta = (ca * scaled gradient + cb * Gauss-Newton step) / dogleg diagonal * Jacobi scaling, 15 entries
+                double d15[15], sg[15], gr[15], gn[15], dg[15];
+#pragma unroll
+                for (int a = 0; a < 15; ++a) {
+                    sg[a] = w.sig_p[15 * c + a]; gr[a] = w.grad_p[15 * c + a]; gn[a] = w.gn_p[15 * c + a]; dg[a] = w.diag_p[15 * c + a];
+                }
+#pragma unroll
+                for (int a = 0; a < 15; ++a) d15[a] = sg[a] * ((ca * gr[a] + cb * gn[a]) / dg[a]);
+                state_plus(w.x + 16 * i, d15, o);
+                if (sh.pfix[i])
+#pragma unroll
+                    for (int a = 0; a < 7; ++a) o[a] = w.x[16 * i + a];  // constant pose block
+#pragma unroll
+                for (int a = 0; a < 16; ++a)
+                    if (!(sh.pfix[i] && a < 7)) { const double e = w.x[16 * i + a] - o[a]; sn2 += e * e; }
+            }
+#pragma unroll
+            for (int a = 0; a < 16; ++a) { w.xc[16 * i + a] = o[a]; sh.st[16 * i + a] = o[a]; }
+            camera_pose_of(o, w.extr, sh.cam + 12 * i);
+        }
+        for (int l = t; l < w.nl; l += T) {
+            const double v = w.xd[l] + (w.lfree[l] ? w.sig_l[l] * ((ca * w.grad_l[l] + cb * w.gn_l[l]) / w.diag_l[l]) : 0.0);
+            w.xdc[l] = v;
+            if (w.lfree[l]) { const double e = w.xd[l] - v; sn2 += e * e; }
+        }
+    } else {
+        for (int i = t; i < w.nfr * 16; i += T) sh.st[i] = states[i];
+        if (!LIN)  // camera poses for the cost-only residuals (the last wave is idle here: its work starts after the barrier)
+            for (int i = T - 1 - t; i < w.nfr; i += T) camera_pose_of(states + 16 * i, w.extr, sh.cam + 12 * i);
+    }
     for (int i = t; i < w.nfr * 6; i += T) sh.ub[i] = w.user[16 * (i / 6) + ST_BG + (i % 6)];
-    if (!LIN)  // camera poses for the cost-only residuals (the last wave is idle here: its work starts after the barrier)
-        for (int i = T - 1 - t; i < w.nfr; i += T) camera_pose_of(states + 16 * i, w.extr, sh.cam + 12 * i);
     __syncthreads();
+    STAMP(LIN ? 30 : 31);
     states = sh.st;
     const double *W = sh.ext + 14, *extr = sh.ext;
     double cost = 0.0;
@@ -366,6 +407,12 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
         }
     }
     if (w.n_wg > 1) cost += collect_partials(w, sh);  // (thread 0 carries the helpers' partial sums into the reduction)
+    if (CAND) {
+        double v2[2] = {cost, sn2};
+        block_sum_n<T, 2>(sh, v2, phase);
+        *sn2_out = v2[1];
+        return v2[0];
+    }
     return block_sum(sh, cost, phase);
 }
 
@@ -971,7 +1018,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                 STAMP(7);
             }
             int step_valid = 0;
-            double model_cost_change = 0.0;
+            double model_cost_change = 0.0, step_ca = 0.0, step_cb = 0.0;
             if (solve_ok) {
                 double ca, cb;
                 bool need_norm = false;
@@ -988,11 +1035,8 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     cb = beta;
                     need_norm = true;
                 }
-                for (int i = t; i < N; i += T)
-                    w.tp[i] = w.sig_p[i] * ((ca * w.grad_p[i] + cb * w.gn_p[i]) / w.diag_p[i]);  // delta = step * jacobi scaling
-                for (int l = t; l < nl; l += T)
-                    w.tl[l] = w.lfree[l] ? w.sig_l[l] * ((ca * w.grad_l[l] + cb * w.gn_l[l]) / w.diag_l[l]) : 0.0;
-                __syncthreads();  // tp / tl are read by other threads when the candidate is formed
+                step_ca = ca;  // delta = (ca grad + cb gn) / D * Jacobi scaling is formed inside the candidate evaluation
+                step_cb = cb;
                 if (need_norm) dogleg_step_norm = sqrt(ca * ca * gnorm * gnorm + 2.0 * ca * cb * gdotgn + cb * cb * gn_norm * gn_norm);
                 const double jsq = ca * ca * msc[0] + 2.0 * ca * cb * msc[1] + cb * cb * msc[2];
                 const double jdr = ca * msc[3] + cb * msc[4];
@@ -1007,28 +1051,13 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                 continue;
             }
             invalid_steps = 0;
-            // candidate = Plus(x, delta)
-            for (int i = t; i < w.nfr; i += T) {
-                const int c = w.fcol[i];
-                if (c < 0) {
-                    for (int a = 0; a < 16; ++a) w.xc[16 * i + a] = w.x[16 * i + a];
-                } else {
-                    state_plus(w.x + 16 * i, w.tp + 15 * c, w.xc + 16 * i);
-                    if (sh.pfix[i])
-                        for (int a = 0; a < 7; ++a) w.xc[16 * i + a] = w.x[16 * i + a];  // constant pose block
-                }
-            }
-            for (int l = t; l < nl; l += T) w.xdc[l] = w.xd[l] + (w.lfree[l] ? w.tl[l] : 0.0);
-            __syncthreads();
-            double cand_cost = evaluate<false>(w, sh, phase, w.xc, w.xdc, prof_last);
+            // candidate = Plus(x, delta), its cost and the ambient step norm in one pass
+            STAMP(28);
+            double sn2 = 0.0;
+            double cand_cost = evaluate<false, true>(w, sh, phase, w.xc, w.xdc, prof_last, &sn2, step_ca, step_cb);
             if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
             STAMP(9);
-            double sn2 = 0.0;
-            for (int o = t; o < w.nfr * 16; o += T)
-                if (w.fcol[o / 16] >= 0 && !(sh.pfix[o / 16] && (o & 15) < 7)) { const double e = w.x[o] - w.xc[o]; sn2 += e * e; }
-            for (int l = t; l < nl; l += T)
-                if (w.lfree[l]) { const double e = w.xd[l] - w.xdc[l]; sn2 += e * e; }
-            const double step_norm = sqrt(block_sum(sh, sn2, phase));
+            const double step_norm = sqrt(sn2);
             if (step_norm <= 1e-8 * (x_norm + 1e-8)) { term = 0; break; }
             const double cost_change = x_cost - cand_cost;
             if (fabs(cost_change) <= 1e-6 * x_cost) { term = 0; break; }
