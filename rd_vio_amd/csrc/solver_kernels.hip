@@ -334,24 +334,28 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
         if (!LIN) cost += cost_factors(w, sh, invd, W, gid, P);
         for (int k = gid; LIN && k < w.nf; k += P) cost += linearize_factor(w, sh, k, states, invd, extr, W);
         cost += rotation_factors<LIN>(w, sh, states, extr, W, gid, P);
+        // the prior's per-frame errors ride on the tail of the last factor wave (they used to share the preintegration
+        // wave, where the two divergent branches ran one after the other); e goes straight into the LDS operand of S e
+        for (int i = t - (TF - 64); i >= 0 && i < w.np; i += 64) {
+            M3 Jri;
+            double e15[15];
+            marginalization_frame_error(states + 16 * w.prior_frames[i], w.lin + 16 * i, e15, LIN ? &Jri : nullptr);
+#pragma unroll
+            for (int a = 0; a < 15; ++a) {
+                w.e_m[15 * i + a] = e15[a];
+                sh.xv[15 * i + a] = e15[a];
+            }
+            if (LIN)
+                for (int q = 0; q < 9; ++q) sh.Jri[9 * i + q] = Jri.m[q];
+        }
     } else {
-        const int j = t - TF;  // last wave: lanes 0..31 preintegration factors, lanes 32..63 prior frames
+        const int j = t - TF;  // last wave: the (long, serial) preintegration factors, one per lane
         if (LIN)  // the Jacobian blocks are sparse: clear them with the whole wave (coalesced) before the per-lane evaluation
             for (int i = j; i < w.npre * 450; i += 64) w.G[i] = 0.0;
-        if (j < 32) {
-            for (int k = j; k < w.npre; k += 32) {
-                double *G = w.G + 450 * k;
-                preintegration_unwhitened<LIN>(states + 16 * w.pre_i[k], states + 16 * w.pre_j[k],
-                                               w.preint + (size_t)RDVIO_PREINT_SIZE * k, sh.ub + 6 * w.pre_i[k],
-                                               extr, w.e_p + 15 * k, G, G + 225);
-            }
-        } else {
-            for (int i = j - 32; i < w.np; i += 32) {
-                M3 Jri;
-                marginalization_frame_error(states + 16 * w.prior_frames[i], w.lin + 16 * i, w.e_m + 15 * i, LIN ? &Jri : nullptr);
-                if (LIN)
-                    for (int q = 0; q < 9; ++q) sh.Jri[9 * i + q] = Jri.m[q];
-            }
+        for (int k = j; k < w.npre; k += 64) {
+            double *G = w.G + 450 * k;
+            preintegration_unwhitened<LIN>(states + 16 * w.pre_i[k], states + 16 * w.pre_j[k], w.preint + (size_t)RDVIO_PREINT_SIZE * k,
+                                           sh.ub + 6 * w.pre_i[k], extr, w.e_p + 15 * k, G, G + 225);
         }
     }
     STAMP(LIN ? 17 : 20);
@@ -389,8 +393,7 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
     if (w.np > 0) {
         double *r_m = LIN ? w.r_m : w.c_m;
         const int D = w.D;
-        for (int c = t; c < D; c += T) sh.xv[c] = w.e_m[c];
-        __syncthreads();
+        // (sh.xv = e was filled by the factor wave's tail before the barrier above)
         for (int base = 0; base < D; base += T / 4) {
             const int row = base + (t >> 2), part = t & 3;
             if (row < D) {
