@@ -343,6 +343,11 @@ DM void cholesky_solve(BlockShared<T> &sh, const double *M, int N, double *b, bo
 // ---------------------------------------------------------------------------------------------------------
 DM int tri(int r) { return r * (r + 1) / 2; }
 
+// Pointers that keep the LDS address space across (noinline) function boundaries: a generic `double *` to LDS makes the
+// compiler emit FLAT loads / stores, which resolve the aperture first and cost about twice the latency of ds_read / ds_write.
+typedef __attribute__((address_space(3))) double lds_double;
+#define RDVIO_LDS(p) ((lds_double *)(p))
+
 // broadcast a double from a (wave-uniform) lane through SGPRs
 DM double readlane_d(double v, int src_lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
@@ -364,7 +369,7 @@ DM double rsqrt_nr(double x) {
 //   (3) the trailing matrix is updated with v_mfma_f64_16x16x4 tiles (K = 15): ~0.2 instructions per entry instead of
 //       ~30 for scalar indexed updates -- with one workgroup the factorisation is instruction-issue bound.
 template <int T>
-__device__ __attribute__((noinline)) int cholesky_lds(BlockShared<T> &sh, double *Lp, double *Dinv, int N) {
+__device__ __attribute__((noinline)) int cholesky_lds(BlockShared<T> &sh, lds_double *Lp, lds_double *Dinv, int N) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, nw = T / 64;
     const int nb = N / 15;
     if (t == 0) sh.flag = 1;
@@ -374,7 +379,7 @@ __device__ __attribute__((noinline)) int cholesky_lds(BlockShared<T> &sh, double
         // ---- (1) diagonal block in registers (wave 0); rinv[c] = 1 / L_cc goes to sh.vec for the panel
         if (wave == 0) {
             const int r = lane < 15 ? lane : 14;
-            const double *row = Lp + tri(k0 + r) + k0;
+            const lds_double *row = Lp + tri(k0 + r) + k0;
             double a[15];
 #pragma unroll
             for (int c = 0; c < 15; ++c) a[c] = (lane < 15 && c <= lane) ? row[c] : 0.0;
@@ -395,7 +400,7 @@ __device__ __attribute__((noinline)) int cholesky_lds(BlockShared<T> &sh, double
             }
             if (bad && lane == 0) sh.flag = 0;
             if (lane < 15) {
-                double *wrow = Lp + tri(k0 + lane) + k0;
+                lds_double *wrow = Lp + tri(k0 + lane) + k0;
 #pragma unroll
                 for (int c = 0; c < 15; ++c)
                     if (c <= lane) wrow[c] = a[c];
@@ -404,13 +409,13 @@ __device__ __attribute__((noinline)) int cholesky_lds(BlockShared<T> &sh, double
         __syncthreads();
         // ---- (2) panel: row i solves x L_kk^T = row  (forward substitution with reciprocal pivots)
         for (int i = k0 + 15 + t; i < N; i += T) {
-            double *row = Lp + tri(i) + k0;
+            lds_double *row = Lp + tri(i) + k0;
             double x[15];
 #pragma unroll
             for (int c = 0; c < 15; ++c) x[c] = row[c];
 #pragma unroll
             for (int c = 0; c < 15; ++c) {
-                const double *Lc = Lp + tri(k0 + c) + k0;
+                const lds_double *Lc = Lp + tri(k0 + c) + k0;
                 double s = x[c];
 #pragma unroll
                 for (int q = 0; q < 15; ++q)
@@ -428,7 +433,7 @@ __device__ __attribute__((noinline)) int cholesky_lds(BlockShared<T> &sh, double
             if (bj > bi) continue;
             const int i = lane & 15, kk = lane >> 4;
             const int ra = k0 + 15 + 16 * bi + i, rb = k0 + 15 + 16 * bj + i;
-            const double *pa = Lp + tri(ra < N ? ra : N - 1) + k0, *pb = Lp + tri(rb < N ? rb : N - 1) + k0;
+            const lds_double *pa = Lp + tri(ra < N ? ra : N - 1) + k0, *pb = Lp + tri(rb < N ? rb : N - 1) + k0;
             double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -451,7 +456,7 @@ __device__ __attribute__((noinline)) int cholesky_lds(BlockShared<T> &sh, double
         double x[15];
 #pragma unroll
         for (int r = 0; r < 15; ++r) {
-            const double *Lr = Lp + tri(15 * kb + r) + 15 * kb;
+            const lds_double *Lr = Lp + tri(15 * kb + r) + 15 * kb;
             double s = (r == c) ? 1.0 : 0.0;
 #pragma unroll
             for (int q = 0; q < 15; ++q)
@@ -467,7 +472,7 @@ __device__ __attribute__((noinline)) int cholesky_lds(BlockShared<T> &sh, double
 
 // solve L L^T y = b with L packed in LDS and Dinv = inverses of its 15 x 15 diagonal blocks; b in place.
 template <int T>
-__device__ __attribute__((noinline)) void cholesky_solve_lds(BlockShared<T> &sh, const double *Lp, const double *Dinv, int N, double *b) {
+__device__ __attribute__((noinline)) void cholesky_solve_lds(BlockShared<T> &sh, const lds_double *Lp, const lds_double *Dinv, int N, double *b) {
     const int t = threadIdx.x, nb = N / 15;
     double *y = sh.xv;  // N <= 512
     for (int i = t; i < N; i += T) y[i] = b[i];
@@ -482,7 +487,7 @@ __device__ __attribute__((noinline)) void cholesky_solve_lds(BlockShared<T> &sh,
         if (t < 15) y[15 * kb + t] = v;
         __syncthreads();
         for (int i = 15 * (kb + 1) + t; i < N; i += T) {
-            const double *Lr = Lp + tri(i) + 15 * kb;
+            const lds_double *Lr = Lp + tri(i) + 15 * kb;
             double s = 0.0;
 #pragma unroll
             for (int q = 0; q < 15; ++q) s += Lr[q] * y[15 * kb + q];

@@ -160,7 +160,7 @@ DM int wave_min_i(int v) {
 // set of packed entries whose (i, k) coordinates are decoded once.  Factor column j goes straight to row j of S_out
 // (scattered through nz to the retained rows' original positions), f[j] to f_out.
 template <int T>
-__device__ __attribute__((noinline)) int pivoted_cholesky_lds(double *Ap, double *dg, double *lcol, double *eta,
+__device__ __attribute__((noinline)) int pivoted_cholesky_lds(lds_double *Ap, lds_double *dg, lds_double *lcol, lds_double *eta,
                                                               const double *__restrict__ src, const double *__restrict__ er,
                                                               const int32_t *__restrict__ nz, int n, int R, double tol,
                                                               double *__restrict__ S_out, double *__restrict__ f_out) {
@@ -360,7 +360,7 @@ DM void marginalize_tail(const SolverWs &w, BlockShared<T> &sh, int &phase, doub
     int path = 0;
     if (!w.marg_force_eigen && w.lds_chol) {
         double *Ap = lds + 450, *dg = Ap + tri(Rn), *lcol = dg + Rn, *eta = lcol + Rn;
-        (void)pivoted_cholesky_lds<T>(Ap, dg, lcol, eta, w.m_Lr, w.m_er, w.m_nz, Rn, R, 1.0e-8, w.S_out, w.f_out);
+        (void)pivoted_cholesky_lds<T>(RDVIO_LDS(Ap), RDVIO_LDS(dg), RDVIO_LDS(lcol), RDVIO_LDS(eta), w.m_Lr, w.m_er, w.m_nz, Rn, R, 1.0e-8, w.S_out, w.f_out);
         path = 2;
     } else if (!w.marg_force_eigen) {
         // large window: plain blocked Cholesky when the information is positive definite beyond the threshold

@@ -955,10 +955,10 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     __syncthreads();
                     STAMP(4);
                     int ok = 1;
-                    if (N > 0) ok = w.lds_chol ? cholesky_lds(sh, Sl, Dinv, N) : cholesky_blocked(sh, w.Sm, N);
+                    if (N > 0) ok = w.lds_chol ? cholesky_lds(sh, RDVIO_LDS(Sl), RDVIO_LDS(Dinv), N) : cholesky_blocked(sh, w.Sm, N);
                     STAMP(5);
                     if (ok && N > 0) {
-                        if (w.lds_chol) cholesky_solve_lds(sh, Sl, Dinv, N, w.yp);
+                        if (w.lds_chol) cholesky_solve_lds(sh, RDVIO_LDS(Sl), RDVIO_LDS(Dinv), N, w.yp);
                         else cholesky_solve(sh, w.Sm, N, w.yp);
                     }
                     STAMP(6);
