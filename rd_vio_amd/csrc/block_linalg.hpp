@@ -203,7 +203,7 @@ DM void block_matvec_rows(const double *__restrict__ Mx, int ld, int R, int C, c
 // Diagonal block: LDS, first wave.  Panel: one thread per row.  Trailing update: MFMA tiles.
 // Returns 0 on a non-positive / non-finite pivot.
 template <int T>
-DM int cholesky_blocked(BlockShared<T> &sh, double *M, int N) {
+__device__ __attribute__((noinline)) int cholesky_blocked(BlockShared<T> &sh, double *M, int N) {
     const int t = threadIdx.x;
     const int nb = N / 15;
     if (t == 0) sh.flag = 1;
@@ -280,7 +280,7 @@ DM int cholesky_blocked(BlockShared<T> &sh, double *M, int N) {
 // solve L L^T y = b in place (y overwrites b), blocked like the factorisation; the 15x15 diagonal block is
 // staged in LDS so the sequential triangular solve never waits on global memory
 template <int T>
-DM void cholesky_solve(BlockShared<T> &sh, const double *M, int N, double *b, bool forward = true, bool backward = true) {
+__device__ __attribute__((noinline)) void cholesky_solve(BlockShared<T> &sh, const double *M, int N, double *b, bool forward = true, bool backward = true) {
     const int t = threadIdx.x;
     const int nb = N / 15;
     if (forward)

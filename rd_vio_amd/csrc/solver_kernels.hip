@@ -33,6 +33,9 @@ namespace {
 constexpr int T = RDVIO_SOLVER_THREADS;
 constexpr int NW = T / 64;
 using Shared = BlockShared<T>;
+// The by-value kernel argument cannot be handed to a noinline function without a private (scratch) copy, and every
+// `w.field` read there would be an L2 round trip ahead of the access it feeds; the kernels keep one copy in LDS instead.
+typedef const __attribute__((address_space(3))) SolverWs LdsWs;
 
 #ifdef RDVIO_PROF
 // diagnostic build only: accumulate wall-clock ticks (100 MHz) per phase into summary[8 + id], counts into [40 + id]
@@ -59,7 +62,8 @@ DM double prior_E(const Shared &sh, int i, int a, int b) {
 
 // one reprojection factor of the stored linearisation (robustified residual + Jacobians, per-factor landmark products,
 // the target slot of the coupling row, the group-ordered record); returns the factor's cost
-DM double linearize_factor(const SolverWs &w, Shared &sh, int k, const double *states, const double *invd, const double *extr, const double *W) {
+template <class WS>
+DM double linearize_factor(const WS &w, Shared &sh, int k, const double *states, const double *invd, const double *extr, const double *W) {
     double cost = 0.0;
     double r[2], Jt[12], Jr[12], Jd[2];
     const int l = w.lm[k];
@@ -144,7 +148,8 @@ DM unsigned sync_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_
 DM void sync_store(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
 // leader: publish a command (all earlier global writes of the workgroup become visible to the helpers)
-DM void post_command(const SolverWs &w, Shared &sh, unsigned cmd) {
+template <class WS>
+DM void post_command(const WS &w, Shared &sh, unsigned cmd) {
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -154,7 +159,8 @@ DM void post_command(const SolverWs &w, Shared &sh, unsigned cmd) {
     }
 }
 // leader: wait for all helpers; returns the sum of their partial costs in workgroup order (NaN on timeout)
-DM double collect_partials(const SolverWs &w, Shared &sh) {
+template <class WS>
+DM double collect_partials(const WS &w, Shared &sh) {
     const int G = w.n_wg - 1;
     if (threadIdx.x == 0) {
         int spins = 0;
@@ -175,7 +181,8 @@ DM double collect_partials(const SolverWs &w, Shared &sh) {
 
 // cost-only pass over the factors gid, gid + P, ...: two independent factors per trip so that their FP64 dependency
 // chains interleave (a workgroup has only two wavefronts per SIMD to hide latency with); fixed summation order
-DM double cost_factors(const SolverWs &w, const Shared &sh, const double *invd, const double *W, int gid, int P) {
+template <class WS>
+DM double cost_factors(const WS &w, const Shared &sh, const double *invd, const double *W, int gid, int P) {
     double cost = 0.0;
     for (int k = gid; k < w.nf; k += 2 * P) {
         const int k2 = k + P;
@@ -193,8 +200,8 @@ DM double cost_factors(const SolverWs &w, const Shared &sh, const double *invd, 
 }
 
 // rotation-prior factors gid, gid + P, ...
-template <bool LIN>
-DM double rotation_factors(const SolverWs &w, Shared &sh, const double *states, const double *extr, const double *W, int gid, int P) {
+template <bool LIN, class WS>
+DM double rotation_factors(const WS &w, Shared &sh, const double *states, const double *extr, const double *W, int gid, int P) {
     double cost = 0.0;
     for (int k = gid; k < w.nrot; k += P) {
         double r[2], J[6];
@@ -215,7 +222,7 @@ DM double rotation_factors(const SolverWs &w, Shared &sh, const double *states, 
 }
 
 // the helpers' side: serve evaluation commands until told to exit (or until the leader goes silent)
-__device__ __attribute__((noinline)) void helper_loop(const SolverWs &w, Shared &sh) {
+__device__ __attribute__((noinline)) void helper_loop(LdsWs &w, Shared &sh) {
     const int t = threadIdx.x;
     constexpr int TFm = T - 64;
     const int P = TFm + (w.n_wg - 1) * T, gid = TFm + ((int)blockIdx.x - 1) * T + t;
@@ -276,7 +283,7 @@ __device__ __attribute__((noinline)) void helper_loop(const SolverWs &w, Shared 
 // squared ambient step norm -- instead of being written to global memory, fenced and read back (a rejected trust-region
 // iteration is a chain of such 1-5 us phases); *sn2_out receives the step norm squared.
 template <bool LIN, bool CAND = false>
-__device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &sh, int &phase, const double *states, const double *invd, unsigned long long &prof_last,
+__device__ __attribute__((noinline)) double evaluate(LdsWs &w, Shared &sh, int &phase, const double *states, const double *invd, unsigned long long &prof_last,
                                                      double *sn2_out = nullptr, double ca = 0.0, double cb = 0.0) {
     const int t = threadIdx.x;
     double sn2 = 0.0;
@@ -425,7 +432,8 @@ __device__ __attribute__((noinline)) double evaluate(const SolverWs &w, Shared &
 // frame pair streaming that pair's contiguous records), landmark rows, per-factor preintegration products.
 // Phase 2: one output-stationary pass writes every H / g entry as prior + preintegration + reprojection part.
 // ---------------------------------------------------------------------------------------------
-DM double prior_part(const SolverWs &w, const Shared &sh, int pi, int a, int pj, int b) {
+template <class WS>
+DM double prior_part(const WS &w, const Shared &sh, int pi, int a, int pj, int b) {
     const int D = w.D;
     if (a >= 3 && b >= 3) return w.Lam[(size_t)(15 * pi + a) * D + 15 * pj + b];
     double acc = 0.0;
@@ -439,7 +447,7 @@ DM double prior_part(const SolverWs &w, const Shared &sh, int pi, int a, int pj,
 // index of the frame pair (lo <= hi) in the host's enumeration
 DM int pair_id(int lo, int hi, int nfree) { return lo * nfree - lo * (lo - 1) / 2 + (hi - lo); }
 
-__device__ __attribute__((noinline)) void build_normal_equations(const SolverWs &w, Shared &sh, unsigned long long &prof_last) {
+__device__ __attribute__((noinline)) void build_normal_equations(LdsWs &w, Shared &sh, unsigned long long &prof_last) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int N = w.N, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
     // ---- phase 1a: per factor group, X^T X with X = [J_lo | J_hi | r] (2 n_g x 13) on the matrix cores:
@@ -634,7 +642,8 @@ __device__ __attribute__((noinline)) void build_normal_equations(const SolverWs 
 }
 
 // q = x^T (J^T J) x and l = (J x) . r from the assembled normal equations; x = (xp: N pose entries, xl: landmarks)
-DM void model_products(const SolverWs &w, Shared &sh, int &phase, const double *xp, const double *xl, double *q_out,
+template <class WS>
+DM void model_products(const WS &w, Shared &sh, int &phase, const double *xp, const double *xl, double *q_out,
                        double *l_out) {
     const int t = threadIdx.x;
     const int N = w.N, NA = 6 * w.nfree;
@@ -669,7 +678,7 @@ DM void model_products(const SolverWs &w, Shared &sh, int &phase, const double *
 // (Gauss-Newton), both in unscaled-J coordinates:  q_xy = (J x)^T (J y),  l_x = (J x)^T r.  Every dogleg step is
 // delta = ca u + cb v, so |J delta|^2 and (J delta).r follow from these five numbers for ANY trust-region radius:
 // a rejected step re-interpolates without touching H again.
-__device__ __attribute__((noinline)) void model_scalars(const SolverWs &w, Shared &sh, int &phase, double (&out)[5]) {
+__device__ __attribute__((noinline)) void model_scalars(LdsWs &w, Shared &sh, int &phase, double (&out)[5]) {
     const int t = threadIdx.x;
     const int N = w.N, NA = 6 * w.nfree;
     double *u = sh.xv, *v = sh.xv + 256;
@@ -721,7 +730,7 @@ __device__ __attribute__((noinline)) void model_scalars(const SolverWs &w, Share
     for (int i = 0; i < 5; ++i) out[i] = a5[i];
 }
 
-DM double x_norm_of(const SolverWs &w, Shared &sh, int &phase, const double *st, const double *dep) {
+__device__ __attribute__((noinline)) double x_norm_of(LdsWs &w, Shared &sh, int &phase, const double *st, const double *dep) {
     const int t = threadIdx.x;
     double s = 0.0;
     for (int o = t; o < w.nfr * 16; o += T)
@@ -732,7 +741,7 @@ DM double x_norm_of(const SolverWs &w, Shared &sh, int &phase, const double *st,
 }
 
 // gradient_max_norm = || x - Plus(x, -g) ||_inf  (TrustRegionMinimizer::EvaluateGradientAndJacobian)
-DM double grad_max_norm(const SolverWs &w, Shared &sh, int &phase) {
+__device__ __attribute__((noinline)) double grad_max_norm(LdsWs &w, Shared &sh, int &phase) {
     const int t = threadIdx.x;
     double m = 0.0;
     for (int i = t; i < w.nfr; i += T) {
@@ -750,7 +759,7 @@ DM double grad_max_norm(const SolverWs &w, Shared &sh, int &phase) {
 
 // per-launch setup shared by the solver and the marginalisation kernel: user state, free-landmark flags, LDS index
 // tables, zeroed coupling rows, and the constant parts of the prior (S^T, Lambda = S^T S, eta0 = S^T f)
-DM void solver_setup(const SolverWs &w, Shared &sh, double *lds, size_t lds_cap, unsigned long long &prof_last) {
+__device__ __attribute__((noinline)) void solver_setup(LdsWs &w, Shared &sh, double *lds, size_t lds_cap, unsigned long long &prof_last) {
     const int t = threadIdx.x;
     const int nl = w.nl, nfree = w.nfree, NAs = 6 * nfree + 2;
     if (t == 0) sh.seq = 0;
@@ -807,6 +816,182 @@ DM void solver_setup(const SolverWs &w, Shared &sh, double *lds, size_t lds_cap,
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Phases of one trust-region iteration.  Each is its own (noinline) function on the LDS-resident workspace: the kernel
+// body keeps only the scalar accept / reject logic, so that its registers are not shared with -- and spilled around --
+// every phase's working set.
+// ---------------------------------------------------------------------------------------------
+#define PHASE_FN __device__ __attribute__((noinline))
+
+// Jacobi scaling from the iteration-0 Jacobian
+PHASE_FN void jacobi_scaling(LdsWs &w) {
+    const int t = threadIdx.x, N = w.N, nl = w.nl;
+    for (int i = t; i < N; i += T) w.sig_p[i] = 1.0 / (1.0 + sqrt(w.H[(size_t)i * N + i]));
+    for (int l = t; l < nl; l += T) w.sig_l[l] = 1.0 / (1.0 + sqrt(w.lm_m[l]));
+    __syncthreads();
+}
+
+// state-updating callback: `user` (the bias linearisation point of the preintegration factors) follows an accepted step
+PHASE_FN void publish_user_state(LdsWs &w) {
+    for (int i = threadIdx.x; i < w.nfr * 16; i += T) w.user[i] = w.x[i];
+    __syncthreads();
+}
+
+// dogleg diagonal and scaled gradient; returns |scaled gradient|^2
+PHASE_FN double dogleg_prepare(LdsWs &w, Shared &sh, int &phase) {
+    const int t = threadIdx.x, N = w.N, nl = w.nl;
+    double gsq = 0.0;
+    for (int i = t; i < N; i += T) {
+        const double s = w.sig_p[i];
+        const double d = sqrt(clampd(s * s * w.H[(size_t)i * N + i], 1e-6, 1e32));
+        w.diag_p[i] = d;
+        const double gv = s * w.g[i] / d;
+        w.grad_p[i] = gv;
+        gsq += gv * gv;
+    }
+    for (int l = t; l < nl; l += T) {
+        double d = 1.0, gv = 0.0;
+        if (w.lfree[l]) {
+            const double s = w.sig_l[l];
+            d = sqrt(clampd(s * s * w.lm_m[l], 1e-6, 1e32));
+            gv = s * w.lm_g[l] / d;
+        }
+        w.diag_l[l] = d;
+        w.grad_l[l] = gv;
+        gsq += gv * gv;
+    }
+    return block_sum(sh, gsq, phase);
+}
+
+// landmark elimination for the damping mu:  [C | Cg] = A^T W [A | g] on the matrix cores, then
+// S = Sigma (H - C) Sigma + mu D^2 (lower triangle, LDS-packed when the window fits) and the reduced right-hand side
+PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, double *lds, size_t lds_cap, double mu, unsigned long long &prof_last) {
+    const int t = threadIdx.x;
+    const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
+    const bool has_lm = nl > 0 && w.n_lfree_hint > 0;
+    double *Sl = lds;
+    for (int l = t; l < nl; l += T) {
+        double lw = 0.0;
+        if (w.lfree[l]) {
+            const double s2 = w.sig_l[l] * w.sig_l[l];
+            lw = s2 / (s2 * w.lm_m[l] + mu * w.diag_l[l] * w.diag_l[l]);
+        }
+        w.lm_w[l] = lw;
+    }
+    __syncthreads();
+    // The operand is first staged into the (currently idle) LDS Cholesky buffer with one batch of coalesced loads: a
+    // K-loop over global memory is a chain of ~nl/16 dependent L2 round trips per tile.
+    if (NA > 0 && has_lm) {
+        if (w.lds_chol && (size_t)nl * NAs + nl <= lds_cap) {
+            double *As = lds, *ws = lds + (size_t)nl * NAs;
+            for (int i = t; i < nl * NAs; i += T) As[i] = w.A[i];
+            for (int l = t; l < nl; l += T) ws[l] = w.lm_w[l];
+            __syncthreads();
+            block_gemm_tn<T>(w.Cm, NAs, As, NAs, As, NAs, ws, NA, NA + 1, nl, true);
+        } else {
+            block_gemm_tn<T>(w.Cm, NAs, w.A, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, true);
+        }
+    }
+    __syncthreads();
+    STAMP(29);
+    // one wave per 15 x 15 block, 4 passes in flight
+    for (int i = t; i < N; i += T) sh.xv[i] = w.sig_p[i];
+    __syncthreads();
+    for (int blk = t >> 6; blk < nfree * nfree; blk += NW) {
+        const int fi = blk / nfree, fj = blk - fi * nfree;
+        if (fj > fi) continue;
+        double vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = (t & 63) + 64 * u, a = e / 15, b = e - 15 * a;
+            double v = 0.0;
+            if (e < 225 && (fi != fj || b <= a)) {
+                const int i = 15 * fi + a, j = 15 * fj + b;
+                v = w.H[(size_t)i * N + j];
+                if (a < 6 && b < 6 && has_lm) v -= w.Cm[(size_t)(6 * fi + a) * NAs + 6 * fj + b];
+                v *= sh.xv[i] * sh.xv[j];
+                if (i == j) v += mu * w.diag_p[i] * w.diag_p[i];
+            }
+            vv[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = (t & 63) + 64 * u, a = e / 15, b = e - 15 * a;
+            if (e < 225 && (fi != fj || b <= a)) {
+                const int i = 15 * fi + a, j = 15 * fj + b;
+                if (w.lds_chol) Sl[tri(i) + j] = vv[u];
+                else w.Sm[(size_t)i * N + j] = vv[u];
+            }
+        }
+    }
+    for (int i = t; i < N; i += T) {
+        const int fi = i / 15, a = i - 15 * fi;
+        double v = w.g[i];
+        if (a < 6 && has_lm) v -= w.Cm[(size_t)(6 * fi + a) * NAs + NA];
+        w.yp[i] = v * w.sig_p[i];
+    }
+    __syncthreads();
+}
+
+// landmark part of the Gauss-Newton solve from the frame part in yp; returns > 0 when a component is not finite
+PHASE_FN double back_substitute(LdsWs &w, Shared &sh, int &phase, double mu) {
+    const int t = threadIdx.x;
+    const int N = w.N, nl = w.nl, nfree = w.nfree, NAs = 6 * nfree + 2;
+    double bad = 0.0;
+    for (int i = t; i < N; i += T) sh.xv[i] = w.sig_p[i] * w.yp[i];
+    __syncthreads();
+    for (int l = t; l < nl; l += T) {
+        double y = 0.0;
+        if (w.lfree[l]) {
+            double s = w.lm_g[l];
+            const double *Arow = w.A + (size_t)l * NAs;
+            for (int f = 0; f < nfree; ++f) {
+                double av[6];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) av[a] = Arow[6 * f + a];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) s -= av[a] * sh.xv[15 * f + a];
+            }
+            const double s2 = w.sig_l[l] * w.sig_l[l];
+            y = w.sig_l[l] * s / (s2 * w.lm_m[l] + mu * w.diag_l[l] * w.diag_l[l]);
+            if (!isfinite(y)) bad = 1.0;
+        }
+        w.yl[l] = y;
+    }
+    for (int i = t; i < N; i += T)
+        if (!isfinite(w.yp[i])) bad = 1.0;
+    return block_max(sh, bad, phase);
+}
+
+// Gauss-Newton step in dogleg coordinates and the three norms the step selection needs: |g|^2, |gn|^2, g . gn
+PHASE_FN void gauss_newton_norms(LdsWs &w, Shared &sh, int &phase, double (&a3)[3]) {
+    const int t = threadIdx.x, N = w.N, nl = w.nl;
+    a3[0] = a3[1] = a3[2] = 0.0;
+    for (int i = t; i < N; i += T) {
+        const double gn = -w.yp[i] * w.diag_p[i];
+        w.gn_p[i] = gn;
+        a3[0] += w.grad_p[i] * w.grad_p[i];
+        a3[1] += gn * gn;
+        a3[2] += w.grad_p[i] * gn;
+    }
+    for (int l = t; l < nl; l += T) {
+        const double gn = -w.yl[l] * w.diag_l[l];
+        w.gn_l[l] = gn;
+        a3[0] += w.grad_l[l] * w.grad_l[l];
+        a3[1] += gn * gn;
+        a3[2] += w.grad_l[l] * gn;
+    }
+    block_sum_n<T, 3>(sh, a3, phase);
+}
+
+// x <- candidate
+PHASE_FN void accept_candidate(LdsWs &w) {
+    const int t = threadIdx.x;
+    for (int o = t; o < w.nfr * 16; o += T) w.x[o] = w.xc[o];
+    for (int l = t; l < w.nl; l += T) w.xd[l] = w.xdc[l];
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     __shared__ Shared sh;
     // packed 15x15 blocks of S and the inverses of its diagonal factors, LDS-resident when the window has at most
@@ -816,12 +1001,16 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     __shared__ __attribute__((aligned(16))) double lds_chol_buf[LDS_CAP];
     double *Sl = lds_chol_buf, *Dinv = lds_chol_buf + w.N * (w.N + 1) / 2;
     const int t = threadIdx.x;
+    __shared__ SolverWs w_lds;
+    for (int i = t; i < (int)(sizeof(SolverWs) / 8); i += T)
+        ((__attribute__((address_space(3))) unsigned long long *)&w_lds)[i] = ((const unsigned long long *)&w)[i];
+    __syncthreads();
+    LdsWs &wl = *(LdsWs *)&w_lds;
     if (blockIdx.x > 0) {  // helper workgroup: factor evaluation on request
-        helper_loop(w, sh);
+        helper_loop(wl, sh);
         return;
     }
-    const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
-    const bool has_lm = nl > 0 && w.n_lfree_hint > 0;  // no free landmark (localize_newframe, prior-only solves): no Schur term
+    const int N = w.N;
     int phase = 0;
     unsigned long long prof_last = 0;
 #ifdef RDVIO_PROF
@@ -829,7 +1018,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     if (t == 0) for (int i = 8; i < 72; ++i) w.summary[i] = 0.0;
 #endif
 
-    solver_setup(w, sh, lds_chol_buf, LDS_CAP, prof_last);
+    solver_setup(wl, sh, lds_chol_buf, LDS_CAP, prof_last);
 
     double radius = 1e4, mu = 1e-8, alpha = 0.0, dogleg_step_norm = 0.0;
     double gnorm = 0.0, gn_norm = 0.0, gdotgn = 0.0, gsq_keep = 0.0;
@@ -837,25 +1026,19 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     int reuse = 0, iteration = 0, invalid_steps = 0, last_successful = 0, n_success = 0;
     int term = 1;  // NO_CONVERGENCE
     STAMP(0);
-    double x_norm = x_norm_of(w, sh, phase, w.x, w.xd);
-    double x_cost = evaluate<true>(w, sh, phase, w.x, w.xd, prof_last);
+    double x_norm = x_norm_of(wl, sh, phase, w.x, w.xd);
+    double x_cost = evaluate<true>(wl, sh, phase, w.x, w.xd, prof_last);
     STAMP(1);
     const double initial_cost = x_cost;
-    build_normal_equations(w, sh, prof_last);
+    build_normal_equations(wl, sh, prof_last);
     STAMP(2);
-    // Jacobi scaling from the iteration-0 Jacobian
-    for (int i = t; i < N; i += T) w.sig_p[i] = 1.0 / (1.0 + sqrt(w.H[(size_t)i * N + i]));
-    for (int l = t; l < nl; l += T) w.sig_l[l] = 1.0 / (1.0 + sqrt(w.lm_m[l]));
-    __syncthreads();
-    double grad_max = grad_max_norm(w, sh, phase);
+    jacobi_scaling(wl);
+    double grad_max = grad_max_norm(wl, sh, phase);
 
     if (N == 0 && w.n_lfree_hint == 0) term = 0;
     else
         for (;;) {
-            if (last_successful) {  // state-updating callback
-                for (int i = t; i < w.nfr * 16; i += T) w.user[i] = w.x[i];
-                __syncthreads();
-            }
+            if (last_successful) publish_user_state(wl);
             if (iteration >= w.max_iter) { term = 1; break; }
             if (grad_max <= 1e-10) { term = 0; break; }
             if (radius <= 1e-32) { term = 0; break; }
@@ -866,93 +1049,12 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             int solve_ok = 1;
             if (!reuse) {
                 reuse = 1;
-                // dogleg diagonal, scaled gradient
-                double gsq = 0.0;
-                for (int i = t; i < N; i += T) {
-                    const double s = w.sig_p[i];
-                    const double d = sqrt(clampd(s * s * w.H[(size_t)i * N + i], 1e-6, 1e32));
-                    w.diag_p[i] = d;
-                    const double gv = s * w.g[i] / d;
-                    w.grad_p[i] = gv;
-                    gsq += gv * gv;
-                }
-                for (int l = t; l < nl; l += T) {
-                    if (!w.lfree[l]) { w.diag_l[l] = 1.0; w.grad_l[l] = 0.0; continue; }
-                    const double s = w.sig_l[l];
-                    const double d = sqrt(clampd(s * s * w.lm_m[l], 1e-6, 1e32));
-                    w.diag_l[l] = d;
-                    const double gv = s * w.lm_g[l] / d;
-                    w.grad_l[l] = gv;
-                    gsq += gv * gv;
-                }
-                gsq = block_sum(sh, gsq, phase);
-                gsq_keep = gsq;
+                gsq_keep = dogleg_prepare(wl, sh, phase);
                 STAMP(3);
                 // Gauss-Newton step: (H_s + mu D^2) y = g_s with the landmarks eliminated
                 solve_ok = 0;
                 while (mu < 1.0) {
-                    for (int l = t; l < nl; l += T) {
-                        double wl = 0.0;
-                        if (w.lfree[l]) {
-                            const double s2 = w.sig_l[l] * w.sig_l[l];
-                            wl = s2 / (s2 * w.lm_m[l] + mu * w.diag_l[l] * w.diag_l[l]);
-                        }
-                        w.lm_w[l] = wl;
-                    }
-                    __syncthreads();
-                    // [C | Cg] = A^T W [A | g] (lower tiles + the gradient column) on the matrix cores.  The operand is
-                    // first staged into the (currently idle) LDS Cholesky buffer with one batch of coalesced loads: a
-                    // K-loop over global memory is a chain of ~nl/16 dependent L2 round trips per tile.
-                    if (NA > 0 && has_lm) {
-                        if (w.lds_chol && (size_t)nl * NAs + nl <= LDS_CAP) {
-                            double *As = lds_chol_buf, *ws = lds_chol_buf + (size_t)nl * NAs;
-                            for (int i = t; i < nl * NAs; i += T) As[i] = w.A[i];
-                            for (int l = t; l < nl; l += T) ws[l] = w.lm_w[l];
-                            __syncthreads();
-                            block_gemm_tn<T>(w.Cm, NAs, As, NAs, As, NAs, ws, NA, NA + 1, nl, true);
-                        } else {
-                            block_gemm_tn<T>(w.Cm, NAs, w.A, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, true);
-                        }
-                    }
-                    __syncthreads();
-                    STAMP(29);
-                    // S = Sigma (H - C) Sigma + mu D^2   (lower triangle); one wave per 15 x 15 block, 4 passes in flight
-                    for (int i = t; i < N; i += T) sh.xv[i] = w.sig_p[i];
-                    __syncthreads();
-                    for (int blk = t >> 6; blk < nfree * nfree; blk += NW) {
-                        const int fi = blk / nfree, fj = blk - fi * nfree;
-                        if (fj > fi) continue;
-                        double vv[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int e = (t & 63) + 64 * u, a = e / 15, b = e - 15 * a;
-                            double v = 0.0;
-                            if (e < 225 && (fi != fj || b <= a)) {
-                                const int i = 15 * fi + a, j = 15 * fj + b;
-                                v = w.H[(size_t)i * N + j];
-                                if (a < 6 && b < 6 && has_lm) v -= w.Cm[(size_t)(6 * fi + a) * NAs + 6 * fj + b];
-                                v *= sh.xv[i] * sh.xv[j];
-                                if (i == j) v += mu * w.diag_p[i] * w.diag_p[i];
-                            }
-                            vv[u] = v;
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int e = (t & 63) + 64 * u, a = e / 15, b = e - 15 * a;
-                            if (e < 225 && (fi != fj || b <= a)) {
-                                const int i = 15 * fi + a, j = 15 * fj + b;
-                                if (w.lds_chol) Sl[tri(i) + j] = vv[u];
-                                else w.Sm[(size_t)i * N + j] = vv[u];
-                            }
-                        }
-                    }
-                    for (int i = t; i < N; i += T) {
-                        const int fi = i / 15, a = i - 15 * fi;
-                        double v = w.g[i];
-                        if (a < 6 && has_lm) v -= w.Cm[(size_t)(6 * fi + a) * NAs + NA];
-                        w.yp[i] = v * w.sig_p[i];
-                    }
-                    __syncthreads();
+                    schur_reduce(wl, sh, lds_chol_buf, LDS_CAP, mu, prof_last);
                     STAMP(4);
                     int ok = 1;
                     if (N > 0) ok = w.lds_chol ? cholesky_lds(sh, RDVIO_LDS(Sl), RDVIO_LDS(Dinv), N) : cholesky_blocked(sh, w.Sm, N);
@@ -962,32 +1064,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                         else cholesky_solve(sh, w.Sm, N, w.yp);
                     }
                     STAMP(6);
-                    double bad = 0.0;
-                    if (ok) {
-                        for (int i = t; i < N; i += T) sh.xv[i] = w.sig_p[i] * w.yp[i];
-                        __syncthreads();
-                        for (int l = t; l < nl; l += T) {
-                            double y = 0.0;
-                            if (w.lfree[l]) {
-                                double s = w.lm_g[l];
-                                const double *Arow = w.A + (size_t)l * NAs;
-                                for (int f = 0; f < nfree; ++f) {
-                                    double av[6];
-#pragma unroll
-                                    for (int a = 0; a < 6; ++a) av[a] = Arow[6 * f + a];
-#pragma unroll
-                                    for (int a = 0; a < 6; ++a) s -= av[a] * sh.xv[15 * f + a];
-                                }
-                                const double s2 = w.sig_l[l] * w.sig_l[l];
-                                y = w.sig_l[l] * s / (s2 * w.lm_m[l] + mu * w.diag_l[l] * w.diag_l[l]);
-                                if (!isfinite(y)) bad = 1.0;
-                            }
-                            w.yl[l] = y;
-                        }
-                        for (int i = t; i < N; i += T)
-                            if (!isfinite(w.yp[i])) bad = 1.0;
-                        bad = block_max(sh, bad, phase);
-                    }
+                    const double bad = ok ? back_substitute(wl, sh, phase, mu) : 0.0;
                     if (!ok || bad > 0.0) {
                         mu *= 10.0;
                         continue;
@@ -996,26 +1073,12 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     break;
                 }
                 if (solve_ok) {
-                    double a3[3] = {0.0, 0.0, 0.0};
-                    for (int i = t; i < N; i += T) {
-                        const double gn = -w.yp[i] * w.diag_p[i];
-                        w.gn_p[i] = gn;
-                        a3[0] += w.grad_p[i] * w.grad_p[i];
-                        a3[1] += gn * gn;
-                        a3[2] += w.grad_p[i] * gn;
-                    }
-                    for (int l = t; l < nl; l += T) {
-                        const double gn = -w.yl[l] * w.diag_l[l];
-                        w.gn_l[l] = gn;
-                        a3[0] += w.grad_l[l] * w.grad_l[l];
-                        a3[1] += gn * gn;
-                        a3[2] += w.grad_l[l] * gn;
-                    }
-                    block_sum_n<T, 3>(sh, a3, phase);
+                    double a3[3];
+                    gauss_newton_norms(wl, sh, phase, a3);
                     gnorm = sqrt(a3[0]);
                     gn_norm = sqrt(a3[1]);
                     gdotgn = a3[2];
-                    model_scalars(w, sh, phase, msc);
+                    model_scalars(wl, sh, phase, msc);
                     alpha = gsq_keep / msc[0];
                 }
                 STAMP(7);
@@ -1057,7 +1120,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             // candidate = Plus(x, delta), its cost and the ambient step norm in one pass
             STAMP(28);
             double sn2 = 0.0;
-            double cand_cost = evaluate<false, true>(w, sh, phase, w.xc, w.xdc, prof_last, &sn2, step_ca, step_cb);
+            double cand_cost = evaluate<false, true>(wl, sh, phase, w.xc, w.xdc, prof_last, &sn2, step_ca, step_cb);
             if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
             STAMP(9);
             const double step_norm = sqrt(sn2);
@@ -1066,16 +1129,14 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             if (fabs(cost_change) <= 1e-6 * x_cost) { term = 0; break; }
             const double rel = (cand_cost >= 1.7976931348623157e308) ? -1.7976931348623157e308 : (x_cost - cand_cost) / model_cost_change;
             if (rel > 1e-3) {
-                for (int o = t; o < w.nfr * 16; o += T) w.x[o] = w.xc[o];
-                for (int l = t; l < nl; l += T) w.xd[l] = w.xdc[l];
-                __syncthreads();
-                x_norm = x_norm_of(w, sh, phase, w.x, w.xd);
+                accept_candidate(wl);
+                x_norm = x_norm_of(wl, sh, phase, w.x, w.xd);
                 STAMP(10);
-                x_cost = evaluate<true>(w, sh, phase, w.x, w.xd, prof_last);  // `user` still holds the previous point here
+                x_cost = evaluate<true>(wl, sh, phase, w.x, w.xd, prof_last);  // `user` still holds the previous point here
                 STAMP(1);
-                build_normal_equations(w, sh, prof_last);
+                build_normal_equations(wl, sh, prof_last);
                 STAMP(2);
-                grad_max = grad_max_norm(w, sh, phase);
+                grad_max = grad_max_norm(wl, sh, phase);
                 STAMP(11);
                 last_successful = 1;
                 n_success++;
@@ -1105,17 +1166,22 @@ __global__ __launch_bounds__(T) void marginalize_kernel(SolverWs w) {
     __shared__ Shared sh;
     constexpr int NMAX = 15 * RDVIO_LDS_CHOL_MAX_FRAMES;
     __shared__ __attribute__((aligned(16))) double lds_buf[NMAX * (NMAX + 1) / 2 + 225 * RDVIO_LDS_CHOL_MAX_FRAMES];
+    __shared__ SolverWs w_lds;
+    for (int i = threadIdx.x; i < (int)(sizeof(SolverWs) / 8); i += T)
+        ((__attribute__((address_space(3))) unsigned long long *)&w_lds)[i] = ((const unsigned long long *)&w)[i];
+    __syncthreads();
+    LdsWs &wl = *(LdsWs *)&w_lds;
     int phase = 0;
     unsigned long long prof_last = 0;
 #ifdef RDVIO_PROF
     prof_last = wall_clock64();
     if (threadIdx.x == 0) for (int i = 8; i < 72; ++i) w.summary[i] = 0.0;
 #endif
-    solver_setup(w, sh, lds_buf, sizeof(lds_buf) / sizeof(double), prof_last);
+    solver_setup(wl, sh, lds_buf, sizeof(lds_buf) / sizeof(double), prof_last);
     STAMP(0);
-    (void)evaluate<true>(w, sh, phase, w.x, w.xd, prof_last);
+    (void)evaluate<true>(wl, sh, phase, w.x, w.xd, prof_last);
     STAMP(1);
-    build_normal_equations(w, sh, prof_last);
+    build_normal_equations(wl, sh, prof_last);
     STAMP(2);
     marginalize_tail<T>(w, sh, phase, lds_buf);
     STAMP(3);
