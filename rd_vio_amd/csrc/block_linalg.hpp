@@ -28,6 +28,12 @@ struct BlockShared {
     double ext[18];      // extrinsics (14) + sqrt_inv_cov (4)
     double cam[64 * 12]; // per frame: camera-to-world rotation (row-major 3x3) and camera centre of the states being evaluated
 };
+// the kernels hand the block around as an LDS-typed reference, so that accesses compile to ds_read / ds_write in
+// noinline callees too (a generic reference makes them FLAT)
+template <int T>
+using LdsShared = __attribute__((address_space(3))) BlockShared<T>;
+// a member array handed to an (inlined) routine that takes plain pointers: the cast folds away after inlining
+#define RDVIO_GEN(a) ((double *)(a))
 
 // sum_i a[i * sa] * x[i * sx] with the loads of U iterations issued together (memory-level parallelism: a single
 // workgroup has little other latency hiding).  Summation order is fixed.
@@ -94,7 +100,7 @@ DM double wave_max(double v) {
 // Sum NV values over the workgroup; every thread receives the totals.  One __syncthreads per call: the partial
 // buffers alternate between two banks, so the next call cannot overwrite values another wave is still reading.
 template <int T, int NV>
-DM void block_sum_n(BlockShared<T> &sh, double (&v)[NV], int &phase) {
+DM void block_sum_n(LdsShared<T> &sh, double (&v)[NV], int &phase) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -112,13 +118,13 @@ DM void block_sum_n(BlockShared<T> &sh, double (&v)[NV], int &phase) {
     phase ^= 1;
 }
 template <int T>
-DM double block_sum(BlockShared<T> &sh, double v, int &phase) {
+DM double block_sum(LdsShared<T> &sh, double v, int &phase) {
     double a[1] = {v};
     block_sum_n<T, 1>(sh, a, phase);
     return a[0];
 }
 template <int T>
-DM double block_max(BlockShared<T> &sh, double v, int &phase) {
+DM double block_max(LdsShared<T> &sh, double v, int &phase) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const double s = wave_max(v);
     if (lane == 0) sh.red[phase][0][wave] = s;
@@ -203,7 +209,7 @@ DM void block_matvec_rows(const double *__restrict__ Mx, int ld, int R, int C, c
 // Diagonal block: LDS, first wave.  Panel: one thread per row.  Trailing update: MFMA tiles.
 // Returns 0 on a non-positive / non-finite pivot.
 template <int T>
-__device__ __attribute__((noinline)) int cholesky_blocked(BlockShared<T> &sh, double *M, int N) {
+__device__ __attribute__((noinline)) int cholesky_blocked(LdsShared<T> &sh, double *M, int N) {
     const int t = threadIdx.x;
     const int nb = N / 15;
     if (t == 0) sh.flag = 1;
@@ -280,7 +286,7 @@ __device__ __attribute__((noinline)) int cholesky_blocked(BlockShared<T> &sh, do
 // solve L L^T y = b in place (y overwrites b), blocked like the factorisation; the 15x15 diagonal block is
 // staged in LDS so the sequential triangular solve never waits on global memory
 template <int T>
-__device__ __attribute__((noinline)) void cholesky_solve(BlockShared<T> &sh, const double *M, int N, double *b, bool forward = true, bool backward = true) {
+__device__ __attribute__((noinline)) void cholesky_solve(LdsShared<T> &sh, const double *M, int N, double *b, bool forward = true, bool backward = true) {
     const int t = threadIdx.x;
     const int nb = N / 15;
     if (forward)
@@ -369,7 +375,7 @@ DM double rsqrt_nr(double x) {
 //   (3) the trailing matrix is updated with v_mfma_f64_16x16x4 tiles (K = 15): ~0.2 instructions per entry instead of
 //       ~30 for scalar indexed updates -- with one workgroup the factorisation is instruction-issue bound.
 template <int T>
-__device__ __attribute__((noinline)) int cholesky_lds(BlockShared<T> &sh, lds_double *Lp, lds_double *Dinv, int N) {
+__device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_double *Lp, lds_double *Dinv, int N) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, nw = T / 64;
     const int nb = N / 15;
     if (t == 0) sh.flag = 1;
@@ -472,9 +478,9 @@ __device__ __attribute__((noinline)) int cholesky_lds(BlockShared<T> &sh, lds_do
 
 // solve L L^T y = b with L packed in LDS and Dinv = inverses of its 15 x 15 diagonal blocks; b in place.
 template <int T>
-__device__ __attribute__((noinline)) void cholesky_solve_lds(BlockShared<T> &sh, const lds_double *Lp, const lds_double *Dinv, int N, double *b) {
+__device__ __attribute__((noinline)) void cholesky_solve_lds(LdsShared<T> &sh, const lds_double *Lp, const lds_double *Dinv, int N, double *b) {
     const int t = threadIdx.x, nb = N / 15;
-    double *y = sh.xv;  // N <= 512
+    double *y = RDVIO_GEN(sh.xv);  // N <= 512
     for (int i = t; i < N; i += T) y[i] = b[i];
     __syncthreads();
     for (int kb = 0; kb < nb; ++kb) {  // forward: y_k = Dinv_k y_k ; later rows -= L_ik y_k

@@ -29,7 +29,7 @@
 // Parallel-ordered (round-robin) two-sided Jacobi on the symmetric R x R matrix A (row-major, global).
 // V accumulates the rotations (columns = eigenvectors).  cs: scratch for 2 * (Rp/2) rotation parameters.
 template <int T>
-DM void jacobi_eigen(BlockShared<T> &sh, double *A, double *V, double *cs, int R) {
+__device__ __attribute__((noinline)) void jacobi_eigen(LdsShared<T> &sh, double *A, double *V, double *cs, int R) {
     const int t = threadIdx.x;
     int phase = 0;
     const int Rp = (R + 1) & ~1, half = Rp / 2;
@@ -103,7 +103,7 @@ DM void jacobi_eigen(BlockShared<T> &sh, double *A, double *V, double *cs, int R
 // factor column j (length n, zero on rows pivoted earlier) to Lc[j * n ..] and f[j]; eta (length n) is eliminated
 // alongside.  Stops when the largest remaining diagonal entry is <= tol.  Returns the numerical rank.
 template <int T>
-DM int pivoted_cholesky(BlockShared<T> &sh, int &phase, double *A, double *eta, double *Lc, double *fv, double *lcol,
+__device__ __attribute__((noinline)) int pivoted_cholesky(LdsShared<T> &sh, int &phase, double *A, double *eta, double *Lc, double *fv, double *lcol,
                         int *done, int n, double tol) {
     const int t = threadIdx.x;
     for (int i = t; i < n; i += T) done[i] = 0;
@@ -232,7 +232,7 @@ __device__ __attribute__((noinline)) int pivoted_cholesky_lds(lds_double *Ap, ld
 
 // lds: LDS scratch of at least tri(R) + 3 R + 450 doubles when w.lds_chol, otherwise only the first 450 are used.
 template <int T>
-DM void marginalize_tail(const SolverWs &w, BlockShared<T> &sh, int &phase, double *lds) {
+__device__ __attribute__((noinline)) void marginalize_tail(LdsWs &w, LdsShared<T> &sh, int &phase, double *lds) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, nw = T / 64;
     const int N = w.N, R = N - 15, nl = w.nl, NA = 6 * w.nfree, NAs = NA + 2;
     double *sM = lds;  // 15 x 30 augmented block for the victim's inverse

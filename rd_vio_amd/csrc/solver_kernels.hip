@@ -32,10 +32,7 @@ namespace {
 
 constexpr int T = RDVIO_SOLVER_THREADS;
 constexpr int NW = T / 64;
-using Shared = BlockShared<T>;
-// The by-value kernel argument cannot be handed to a noinline function without a private (scratch) copy, and every
-// `w.field` read there would be an L2 round trip ahead of the access it feeds; the kernels keep one copy in LDS instead.
-typedef const __attribute__((address_space(3))) SolverWs LdsWs;
+using Shared = LdsShared<T>;
 
 #ifdef RDVIO_PROF
 // diagnostic build only: accumulate wall-clock ticks (100 MHz) per phase into summary[8 + id], counts into [40 + id]
@@ -190,8 +187,8 @@ DM double cost_factors(const WS &w, const Shared &sh, const double *invd, const 
         const int kb = has2 ? k2 : k;
         double ra[2], rb[2];
         const int la = w.lm[k], lb = w.lm[kb];
-        reprojection_residual(sh.cam + 12 * w.tgt[k], sh.cam + 12 * w.ref[k], w.tangent + 9 * (size_t)k, w.z_ref + 3 * (size_t)la, invd[la], W, ra);
-        reprojection_residual(sh.cam + 12 * w.tgt[kb], sh.cam + 12 * w.ref[kb], w.tangent + 9 * (size_t)kb, w.z_ref + 3 * (size_t)lb, invd[lb], W, rb);
+        reprojection_residual(RDVIO_GEN(sh.cam) + 12 * w.tgt[k], RDVIO_GEN(sh.cam) + 12 * w.ref[k], w.tangent + 9 * (size_t)k, w.z_ref + 3 * (size_t)la, invd[la], W, ra);
+        reprojection_residual(RDVIO_GEN(sh.cam) + 12 * w.tgt[kb], RDVIO_GEN(sh.cam) + 12 * w.ref[kb], w.tangent + 9 * (size_t)kb, w.z_ref + 3 * (size_t)lb, invd[lb], W, rb);
         const double sa = ra[0] * ra[0] + ra[1] * ra[1], sb = rb[0] * rb[0] + rb[1] * rb[1];
         cost += w.no_loss ? 0.5 * sa : 0.5 * log(1.0 + sa);
         if (has2) cost += w.no_loss ? 0.5 * sb : 0.5 * log(1.0 + sb);
@@ -252,16 +249,16 @@ __device__ __attribute__((noinline)) void helper_loop(LdsWs &w, Shared &sh) {
         }
         for (int i = t; i < w.nfr * 16; i += T) sh.st[i] = states[i];
         if (!(cmd & CMD_LIN))
-            for (int i = t; i < w.nfr; i += T) camera_pose_of(states + 16 * i, w.extr, sh.cam + 12 * i);
+            for (int i = t; i < w.nfr; i += T) camera_pose_of(states + 16 * i, w.extr, RDVIO_GEN(sh.cam) + 12 * i);
         __syncthreads();
-        const double *W = sh.ext + 14, *extr = sh.ext;
+        const double *W = RDVIO_GEN(sh.ext) + 14, *extr = RDVIO_GEN(sh.ext);
         double cost = 0.0;
         if (cmd & CMD_LIN) {
-            for (int k = gid; k < w.nf; k += P) cost += linearize_factor(w, sh, k, sh.st, invd, extr, W);
-            cost += rotation_factors<true>(w, sh, sh.st, extr, W, gid, P);
+            for (int k = gid; k < w.nf; k += P) cost += linearize_factor(w, sh, k, RDVIO_GEN(sh.st), invd, extr, W);
+            cost += rotation_factors<true>(w, sh, RDVIO_GEN(sh.st), extr, W, gid, P);
         } else {
             cost += cost_factors(w, sh, invd, W, gid, P);
-            cost += rotation_factors<false>(w, sh, sh.st, extr, W, gid, P);
+            cost += rotation_factors<false>(w, sh, RDVIO_GEN(sh.st), extr, W, gid, P);
         }
         cost = block_sum(sh, cost, phase);
         __threadfence();
@@ -314,7 +311,7 @@ __device__ __attribute__((noinline)) double evaluate(LdsWs &w, Shared &sh, int &
             }
 #pragma unroll
             for (int a = 0; a < 16; ++a) { w.xc[16 * i + a] = o[a]; sh.st[16 * i + a] = o[a]; }
-            camera_pose_of(o, w.extr, sh.cam + 12 * i);
+            camera_pose_of(o, w.extr, RDVIO_GEN(sh.cam) + 12 * i);
         }
         for (int l = t; l < w.nl; l += T) {
             const double v = w.xd[l] + (w.lfree[l] ? w.sig_l[l] * ((ca * w.grad_l[l] + cb * w.gn_l[l]) / w.diag_l[l]) : 0.0);
@@ -324,13 +321,13 @@ __device__ __attribute__((noinline)) double evaluate(LdsWs &w, Shared &sh, int &
     } else {
         for (int i = t; i < w.nfr * 16; i += T) sh.st[i] = states[i];
         if (!LIN)  // camera poses for the cost-only residuals (the last wave is idle here: its work starts after the barrier)
-            for (int i = T - 1 - t; i < w.nfr; i += T) camera_pose_of(states + 16 * i, w.extr, sh.cam + 12 * i);
+            for (int i = T - 1 - t; i < w.nfr; i += T) camera_pose_of(states + 16 * i, w.extr, RDVIO_GEN(sh.cam) + 12 * i);
     }
     for (int i = t; i < w.nfr * 6; i += T) sh.ub[i] = w.user[16 * (i / 6) + ST_BG + (i % 6)];
     __syncthreads();
     STAMP(LIN ? 30 : 31);
-    states = sh.st;
-    const double *W = sh.ext + 14, *extr = sh.ext;
+    states = RDVIO_GEN(sh.st);
+    const double *W = RDVIO_GEN(sh.ext) + 14, *extr = RDVIO_GEN(sh.ext);
     double cost = 0.0;
     constexpr int TF = T - 64;
     // threads that evaluate reprojection factors: TF of this workgroup + every thread of the helper workgroups
@@ -362,7 +359,7 @@ __device__ __attribute__((noinline)) double evaluate(LdsWs &w, Shared &sh, int &
         for (int k = j; k < w.npre; k += 64) {
             double *G = w.G + 450 * k;
             preintegration_unwhitened<LIN>(states + 16 * w.pre_i[k], states + 16 * w.pre_j[k], w.preint + (size_t)RDVIO_PREINT_SIZE * k,
-                                           sh.ub + 6 * w.pre_i[k], extr, w.e_p + 15 * k, G, G + 225);
+                                           RDVIO_GEN(sh.ub) + 6 * w.pre_i[k], extr, w.e_p + 15 * k, G, G + 225);
         }
     }
     STAMP(LIN ? 17 : 20);
@@ -404,13 +401,13 @@ __device__ __attribute__((noinline)) double evaluate(LdsWs &w, Shared &sh, int &
         for (int base = 0; base < D; base += T / 4) {
             const int row = base + (t >> 2), part = t & 3;
             if (row < D) {
-                const double r = quad_col_dot(w.ST, D, sh.xv, D, row, part) + w.f[row];
+                const double r = quad_col_dot(w.ST, D, RDVIO_GEN(sh.xv), D, row, part) + w.f[row];
                 if (part == 0) {
                     r_m[row] = r;
                     cost += 0.5 * r * r;
                 }
                 if (LIN) {
-                    const double le = quad_col_dot(w.Lam, D, sh.xv, D, row, part) + w.eta0[row];
+                    const double le = quad_col_dot(w.Lam, D, RDVIO_GEN(sh.xv), D, row, part) + w.eta0[row];
                     if (part == 0) w.le[row] = le;
                 }
             }
@@ -681,7 +678,7 @@ DM void model_products(const WS &w, Shared &sh, int &phase, const double *xp, co
 __device__ __attribute__((noinline)) void model_scalars(LdsWs &w, Shared &sh, int &phase, double (&out)[5]) {
     const int t = threadIdx.x;
     const int N = w.N, NA = 6 * w.nfree;
-    double *u = sh.xv, *v = sh.xv + 256;
+    double *u = RDVIO_GEN(sh.xv), *v = RDVIO_GEN(sh.xv) + 256;
     for (int i = t; i < N; i += T) {
         const double sd = w.sig_p[i] / w.diag_p[i];
         u[i] = sd * w.grad_p[i];
@@ -993,7 +990,8 @@ PHASE_FN void accept_candidate(LdsWs &w) {
 }
 
 __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
-    __shared__ Shared sh;
+    __shared__ BlockShared<T> sh_store;
+    Shared &sh = *(Shared *)&sh_store;
     // packed 15x15 blocks of S and the inverses of its diagonal factors, LDS-resident when the window has at most
     // RDVIO_LDS_CHOL_MAX_FRAMES free frames (138.6 KB of the CU's 160 KB); larger windows factor in global memory
     constexpr int NMAX = 15 * RDVIO_LDS_CHOL_MAX_FRAMES;
@@ -1163,7 +1161,8 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
 // loss), assemble the normal equations with the solver's own routines, then Schur out the landmarks and the victim
 // frame and rebuild the sqrt prior (marg_tail.hpp).
 __global__ __launch_bounds__(T) void marginalize_kernel(SolverWs w) {
-    __shared__ Shared sh;
+    __shared__ BlockShared<T> sh_store;
+    Shared &sh = *(Shared *)&sh_store;
     constexpr int NMAX = 15 * RDVIO_LDS_CHOL_MAX_FRAMES;
     __shared__ __attribute__((aligned(16))) double lds_buf[NMAX * (NMAX + 1) / 2 + 225 * RDVIO_LDS_CHOL_MAX_FRAMES];
     __shared__ SolverWs w_lds;
@@ -1183,7 +1182,7 @@ __global__ __launch_bounds__(T) void marginalize_kernel(SolverWs w) {
     STAMP(1);
     build_normal_equations(wl, sh, prof_last);
     STAMP(2);
-    marginalize_tail<T>(w, sh, phase, lds_buf);
+    marginalize_tail<T>(wl, sh, phase, lds_buf);
     STAMP(3);
 }
 

@@ -66,5 +66,11 @@ struct SolverWs {
     double *prof;                        // diagnostic phase stamps (RDVIO_PROF builds only)                     // iterations, successful steps, initial cost, final cost, termination
 };
 
+#ifdef __HIPCC__
+// The by-value kernel argument cannot be handed to a noinline function without a private (scratch) copy, and every
+// `w.field` read there would be an L2 round trip ahead of the access it feeds; the kernels keep one copy in LDS instead.
+typedef const __attribute__((address_space(3))) SolverWs LdsWs;
+#endif
+
 void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w);
 void rdvio_launch_marginalize(hipStream_t stream, const SolverWs &w);
