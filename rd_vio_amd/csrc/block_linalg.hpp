@@ -374,46 +374,77 @@ DM double rsqrt_nr(double x) {
 //   (2) the panel below is solved one thread per row against the block's factor (reciprocal pivots, no divides);
 //   (3) the trailing matrix is updated with v_mfma_f64_16x16x4 tiles (K = 15): ~0.2 instructions per entry instead of
 //       ~30 for scalar indexed updates -- with one workgroup the factorisation is instruction-issue bound.
+// 15 x 15 diagonal block at k0 factored in the registers of one wavefront (lane r = row r); rinv[c] = 1 / L_cc goes
+// to sh.vec for the panel.  The next pivot is finished first in every step, so that its reciprocal square root (a
+// ~200-cycle dependent chain) runs in the shadow of the remaining column updates.
+template <int T>
+DM void cholesky_diag_block(LdsShared<T> &sh, lds_double *Lp, int k0) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane < 15 ? lane : 14;
+    const lds_double *row = Lp + tri(k0 + r) + k0;
+    double a[15];
+#pragma unroll
+    for (int c = 0; c < 15; ++c) a[c] = (lane < 15 && c <= lane) ? row[c] : 0.0;
+    bool bad = false;
+    double piv = readlane_d(a[0], 0);
+#pragma unroll
+    for (int j = 0; j < 15; ++j) {
+        if (!(piv > 0.0) || !isfinite(piv)) bad = true;
+        const double rs = rsqrt_nr(piv);   // 1 / L_jj
+        const double lj = (lane == j) ? piv * rs : a[j] * rs;
+        a[j] = lj;
+        if (lane == j) sh.vec[j] = rs;
+        if (j + 1 < 15) {
+            a[j + 1] -= lj * readlane_d(lj, j + 1);
+            piv = readlane_d(a[j + 1], j + 1);
+        }
+#pragma unroll
+        for (int c = j + 2; c < 15; ++c) a[c] -= lj * readlane_d(lj, c);
+    }
+    if (bad && lane == 0) sh.flag = 0;
+    if (lane < 15) {
+        lds_double *wrow = Lp + tri(k0 + lane) + k0;
+#pragma unroll
+        for (int c = 0; c < 15; ++c)
+            if (c <= lane) wrow[c] = a[c];
+    }
+}
+
+// one lower 16 x 16 tile (bi, bj) of the trailing update C -= P P^T behind block column k0, on the matrix cores
+DM void cholesky_trailing_tile(lds_double *Lp, int k0, int N, int bi, int bj) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, kk = lane >> 4;
+    const int ra = k0 + 15 + 16 * bi + i, rb = k0 + 15 + 16 * bj + i;
+    const lds_double *pa = Lp + tri(ra < N ? ra : N - 1) + k0, *pb = Lp + tri(rb < N ? rb : N - 1) + k0;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int q = 4 * u + kk;
+        const double av = (ra < N && q < 15) ? pa[q] : 0.0, bv = (rb < N && q < 15) ? pb[q] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+    const int col = k0 + 15 + 16 * bj + (lane & 15);
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int rowi = k0 + 15 + 16 * bi + (lane >> 4) + 4 * r4;
+        if (rowi < N && col <= rowi) Lp[tri(rowi) + col] -= acc[r4];
+    }
+}
+
+// Two barriers per block column, with one block of lookahead: while wavefronts 1.. apply the trailing update of block
+// column k, wavefront 0 applies only the tile that holds the next diagonal block and factors it straight away (the
+// 15 dependent pivots of a diagonal block are the longest serial piece of a column).
 template <int T>
 __device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_double *Lp, lds_double *Dinv, int N) {
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, nw = T / 64;
+    const int t = threadIdx.x, wave = t >> 6, nw = T / 64;
     const int nb = N / 15;
     if (t == 0) sh.flag = 1;
     __syncthreads();
+    if (wave == 0 && nb > 0) cholesky_diag_block<T>(sh, Lp, 0);
+    __syncthreads();
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = 15 * kb;
-        // ---- (1) diagonal block in registers (wave 0); rinv[c] = 1 / L_cc goes to sh.vec for the panel
-        if (wave == 0) {
-            const int r = lane < 15 ? lane : 14;
-            const lds_double *row = Lp + tri(k0 + r) + k0;
-            double a[15];
-#pragma unroll
-            for (int c = 0; c < 15; ++c) a[c] = (lane < 15 && c <= lane) ? row[c] : 0.0;
-            bool bad = false;
-#pragma unroll
-            for (int j = 0; j < 15; ++j) {
-                const double piv = readlane_d(a[j], j);
-                if (!(piv > 0.0) || !isfinite(piv)) bad = true;
-                const double rs = rsqrt_nr(piv);   // 1 / L_jj
-                const double lj = (lane == j) ? piv * rs : a[j] * rs;
-                a[j] = lj;
-                if (lane == j) sh.vec[j] = rs;
-#pragma unroll
-                for (int c = j + 1; c < 15; ++c) {
-                    const double lc = readlane_d(lj, c);
-                    a[c] -= lj * lc;
-                }
-            }
-            if (bad && lane == 0) sh.flag = 0;
-            if (lane < 15) {
-                lds_double *wrow = Lp + tri(k0 + lane) + k0;
-#pragma unroll
-                for (int c = 0; c < 15; ++c)
-                    if (c <= lane) wrow[c] = a[c];
-            }
-        }
-        __syncthreads();
-        // ---- (2) panel: row i solves x L_kk^T = row  (forward substitution with reciprocal pivots)
+        // ---- panel: row i solves x L_kk^T = row  (forward substitution with reciprocal pivots)
         for (int i = k0 + 15 + t; i < N; i += T) {
             lds_double *row = Lp + tri(i) + k0;
             double x[15];
@@ -431,31 +462,23 @@ __device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_doub
 #pragma unroll
             for (int c = 0; c < 15; ++c) row[c] = x[c];
         }
+        if (kb + 1 == nb) break;
         __syncthreads();
-        // ---- (3) trailing update C -= P P^T on the matrix cores, lower 16 x 16 tiles
+        // ---- trailing update C -= P P^T, lower 16 x 16 tiles; tile (0, 0) and the next diagonal block on wavefront 0
         const int rem = N - (k0 + 15), tn = (rem + 15) / 16;
-        for (int tile = wave; tile < tn * tn; tile += nw) {
-            const int bi = tile / tn, bj = tile - bi * tn;
-            if (bj > bi) continue;
-            const int i = lane & 15, kk = lane >> 4;
-            const int ra = k0 + 15 + 16 * bi + i, rb = k0 + 15 + 16 * bj + i;
-            const lds_double *pa = Lp + tri(ra < N ? ra : N - 1) + k0, *pb = Lp + tri(rb < N ? rb : N - 1) + k0;
-            double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = 4 * u + kk;
-                const double av = (ra < N && q < 15) ? pa[q] : 0.0, bv = (rb < N && q < 15) ? pb[q] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            }
-            const int col = k0 + 15 + 16 * bj + (lane & 15);
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int rowi = k0 + 15 + 16 * bi + (lane >> 4) + 4 * r4;
-                if (rowi < N && col <= rowi) Lp[tri(rowi) + col] -= acc[r4];
+        if (wave == 0) {
+            cholesky_trailing_tile(Lp, k0, N, 0, 0);
+            cholesky_diag_block<T>(sh, Lp, k0 + 15);
+        } else {
+            for (int tile = wave; tile < tn * tn; tile += nw - 1) {  // tiles 1.. (tile 0 is (0, 0))
+                const int bi = tile / tn, bj = tile - bi * tn;
+                if (bj > bi) continue;
+                cholesky_trailing_tile(Lp, k0, N, bi, bj);
             }
         }
         __syncthreads();
     }
+    __syncthreads();
     // inverses of the diagonal blocks: column c of L_kk^-1 by forward substitution, one thread per (block, column)
     for (int o = t; o < nb * 15; o += T) {
         const int kb = o / 15, c = o - 15 * kb;
