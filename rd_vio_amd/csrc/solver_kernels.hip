@@ -581,22 +581,34 @@ __device__ __attribute__((noinline)) void build_normal_equations(LdsWs &w, Share
             v[u] = acc;
         }
     };
+    // H is symmetric: only the lower blocks are formed, an off-diagonal block is stored a second time transposed
+    // (the scattered stores cost nothing on the dependent path; forming the block again would be another trip)
     auto block_store = [&](int blk, const double (&v)[4]) {
         const int fi = blk / nfree, fj = blk - fi * nfree;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = lane + 64 * u;
-            if (e < 225) w.H[(size_t)(15 * fi + e / 15) * N + 15 * fj + e % 15] = v[u];
+            if (e < 225) {
+                w.H[(size_t)(15 * fi + e / 15) * N + 15 * fj + e % 15] = v[u];
+                if (fi != fj) w.H[(size_t)(15 * fj + e % 15) * N + 15 * fi + e / 15] = v[u];
+            }
         }
     };
+    auto lower_block = [&](int p) {  // p-th lower block in row-major order -> fi * nfree + fj
+        int fi = 0;
+        while (tri(fi + 1) <= p) ++fi;
+        return fi * nfree + (p - tri(fi));
+    };
     // two blocks per trip: their loads are independent, so twice as many are in flight per L2 round trip
-    for (int blk = wave; blk < nfree * nfree; blk += 2 * NW) {
+    const int n_lower = nfree * (nfree + 1) / 2;
+    for (int p = wave; p < n_lower; p += 2 * NW) {
         double v0[4], v1[4];
-        const bool two = blk + NW < nfree * nfree;
-        block_entries(blk, v0);
-        if (two) block_entries(blk + NW, v1);
-        block_store(blk, v0);
-        if (two) block_store(blk + NW, v1);
+        const bool two = p + NW < n_lower;
+        const int b0 = lower_block(p), b1 = two ? lower_block(p + NW) : 0;
+        block_entries(b0, v0);
+        if (two) block_entries(b1, v1);
+        block_store(b0, v0);
+        if (two) block_store(b1, v1);
     }
     STAMP(27);
     for (int o = t; o < N; o += T) {
