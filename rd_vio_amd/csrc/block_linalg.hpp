@@ -136,6 +136,27 @@ DM double block_max(LdsShared<T> &sh, double v, int &phase) {
     return m;
 }
 
+// Operands of one 15 x 15 x 15 product  C[m][n] = sum_q a(q, m) b(q, n)  for v_mfma_f64_16x16x4_f64 (a(q, m) =
+// Ap[q * sak + m * sam], b likewise): the eight loads of a lane are independent, so one memory round trip feeds the
+// whole tile; mfma_run15 then returns C[row = (lane >> 4) + 4 r][col = lane & 15] in register r.
+DM void mfma_load15(const double *__restrict__ Ap, long sak, long sam, const double *__restrict__ Bp, long sbk, long sbn,
+                    double (&a)[4], double (&b)[4]) {
+    const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int q = 4 * u + kk;
+        const bool ok = i < 15 && q < 15;
+        a[u] = ok ? Ap[q * sak + i * sam] : 0.0;
+        b[u] = ok ? Bp[q * sbk + i * sbn] : 0.0;
+    }
+}
+DM double4_t mfma_run15(const double (&a)[4], const double (&b)[4]) {
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    return acc;
+}
+
 // One 16x16 output tile  C[m0.., n0..] = sum_k a(k, m) * w(k) * b(k, n)  on one wavefront with
 // v_mfma_f64_16x16x4_f64.  a(k, m) = Ap[k * sak + m * sam], b(k, n) = Bp[k * sbk + n * sbn]; w may be null.
 // Lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; result register r of lane l is

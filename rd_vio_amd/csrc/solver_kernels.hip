@@ -378,16 +378,25 @@ __device__ __attribute__((noinline)) double evaluate(LdsWs &w, Shared &sh, int &
             cost += 0.5 * acc * acc;
         }
         if (LIN) {
-            for (int o = t; o < w.npre * 450; o += T) {
-                const int k = o / 450, rem = o - 450 * k, which = rem / 225, rc = rem - 225 * which;
-                const int row = rc / 15, col = rc - 15 * row;
-                const double *Sic = w.preint + (size_t)RDVIO_PREINT_SIZE * k + PRE_SIC;
-                const double *G = w.G + 450 * k + 225 * which;
-                double acc = 0.0;
+            // Jp = Sic G per factor and side: one 15 x 15 x 15 product per wavefront trip on the matrix cores, two per trip
+            const int ntile = w.npre * 2, wave = t >> 6, lane = t & 63;
+            auto store = [&](const double4_t &acc, int tile) {
+                const int k = tile >> 1, which = tile & 1;
+                const bool fix = sh.pfix[which ? w.pre_j[k] : w.pre_i[k]];
 #pragma unroll
-                for (int q = 0; q < 15; ++q) acc += Sic[row * 15 + q] * G[q * 15 + col];
-                if (col < 6 && sh.pfix[which ? w.pre_j[k] : w.pre_i[k]]) acc = 0.0;
-                w.Jp[o] = acc;
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int row = (lane >> 4) + 4 * r4, col = lane & 15;
+                    if (row < 15 && col < 15) w.Jp[450 * k + 225 * which + 15 * row + col] = (col < 6 && fix) ? 0.0 : acc[r4];
+                }
+            };
+            for (int tile = wave; tile < ntile; tile += 2 * NW) {
+                const bool two = tile + NW < ntile;
+                const int t1 = two ? tile + NW : tile;
+                double a0[4], b0[4], a1[4], b1[4];
+                mfma_load15(w.preint + (size_t)RDVIO_PREINT_SIZE * (tile >> 1) + PRE_SIC, 1, 15, w.G + 450 * (tile >> 1) + 225 * (tile & 1), 15, 1, a0, b0);
+                mfma_load15(w.preint + (size_t)RDVIO_PREINT_SIZE * (t1 >> 1) + PRE_SIC, 1, 15, w.G + 450 * (t1 >> 1) + 225 * (t1 & 1), 15, 1, a1, b1);
+                store(mfma_run15(a0, b0), tile);
+                if (two) store(mfma_run15(a1, b1), t1);
             }
         }
     }
@@ -512,16 +521,40 @@ __device__ __attribute__((noinline)) void build_normal_equations(LdsWs &w, Share
     }
     STAMP(13);
     // ---- phase 1c: per preintegration factor [Ji Jj]^T [Ji Jj] (30 x 30) and [Ji Jj]^T r (30)
-    for (int o = t; o < w.npre * 900; o += T) {
-        const int k = o / 900, rc = o - 900 * k, ra = rc / 30, cb = rc - 30 * ra;
-        const double *Jx = w.Jp + 450 * k + 225 * (ra / 15) + (ra % 15), *Jy = w.Jp + 450 * k + 225 * (cb / 15) + (cb % 15);
-        double xa[15], ya[15];
+    // three 15 x 15 quadrants per factor on the matrix cores -- (Ji,Ji), (Jj,Ji), (Jj,Jj); the fourth is the transpose of
+    // the second -- two tiles per trip so that both tiles' operand loads share one memory round trip
+    {
+        const int ntile = w.npre * 3;
+        auto quadrant = [&](int tile, const double *&Xa, const double *&Xb, int &k, int &qa, int &qb) {
+            k = tile / 3;
+            const int qd = tile - 3 * k;
+            qa = qd >= 1;
+            qb = qd == 2;
+            Xa = w.Jp + 450 * k + 225 * qa;
+            Xb = w.Jp + 450 * k + 225 * qb;
+        };
+        auto store = [&](const double4_t &acc, int k, int qa, int qb) {
 #pragma unroll
-        for (int q = 0; q < 15; ++q) { xa[q] = Jx[q * 15]; ya[q] = Jy[q * 15]; }
-        double acc = 0.0;
-#pragma unroll
-        for (int q = 0; q < 15; ++q) acc += xa[q] * ya[q];
-        w.PP[o] = acc;
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int row = (lane >> 4) + 4 * r4, col = lane & 15;
+                if (row < 15 && col < 15) {
+                    w.PP[900 * k + (15 * qa + row) * 30 + 15 * qb + col] = acc[r4];
+                    if (qa != qb) w.PP[900 * k + (15 * qb + col) * 30 + 15 * qa + row] = acc[r4];
+                }
+            }
+        };
+        for (int tile = wave; tile < ntile; tile += 2 * NW) {
+            const bool two = tile + NW < ntile;
+            const double *Xa0, *Xb0, *Xa1, *Xb1;
+            int k0, qa0, qb0, k1, qa1, qb1;
+            quadrant(tile, Xa0, Xb0, k0, qa0, qb0);
+            quadrant(two ? tile + NW : tile, Xa1, Xb1, k1, qa1, qb1);
+            double a0[4], b0[4], a1[4], b1[4];
+            mfma_load15(Xa0, 15, 1, Xb0, 15, 1, a0, b0);
+            mfma_load15(Xa1, 15, 1, Xb1, 15, 1, a1, b1);
+            store(mfma_run15(a0, b0), k0, qa0, qb0);
+            if (two) store(mfma_run15(a1, b1), k1, qa1, qb1);
+        }
     }
     for (int o = t; o < w.npre * 30; o += T) {
         const int k = o / 30, ra = o - 30 * k;
