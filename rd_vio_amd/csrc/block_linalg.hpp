@@ -86,6 +86,38 @@ DM double quad_col_dot(const double *__restrict__ M, long ld, const double *__re
     return acc;
 }
 
+// two right-hand sides at once: (M x)[r] and (M y)[r] from one pass over the matrix (same summation order as quad_col_dot)
+DM void quad_col_dot2(const double *__restrict__ M, long ld, const double *__restrict__ x, const double *__restrict__ y, int C,
+                      int r, int part, double &ox, double &oy) {
+    double ax = 0.0, ay = 0.0;
+    int c = part;
+    for (; c + 60 < C; c += 64) {
+        double mv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) mv[u] = M[(long)(c + 4 * u) * ld + r];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { ax += mv[u] * x[c + 4 * u]; ay += mv[u] * y[c + 4 * u]; }
+    }
+    for (; c + 28 < C; c += 32) {
+        double mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mv[u] = M[(long)(c + 4 * u) * ld + r];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { ax += mv[u] * x[c + 4 * u]; ay += mv[u] * y[c + 4 * u]; }
+    }
+    for (; c < C; c += 4) {
+        const double m = M[(long)c * ld + r];
+        ax += m * x[c];
+        ay += m * y[c];
+    }
+    ax += __shfl_xor(ax, 1);
+    ax += __shfl_xor(ax, 2);
+    ay += __shfl_xor(ay, 1);
+    ay += __shfl_xor(ay, 2);
+    ox = ax;
+    oy = ay;
+}
+
 DM double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);

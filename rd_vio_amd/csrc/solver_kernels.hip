@@ -734,7 +734,8 @@ __device__ __attribute__((noinline)) void model_scalars(LdsWs &w, Shared &sh, in
     for (int base = 0; base < N; base += T / 4) {
         const int r = base + (t >> 2), part = t & 3;
         if (r < N) {
-            const double hu = quad_col_dot(w.H, N, u, N, r, part), hv = quad_col_dot(w.H, N, v, N, r, part);
+            double hu, hv;
+            quad_col_dot2(w.H, N, u, v, N, r, part, hu, hv);
             if (part == 0) {
                 a5[0] += u[r] * hu;
                 a5[1] += u[r] * hv;
@@ -750,15 +751,17 @@ __device__ __attribute__((noinline)) void model_scalars(LdsWs &w, Shared &sh, in
         const double ul = sd * w.grad_l[l], vl = sd * w.gn_l[l];
         const double *Arow = w.A + (size_t)l * (NA + 2);
         double au = 0.0, av = 0.0;
-        for (int f = 0; f < w.nfree; ++f) {
-            double x6[6];
+        for (int c0 = 0; c0 < NA; c0 += 30) {  // five frames of the coupling row per trip: their loads share one round trip
+            double x30[30];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) x6[a] = Arow[6 * f + a];
+            for (int q = 0; q < 30; ++q) x30[q] = (c0 + q < NA) ? Arow[c0 + q] : 0.0;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                au += x6[a] * u[15 * f + a];
-                av += x6[a] * v[15 * f + a];
-            }
+            for (int q = 0; q < 30; ++q)
+                if (c0 + q < NA) {
+                    const int o = 15 * (c0 / 6 + q / 6) + q % 6;
+                    au += x30[q] * u[o];
+                    av += x30[q] * v[o];
+                }
         }
         const double m = w.lm_m[l];
         a5[0] += 2.0 * ul * au + m * ul * ul;
@@ -987,12 +990,13 @@ PHASE_FN double back_substitute(LdsWs &w, Shared &sh, int &phase, double mu) {
         if (w.lfree[l]) {
             double s = w.lm_g[l];
             const double *Arow = w.A + (size_t)l * NAs;
-            for (int f = 0; f < nfree; ++f) {
-                double av[6];
+            for (int c0 = 0; c0 < 6 * nfree; c0 += 30) {  // five frames of the coupling row per trip
+                double av[30];
 #pragma unroll
-                for (int a = 0; a < 6; ++a) av[a] = Arow[6 * f + a];
+                for (int q = 0; q < 30; ++q) av[q] = (c0 + q < 6 * nfree) ? Arow[c0 + q] : 0.0;
 #pragma unroll
-                for (int a = 0; a < 6; ++a) s -= av[a] * sh.xv[15 * f + a];
+                for (int q = 0; q < 30; ++q)
+                    if (c0 + q < 6 * nfree) s -= av[q] * sh.xv[15 * (c0 / 6 + q / 6) + q % 6];
             }
             const double s2 = w.sig_l[l] * w.sig_l[l];
             y = w.sig_l[l] * s / (s2 * w.lm_m[l] + mu * w.diag_l[l] * w.diag_l[l]);
