@@ -464,7 +464,7 @@ DM void cholesky_diag_block(LdsShared<T> &sh, lds_double *Lp, int k0) {
 }
 
 // one lower 16 x 16 tile (bi, bj) of the trailing update C -= P P^T behind block column k0, on the matrix cores
-DM void cholesky_trailing_tile(lds_double *Lp, int k0, int N, int bi, int bj) {
+DM void cholesky_trailing_tile(lds_double *Lp, int k0, int N, int bi, int bj) {  // N: rows of the packed triangle
     const int lane = threadIdx.x & 63;
     const int i = lane & 15, kk = lane >> 4;
     const int ra = k0 + 15 + 16 * bi + i, rb = k0 + 15 + 16 * bj + i;
@@ -487,10 +487,12 @@ DM void cholesky_trailing_tile(lds_double *Lp, int k0, int N, int bi, int bj) {
 // Two barriers per block column, with one block of lookahead: while wavefronts 1.. apply the trailing update of block
 // column k, wavefront 0 applies only the tile that holds the next diagonal block and factors it straight away (the
 // 15 dependent pivots of a diagonal block are the longest serial piece of a column).
+// The packed triangle carries one extra row, N, holding the right-hand side b: the panel and trailing steps treat it
+// like any other row, and it leaves the factorisation as L^-1 b -- the forward substitution of the solve, for free.
 template <int T>
 __device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_double *Lp, lds_double *Dinv, int N) {
     const int t = threadIdx.x, wave = t >> 6, nw = T / 64;
-    const int nb = N / 15;
+    const int nb = N / 15, NR = N + 1;
     if (t == 0) sh.flag = 1;
     __syncthreads();
     if (wave == 0 && nb > 0) cholesky_diag_block<T>(sh, Lp, 0);
@@ -498,7 +500,7 @@ __device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_doub
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = 15 * kb;
         // ---- panel: row i solves x L_kk^T = row  (forward substitution with reciprocal pivots)
-        for (int i = k0 + 15 + t; i < N; i += T) {
+        for (int i = k0 + 15 + t; i < NR; i += T) {
             lds_double *row = Lp + tri(i) + k0;
             double x[15];
 #pragma unroll
@@ -518,15 +520,15 @@ __device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_doub
         if (kb + 1 == nb) break;
         __syncthreads();
         // ---- trailing update C -= P P^T, lower 16 x 16 tiles; tile (0, 0) and the next diagonal block on wavefront 0
-        const int rem = N - (k0 + 15), tn = (rem + 15) / 16;
+        const int rem = NR - (k0 + 15), tn = (rem + 15) / 16;
         if (wave == 0) {
-            cholesky_trailing_tile(Lp, k0, N, 0, 0);
+            cholesky_trailing_tile(Lp, k0, NR, 0, 0);
             cholesky_diag_block<T>(sh, Lp, k0 + 15);
         } else {
             for (int tile = wave; tile < tn * tn; tile += nw - 1) {  // tiles 1.. (tile 0 is (0, 0))
                 const int bi = tile / tn, bj = tile - bi * tn;
                 if (bj > bi) continue;
-                cholesky_trailing_tile(Lp, k0, N, bi, bj);
+                cholesky_trailing_tile(Lp, k0, NR, bi, bj);
             }
         }
         __syncthreads();
@@ -552,48 +554,39 @@ __device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_doub
     return sh.flag;
 }
 
-// solve L L^T y = b with L packed in LDS and Dinv = inverses of its 15 x 15 diagonal blocks; b in place.
+// solve L L^T y = b: L packed in LDS with row N = L^-1 b left there by cholesky_lds, Dinv = inverses of the 15 x 15
+// diagonal blocks; only the backward substitution remains.  y goes to out.
 template <int T>
 __device__ __attribute__((noinline)) void cholesky_solve_lds(LdsShared<T> &sh, const lds_double *Lp, const lds_double *Dinv, int N, double *b) {
     const int t = threadIdx.x, nb = N / 15;
     double *y = RDVIO_GEN(sh.xv);  // N <= 512
-    for (int i = t; i < N; i += T) y[i] = b[i];
+    for (int i = t; i < N; i += T) y[i] = Lp[tri(N) + i];
     __syncthreads();
-    for (int kb = 0; kb < nb; ++kb) {  // forward: y_k = Dinv_k y_k ; later rows -= L_ik y_k
-        double v = 0.0;
-        if (t < 15) {
+    // backward: y_k = Dinv_k^T y_k ; earlier rows -= L_ki^T y_k.  One wavefront runs the whole chain: its LDS operations
+    // execute in program order, so the nb dependent steps need no workgroup barrier (three per step otherwise).
+    if (t < 64) {
+        for (int kb = nb - 1; kb >= 0; --kb) {
+            double v = 0.0;
+            if (t < 15) {
 #pragma unroll
-            for (int q = 0; q < 15; ++q) v += Dinv[225 * kb + 15 * t + q] * y[15 * kb + q];
-        }
-        __syncthreads();
-        if (t < 15) y[15 * kb + t] = v;
-        __syncthreads();
-        for (int i = 15 * (kb + 1) + t; i < N; i += T) {
-            const lds_double *Lr = Lp + tri(i) + 15 * kb;
-            double s = 0.0;
+                for (int q = 0; q < 15; ++q) v += Dinv[225 * kb + 15 * q + t] * y[15 * kb + q];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (t < 15) y[15 * kb + t] = v;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int i = t; i < 15 * kb; i += 64) {
+                double s = 0.0;
 #pragma unroll
-            for (int q = 0; q < 15; ++q) s += Lr[q] * y[15 * kb + q];
-            y[i] -= s;
+                for (int q = 0; q < 15; ++q) s += Lp[tri(15 * kb + q) + i] * y[15 * kb + q];
+                y[i] -= s;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
     }
-    for (int kb = nb - 1; kb >= 0; --kb) {  // backward: y_k = Dinv_k^T y_k ; earlier rows -= L_ki^T y_k
-        double v = 0.0;
-        if (t < 15) {
-#pragma unroll
-            for (int q = 0; q < 15; ++q) v += Dinv[225 * kb + 15 * q + t] * y[15 * kb + q];
-        }
-        __syncthreads();
-        if (t < 15) y[15 * kb + t] = v;
-        __syncthreads();
-        for (int i = t; i < 15 * kb; i += T) {
-            double s = 0.0;
-#pragma unroll
-            for (int q = 0; q < 15; ++q) s += Lp[tri(15 * kb + q) + i] * y[15 * kb + q];
-            y[i] -= s;
-        }
-        __syncthreads();
-    }
+    __syncthreads();
     for (int i = t; i < N; i += T) b[i] = y[i];
     __syncthreads();
 }

@@ -973,7 +973,9 @@ PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, double *lds, size_t lds_cap, do
         const int fi = i / 15, a = i - 15 * fi;
         double v = w.g[i];
         if (a < 6 && has_lm) v -= w.Cm[(size_t)(6 * fi + a) * NAs + NA];
-        w.yp[i] = v * w.sig_p[i];
+        v *= w.sig_p[i];
+        w.yp[i] = v;
+        if (w.lds_chol) Sl[tri(N) + i] = v;  // right-hand-side row of the packed triangle
     }
     __syncthreads();
 }
@@ -1044,9 +1046,9 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     // packed 15x15 blocks of S and the inverses of its diagonal factors, LDS-resident when the window has at most
     // RDVIO_LDS_CHOL_MAX_FRAMES free frames (138.6 KB of the CU's 160 KB); larger windows factor in global memory
     constexpr int NMAX = 15 * RDVIO_LDS_CHOL_MAX_FRAMES;
-    constexpr size_t LDS_CAP = NMAX * (NMAX + 1) / 2 + 225 * RDVIO_LDS_CHOL_MAX_FRAMES;
+    constexpr size_t LDS_CAP = (NMAX + 1) * (NMAX + 2) / 2 + 225 * RDVIO_LDS_CHOL_MAX_FRAMES;  // (+ the right-hand-side row)
     __shared__ __attribute__((aligned(16))) double lds_chol_buf[LDS_CAP];
-    double *Sl = lds_chol_buf, *Dinv = lds_chol_buf + w.N * (w.N + 1) / 2;
+    double *Sl = lds_chol_buf, *Dinv = lds_chol_buf + (w.N + 1) * (w.N + 2) / 2;
     const int t = threadIdx.x;
     __shared__ SolverWs w_lds;
     for (int i = t; i < (int)(sizeof(SolverWs) / 8); i += T)
