@@ -148,7 +148,9 @@ def build_workload(cfg, ctx, torch, dev, seed=648):
     wl["localize_pb"] = loc
     ctx.ba_upload(pb, slot=0)
     ctx.ba_upload(loc, slot=1)
-    wl["marg_args"] = synth.make_marg_inputs(pb)
+    # marginalisation input: the steady-state prior (what the previous marginalisation leaves behind), as on every
+    # marginalisation of a session but the first
+    wl["marg_args"] = synth.steady_state_marg_inputs(pb, ctx.marginalize)
     ctx.marginalize_upload(*wl["marg_args"])
     wl["L"] = img0.L
     return wl

@@ -431,7 +431,7 @@ DM double rsqrt_nr(double x) {
 // to sh.vec for the panel.  The next pivot is finished first in every step, so that its reciprocal square root (a
 // ~200-cycle dependent chain) runs in the shadow of the remaining column updates.
 template <int T>
-DM void cholesky_diag_block(LdsShared<T> &sh, lds_double *Lp, int k0) {
+DM void cholesky_diag_block(LdsShared<T> &sh, lds_double *Lp, int k0, double tol) {
     const int lane = threadIdx.x & 63;
     const int r = lane < 15 ? lane : 14;
     const lds_double *row = Lp + tri(k0 + r) + k0;
@@ -442,7 +442,7 @@ DM void cholesky_diag_block(LdsShared<T> &sh, lds_double *Lp, int k0) {
     double piv = readlane_d(a[0], 0);
 #pragma unroll
     for (int j = 0; j < 15; ++j) {
-        if (!(piv > 0.0) || !isfinite(piv)) bad = true;
+        if (!(piv > tol) || !isfinite(piv)) bad = true;
         const double rs = rsqrt_nr(piv);   // 1 / L_jj
         const double lj = (lane == j) ? piv * rs : a[j] * rs;
         a[j] = lj;
@@ -487,15 +487,16 @@ DM void cholesky_trailing_tile(lds_double *Lp, int k0, int N, int bi, int bj) { 
 // Two barriers per block column, with one block of lookahead: while wavefronts 1.. apply the trailing update of block
 // column k, wavefront 0 applies only the tile that holds the next diagonal block and factors it straight away (the
 // 15 dependent pivots of a diagonal block are the longest serial piece of a column).
+// Returns 0 when a pivot is not above tol (or not finite).
 // The packed triangle carries one extra row, N, holding the right-hand side b: the panel and trailing steps treat it
 // like any other row, and it leaves the factorisation as L^-1 b -- the forward substitution of the solve, for free.
 template <int T>
-__device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_double *Lp, lds_double *Dinv, int N) {
+__device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_double *Lp, lds_double *Dinv, int N, double tol = 0.0, bool want_dinv = true) {
     const int t = threadIdx.x, wave = t >> 6, nw = T / 64;
     const int nb = N / 15, NR = N + 1;
     if (t == 0) sh.flag = 1;
     __syncthreads();
-    if (wave == 0 && nb > 0) cholesky_diag_block<T>(sh, Lp, 0);
+    if (wave == 0 && nb > 0) cholesky_diag_block<T>(sh, Lp, 0, tol);
     __syncthreads();
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = 15 * kb;
@@ -523,7 +524,7 @@ __device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_doub
         const int rem = NR - (k0 + 15), tn = (rem + 15) / 16;
         if (wave == 0) {
             cholesky_trailing_tile(Lp, k0, NR, 0, 0);
-            cholesky_diag_block<T>(sh, Lp, k0 + 15);
+            cholesky_diag_block<T>(sh, Lp, k0 + 15, tol);
         } else {
             for (int tile = wave; tile < tn * tn; tile += nw - 1) {  // tiles 1.. (tile 0 is (0, 0))
                 const int bi = tile / tn, bj = tile - bi * tn;
@@ -535,7 +536,7 @@ __device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_doub
     }
     __syncthreads();
     // inverses of the diagonal blocks: column c of L_kk^-1 by forward substitution, one thread per (block, column)
-    for (int o = t; o < nb * 15; o += T) {
+    for (int o = t; want_dinv && o < nb * 15; o += T) {
         const int kb = o / 15, c = o - 15 * kb;
         double x[15];
 #pragma unroll

@@ -1,3 +1,5 @@
+#include <cstdio>
+#include <cstdlib>
 // Host side of rdvio_hip_marginalize.  The marginalisation graph
 // (/root/reference/src/rdvio_estimation/include/rdvio/estimation/ceres/marginalization_factor.h:95-380: the current
 // prior, the preintegration factor between frames 0 and 1, every reprojection factor of the victim-observed tracks) is
@@ -87,6 +89,7 @@ int rdvio_hip_marginalize_fetch(rdvio_hip_ctx *ctx, double *S_out, double *f_out
     if (lin_out) memcpy(lin_out, down + (w.lin_out - w.S_out), (size_t)(w.nfr - 1) * 16 * sizeof(double));
     const double *info = down + (w.m_info - w.S_out);
     if (used_fast_path) *used_fast_path = (int)info[0];  // 1 plain Cholesky, 2 pivoted Cholesky, 0 eigen
+    if (getenv("RDVIO_DEBUG_MARG")) fprintf(stderr, "marg: nfr %d N %d nl %d nf %d lds %d path %d Rn %d\n", w.nfr, w.N, w.nl, w.nf, w.lds_chol, (int)info[0], (int)info[1]);
     return RDVIO_OK;
 }
 

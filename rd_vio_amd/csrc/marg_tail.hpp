@@ -359,9 +359,48 @@ __device__ __attribute__((noinline)) void marginalize_tail(LdsWs &w, LdsShared<T
     __syncthreads();
     int path = 0;
     if (!w.marg_force_eigen && w.lds_chol) {
-        double *Ap = lds + 450, *dg = Ap + tri(Rn), *lcol = dg + Rn, *eta = lcol + Rn;
-        (void)pivoted_cholesky_lds<T>(RDVIO_LDS(Ap), RDVIO_LDS(dg), RDVIO_LDS(lcol), RDVIO_LDS(eta), w.m_Lr, w.m_er, w.m_nz, Rn, R, 1.0e-8, w.S_out, w.f_out);
-        path = 2;
+        // The information on the retained rows is normally positive definite: a plain blocked Cholesky (matrix cores, two
+        // barriers per 15 pivots instead of two per pivot) whose pivots all stay above the reference's clamp threshold
+        // gives the exact factor S = L^T, and f = L^-1 eta falls out of the factorisation as the extra row.  A pivot at
+        // or below the threshold sends the (then semi-definite) matrix to the pivoted factorisation.
+        // (57 retained rows in steady state -- 8 frame poses + the oldest frame's velocity and biases: 0.25 ms per
+        // marginalisation with the blocked factorisation, 0.32 ms with the pivoted one; a first-of-session problem, whose
+        // information is rank-deficient, pays 0.03 ms for the failed attempt.)
+        int fast = Rn == 0;
+        if (Rn > 0) {
+            lds_double *Lp = RDVIO_LDS(lds + 450), *Dinv = Lp + tri(Rb + 1);
+            int *nzl = (int *)lds;  // (the 15 x 30 block at the head of the buffer is free again: 900 ints >= Rn)
+            for (int i = t; i < Rn; i += T) nzl[i] = w.m_nz[i];
+            __syncthreads();
+            const int W1 = Rb + 1;
+#pragma unroll 4
+            for (int o = t; o < W1 * W1; o += T) {
+                const int i = o / W1, k = o - i * W1;
+                if (k > i) continue;
+                double v;
+                if (i == Rb) v = (k < Rn) ? w.m_er[nzl[k]] : 0.0;  // right-hand-side row
+                else if (i < Rn) v = w.m_Lr[(size_t)nzl[i] * R + nzl[k]];
+                else v = (i == k) ? 1.0 : 0.0;  // identity padding up to a multiple of 15
+                Lp[tri(i) + k] = v;
+            }
+            __syncthreads();
+            fast = cholesky_lds<T>(sh, Lp, Dinv, Rb, 1.0e-8, false);
+            if (fast) {
+#pragma unroll 4
+                for (int o = t; o < Rn * Rn; o += T) {  // S[i][j] = L[j][i], j >= i
+                    const int j = o / Rn, i = o - j * Rn;
+                    if (i <= j) w.S_out[(size_t)nzl[i] * R + nzl[j]] = Lp[tri(j) + i];
+                }
+                for (int i = t; i < Rn; i += T) w.f_out[nzl[i]] = Lp[tri(Rb) + i];
+            }
+            __syncthreads();
+        }
+        path = 1;
+        if (!fast) {
+            double *Ap = lds + 450, *dg = Ap + tri(Rn), *lcol = dg + Rn, *eta = lcol + Rn;
+            (void)pivoted_cholesky_lds<T>(RDVIO_LDS(Ap), RDVIO_LDS(dg), RDVIO_LDS(lcol), RDVIO_LDS(eta), w.m_Lr, w.m_er, w.m_nz, Rn, R, 1.0e-8, w.S_out, w.f_out);
+            path = 2;
+        }
     } else if (!w.marg_force_eigen) {
         // large window: plain blocked Cholesky when the information is positive definite beyond the threshold
         // (shifted factorisation as the test), else the pivoted factorisation in global memory

@@ -336,6 +336,23 @@ def make_marg_inputs(pb, with_full_prior=False, seed=9):
             pb["tgt"][keep], pb["ref"][keep], pb["lm"][keep], pb["tangent"][keep], pb["z_ref"], pb["inv_depth"])
 
 
+def steady_state_marg_inputs(pb, marginalize):
+    """make_marg_inputs with the prior a running system hands to marginalize(): the first marginalisation of a session
+    starts from the initial prior (frame-0 pose pin, rank-deficient on the other frames); every later one starts from
+    the prior the previous marginalisation left behind -- pose information on every retained frame, velocity / bias
+    information on the oldest.  That structure is produced here by marginalising once (`marginalize` = the HIP
+    binding's or the oracle's marginalize(*args) -> (S, f, lin, ...)) and re-attaching the result to the window's
+    first frames."""
+    first = make_marg_inputs(pb)
+    S1, f1 = marginalize(*first)[:2]
+    args = list(first)
+    npf = len(pb["states"]) - 1
+    args[4] = pb["states"][:npf].copy()   # lin: the prior is linearised at the current states
+    args[5] = np.ascontiguousarray(S1)
+    args[6] = np.ascontiguousarray(f1)
+    return tuple(args)
+
+
 # ------------------------------------------------------------------ 3-D consistent synthetic stream (pipeline tests)
 ROOM_HALF = np.array([6.0, 6.0, 2.5])   # the 12 x 12 x 5 m box of SURVEY.md 8d (config 5)
 
