@@ -9,6 +9,11 @@
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// Pointers that keep the LDS address space across (noinline) function boundaries: a generic `double *` to LDS makes the
+// compiler emit FLAT loads / stores, which resolve the aperture first and cost about twice the latency of ds_read / ds_write.
+typedef __attribute__((address_space(3))) double lds_double;
+#define RDVIO_LDS(p) ((lds_double *)(p))
+
 template <int T>
 struct BlockShared {
     double red[2][8][T / 64];  // double-buffered partials for up to 8 simultaneous reductions
@@ -193,12 +198,14 @@ DM double4_t mfma_run15(const double (&a)[4], const double (&b)[4]) {
 // v_mfma_f64_16x16x4_f64.  a(k, m) = Ap[k * sak + m * sam], b(k, n) = Bp[k * sbk + n * sbn]; w may be null.
 // Lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; result register r of lane l is
 // C[row = (l >> 4) + 4 r][col = l & 15].
-DM double4_t mfma_tile_f64(const double *__restrict__ Ap, long sak, long sam, const double *__restrict__ Bp, long sbk,
-                           long sbn, const double *__restrict__ w, int K, int m0, int n0, int M, int N) {
+// P: pointer type of the operands (plain `const double *` for global memory, `const lds_double *` for operands staged
+// in LDS -- a generic pointer to LDS would compile to FLAT loads); HW: whether the weight vector w is present.
+template <class P, bool HW>
+DM double4_t mfma_tile_g(P Ap, long sak, long sam, P Bp, long sbk, long sbn, P w, int K, int m0, int n0, int M, int N) {
     const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
     const bool am = (m0 + i) < M, bn = (n0 + i) < N;
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
-    const double *ap = Ap + (long)(m0 + i) * sam, *bp = Bp + (long)(n0 + i) * sbn;
+    P ap = Ap + (long)(m0 + i) * sam, bp = Bp + (long)(n0 + i) * sbn;
     int k0 = 0;
     for (; k0 + 16 <= K; k0 += 16) {  // 4 MFMAs per trip: 8 independent loads in flight
         double a[4], b[4];
@@ -207,7 +214,7 @@ DM double4_t mfma_tile_f64(const double *__restrict__ Ap, long sak, long sam, co
             const int k = k0 + 4 * u + kk;
             a[u] = am ? ap[(long)k * sak] : 0.0;
             b[u] = bn ? bp[(long)k * sbk] : 0.0;
-            if (w) a[u] *= w[k];
+            if (HW) a[u] *= w[k];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
@@ -218,31 +225,52 @@ DM double4_t mfma_tile_f64(const double *__restrict__ Ap, long sak, long sam, co
         if (k < K) {
             a = am ? ap[(long)k * sak] : 0.0;
             b = bn ? bp[(long)k * sbk] : 0.0;
-            if (w) a *= w[k];
+            if (HW) a *= w[k];
         }
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
     }
     return acc;
 }
+DM double4_t mfma_tile_f64(const double *__restrict__ Ap, long sak, long sam, const double *__restrict__ Bp, long sbk,
+                           long sbn, const double *__restrict__ w, int K, int m0, int n0, int M, int N) {
+    return w ? mfma_tile_g<const double *, true>(Ap, sak, sam, Bp, sbk, sbn, w, K, m0, n0, M, N)
+             : mfma_tile_g<const double *, false>(Ap, sak, sam, Bp, sbk, sbn, Ap, K, m0, n0, M, N);
+}
 
 // C (M x N, row-major, ld = ldc) = A^T diag(w) B with A: K x M, B: K x N row-major; tiles spread over the waves.
 // If `lower_only`, tiles strictly above the diagonal are skipped (symmetric result, M == N).
-template <int T>
-DM void block_gemm_tn(double *__restrict__ C, int ldc, const double *__restrict__ A, int lda, const double *__restrict__ B,
-                      int ldb, const double *__restrict__ w, int M, int N, int K, bool lower_only) {
+// MIRROR (square, lower_only): an off-diagonal tile is stored a second time transposed, so that C is complete.
+template <int T, class P, bool HW, bool MIRROR = false>
+DM void block_gemm_tn_g(double *__restrict__ C, int ldc, P A, int lda, P B, int ldb, P w, int M, int N, int K, bool lower_only) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = T / 64;
     const int tm = (M + 15) / 16, tn = (N + 15) / 16;
     for (int tile = wave; tile < tm * tn; tile += nw) {
         const int bi = tile / tn, bj = tile - bi * tn;
         if (lower_only && bj > bi && 16 * bj + 16 < N) continue;  // (a trailing extra column, N = M + 1, is always computed)
-        const double4_t acc = mfma_tile_f64(A, lda, 1, B, ldb, 1, w, K, 16 * bi, 16 * bj, M, N);
+        const double4_t acc = mfma_tile_g<P, HW>(A, lda, 1, B, ldb, 1, w, K, 16 * bi, 16 * bj, M, N);
         const int col = 16 * bj + (lane & 15);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * bi + (lane >> 4) + 4 * r;
-            if (row < M && col < N) C[(long)row * ldc + col] = acc[r];
+            if (row < M && col < N) {
+                C[(long)row * ldc + col] = acc[r];
+                if (MIRROR && bi != bj) C[(long)col * ldc + row] = acc[r];
+            }
         }
     }
+}
+template <int T>
+DM void block_gemm_tn(double *__restrict__ C, int ldc, const double *__restrict__ A, int lda, const double *__restrict__ B,
+                      int ldb, const double *__restrict__ w, int M, int N, int K, bool lower_only) {
+    if (w) block_gemm_tn_g<T, const double *, true>(C, ldc, A, lda, B, ldb, w, M, N, K, lower_only);
+    else block_gemm_tn_g<T, const double *, false>(C, ldc, A, lda, B, ldb, A, M, N, K, lower_only);
+}
+// the same with the operands (and weights, if any) staged in LDS
+template <int T>
+DM void block_gemm_tn_lds(double *__restrict__ C, int ldc, const lds_double *A, int lda, const lds_double *B, int ldb,
+                          const lds_double *w, bool has_w, int M, int N, int K, bool lower_only) {
+    if (has_w) block_gemm_tn_g<T, const lds_double *, true>(C, ldc, A, lda, B, ldb, w, M, N, K, lower_only);
+    else block_gemm_tn_g<T, const lds_double *, false>(C, ldc, A, lda, B, ldb, A, M, N, K, lower_only);
 }
 
 // y[row] = sum_c Mx[row * ld + c] * x[c]  (+ add[row]) for row in [0, R): one wave per row, coalesced row reads.
@@ -402,10 +430,6 @@ __device__ __attribute__((noinline)) void cholesky_solve(LdsShared<T> &sh, const
 // ---------------------------------------------------------------------------------------------------------
 DM int tri(int r) { return r * (r + 1) / 2; }
 
-// Pointers that keep the LDS address space across (noinline) function boundaries: a generic `double *` to LDS makes the
-// compiler emit FLAT loads / stores, which resolve the aperture first and cost about twice the latency of ds_read / ds_write.
-typedef __attribute__((address_space(3))) double lds_double;
-#define RDVIO_LDS(p) ((lds_double *)(p))
 
 // broadcast a double from a (wave-uniform) lane through SGPRs
 DM double readlane_d(double v, int src_lane) {

@@ -835,26 +835,37 @@ __device__ __attribute__((noinline)) void solver_setup(LdsWs &w, Shared &sh, dou
         const int D = w.D;
         // constant parts of the prior: S^T (coalesced S e), Lambda = S^T S (MFMA tiles), eta0 = S^T f.  S is staged in LDS
         // first (one batch of coalesced loads): the K-loops of the GEMM and of S^T f then run at LDS latency.
-        const double *Sp = w.S;
-        if ((size_t)D * D <= lds_cap) {
-            for (int o = t; o < D * D; o += T) lds[o] = w.S[o];
+        if ((size_t)D * D + D <= lds_cap) {
+            lds_double *Sl = RDVIO_LDS(lds), *fl = Sl + D * D;
+            for (int o = t; o < D * D; o += T) Sl[o] = w.S[o];
+            for (int q = t; q < D; q += T) fl[q] = w.f[q];
             __syncthreads();
-            Sp = lds;
-        }
-        for (int o = t; o < D * D; o += T) w.ST[o] = Sp[(size_t)(o % D) * D + o / D];
-        STAMP(24);
-        block_gemm_tn<T>(w.Lam, D, Sp, D, Sp, D, nullptr, D, D, D, true);
-        STAMP(25);
-        for (int a = t; a < D; a += T) {
-            double acc = 0.0;
-            for (int q = 0; q < D; ++q) acc += Sp[(size_t)q * D + a] * w.f[q];
-            w.eta0[a] = acc;
-        }
-        __syncthreads();
-        // mirror the lower tiles (the assembly reads Lambda as a full symmetric matrix)
-        for (int o = t; o < D * D; o += T) {
-            const int r = o / D, c = o - r * D;
-            if ((c >> 4) > (r >> 4)) w.Lam[o] = w.Lam[(size_t)c * D + r];
+            for (int o = t; o < D * D; o += T) w.ST[o] = Sl[(o % D) * D + o / D];
+            STAMP(24);
+            block_gemm_tn_g<T, const lds_double *, false, true>(w.Lam, D, Sl, D, Sl, D, Sl, D, D, D, true);
+            STAMP(25);
+            for (int a = t; a < D; a += T) {
+                double acc = 0.0;
+                for (int q = 0; q < D; ++q) acc += Sl[q * D + a] * fl[q];
+                w.eta0[a] = acc;
+            }
+        } else {
+            const double *Sp = w.S;
+            for (int o = t; o < D * D; o += T) w.ST[o] = Sp[(size_t)(o % D) * D + o / D];
+            STAMP(24);
+            block_gemm_tn<T>(w.Lam, D, Sp, D, Sp, D, nullptr, D, D, D, true);
+            STAMP(25);
+            for (int a = t; a < D; a += T) {
+                double acc = 0.0;
+                for (int q = 0; q < D; ++q) acc += Sp[(size_t)q * D + a] * w.f[q];
+                w.eta0[a] = acc;
+            }
+            __syncthreads();
+            // mirror the lower tiles (the assembly reads Lambda as a full symmetric matrix)
+            for (int o = t; o < D * D; o += T) {
+                const int r = o / D, c = o - r * D;
+                if ((c >> 4) > (r >> 4)) w.Lam[o] = w.Lam[(size_t)c * D + r];
+            }
         }
         STAMP(26);
     }
@@ -932,7 +943,7 @@ PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, double *lds, size_t lds_cap, do
             for (int i = t; i < nl * NAs; i += T) As[i] = w.A[i];
             for (int l = t; l < nl; l += T) ws[l] = w.lm_w[l];
             __syncthreads();
-            block_gemm_tn<T>(w.Cm, NAs, As, NAs, As, NAs, ws, NA, NA + 1, nl, true);
+            block_gemm_tn_lds<T>(w.Cm, NAs, RDVIO_LDS(As), NAs, RDVIO_LDS(As), NAs, RDVIO_LDS(ws), true, NA, NA + 1, nl, true);
         } else {
             block_gemm_tn<T>(w.Cm, NAs, w.A, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, true);
         }
