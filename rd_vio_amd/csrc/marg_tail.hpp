@@ -232,10 +232,10 @@ __device__ __attribute__((noinline)) int pivoted_cholesky_lds(lds_double *Ap, ld
 
 // lds: LDS scratch of at least tri(R) + 3 R + 450 doubles when w.lds_chol, otherwise only the first 450 are used.
 template <int T>
-__device__ __attribute__((noinline)) void marginalize_tail(LdsWs &w, LdsShared<T> &sh, int &phase, double *lds) {
+__device__ __attribute__((noinline)) void marginalize_tail(LdsWs &w, LdsShared<T> &sh, int &phase, lds_double *lds) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, nw = T / 64;
     const int N = w.N, R = N - 15, nl = w.nl, NA = 6 * w.nfree, NAs = NA + 2;
-    double *sM = lds;  // 15 x 30 augmented block for the victim's inverse
+    lds_double *sM = lds;  // 15 x 30 augmented block for the victim's inverse
     // ---- (iv) landmark Schur: [C | Cg] = A^T diag(1/m) [A | g]; a landmark is skipped if 1/m is not finite (:384-386)
     for (int l = t; l < nl; l += T) {
         const double inv = 1.0 / w.lm_m[l];
@@ -368,8 +368,8 @@ __device__ __attribute__((noinline)) void marginalize_tail(LdsWs &w, LdsShared<T
         // information is rank-deficient, pays 0.03 ms for the failed attempt.)
         int fast = Rn == 0;
         if (Rn > 0) {
-            lds_double *Lp = RDVIO_LDS(lds + 450), *Dinv = Lp + tri(Rb + 1);
-            int *nzl = (int *)lds;  // (the 15 x 30 block at the head of the buffer is free again: 900 ints >= Rn)
+            lds_double *Lp = lds + 450, *Dinv = Lp + tri(Rb + 1);
+            __attribute__((address_space(3))) int *nzl = (__attribute__((address_space(3))) int *)lds;  // (the 15 x 30 block at the head of the buffer is free again: 900 ints >= Rn)
             for (int i = t; i < Rn; i += T) nzl[i] = w.m_nz[i];
             __syncthreads();
             const int W1 = Rb + 1;
@@ -397,8 +397,8 @@ __device__ __attribute__((noinline)) void marginalize_tail(LdsWs &w, LdsShared<T
         }
         path = 1;
         if (!fast) {
-            double *Ap = lds + 450, *dg = Ap + tri(Rn), *lcol = dg + Rn, *eta = lcol + Rn;
-            (void)pivoted_cholesky_lds<T>(RDVIO_LDS(Ap), RDVIO_LDS(dg), RDVIO_LDS(lcol), RDVIO_LDS(eta), w.m_Lr, w.m_er, w.m_nz, Rn, R, 1.0e-8, w.S_out, w.f_out);
+            lds_double *Ap = lds + 450, *dg = Ap + tri(Rn), *lcol = dg + Rn, *eta = lcol + Rn;
+            (void)pivoted_cholesky_lds<T>(Ap, dg, lcol, eta, w.m_Lr, w.m_er, w.m_nz, Rn, R, 1.0e-8, w.S_out, w.f_out);
             path = 2;
         }
     } else if (!w.marg_force_eigen) {

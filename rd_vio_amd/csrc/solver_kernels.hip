@@ -804,7 +804,7 @@ __device__ __attribute__((noinline)) double grad_max_norm(LdsWs &w, Shared &sh, 
 
 // per-launch setup shared by the solver and the marginalisation kernel: user state, free-landmark flags, LDS index
 // tables, zeroed coupling rows, and the constant parts of the prior (S^T, Lambda = S^T S, eta0 = S^T f)
-__device__ __attribute__((noinline)) void solver_setup(LdsWs &w, Shared &sh, double *lds, size_t lds_cap, unsigned long long &prof_last) {
+__device__ __attribute__((noinline)) void solver_setup(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap, unsigned long long &prof_last) {
     const int t = threadIdx.x;
     const int nl = w.nl, nfree = w.nfree, NAs = 6 * nfree + 2;
     if (t == 0) sh.seq = 0;
@@ -836,7 +836,7 @@ __device__ __attribute__((noinline)) void solver_setup(LdsWs &w, Shared &sh, dou
         // constant parts of the prior: S^T (coalesced S e), Lambda = S^T S (MFMA tiles), eta0 = S^T f.  S is staged in LDS
         // first (one batch of coalesced loads): the K-loops of the GEMM and of S^T f then run at LDS latency.
         if ((size_t)D * D + D <= lds_cap) {
-            lds_double *Sl = RDVIO_LDS(lds), *fl = Sl + D * D;
+            lds_double *Sl = lds, *fl = Sl + D * D;
             for (int o = t; o < D * D; o += T) Sl[o] = w.S[o];
             for (int q = t; q < D; q += T) fl[q] = w.f[q];
             __syncthreads();
@@ -921,11 +921,11 @@ PHASE_FN double dogleg_prepare(LdsWs &w, Shared &sh, int &phase) {
 
 // landmark elimination for the damping mu:  [C | Cg] = A^T W [A | g] on the matrix cores, then
 // S = Sigma (H - C) Sigma + mu D^2 (lower triangle, LDS-packed when the window fits) and the reduced right-hand side
-PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, double *lds, size_t lds_cap, double mu, unsigned long long &prof_last) {
+PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap, double mu, unsigned long long &prof_last) {
     const int t = threadIdx.x;
     const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
     const bool has_lm = nl > 0 && w.n_lfree_hint > 0;
-    double *Sl = lds;
+    lds_double *Sl = lds;
     for (int l = t; l < nl; l += T) {
         double lw = 0.0;
         if (w.lfree[l]) {
@@ -939,11 +939,11 @@ PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, double *lds, size_t lds_cap, do
     // K-loop over global memory is a chain of ~nl/16 dependent L2 round trips per tile.
     if (NA > 0 && has_lm) {
         if (w.lds_chol && (size_t)nl * NAs + nl <= lds_cap) {
-            double *As = lds, *ws = lds + (size_t)nl * NAs;
+            lds_double *As = lds, *ws = lds + nl * NAs;
             for (int i = t; i < nl * NAs; i += T) As[i] = w.A[i];
             for (int l = t; l < nl; l += T) ws[l] = w.lm_w[l];
             __syncthreads();
-            block_gemm_tn_lds<T>(w.Cm, NAs, RDVIO_LDS(As), NAs, RDVIO_LDS(As), NAs, RDVIO_LDS(ws), true, NA, NA + 1, nl, true);
+            block_gemm_tn_lds<T>(w.Cm, NAs, As, NAs, As, NAs, ws, true, NA, NA + 1, nl, true);
         } else {
             block_gemm_tn<T>(w.Cm, NAs, w.A, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, true);
         }
@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     if (t == 0) for (int i = 8; i < 72; ++i) w.summary[i] = 0.0;
 #endif
 
-    solver_setup(wl, sh, lds_chol_buf, LDS_CAP, prof_last);
+    solver_setup(wl, sh, RDVIO_LDS(lds_chol_buf), LDS_CAP, prof_last);
 
     double radius = 1e4, mu = 1e-8, alpha = 0.0, dogleg_step_norm = 0.0;
     double gnorm = 0.0, gn_norm = 0.0, gdotgn = 0.0, gsq_keep = 0.0;
@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                 // Gauss-Newton step: (H_s + mu D^2) y = g_s with the landmarks eliminated
                 solve_ok = 0;
                 while (mu < 1.0) {
-                    schur_reduce(wl, sh, lds_chol_buf, LDS_CAP, mu, prof_last);
+                    schur_reduce(wl, sh, RDVIO_LDS(lds_chol_buf), LDS_CAP, mu, prof_last);
                     STAMP(4);
                     int ok = 1;
                     if (N > 0) ok = w.lds_chol ? cholesky_lds(sh, RDVIO_LDS(Sl), RDVIO_LDS(Dinv), N) : cholesky_blocked(sh, w.Sm, N);
@@ -1238,13 +1238,13 @@ __global__ __launch_bounds__(T) void marginalize_kernel(SolverWs w) {
     prof_last = wall_clock64();
     if (threadIdx.x == 0) for (int i = 8; i < 72; ++i) w.summary[i] = 0.0;
 #endif
-    solver_setup(wl, sh, lds_buf, sizeof(lds_buf) / sizeof(double), prof_last);
+    solver_setup(wl, sh, RDVIO_LDS(lds_buf), sizeof(lds_buf) / sizeof(double), prof_last);
     STAMP(0);
     (void)evaluate<true>(wl, sh, phase, w.x, w.xd, prof_last);
     STAMP(1);
     build_normal_equations(wl, sh, prof_last);
     STAMP(2);
-    marginalize_tail<T>(wl, sh, phase, lds_buf);
+    marginalize_tail<T>(wl, sh, phase, RDVIO_LDS(lds_buf));
     STAMP(3);
 }
 
