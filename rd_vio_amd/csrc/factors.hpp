@@ -157,7 +157,7 @@ DM void blk3_set(double *M, int ld, int r0, int c0, const M3 &B, double s) {
 // e (15) and, if requested, the 15x15 blocks Gi, Gj (tangent columns; must be zero-initialised by the caller)
 // before the left multiplication by delta.sqrt_inv_cov (:155 and the per-block products).
 template <bool WITH_JAC>
-DM void preintegration_unwhitened(const double *si, const double *sj, const double *pre, const double *bias_lin,
+__device__ __attribute__((noinline)) void preintegration_unwhitened(const double *si, const double *sj, const double *pre, const double *bias_lin,
                                   const double *extr, double *e, double *Gi, double *Gj) {
     const V3 g = v3(0, 0, -9.80665);
     const Q4 q_ci = q_load(si + ST_Q), q_cj = q_load(sj + ST_Q);
@@ -168,51 +168,61 @@ DM void preintegration_unwhitened(const double *si, const double *sj, const doub
     const Q4 q_i = q_ci * iq, q_j = q_cj * iq;
     const V3 p_i = p_ci + rot(q_ci, ip), p_j = p_cj + rot(q_cj, ip);
     const double dt = pre[PRE_T];
-    const Q4 dq = q_load(pre + PRE_Q);
-    const V3 dp = v3_load(pre + PRE_P), dv = v3_load(pre + PRE_V);
-    const M3 dq_dbg = m3_load(pre + PRE_JAC), dp_dbg = m3_load(pre + PRE_JAC + 9), dp_dba = m3_load(pre + PRE_JAC + 18),
-             dv_dbg = m3_load(pre + PRE_JAC + 27), dv_dba = m3_load(pre + PRE_JAC + 36);
     const V3 dbg = bg_i - v3_load(bias_lin), dba = ba_i - v3_load(bias_lin + 3);
-
-    const V3 th = dq_dbg * dbg;
-    const Q4 corr = dq * expmap(th);
-    const V3 r_th = logmap(conj(corr) * conj(q_i) * q_j);
-    const V3 r_p = rot_inv(q_i, p_j - p_i - dt * v_i - (0.5 * dt * dt) * g) - (dp + dp_dbg * dbg + dp_dba * dba);
-    const V3 r_v = rot_inv(q_i, v_j - v_i - dt * g) - (dv + dv_dbg * dbg + dv_dba * dba);
-    v3_store(e + ES_Q, r_th);
-    v3_store(e + ES_P, r_p);
-    v3_store(e + ES_V, r_v);
-    v3_store(e + ES_BG, bg_j - bg_i);
-    v3_store(e + ES_BA, ba_j - ba_i);
+    // (the five 3x3 bias Jacobians of the preintegration are read where they are used -- first for the residual, again
+    // for the blocks they fill -- instead of being held across the whole evaluation: one lane evaluates a factor, and
+    // 45 extra live doubles are what tipped the register allocation into scratch)
+    V3 th, r_th;
+    {
+        const Q4 dq = q_load(pre + PRE_Q);
+        th = m3_load(pre + PRE_JAC) * dbg;
+        const Q4 corr = dq * expmap(th);
+        r_th = logmap(conj(corr) * conj(q_i) * q_j);
+    }
+    const V3 wp = p_j - p_i - dt * v_i - (0.5 * dt * dt) * g, wv = v_j - v_i - dt * g;
+    {
+        const V3 dp = v3_load(pre + PRE_P), dv = v3_load(pre + PRE_V);
+        const V3 r_p = rot_inv(q_i, wp) - (dp + m3_load(pre + PRE_JAC + 9) * dbg + m3_load(pre + PRE_JAC + 18) * dba);
+        const V3 r_v = rot_inv(q_i, wv) - (dv + m3_load(pre + PRE_JAC + 27) * dbg + m3_load(pre + PRE_JAC + 36) * dba);
+        v3_store(e + ES_Q, r_th);
+        v3_store(e + ES_P, r_p);
+        v3_store(e + ES_V, r_v);
+        v3_store(e + ES_BG, bg_j - bg_i);
+        v3_store(e + ES_BA, ba_j - ba_i);
+    }
     if (!WITH_JAC) return;
 
-    const M3 Jrinv = inverse3(right_jacobian(r_th));
-    const M3 RjT = to_mat(conj(q_j)), Rci = to_mat(q_ci), RciT = transpose(Rci), Rcj = to_mat(q_cj);
-    const M3 RiT = to_mat(conj(q_i)), IqT = to_mat(conj(iq));
     const M3 I3 = m3_identity();
-    // d/d theta_i
-    blk3_set(Gi, 15, ES_Q, ES_Q, Jrinv * (RjT * Rci), -1.0);
-    blk3_set(Gi, 15, ES_P, ES_Q, IqT * hat(RciT * (p_j - p_ci - dt * v_i - (0.5 * dt * dt) * g)), 1.0);
-    blk3_set(Gi, 15, ES_V, ES_Q, IqT * hat(RciT * (v_j - v_i - dt * g)), 1.0);
-    // d/d p_i, d/d v_i
-    blk3_set(Gi, 15, ES_P, ES_P, RiT, -1.0);
-    blk3_set(Gi, 15, ES_P, ES_V, RiT, -dt);
-    blk3_set(Gi, 15, ES_V, ES_V, RiT, -1.0);
-    // d/d bg_i
-    const M3 ERt = to_mat(conj(expmap(r_th)));
-    blk3_set(Gi, 15, ES_Q, ES_BG, ((Jrinv * ERt) * right_jacobian(th)) * dq_dbg, -1.0);
-    blk3_set(Gi, 15, ES_P, ES_BG, dp_dbg, -1.0);
-    blk3_set(Gi, 15, ES_V, ES_BG, dv_dbg, -1.0);
+    const M3 Jrinv = inverse3(right_jacobian(r_th));
+    const M3 IqT = to_mat(conj(iq));
+    {   // rotation rows
+        const M3 Rci = to_mat(q_ci);
+        blk3_set(Gi, 15, ES_Q, ES_Q, Jrinv * (to_mat(conj(q_j)) * Rci), -1.0);
+        const M3 ERt = to_mat(conj(expmap(r_th)));
+        blk3_set(Gi, 15, ES_Q, ES_BG, ((Jrinv * ERt) * right_jacobian(th)) * m3_load(pre + PRE_JAC), -1.0);
+        blk3_set(Gj, 15, ES_Q, ES_Q, Jrinv * IqT, 1.0);
+    }
+    {   // position / velocity rows against theta_i
+        const M3 RciT = transpose(to_mat(q_ci));
+        blk3_set(Gi, 15, ES_P, ES_Q, IqT * hat(RciT * (p_j - p_ci - dt * v_i - (0.5 * dt * dt) * g)), 1.0);
+        blk3_set(Gi, 15, ES_V, ES_Q, IqT * hat(RciT * wv), 1.0);
+    }
+    {
+        const M3 RiT = to_mat(conj(q_i));
+        blk3_set(Gi, 15, ES_P, ES_P, RiT, -1.0);
+        blk3_set(Gi, 15, ES_P, ES_V, RiT, -dt);
+        blk3_set(Gi, 15, ES_V, ES_V, RiT, -1.0);
+        blk3_set(Gj, 15, ES_P, ES_Q, (RiT * to_mat(q_cj)) * hat(ip), -1.0);
+        blk3_set(Gj, 15, ES_P, ES_P, RiT, 1.0);
+        blk3_set(Gj, 15, ES_V, ES_V, RiT, 1.0);
+    }
+    // bias columns: the preintegration's own Jacobians and identities
+    blk3_set(Gi, 15, ES_P, ES_BG, m3_load(pre + PRE_JAC + 9), -1.0);
+    blk3_set(Gi, 15, ES_V, ES_BG, m3_load(pre + PRE_JAC + 27), -1.0);
     blk3_set(Gi, 15, ES_BG, ES_BG, I3, -1.0);
-    // d/d ba_i
-    blk3_set(Gi, 15, ES_P, ES_BA, dp_dba, -1.0);
-    blk3_set(Gi, 15, ES_V, ES_BA, dv_dba, -1.0);
+    blk3_set(Gi, 15, ES_P, ES_BA, m3_load(pre + PRE_JAC + 18), -1.0);
+    blk3_set(Gi, 15, ES_V, ES_BA, m3_load(pre + PRE_JAC + 36), -1.0);
     blk3_set(Gi, 15, ES_BA, ES_BA, I3, -1.0);
-    // d/d theta_j, p_j, v_j, bg_j, ba_j
-    blk3_set(Gj, 15, ES_Q, ES_Q, Jrinv * IqT, 1.0);
-    blk3_set(Gj, 15, ES_P, ES_Q, (RiT * Rcj) * hat(ip), -1.0);
-    blk3_set(Gj, 15, ES_P, ES_P, RiT, 1.0);
-    blk3_set(Gj, 15, ES_V, ES_V, RiT, 1.0);
     blk3_set(Gj, 15, ES_BG, ES_BG, I3, 1.0);
     blk3_set(Gj, 15, ES_BA, ES_BA, I3, 1.0);
 }
