@@ -152,6 +152,42 @@ DM void blk3_set(double *M, int ld, int r0, int c0, const M3 &B, double s) {
         for (int j = 0; j < 3; ++j) M[(r0 + i) * ld + c0 + j] = s * B.m[i * 3 + j];
 }
 
+// rotation rows of the preintegration Jacobian (preintegration_factor.h:84-86, 111-113, 131-133)
+__device__ __attribute__((noinline)) void preintegration_rotation_blocks(const double *si, const double *sj, const double *pre,
+                                                                          const double *extr, V3 th, V3 r_th, double *Gi, double *Gj) {
+    const Q4 q_ci = q_load(si + ST_Q), iq = q_load(extr + EX_IQ);
+    const M3 Jrinv = inverse3(right_jacobian(r_th));
+    {
+        const Q4 q_j = q_load(sj + ST_Q) * iq;
+        blk3_set(Gi, 15, ES_Q, ES_Q, Jrinv * (to_mat(conj(q_j)) * to_mat(q_ci)), -1.0);
+    }
+    blk3_set(Gj, 15, ES_Q, ES_Q, Jrinv * to_mat(conj(iq)), 1.0);
+    const M3 ERt = to_mat(conj(expmap(r_th)));
+    blk3_set(Gi, 15, ES_Q, ES_BG, ((Jrinv * ERt) * right_jacobian(th)) * m3_load(pre + PRE_JAC), -1.0);
+}
+
+// position / velocity rows against the two poses and velocities (preintegration_factor.h:88-109, 135-147)
+__device__ __attribute__((noinline)) void preintegration_translation_blocks(const double *si, const double *sj, const double *extr,
+                                                                             double dt, double *Gi, double *Gj) {
+    const V3 g = v3(0, 0, -9.80665);
+    const Q4 q_ci = q_load(si + ST_Q), q_cj = q_load(sj + ST_Q), iq = q_load(extr + EX_IQ);
+    const V3 ip = v3_load(extr + EX_IP);
+    const V3 p_ci = v3_load(si + ST_P), v_i = v3_load(si + ST_V), v_j = v3_load(sj + ST_V);
+    const V3 p_j = v3_load(sj + ST_P) + rot(q_cj, ip);
+    {
+        const M3 IqT = to_mat(conj(iq)), RciT = transpose(to_mat(q_ci));
+        blk3_set(Gi, 15, ES_P, ES_Q, IqT * hat(RciT * (p_j - p_ci - dt * v_i - (0.5 * dt * dt) * g)), 1.0);
+        blk3_set(Gi, 15, ES_V, ES_Q, IqT * hat(RciT * (v_j - v_i - dt * g)), 1.0);
+    }
+    const M3 RiT = to_mat(conj(q_ci * iq));
+    blk3_set(Gi, 15, ES_P, ES_P, RiT, -1.0);
+    blk3_set(Gi, 15, ES_P, ES_V, RiT, -dt);
+    blk3_set(Gi, 15, ES_V, ES_V, RiT, -1.0);
+    blk3_set(Gj, 15, ES_P, ES_Q, (RiT * to_mat(q_cj)) * hat(ip), -1.0);
+    blk3_set(Gj, 15, ES_P, ES_P, RiT, 1.0);
+    blk3_set(Gj, 15, ES_V, ES_V, RiT, 1.0);
+}
+
 // CeresPreIntegrationErrorFactor::Evaluate, UNWHITENED part
 // (src/rdvio_estimation/include/rdvio/estimation/ceres/preintegration_factor.h:19-153):
 // e (15) and, if requested, the 15x15 blocks Gi, Gj (tangent columns; must be zero-initialised by the caller)
@@ -192,31 +228,13 @@ __device__ __attribute__((noinline)) void preintegration_unwhitened(const double
     }
     if (!WITH_JAC) return;
 
-    const M3 I3 = m3_identity();
-    const M3 Jrinv = inverse3(right_jacobian(r_th));
-    const M3 IqT = to_mat(conj(iq));
-    {   // rotation rows
-        const M3 Rci = to_mat(q_ci);
-        blk3_set(Gi, 15, ES_Q, ES_Q, Jrinv * (to_mat(conj(q_j)) * Rci), -1.0);
-        const M3 ERt = to_mat(conj(expmap(r_th)));
-        blk3_set(Gi, 15, ES_Q, ES_BG, ((Jrinv * ERt) * right_jacobian(th)) * m3_load(pre + PRE_JAC), -1.0);
-        blk3_set(Gj, 15, ES_Q, ES_Q, Jrinv * IqT, 1.0);
-    }
-    {   // position / velocity rows against theta_i
-        const M3 RciT = transpose(to_mat(q_ci));
-        blk3_set(Gi, 15, ES_P, ES_Q, IqT * hat(RciT * (p_j - p_ci - dt * v_i - (0.5 * dt * dt) * g)), 1.0);
-        blk3_set(Gi, 15, ES_V, ES_Q, IqT * hat(RciT * wv), 1.0);
-    }
-    {
-        const M3 RiT = to_mat(conj(q_i));
-        blk3_set(Gi, 15, ES_P, ES_P, RiT, -1.0);
-        blk3_set(Gi, 15, ES_P, ES_V, RiT, -dt);
-        blk3_set(Gi, 15, ES_V, ES_V, RiT, -1.0);
-        blk3_set(Gj, 15, ES_P, ES_Q, (RiT * to_mat(q_cj)) * hat(ip), -1.0);
-        blk3_set(Gj, 15, ES_P, ES_P, RiT, 1.0);
-        blk3_set(Gj, 15, ES_V, ES_V, RiT, 1.0);
-    }
+    // Each group of blocks is its own (noinline) function that re-reads the few state entries it needs (the states are
+    // LDS-resident): a factor is evaluated by ONE lane, so the live set of the whole Jacobian -- ~100 doubles of
+    // rotations, translations and trigonometric temporaries -- does not fit the register file in one piece.
+    preintegration_rotation_blocks(si, sj, pre, extr, th, r_th, Gi, Gj);
+    preintegration_translation_blocks(si, sj, extr, dt, Gi, Gj);
     // bias columns: the preintegration's own Jacobians and identities
+    const M3 I3 = m3_identity();
     blk3_set(Gi, 15, ES_P, ES_BG, m3_load(pre + PRE_JAC + 9), -1.0);
     blk3_set(Gi, 15, ES_V, ES_BG, m3_load(pre + PRE_JAC + 27), -1.0);
     blk3_set(Gi, 15, ES_BG, ES_BG, I3, -1.0);
