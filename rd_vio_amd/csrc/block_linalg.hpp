@@ -16,7 +16,7 @@ typedef __attribute__((address_space(3))) double lds_double;
 
 template <int T>
 struct BlockShared {
-    double red[2][8][T / 64];  // double-buffered partials for up to 8 simultaneous reductions
+    double red[2][10][T / 64];  // double-buffered partials for up to 10 simultaneous reductions
     double blk[15 * 16];
     double vec[16];
     int flag;
@@ -244,9 +244,21 @@ template <int T, class P, bool HW, bool MIRROR = false>
 DM void block_gemm_tn_g(double *__restrict__ C, int ldc, P A, int lda, P B, int ldb, P w, int M, int N, int K, bool lower_only) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = T / 64;
     const int tm = (M + 15) / 16, tn = (N + 15) / 16;
-    for (int tile = wave; tile < tm * tn; tile += nw) {
-        const int bi = tile / tn, bj = tile - bi * tn;
-        if (lower_only && bj > bi && 16 * bj + 16 < N) continue;  // (a trailing extra column, N = M + 1, is always computed)
+    // a square lower-only product walks the list of lower tiles, so that every wavefront gets the same number of them
+    // (tile = wave, wave + nw, ... over the full grid would hand wavefront 0 a whole tile column and the last one a tile)
+    const bool tri_walk = lower_only && M == N;
+    const int ntile = tri_walk ? tm * (tm + 1) / 2 : tm * tn;
+    for (int tile = wave; tile < ntile; tile += nw) {
+        int bi, bj;
+        if (tri_walk) {
+            bi = 0;
+            while ((bi + 1) * (bi + 2) / 2 <= tile) ++bi;
+            bj = tile - bi * (bi + 1) / 2;
+        } else {
+            bi = tile / tn;
+            bj = tile - bi * tn;
+            if (lower_only && bj > bi && 16 * bj + 16 < N) continue;  // (a trailing extra column, N = M + 1, is always computed)
+        }
         const double4_t acc = mfma_tile_g<P, HW>(A, lda, 1, B, ldb, 1, w, K, 16 * bi, 16 * bj, M, N);
         const int col = 16 * bj + (lane & 15);
 #pragma unroll

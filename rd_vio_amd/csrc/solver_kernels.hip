@@ -1043,6 +1043,88 @@ PHASE_FN void gauss_newton_norms(LdsWs &w, Shared &sh, int &phase, double (&a3)[
     block_sum_n<T, 3>(sh, a3, phase);
 }
 
+// back_substitute + gauss_newton_norms + model_scalars in one pass (windows whose three staged pose vectors fit the LDS
+// operand: 3 N <= 512): every landmark's coupling row is read once instead of twice, the pose vectors are staged once,
+// and the nine scalars share one reduction.  out = {|g|^2, |gn|^2, g.gn, q_uu, q_uv, q_vv, l_u, l_v}; returns > 0 when a
+// component of the solve is not finite.  Per-thread accumulation order is that of the three separate routines.
+PHASE_FN double gauss_newton_step_and_model(LdsWs &w, Shared &sh, int &phase, double mu, double (&out)[8]) {
+    const int t = threadIdx.x;
+    const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
+    double *y = RDVIO_GEN(sh.xv), *u = y + N, *v = y + 2 * N;
+    double r[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // r[8]: count of non-finite components
+    for (int i = t; i < N; i += T) {
+        const double yp = w.yp[i], sg = w.sig_p[i], dg = w.diag_p[i], gr = w.grad_p[i];
+        if (!isfinite(yp)) r[8] += 1.0;
+        y[i] = sg * yp;
+        const double gn = -yp * dg;
+        w.gn_p[i] = gn;
+        r[0] += gr * gr;
+        r[1] += gn * gn;
+        r[2] += gr * gn;
+        const double sd = sg / dg;
+        u[i] = sd * gr;
+        v[i] = sd * gn;
+    }
+    __syncthreads();
+    for (int base = 0; base < N; base += T / 4) {
+        const int row = base + (t >> 2), part = t & 3;
+        if (row < N) {
+            double hu, hv;
+            quad_col_dot2(w.H, N, u, v, N, row, part, hu, hv);
+            if (part == 0) {
+                r[3] += u[row] * hu;
+                r[4] += u[row] * hv;
+                r[5] += v[row] * hv;
+                r[6] += w.g[row] * u[row];
+                r[7] += w.g[row] * v[row];
+            }
+        }
+    }
+    for (int l = t; l < nl; l += T) {
+        double yl = 0.0, gnl = 0.0;
+        const bool lf = w.lfree[l];
+        const double gl = w.grad_l[l], dl = w.diag_l[l];
+        if (lf) {
+            const double sl = w.sig_l[l], m = w.lm_m[l], lg = w.lm_g[l];
+            double s = lg, au = 0.0, av = 0.0;
+            const double *Arow = w.A + (size_t)l * NAs;
+            for (int c0 = 0; c0 < NA; c0 += 30) {  // five frames of the coupling row per trip
+                double a30[30];
+#pragma unroll
+                for (int q = 0; q < 30; ++q) a30[q] = (c0 + q < NA) ? Arow[c0 + q] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 30; ++q)
+                    if (c0 + q < NA) {
+                        const int o = 15 * (c0 / 6 + q / 6) + q % 6;
+                        s -= a30[q] * y[o];
+                        au += a30[q] * u[o];
+                        av += a30[q] * v[o];
+                    }
+            }
+            const double s2 = sl * sl;
+            yl = sl * s / (s2 * m + mu * dl * dl);
+            if (!isfinite(yl)) r[8] += 1.0;
+            gnl = -yl * dl;
+            const double sd = sl / dl;
+            const double ul = sd * gl, vl = sd * gnl;
+            r[3] += 2.0 * ul * au + m * ul * ul;
+            r[4] += ul * av + vl * au + m * ul * vl;
+            r[5] += 2.0 * vl * av + m * vl * vl;
+            r[6] += lg * ul;
+            r[7] += lg * vl;
+        }
+        w.yl[l] = yl;
+        w.gn_l[l] = gnl;
+        r[0] += gl * gl;
+        r[1] += gnl * gnl;
+        r[2] += gl * gnl;
+    }
+    block_sum_n<T, 9>(sh, r, phase);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = r[i];
+    return r[8];
+}
+
 // x <- candidate
 PHASE_FN void accept_candidate(LdsWs &w) {
     const int t = threadIdx.x;
@@ -1124,23 +1206,31 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                         else cholesky_solve(sh, w.Sm, N, w.yp);
                     }
                     STAMP(6);
-                    const double bad = ok ? back_substitute(wl, sh, phase, mu) : 0.0;
+                    const bool fused = 3 * N <= 512;
+                    double pm[8];
+                    const double bad = !ok ? 0.0 : fused ? gauss_newton_step_and_model(wl, sh, phase, mu, pm) : back_substitute(wl, sh, phase, mu);
                     if (!ok || bad > 0.0) {
                         mu *= 10.0;
                         continue;
                     }
+                    if (fused) {
+                        gnorm = sqrt(pm[0]);
+                        gn_norm = sqrt(pm[1]);
+                        gdotgn = pm[2];
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) msc[i] = pm[3 + i];
+                    } else {
+                        double a3[3];
+                        gauss_newton_norms(wl, sh, phase, a3);
+                        gnorm = sqrt(a3[0]);
+                        gn_norm = sqrt(a3[1]);
+                        gdotgn = a3[2];
+                        model_scalars(wl, sh, phase, msc);
+                    }
                     solve_ok = 1;
                     break;
                 }
-                if (solve_ok) {
-                    double a3[3];
-                    gauss_newton_norms(wl, sh, phase, a3);
-                    gnorm = sqrt(a3[0]);
-                    gn_norm = sqrt(a3[1]);
-                    gdotgn = a3[2];
-                    model_scalars(wl, sh, phase, msc);
-                    alpha = gsq_keep / msc[0];
-                }
+                if (solve_ok) alpha = gsq_keep / msc[0];
                 STAMP(7);
             }
             int step_valid = 0;
