@@ -123,6 +123,45 @@ DM void quad_col_dot2(const double *__restrict__ M, long ld, const double *__res
     oy = ay;
 }
 
+// up to four right-hand sides x_k = x + k * xs at once, each summed exactly like quad_col_dot sums it
+DM void quad_col_dot4(const double *__restrict__ M, long ld, const double *__restrict__ x, int xs, int K, int C, int r, int part,
+                      double (&out)[4]) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int c = part;
+    for (; c + 60 < C; c += 64) {
+        double mv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) mv[u] = M[(long)(c + 4 * u) * ld + r];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < K)
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc[k] += mv[u] * x[k * xs + c + 4 * u];
+    }
+    for (; c + 28 < C; c += 32) {
+        double mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mv[u] = M[(long)(c + 4 * u) * ld + r];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < K)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[k] += mv[u] * x[k * xs + c + 4 * u];
+    }
+    for (; c < C; c += 4) {
+        const double m = M[(long)c * ld + r];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < K) acc[k] += m * x[k * xs + c];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        acc[k] += __shfl_xor(acc[k], 1);
+        acc[k] += __shfl_xor(acc[k], 2);
+        out[k] = acc[k];
+    }
+}
+
 DM double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);

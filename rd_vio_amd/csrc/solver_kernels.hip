@@ -1125,6 +1125,180 @@ PHASE_FN double gauss_newton_step_and_model(LdsWs &w, Shared &sh, int &phase, do
     return r[8];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Speculative evaluation of up to four trial steps in ONE pass.  After a rejected step the next trial is known in
+// advance: the radius halves, the dogleg step is re-interpolated from the same model scalars, nothing else changes --
+// so a run of rejections (the usual end of a window solve: the radius shrinks until a termination test fires) is a
+// chain of identical phases, each a few barriers and memory round trips long.  Here the K candidates of the radii
+// r, r/2, r/4, r/8 are formed and costed together; the kernel then replays the accept / reject decisions in order on the
+// K results, so the iteration sequence is exactly the sequential one (every thread accumulates every candidate's terms
+// in the order the one-candidate evaluation does).  Candidates live in the idle LDS Cholesky buffer:
+//   states [4][nfr*16] | camera poses [4][nfr*12] | inverse depths [4][nl] | preintegration errors [4][npre*15].
+// ---------------------------------------------------------------------------------------------
+DM size_t candidates_lds_doubles(int nfr, int nl, int npre) { return 4 * ((size_t)28 * nfr + nl + 15 * npre); }
+
+PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int &phase, int K, const double (&ca4)[4],
+                                  const double (&cb4)[4], double (&cost_out)[4], double (&sn2_out)[4]) {
+    const int t = threadIdx.x, nfr = w.nfr, nl = w.nl, npre = w.npre, D = w.D;
+    lds_double *stK = lds, *camK = stK + 4 * nfr * 16, *xdK = camK + 4 * nfr * 12, *epK = xdK + 4 * nl;
+    double ca[4], cb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ca[k] = ca4[k]; cb[k] = cb4[k]; }
+    double cost[4] = {0.0, 0.0, 0.0, 0.0}, sn2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = T - 1 - t; i < nfr; i += T) {
+        const int c = sh.fcol[i];
+        double x16[16], sg[15], gr[15], gn[15], dg[15];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) x16[a] = w.x[16 * i + a];
+        if (c >= 0) {
+#pragma unroll
+            for (int a = 0; a < 15; ++a) {
+                sg[a] = w.sig_p[15 * c + a]; gr[a] = w.grad_p[15 * c + a]; gn[a] = w.gn_p[15 * c + a]; dg[a] = w.diag_p[15 * c + a];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k >= K) break;
+            double o[16];
+            if (c < 0) {
+#pragma unroll
+                for (int a = 0; a < 16; ++a) o[a] = x16[a];
+            } else {
+                double d15[15];
+#pragma unroll
+                for (int a = 0; a < 15; ++a) d15[a] = sg[a] * ((ca[k] * gr[a] + cb[k] * gn[a]) / dg[a]);
+                state_plus(x16, d15, o);
+                if (sh.pfix[i])
+#pragma unroll
+                    for (int a = 0; a < 7; ++a) o[a] = x16[a];  // constant pose block
+#pragma unroll
+                for (int a = 0; a < 16; ++a)
+                    if (!(sh.pfix[i] && a < 7)) { const double e = x16[a] - o[a]; sn2[k] += e * e; }
+            }
+#pragma unroll
+            for (int a = 0; a < 16; ++a) stK[(k * nfr + i) * 16 + a] = o[a];
+            double cam[12];
+            camera_pose_of(o, w.extr, cam);
+#pragma unroll
+            for (int a = 0; a < 12; ++a) camK[(k * nfr + i) * 12 + a] = cam[a];
+        }
+    }
+    for (int l = t; l < nl; l += T) {
+        const double xd = w.xd[l];
+        const bool lf = w.lfree[l];
+        double sl = 0.0, gl = 0.0, gnl = 0.0, dl = 1.0;
+        if (lf) { sl = w.sig_l[l]; gl = w.grad_l[l]; gnl = w.gn_l[l]; dl = w.diag_l[l]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k >= K) break;
+            const double v = xd + (lf ? sl * ((ca[k] * gl + cb[k] * gnl) / dl) : 0.0);
+            xdK[k * nl + l] = v;
+            if (lf) { const double e = xd - v; sn2[k] += e * e; }
+        }
+    }
+    for (int i = t; i < nfr * 6; i += T) sh.ub[i] = w.user[16 * (i / 6) + ST_BG + (i % 6)];
+    __syncthreads();
+    const double *W = RDVIO_GEN(sh.ext) + 14, *extr = RDVIO_GEN(sh.ext);
+    constexpr int TF = T - 64;
+    if (t < TF) {
+        // reprojection factors, two per trip as in cost_factors; the factor's own data is loaded once for all candidates
+        for (int f = t; f < w.nf; f += 2 * TF) {
+            const int f2 = f + TF;
+            const bool has2 = f2 < w.nf;
+            const int fb = has2 ? f2 : f;
+            const int la = w.lm[f], lb = w.lm[fb];
+            const int ta = w.tgt[f], ra_ = w.ref[f], tb = w.tgt[fb], rb_ = w.ref[fb];
+            double Ta[9], Tb[9], za[3], zb[3];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { Ta[q] = w.tangent[9 * (size_t)f + q]; Tb[q] = w.tangent[9 * (size_t)fb + q]; }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { za[q] = w.z_ref[3 * (size_t)la + q]; zb[q] = w.z_ref[3 * (size_t)lb + q]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k >= K) break;
+                const double *cam = RDVIO_GEN(camK) + (size_t)k * nfr * 12;
+                double ra[2], rb[2];
+                reprojection_residual(cam + 12 * ta, cam + 12 * ra_, Ta, za, xdK[k * nl + la], W, ra);
+                reprojection_residual(cam + 12 * tb, cam + 12 * rb_, Tb, zb, xdK[k * nl + lb], W, rb);
+                const double sa = ra[0] * ra[0] + ra[1] * ra[1], sb = rb[0] * rb[0] + rb[1] * rb[1];
+                cost[k] += w.no_loss ? 0.5 * sa : 0.5 * log(1.0 + sa);
+                if (has2) cost[k] += w.no_loss ? 0.5 * sb : 0.5 * log(1.0 + sb);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k >= K) break;
+            cost[k] += rotation_factors<false>(w, sh, RDVIO_GEN(stK) + (size_t)k * nfr * 16, extr, W, t, TF);
+        }
+        // the prior's per-frame errors on the tail of the last factor wave, one operand vector per candidate
+        for (int i = t - (TF - 64); i >= 0 && i < w.np; i += 64) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k >= K) break;
+                double e15[15];
+                marginalization_frame_error(RDVIO_GEN(stK) + ((size_t)k * nfr + w.prior_frames[i]) * 16, w.lin + 16 * i, e15, nullptr);
+#pragma unroll
+                for (int a = 0; a < 15; ++a) sh.xv[k * D + 15 * i + a] = e15[a];
+            }
+        }
+    } else {
+        // last wave: one (candidate, preintegration factor) pair per lane
+        for (int j = t - TF; j < K * npre; j += 64) {
+            const int k = j / npre, f = j - k * npre;
+            const double *st = RDVIO_GEN(stK) + (size_t)k * nfr * 16;
+            double e15[15];
+            preintegration_unwhitened<false>(st + 16 * w.pre_i[f], st + 16 * w.pre_j[f], w.preint + (size_t)RDVIO_PREINT_SIZE * f,
+                                             RDVIO_GEN(sh.ub) + 6 * w.pre_i[f], extr, e15, nullptr, nullptr);
+#pragma unroll
+            for (int a = 0; a < 15; ++a) epK[(k * npre + f) * 15 + a] = e15[a];
+        }
+    }
+    __syncthreads();
+    for (int o = t; o < npre * 15; o += T) {
+        const int f = o / 15, row = o - 15 * f;
+        const double *Sic = w.preint + (size_t)RDVIO_PREINT_SIZE * f + PRE_SIC;
+        double sr[15];
+#pragma unroll
+        for (int q = 0; q < 15; ++q) sr[q] = Sic[row * 15 + q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k >= K) break;
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 15; ++q) acc += sr[q] * epK[(k * npre + f) * 15 + q];
+            cost[k] += 0.5 * acc * acc;
+        }
+    }
+    if (w.np > 0) {
+        for (int base = 0; base < D; base += T / 4) {
+            const int row = base + (t >> 2), part = t & 3;
+            if (row < D) {
+                double r4[4];
+                quad_col_dot4(w.ST, D, RDVIO_GEN(sh.xv), D, K, D, row, part, r4);
+                if (part == 0) {
+                    const double fr = w.f[row];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < K) { const double r = r4[k] + fr; cost[k] += 0.5 * r * r; }
+                }
+            }
+        }
+    }
+    double v8[8] = {cost[0], cost[1], cost[2], cost[3], sn2[0], sn2[1], sn2[2], sn2[3]};
+    block_sum_n<T, 8>(sh, v8, phase);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { cost_out[k] = v8[k]; sn2_out[k] = v8[4 + k]; }
+}
+
+// x <- speculative candidate k (still in the LDS buffer evaluate_candidates filled)
+PHASE_FN void accept_speculative(LdsWs &w, lds_double *lds, int k) {
+    const int t = threadIdx.x, nfr = w.nfr, nl = w.nl;
+    const lds_double *stK = lds + (size_t)k * nfr * 16, *xdK = lds + 4 * nfr * 28 + (size_t)k * nl;
+    for (int o = t; o < nfr * 16; o += T) w.x[o] = stK[o];
+    for (int l = t; l < nl; l += T) w.xd[l] = xdK[l];
+    __syncthreads();
+}
+
 // x <- candidate
 PHASE_FN void accept_candidate(LdsWs &w) {
     const int t = threadIdx.x;
@@ -1168,14 +1342,61 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     int reuse = 0, iteration = 0, invalid_steps = 0, last_successful = 0, n_success = 0;
     int term = 1;  // NO_CONVERGENCE
     STAMP(0);
-    double x_norm = x_norm_of(wl, sh, phase, w.x, w.xd);
-    double x_cost = evaluate<true>(wl, sh, phase, w.x, w.xd, prof_last);
+    // dogleg step for a trust-region radius from the scalars of the current linearisation (no memory traffic)
+    auto dogleg_step = [&](double rad, double &ca, double &cb, double &step_norm, double &model_change) -> int {
+        bool need_norm = false;
+        if (gn_norm <= rad) { ca = 0.0; cb = 1.0; step_norm = gn_norm; }
+        else if (gnorm * alpha >= rad) { ca = -(rad / gnorm); cb = 0.0; step_norm = rad; }
+        else {
+            const double b_dot_a = -alpha * gdotgn;
+            const double a_sq = (alpha * gnorm) * (alpha * gnorm);
+            const double bma_sq = a_sq - 2 * b_dot_a + gn_norm * gn_norm;
+            const double c = b_dot_a - a_sq;
+            const double d = sqrt(c * c + bma_sq * (rad * rad - a_sq));
+            const double beta = (c <= 0) ? (d - c) / bma_sq : (rad * rad - a_sq) / (d + c);
+            ca = -alpha * (1.0 - beta);
+            cb = beta;
+            need_norm = true;
+        }
+        // delta = (ca grad + cb gn) / D * Jacobi scaling is formed inside the candidate evaluation
+        if (need_norm) step_norm = sqrt(ca * ca * gnorm * gnorm + 2.0 * ca * cb * gdotgn + cb * cb * gn_norm * gn_norm);
+        const double jsq = ca * ca * msc[0] + 2.0 * ca * cb * msc[1] + cb * cb * msc[2];
+        const double jdr = ca * msc[3] + cb * msc[4];
+        model_change = -(jdr + 0.5 * jsq);
+        return model_change > 0.0;
+    };
+    int prev_rejected = 0;
+    double x_norm = 0.0, x_cost = 0.0, grad_max = 0.0;
+    // bookkeeping of an accepted step (x already holds the candidate): new linearisation, radius and damping updates
+    auto accepted_step = [&](double rel) {
+        x_norm = x_norm_of(wl, sh, phase, w.x, w.xd);
+        STAMP(10);
+        x_cost = evaluate<true>(wl, sh, phase, w.x, w.xd, prof_last);  // `user` still holds the previous point here
+        STAMP(1);
+        build_normal_equations(wl, sh, prof_last);
+        STAMP(2);
+        grad_max = grad_max_norm(wl, sh, phase);
+        STAMP(11);
+        last_successful = 1;
+        n_success++;
+        if (rel < 0.25) radius *= 0.5;
+        if (rel > 0.75) radius = fmax(radius, 3.0 * dogleg_step_norm);
+        mu = fmax(1e-8, 2.0 * mu / 10.0);
+        reuse = 0;
+        prev_rejected = 0;
+    };
+    // a run of rejections is evaluated four trial radii at a time (evaluate_candidates) when the candidates fit the LDS
+    const bool speculate = w.n_wg == 1 && w.lds_chol && candidates_lds_doubles(w.nfr, w.nl, w.npre) <= LDS_CAP &&
+                           4 * w.D <= 512 && 4 * w.npre <= 64;
+
+    x_norm = x_norm_of(wl, sh, phase, w.x, w.xd);
+    x_cost = evaluate<true>(wl, sh, phase, w.x, w.xd, prof_last);
     STAMP(1);
     const double initial_cost = x_cost;
     build_normal_equations(wl, sh, prof_last);
     STAMP(2);
     jacobi_scaling(wl);
-    double grad_max = grad_max_norm(wl, sh, phase);
+    grad_max = grad_max_norm(wl, sh, phase);
 
     if (N == 0 && w.n_lfree_hint == 0) term = 0;
     else
@@ -1184,6 +1405,42 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             if (iteration >= w.max_iter) { term = 1; break; }
             if (grad_max <= 1e-10) { term = 0; break; }
             if (radius <= 1e-32) { term = 0; break; }
+            if (speculate && prev_rejected && reuse) {
+                // the trial steps the next iterations would take one by one, as long as each is a valid step within the limits
+                double ca4[4] = {0.0, 0.0, 0.0, 0.0}, cb4[4] = {0.0, 0.0, 0.0, 0.0}, dsn4[4], mcc4[4];
+                int Kc = 0;
+                double rk = radius;
+                while (Kc < 4 && iteration + Kc < w.max_iter && rk > 1e-32) {
+                    if (!dogleg_step(rk, ca4[Kc], cb4[Kc], dsn4[Kc], mcc4[Kc])) break;
+                    ++Kc;
+                    rk *= 0.5;
+                }
+                if (Kc >= 2) {
+                    double cost4[4], sn24[4];
+                    evaluate_candidates(wl, sh, RDVIO_LDS(lds_chol_buf), phase, Kc, ca4, cb4, cost4, sn24);
+                    STAMP(9);
+                    int accepted = -1, finished = 0;
+                    double rel_acc = 0.0;
+                    for (int k = 0; k < Kc; ++k) {  // replay: exactly the decisions of Kc sequential iterations
+                        iteration++;
+                        last_successful = 0;
+                        invalid_steps = 0;
+                        const double cand_cost = isfinite(cost4[k]) ? cost4[k] : 1.7976931348623157e308;
+                        if (sqrt(sn24[k]) <= 1e-8 * (x_norm + 1e-8)) { term = 0; finished = 1; break; }
+                        if (fabs(x_cost - cand_cost) <= 1e-6 * x_cost) { term = 0; finished = 1; break; }
+                        const double rel = (cand_cost >= 1.7976931348623157e308) ? -1.7976931348623157e308 : (x_cost - cand_cost) / mcc4[k];
+                        if (rel > 1e-3) { accepted = k; rel_acc = rel; break; }
+                        radius *= 0.5;
+                    }
+                    if (finished) break;
+                    if (accepted >= 0) {
+                        accept_speculative(wl, RDVIO_LDS(lds_chol_buf), accepted);
+                        dogleg_step_norm = dsn4[accepted];
+                        accepted_step(rel_acc);
+                    }
+                    continue;
+                }
+            }
             iteration++;
             last_successful = 0;
             STAMP(10);
@@ -1235,35 +1492,13 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             }
             int step_valid = 0;
             double model_cost_change = 0.0, step_ca = 0.0, step_cb = 0.0;
-            if (solve_ok) {
-                double ca, cb;
-                bool need_norm = false;
-                if (gn_norm <= radius) { ca = 0.0; cb = 1.0; dogleg_step_norm = gn_norm; }
-                else if (gnorm * alpha >= radius) { ca = -(radius / gnorm); cb = 0.0; dogleg_step_norm = radius; }
-                else {
-                    const double b_dot_a = -alpha * gdotgn;
-                    const double a_sq = (alpha * gnorm) * (alpha * gnorm);
-                    const double bma_sq = a_sq - 2 * b_dot_a + gn_norm * gn_norm;
-                    const double c = b_dot_a - a_sq;
-                    const double d = sqrt(c * c + bma_sq * (radius * radius - a_sq));
-                    const double beta = (c <= 0) ? (d - c) / bma_sq : (radius * radius - a_sq) / (d + c);
-                    ca = -alpha * (1.0 - beta);
-                    cb = beta;
-                    need_norm = true;
-                }
-                step_ca = ca;  // delta = (ca grad + cb gn) / D * Jacobi scaling is formed inside the candidate evaluation
-                step_cb = cb;
-                if (need_norm) dogleg_step_norm = sqrt(ca * ca * gnorm * gnorm + 2.0 * ca * cb * gdotgn + cb * cb * gn_norm * gn_norm);
-                const double jsq = ca * ca * msc[0] + 2.0 * ca * cb * msc[1] + cb * cb * msc[2];
-                const double jdr = ca * msc[3] + cb * msc[4];
-                model_cost_change = -(jdr + 0.5 * jsq);
-                step_valid = model_cost_change > 0.0;
-            }
+            if (solve_ok) step_valid = dogleg_step(radius, step_ca, step_cb, dogleg_step_norm, model_cost_change);
             STAMP(8);
             if (!step_valid) {
                 if (++invalid_steps >= 5) { term = 2; break; }
                 mu *= 10.0;
                 reuse = 0;
+                prev_rejected = 0;
                 continue;
             }
             invalid_steps = 0;
@@ -1280,23 +1515,11 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             const double rel = (cand_cost >= 1.7976931348623157e308) ? -1.7976931348623157e308 : (x_cost - cand_cost) / model_cost_change;
             if (rel > 1e-3) {
                 accept_candidate(wl);
-                x_norm = x_norm_of(wl, sh, phase, w.x, w.xd);
-                STAMP(10);
-                x_cost = evaluate<true>(wl, sh, phase, w.x, w.xd, prof_last);  // `user` still holds the previous point here
-                STAMP(1);
-                build_normal_equations(wl, sh, prof_last);
-                STAMP(2);
-                grad_max = grad_max_norm(wl, sh, phase);
-                STAMP(11);
-                last_successful = 1;
-                n_success++;
-                if (rel < 0.25) radius *= 0.5;
-                if (rel > 0.75) radius = fmax(radius, 3.0 * dogleg_step_norm);
-                mu = fmax(1e-8, 2.0 * mu / 10.0);
-                reuse = 0;
+                accepted_step(rel);
             } else {
                 radius *= 0.5;
                 reuse = 1;
+                prev_rejected = 1;
             }
         }
     if (w.n_wg > 1) post_command(w, sh, CMD_EXIT);
