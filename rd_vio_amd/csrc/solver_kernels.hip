@@ -1145,42 +1145,67 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int &ph
 #pragma unroll
     for (int k = 0; k < 4; ++k) { ca[k] = ca4[k]; cb[k] = cb4[k]; }
     double cost[4] = {0.0, 0.0, 0.0, 0.0}, sn2[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int i = T - 1 - t; i < nfr; i += T) {
+    // candidate states: one (candidate, frame) pair per lane of the last wavefront (16 frames per candidate); the squared
+    // step of frame i is then handed to the lane that owns frame i in the one-candidate evaluation, so that the step
+    // norm is reduced from the same lanes, in the same order
+    auto candidate_state = [&](int k, int i, double cak, double cbk, double &e2) {
         const int c = sh.fcol[i];
-        double x16[16], sg[15], gr[15], gn[15], dg[15];
+        double x16[16], o[16];
 #pragma unroll
         for (int a = 0; a < 16; ++a) x16[a] = w.x[16 * i + a];
-        if (c >= 0) {
+        e2 = 0.0;
+        if (c < 0) {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) o[a] = x16[a];
+        } else {
+            double d15[15], sg[15], gr[15], gn[15], dg[15];
 #pragma unroll
             for (int a = 0; a < 15; ++a) {
                 sg[a] = w.sig_p[15 * c + a]; gr[a] = w.grad_p[15 * c + a]; gn[a] = w.gn_p[15 * c + a]; dg[a] = w.diag_p[15 * c + a];
             }
+#pragma unroll
+            for (int a = 0; a < 15; ++a) d15[a] = sg[a] * ((cak * gr[a] + cbk * gn[a]) / dg[a]);
+            state_plus(x16, d15, o);
+            if (sh.pfix[i])
+#pragma unroll
+                for (int a = 0; a < 7; ++a) o[a] = x16[a];  // constant pose block
+#pragma unroll
+            for (int a = 0; a < 16; ++a)
+                if (!(sh.pfix[i] && a < 7)) { const double e = x16[a] - o[a]; e2 += e * e; }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k >= K) break;
-            double o[16];
-            if (c < 0) {
+        for (int a = 0; a < 16; ++a) stK[(k * nfr + i) * 16 + a] = o[a];
+        double cam[12];
+        camera_pose_of(o, w.extr, cam);
 #pragma unroll
-                for (int a = 0; a < 16; ++a) o[a] = x16[a];
-            } else {
-                double d15[15];
+        for (int a = 0; a < 12; ++a) camK[(k * nfr + i) * 12 + a] = cam[a];
+    };
+    if (nfr <= 16) {
+        if (t >= T - 64) {
+            const int L = T - 1 - t, k = L >> 4, i = L & 15;  // (L = 0 is the workgroup's last thread)
+            double e2 = 0.0;
+            if (k < K && i < nfr) {
+                double cak = ca[0], cbk = cb[0];  // (select the candidate's coefficients without indexing the register arrays)
 #pragma unroll
-                for (int a = 0; a < 15; ++a) d15[a] = sg[a] * ((ca[k] * gr[a] + cb[k] * gn[a]) / dg[a]);
-                state_plus(x16, d15, o);
-                if (sh.pfix[i])
-#pragma unroll
-                    for (int a = 0; a < 7; ++a) o[a] = x16[a];  // constant pose block
-#pragma unroll
-                for (int a = 0; a < 16; ++a)
-                    if (!(sh.pfix[i] && a < 7)) { const double e = x16[a] - o[a]; sn2[k] += e * e; }
+                for (int q = 1; q < 4; ++q)
+                    if (k == q) { cak = ca[q]; cbk = cb[q]; }
+                candidate_state(k, i, cak, cbk, e2);
             }
 #pragma unroll
-            for (int a = 0; a < 16; ++a) stK[(k * nfr + i) * 16 + a] = o[a];
-            double cam[12];
-            camera_pose_of(o, w.extr, cam);
+            for (int q = 0; q < 4; ++q) {
+                const double v = __shfl(e2, 63 - ((L & 15) + 16 * q));  // from the lane that formed candidate q of this frame
+                if (L < 16 && L < nfr && q < K && sh.fcol[L] >= 0) sn2[q] += v;
+            }
+        }
+    } else {
+        for (int i = T - 1 - t; i < nfr; i += T) {
 #pragma unroll
-            for (int a = 0; a < 12; ++a) camK[(k * nfr + i) * 12 + a] = cam[a];
+            for (int k = 0; k < 4; ++k) {
+                if (k >= K) break;
+                double e2;
+                candidate_state(k, i, ca[k], cb[k], e2);
+                if (sh.fcol[i] >= 0) sn2[k] += e2;
+            }
         }
     }
     for (int l = t; l < nl; l += T) {
