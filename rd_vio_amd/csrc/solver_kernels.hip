@@ -1256,14 +1256,24 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int &ph
             cost[k] += rotation_factors<false>(w, sh, RDVIO_GEN(stK) + (size_t)k * nfr * 16, extr, W, t, TF);
         }
         // the prior's per-frame errors on the tail of the last factor wave, one operand vector per candidate
-        for (int i = t - (TF - 64); i >= 0 && i < w.np; i += 64) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k >= K) break;
+        if (w.np <= 16) {  // one (candidate, prior frame) pair per lane
+            const int j = t - (TF - 64), k = j >> 4, i = j & 15;
+            if (j >= 0 && k < K && i < w.np) {
                 double e15[15];
                 marginalization_frame_error(RDVIO_GEN(stK) + ((size_t)k * nfr + w.prior_frames[i]) * 16, w.lin + 16 * i, e15, nullptr);
 #pragma unroll
                 for (int a = 0; a < 15; ++a) sh.xv[k * D + 15 * i + a] = e15[a];
+            }
+        } else {
+            for (int i = t - (TF - 64); i >= 0 && i < w.np; i += 64) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k >= K) break;
+                    double e15[15];
+                    marginalization_frame_error(RDVIO_GEN(stK) + ((size_t)k * nfr + w.prior_frames[i]) * 16, w.lin + 16 * i, e15, nullptr);
+#pragma unroll
+                    for (int a = 0; a < 15; ++a) sh.xv[k * D + 15 * i + a] = e15[a];
+                }
             }
         }
     } else {
