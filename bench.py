@@ -73,10 +73,10 @@ def ba_algorithmic_flops(pb, iterations, successful_steps):
 
 def pmc_traffic_bytes():
     """HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate
-    runs of this script; profiles/r01_d_pmc_fetch_write.csv).  FETCH_SIZE + WRITE_SIZE in KB, RAW: the gfx950 x2
+    runs of this script; profiles/r01_e_pmc_fetch_write.csv).  FETCH_SIZE + WRITE_SIZE in KB, RAW: the gfx950 x2
     FETCH_SIZE correction of MI355X_MICROARCH.md is calibrated for 16-B-per-lane streaming reads only, these kernels
     read bytes / shorts / scattered doubles, so no correction is applied (the guide calls such widths uncalibrated)."""
-    path = os.path.join(ROOT, "profiles", "r01_d_pmc_fetch_write.csv")
+    path = os.path.join(ROOT, "profiles", "r01_e_pmc_fetch_write.csv")
     out = {}
     if os.path.exists(path):
         for line in open(path).read().strip().splitlines()[1:]:
@@ -378,7 +378,7 @@ def main():
         pmc = pmc_traffic_bytes() if args.config == "euroc_v101" else {}
         roof = dict(kernel="ba_solve_kernel", bound="mfma", achieved=round(tfl, 5), peak=FP64_PEAK_TFLOPS,
                     unit="TFLOP/s", frac=round(tfl / FP64_PEAK_TFLOPS, 7), traffic=pmc.get("ba_solve_kernel"),
-                    traffic_unit="bytes per launch, FETCH_SIZE + WRITE_SIZE raw (profiles/r01_d_pmc_fetch_write.csv)",
+                    traffic_unit="bytes per launch, FETCH_SIZE + WRITE_SIZE raw (profiles/r01_e_pmc_fetch_write.csv)",
                     algorithmic_flops_per_launch=int(fl / 2), avg_launch_us=round(float(ba_ms) * 1e3 / 2, 2),
                     launches_per_frame=2, dominant_stage=stage_names[dom],
                     note="single-workgroup latency-bound trust-region loop; see DESIGN.md section 4 for the phase table")
