@@ -55,18 +55,34 @@ class PoissonDisk2 {
 
 int rdvio_host_select_keypoints(HarrisCand *cand, int nc, int w, int h, int max_corners, double gftt_min_dist,
                                 double poisson_radius, double *keypoints, int n_existing, int capacity) {
-    // std::sort(tmpCorners, greaterThanPtr()): by response, ties by higher address == higher pixel index
-    std::sort(cand, cand + nc, [](const HarrisCand &a, const HarrisCand &b) {
-        return a.v > b.v || (a.v == b.v && a.idx > b.idx);
-    });
+    // std::sort(tmpCorners, greaterThanPtr()): by response, ties by higher address == higher pixel index -- a strict total
+    // order, so the sequence is the same however it is produced.  The greedy selection below usually stops after a few
+    // hundred candidates (max_corners accepted), so the list is sorted lazily, one chunk of the best remaining
+    // candidates at a time (nth_element + sort of the chunk) instead of all at once.
+    const auto before = [](const HarrisCand &a, const HarrisCand &b) { return a.v > b.v || (a.v == b.v && a.idx > b.idx); };
+    int sorted = 0;
+    const int chunk = max_corners > 0 ? std::max(256, 4 * max_corners) : nc;
+    auto ensure_sorted = [&](int upto) {  // candidates [0, upto) in final order
+        while (sorted < upto) {
+            const int end = std::min(nc, sorted + chunk);
+            if (end < nc) std::nth_element(cand + sorted, cand + end, cand + nc, before);
+            std::sort(cand + sorted, cand + end, before);
+            sorted = end;
+        }
+    };
     // greedy minDistance selection on a cell grid (goodFeaturesToTrack)
     std::vector<float> corners;  // x,y
     if (gftt_min_dist >= 1) {
         const int cell = (int)std::lrint(gftt_min_dist);
         const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
         const double md2 = gftt_min_dist * gftt_min_dist;
-        std::vector<std::vector<int>> grid((size_t)gw * gh);
+        // per-cell singly linked lists in two flat arrays (reused between calls: no per-frame allocation)
+        static thread_local std::vector<int> head, next;
+        head.assign((size_t)gw * gh, -1);
+        next.clear();
+        corners.reserve(max_corners > 0 ? 2 * (size_t)max_corners : 512);
         for (int i = 0; i < nc; ++i) {
+            ensure_sorted(i + 1);
             const int y = cand[i].idx / w, x = cand[i].idx - y * w;
             const int xc = x / cell, yc = y / cell;
             const int x1 = std::max(0, xc - 1), y1 = std::max(0, yc - 1);
@@ -74,7 +90,7 @@ int rdvio_host_select_keypoints(HarrisCand *cand, int nc, int w, int h, int max_
             bool good = true;
             for (int yy = y1; yy <= y2 && good; ++yy)
                 for (int xx = x1; xx <= x2 && good; ++xx)
-                    for (int c : grid[(size_t)yy * gw + xx]) {
+                    for (int c = head[(size_t)yy * gw + xx]; c >= 0; c = next[c]) {
                         const float dx = (float)x - corners[2 * c], dy = (float)y - corners[2 * c + 1];
                         if ((double)(dx * dx + dy * dy) < md2) {
                             good = false;
@@ -82,12 +98,15 @@ int rdvio_host_select_keypoints(HarrisCand *cand, int nc, int w, int h, int max_
                         }
                     }
             if (!good) continue;
-            grid[(size_t)yc * gw + xc].push_back((int)corners.size() / 2);
+            const int id = (int)corners.size() / 2;
+            next.push_back(head[(size_t)yc * gw + xc]);
+            head[(size_t)yc * gw + xc] = id;
             corners.push_back((float)x);
             corners.push_back((float)y);
-            if (max_corners > 0 && (int)corners.size() / 2 == max_corners) break;
+            if (max_corners > 0 && id + 1 == max_corners) break;
         }
     } else {
+        ensure_sorted(max_corners > 0 ? std::min(nc, max_corners) : nc);
         for (int i = 0; i < nc && (max_corners <= 0 || i < max_corners); ++i) {
             corners.push_back((float)(cand[i].idx % w));
             corners.push_back((float)(cand[i].idx / w));

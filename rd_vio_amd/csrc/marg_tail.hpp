@@ -242,7 +242,19 @@ __device__ __attribute__((noinline)) void marginalize_tail(LdsWs &w, LdsShared<T
         w.lm_w[l] = (w.lfree[l] && isfinite(inv)) ? inv : 0.0;
     }
     __syncthreads();
-    if (NA > 0 && nl > 0) block_gemm_tn<T>(w.Cm, NAs, w.A, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, true);
+    if (NA > 0 && nl > 0) {
+        // operand staged in the (still idle) LDS buffer with one batch of coalesced loads, as in the solver's schur_reduce
+        constexpr size_t LDS_DOUBLES = (size_t)(15 * RDVIO_LDS_CHOL_MAX_FRAMES) * (15 * RDVIO_LDS_CHOL_MAX_FRAMES + 1) / 2 + 225 * RDVIO_LDS_CHOL_MAX_FRAMES;
+        if (w.lds_chol && (size_t)nl * NAs + nl <= LDS_DOUBLES) {
+            lds_double *As = lds, *ws = lds + nl * NAs;
+            for (int i = t; i < nl * NAs; i += T) As[i] = w.A[i];
+            for (int l = t; l < nl; l += T) ws[l] = w.lm_w[l];
+            __syncthreads();
+            block_gemm_tn_lds<T>(w.Cm, NAs, As, NAs, As, NAs, ws, true, NA, NA + 1, nl, true);
+        } else {
+            block_gemm_tn<T>(w.Cm, NAs, w.A, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, true);
+        }
+    }
     __syncthreads();
     // Hs = H - C (full, natural frame order) into Sm; gs = g - Cg into yp
     for (int o = t; o < N * N; o += T) {

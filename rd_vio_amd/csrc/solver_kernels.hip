@@ -790,15 +790,22 @@ __device__ __attribute__((noinline)) double grad_max_norm(LdsWs &w, Shared &sh, 
     const int t = threadIdx.x;
     double m = 0.0;
     for (int i = t; i < w.nfr; i += T) {
-        const int c = w.fcol[i];
+        const int c = sh.fcol[i];
         if (c < 0) continue;
-        double d15[15], o[16];
+        double d15[15], x16[16], o[16];
+#pragma unroll
         for (int a = 0; a < 15; ++a) d15[a] = -w.g[15 * c + a];
-        state_plus(w.x + 16 * i, d15, o);
-        for (int a = sh.pfix[i] ? 7 : 0; a < 16; ++a) m = fmax(m, fabs(w.x[16 * i + a] - o[a]));
+#pragma unroll
+        for (int a = 0; a < 16; ++a) x16[a] = w.x[16 * i + a];
+        state_plus(x16, d15, o);
+        const bool pf = sh.pfix[i];
+#pragma unroll
+        for (int a = 0; a < 16; ++a)  // (static indices: a run-time start index would put o[] in scratch)
+            if (!(pf && a < 7)) m = fmax(m, fabs(x16[a] - o[a]));
     }
-    for (int l = t; l < w.nl; l += T)
-        if (w.lfree[l]) m = fmax(m, fabs(w.lm_g[l]));
+    if (w.n_lfree_hint > 0)
+        for (int l = t; l < w.nl; l += T)
+            if (w.lfree[l]) m = fmax(m, fabs(w.lm_g[l]));
     return block_max(sh, m, phase);
 }
 
@@ -1080,7 +1087,7 @@ PHASE_FN double gauss_newton_step_and_model(LdsWs &w, Shared &sh, int &phase, do
             }
         }
     }
-    for (int l = t; l < nl; l += T) {
+    for (int l = t; l < nl && w.n_lfree_hint > 0; l += T) {  // (no free landmark: nothing below contributes)
         double yl = 0.0, gnl = 0.0;
         const bool lf = w.lfree[l];
         const double gl = w.grad_l[l], dl = w.diag_l[l];
