@@ -442,11 +442,26 @@ template <class WS>
 DM double prior_part(const WS &w, const Shared &sh, int pi, int a, int pj, int b) {
     const int D = w.D;
     if (a >= 3 && b >= 3) return w.Lam[(size_t)(15 * pi + a) * D + 15 * pj + b];
+    // rows {0,1,2} (a < 3) or {a}, columns {0,1,2} (b < 3) or {b}: fixed 3 x 3 trip counts with the unused terms masked, so
+    // that the (up to nine) loads are issued together instead of one per trip of a run-time loop; same summation order
+    double lam[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const bool valid = (a < 3 || i == 0) && (b < 3 || j == 0);
+            const int aa = a < 3 ? i : a, bb = b < 3 ? j : b;
+            lam[3 * i + j] = valid ? w.Lam[(size_t)(15 * pi + aa) * D + 15 * pj + bb] : 0.0;
+        }
     double acc = 0.0;
-    const int a0 = a < 3 ? 0 : a, a1 = a < 3 ? 3 : a + 1, b0 = b < 3 ? 0 : b, b1 = b < 3 ? 3 : b + 1;
-    for (int aa = a0; aa < a1; ++aa)
-        for (int bb = b0; bb < b1; ++bb)
-            acc += prior_E(sh, pi, aa, a) * w.Lam[(size_t)(15 * pi + aa) * D + 15 * pj + bb] * prior_E(sh, pj, bb, b);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const bool valid = (a < 3 || i == 0) && (b < 3 || j == 0);
+            const int aa = a < 3 ? i : a, bb = b < 3 ? j : b;
+            if (valid) acc += prior_E(sh, pi, aa, a) * lam[3 * i + j] * prior_E(sh, pj, bb, b);
+        }
     return acc;
 }
 
@@ -588,18 +603,20 @@ __device__ __attribute__((noinline)) void build_normal_equations(LdsWs &w, Share
                 if (src1 >= 0) acc += w.PP[900 * (size_t)(src1 >> 2) + 30 * (15 * ((src1 >> 1) & 1) + a) + 15 * (src1 & 1) + b];
                 if (a < 6 && b < 6) {
                     if (fi == fj) {
-                        // the nfree group tiles that touch this frame, four loads in flight (summed in f2 order)
-                        for (int f0 = 0; f0 < nfree; f0 += 4) {
-                            double gv[4];
+                        // the nfree group tiles that touch this frame, twelve loads in flight: one round trip covers a
+                        // window of up to 12 free frames (summed in f2 order)
+                        for (int f0 = 0; f0 < nfree; f0 += 12) {
+                            double gv[12];
 #pragma unroll
-                            for (int u4 = 0; u4 < 4; ++u4) {
+                            for (int u4 = 0; u4 < 12; ++u4) {
                                 const int f2 = f0 + u4;
                                 const int lo = f2 < fi ? f2 : fi, hi = f2 < fi ? fi : f2;
                                 const int off = (fi == lo) ? 0 : 6;  // quadrant (lo,lo) or (hi,hi); the single group (f,f) uses (lo,lo)
                                 gv[u4] = f2 < nfree ? w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + off + b] : 0.0;
                             }
 #pragma unroll
-                            for (int u4 = 0; u4 < 4; ++u4) acc += gv[u4];
+                            for (int u4 = 0; u4 < 12; ++u4)
+                                if (f0 + u4 < nfree) acc += gv[u4];
                         }
                         if (a < 3 && b < 3)
                             for (int k = 0; k < w.nrot; ++k)
@@ -648,17 +665,18 @@ __device__ __attribute__((noinline)) void build_normal_equations(LdsWs &w, Share
         const int c = o / 15, a = o - 15 * c;
         double acc = 0.0;
         if (a < 6) {
-            for (int f0 = 0; f0 < nfree; f0 += 4) {
-                double gv[4];
+            for (int f0 = 0; f0 < nfree; f0 += 12) {
+                double gv[12];
 #pragma unroll
-                for (int u4 = 0; u4 < 4; ++u4) {
+                for (int u4 = 0; u4 < 12; ++u4) {
                     const int f2 = f0 + u4;
                     const int lo = f2 < c ? f2 : c, hi = f2 < c ? c : f2;
                     const int off = (c == lo) ? 0 : 6;
                     gv[u4] = f2 < nfree ? w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + 12] : 0.0;
                 }
 #pragma unroll
-                for (int u4 = 0; u4 < 4; ++u4) acc += gv[u4];
+                for (int u4 = 0; u4 < 12; ++u4)
+                    if (f0 + u4 < nfree) acc += gv[u4];
             }
             if (a < 3)
                 for (int k = 0; k < w.nrot; ++k)
