@@ -490,9 +490,12 @@ DM double readlane_d(double v, int src_lane) {
 }
 // 1/sqrt(x) to full double precision: hardware estimate + two Newton steps (no FP64 divide / sqrt sequence)
 DM double rsqrt_nr(double x) {
+    // (explicit FMAs: the factorisation is not compared bit for bit with anything, and on the pivot chain -- which is
+    // instruction-issue bound -- a fused step is one instruction instead of two)
     double y = __builtin_amdgcn_rsq(x);
-    y = y * (1.5 - 0.5 * x * y * y);
-    y = y * (1.5 - 0.5 * x * y * y);
+    const double h = 0.5 * x;
+    y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);
+    y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);
     return y;
 }
 
@@ -523,11 +526,11 @@ DM void cholesky_diag_block(LdsShared<T> &sh, lds_double *Lp, int k0, double tol
         a[j] = lj;
         if (lane == j) sh.vec[j] = rs;
         if (j + 1 < 15) {
-            a[j + 1] -= lj * readlane_d(lj, j + 1);
+            a[j + 1] = __builtin_fma(-lj, readlane_d(lj, j + 1), a[j + 1]);
             piv = readlane_d(a[j + 1], j + 1);
         }
 #pragma unroll
-        for (int c = j + 2; c < 15; ++c) a[c] -= lj * readlane_d(lj, c);
+        for (int c = j + 2; c < 15; ++c) a[c] = __builtin_fma(-lj, readlane_d(lj, c), a[c]);
     }
     if (bad && lane == 0) sh.flag = 0;
     if (lane < 15) {
@@ -587,7 +590,7 @@ __device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_doub
                 double s = x[c];
 #pragma unroll
                 for (int q = 0; q < 15; ++q)
-                    if (q < c) s -= x[q] * Lc[q];
+                    if (q < c) s = __builtin_fma(-x[q], Lc[q], s);
                 x[c] = s * sh.vec[c];
             }
 #pragma unroll
@@ -620,7 +623,7 @@ __device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_doub
             double s = (r == c) ? 1.0 : 0.0;
 #pragma unroll
             for (int q = 0; q < 15; ++q)
-                if (q < r) s -= Lr[q] * x[q];
+                if (q < r) s = __builtin_fma(-Lr[q], x[q], s);
             x[r] = (r >= c) ? s / Lr[r] : 0.0;
         }
 #pragma unroll
@@ -645,7 +648,7 @@ __device__ __attribute__((noinline)) void cholesky_solve_lds(LdsShared<T> &sh, c
             double v = 0.0;
             if (t < 15) {
 #pragma unroll
-                for (int q = 0; q < 15; ++q) v += Dinv[225 * kb + 15 * q + t] * y[15 * kb + q];
+                for (int q = 0; q < 15; ++q) v = __builtin_fma(Dinv[225 * kb + 15 * q + t], y[15 * kb + q], v);
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -655,7 +658,7 @@ __device__ __attribute__((noinline)) void cholesky_solve_lds(LdsShared<T> &sh, c
             for (int i = t; i < 15 * kb; i += 64) {
                 double s = 0.0;
 #pragma unroll
-                for (int q = 0; q < 15; ++q) s += Lp[tri(15 * kb + q) + i] * y[15 * kb + q];
+                for (int q = 0; q < 15; ++q) s = __builtin_fma(Lp[tri(15 * kb + q) + i], y[15 * kb + q], s);
                 y[i] -= s;
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
