@@ -82,17 +82,14 @@ DM double linearize_factor(const WS &w, Shared &sh, int k, const double *states,
         for (int i = 0; i < 12; ++i) {
             Jt[i] *= zt;
             Jr[i] *= zr;
-            o[i] = Jt[i];
-            o[12 + i] = Jr[i];
         }
-        o[24] = Jd[0];
-        o[25] = Jd[1];
-        o[26] = r[0];
-        o[27] = r[1];
-        // per-factor landmark products: ht = Jd^T Jt, hr = Jd^T Jr, m = Jd^T Jd, g = Jd^T r
+        // per-factor landmark products: ht = Jd^T Jt, hr = Jd^T Jr, m = Jd^T Jd, g = Jd^T r.  Only hr, m, g are read back
+        // (landmark pass, record entries 34..41); ht goes straight into the coupling row below, and the Jacobians and the
+        // residual travel in the group-ordered record -- storing them here as well was a third of the phase's stores.
+        double ht[6];
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-            o[28 + a] = Jd[0] * Jt[a] + Jd[1] * Jt[6 + a];
+            ht[a] = Jd[0] * Jt[a] + Jd[1] * Jt[6 + a];
             o[34 + a] = Jd[0] * Jr[a] + Jd[1] * Jr[6 + a];
         }
         o[40] = Jd[0] * Jd[0] + Jd[1] * Jd[1];
@@ -104,7 +101,7 @@ DM double linearize_factor(const WS &w, Shared &sh, int k, const double *states,
             if (ctc >= 0 && w.lfree[l]) {
                 double *Arow = w.A + (size_t)l * (6 * w.nfree + 2) + 6 * ctc;
 #pragma unroll
-                for (int a = 0; a < 6; ++a) Arow[a] = o[28 + a];
+                for (int a = 0; a < 6; ++a) Arow[a] = ht[a];
             }
         }
         // group-ordered record [J_lo | J_hi | r]: the assembly streams these with no indirection
