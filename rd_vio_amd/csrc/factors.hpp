@@ -46,9 +46,11 @@ DM void reprojection_factor(const double *__restrict__ st, const double *__restr
     const double d02 = -u.x / z2, d12 = -u.y / z2;
     const double wd[6] = {w00 * iz, w01 * iz, w00 * d02 + w01 * d12, w10 * iz, w11 * iz, w10 * d02 + w11 * d12};
     double A[6], Bm[6], C[6], D[6], Mt[6], Mr[6];
+    // (Jacobian chain with explicit FMAs: the linearisation is issue-bound, and nothing downstream relies on an exact
+    // cancellation in J; the residual above keeps the reference's unfused arithmetic)
 #define RDVIO_MUL23(OUT, IN, MAT)                                                                                \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 3; ++j) OUT[i * 3 + j] = \
-        IN[i * 3] * (MAT).m[j] + IN[i * 3 + 1] * (MAT).m[3 + j] + IN[i * 3 + 2] * (MAT).m[6 + j];
+        __builtin_fma(IN[i * 3 + 2], (MAT).m[6 + j], __builtin_fma(IN[i * 3 + 1], (MAT).m[3 + j], IN[i * 3] * (MAT).m[j]));
     RDVIO_MUL23(A, wd, Tt)
     const M3 Rcs = to_mat(qcs);
     const M3 RcsT = transpose(Rcs);
