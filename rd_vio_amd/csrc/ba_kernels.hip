@@ -206,16 +206,16 @@ __global__ __launch_bounds__(64) void preintegrate_kernel(int nseg, const int32_
                 const double *Aj = s_Ak[j], *Nj = s_Nk[j], *mk = s_Mk[j];
                 const double dt_j = mk[36];
                 double T0 = 0.0, T1 = 0.0;
+                // 81 outputs on 64 lanes: lanes 0..16 carry a second output in the same loop (two independent chains
+                // instead of a second pass); fused multiply-adds -- the recurrence is a serial chain of such dot products
+                const int r_a = lane / 9, c_a = lane - r_a * 9;
+                const bool two = lane < 17;
+                const int i_b = two ? lane + 64 : lane, r_b = i_b / 9, c_b = i_b - r_b * 9;
                 if (cc) {  // T = A * cov9
-                    {
-                        const int r = lane / 9, c = lane - r * 9;
 #pragma unroll
-                        for (int x = 0; x < 9; ++x) T0 += Aj[r * 9 + x] * s_cov[x * 15 + c];
-                    }
-                    if (lane < 17) {
-                        const int i = lane + 64, r = i / 9, c = i - r * 9;
-#pragma unroll
-                        for (int x = 0; x < 9; ++x) T1 += Aj[r * 9 + x] * s_cov[x * 15 + c];
+                    for (int x = 0; x < 9; ++x) {
+                        T0 = __builtin_fma(Aj[r_a * 9 + x], s_cov[x * 15 + c_a], T0);
+                        T1 = __builtin_fma(Aj[r_b * 9 + x], s_cov[x * 15 + c_b], T1);
                     }
                 }
                 // one entry of each 3x3 Jacobian per lane (preintegrator.cpp:59-70; old values feed p and v)
@@ -249,19 +249,15 @@ __global__ __launch_bounds__(64) void preintegrate_kernel(int nseg, const int32_
                     s_jac[36 + lane] = n_dv_dba;
                 }
                 if (cc) {  // cov9 = T A^T + N; bias random walks
-                    {
-                        const int r = lane / 9, c = lane - r * 9;
-                        double acc = 0.0;
+                    double acc_a = 0.0, acc_b = 0.0;
 #pragma unroll
-                        for (int x = 0; x < 9; ++x) acc += s_T[r * 9 + x] * Aj[c * 9 + x];
-                        s_cov[r * 15 + c] = acc + Nj[lane];
+                    for (int x = 0; x < 9; ++x) {
+                        acc_a = __builtin_fma(s_T[r_a * 9 + x], Aj[c_a * 9 + x], acc_a);
+                        acc_b = __builtin_fma(s_T[r_b * 9 + x], Aj[c_b * 9 + x], acc_b);
                     }
-                    if (lane < 17) {
-                        const int i = lane + 64, r = i / 9, c = i - r * 9;
-                        double acc = 0.0;
-#pragma unroll
-                        for (int x = 0; x < 9; ++x) acc += s_T[r * 9 + x] * Aj[c * 9 + x];
-                        s_cov[r * 15 + c] = acc + Nj[i];
+                    s_cov[r_a * 15 + c_a] = acc_a + Nj[lane];
+                    if (two) {
+                        s_cov[r_b * 15 + c_b] = acc_b + Nj[i_b];
                     } else if (lane < 35) {
                         const int q = lane - 17, which = q / 9, i9 = q % 9, r = i9 / 3, c = i9 % 3;
                         const int o0 = which ? ES_BA : ES_BG;
