@@ -1167,6 +1167,20 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int &ph
 #pragma unroll
     for (int k = 0; k < 4; ++k) { ca[k] = ca4[k]; cb[k] = cb4[k]; }
     double cost[4] = {0.0, 0.0, 0.0, 0.0}, sn2[4] = {0.0, 0.0, 0.0, 0.0};
+    // the candidate loops below are real loops (the bodies are large: four unrolled copies overflow the instruction
+    // cache); the per-candidate accumulators are selected with compares so that they stay in registers
+    auto add_to = [](double (&acc)[4], int k, double v) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q == k) acc[q] += v;
+    };
+    auto pick = [](const double (&arr)[4], int k) {
+        double v = arr[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (q == k) v = arr[q];
+        return v;
+    };
     // candidate states: one (candidate, frame) pair per lane of the last wavefront (16 frames per candidate); the squared
     // step of frame i is then handed to the lane that owns frame i in the one-candidate evaluation, so that the step
     // norm is reduced from the same lanes, in the same order
@@ -1221,12 +1235,11 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int &ph
         }
     } else {
         for (int i = T - 1 - t; i < nfr; i += T) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k >= K) break;
+#pragma unroll 1
+            for (int k = 0; k < K; ++k) {
                 double e2;
-                candidate_state(k, i, ca[k], cb[k], e2);
-                if (sh.fcol[i] >= 0) sn2[k] += e2;
+                candidate_state(k, i, pick(ca, k), pick(cb, k), e2);
+                if (sh.fcol[i] >= 0) add_to(sn2, k, e2);
             }
         }
     }
@@ -1260,23 +1273,19 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int &ph
             for (int q = 0; q < 9; ++q) { Ta[q] = w.tangent[9 * (size_t)f + q]; Tb[q] = w.tangent[9 * (size_t)fb + q]; }
 #pragma unroll
             for (int q = 0; q < 3; ++q) { za[q] = w.z_ref[3 * (size_t)la + q]; zb[q] = w.z_ref[3 * (size_t)lb + q]; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k >= K) break;
+#pragma unroll 1
+            for (int k = 0; k < K; ++k) {
                 const double *cam = RDVIO_GEN(camK) + (size_t)k * nfr * 12;
                 double ra[2], rb[2];
                 reprojection_residual(cam + 12 * ta, cam + 12 * ra_, Ta, za, xdK[k * nl + la], W, ra);
                 reprojection_residual(cam + 12 * tb, cam + 12 * rb_, Tb, zb, xdK[k * nl + lb], W, rb);
                 const double sa = ra[0] * ra[0] + ra[1] * ra[1], sb = rb[0] * rb[0] + rb[1] * rb[1];
-                cost[k] += w.no_loss ? 0.5 * sa : 0.5 * log(1.0 + sa);
-                if (has2) cost[k] += w.no_loss ? 0.5 * sb : 0.5 * log(1.0 + sb);
+                add_to(cost, k, w.no_loss ? 0.5 * sa : 0.5 * log(1.0 + sa));
+                if (has2) add_to(cost, k, w.no_loss ? 0.5 * sb : 0.5 * log(1.0 + sb));
             }
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k >= K) break;
-            cost[k] += rotation_factors<false>(w, sh, RDVIO_GEN(stK) + (size_t)k * nfr * 16, extr, W, t, TF);
-        }
+#pragma unroll 1
+        for (int k = 0; k < K; ++k) add_to(cost, k, rotation_factors<false>(w, sh, RDVIO_GEN(stK) + (size_t)k * nfr * 16, extr, W, t, TF));
         // the prior's per-frame errors on the tail of the last factor wave, one operand vector per candidate
         if (w.np <= 16) {  // one (candidate, prior frame) pair per lane
             const int j = t - (TF - 64), k = j >> 4, i = j & 15;
@@ -1288,9 +1297,8 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int &ph
             }
         } else {
             for (int i = t - (TF - 64); i >= 0 && i < w.np; i += 64) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (k >= K) break;
+#pragma unroll 1
+                for (int k = 0; k < K; ++k) {
                     double e15[15];
                     marginalization_frame_error(RDVIO_GEN(stK) + ((size_t)k * nfr + w.prior_frames[i]) * 16, w.lin + 16 * i, e15, nullptr);
 #pragma unroll
