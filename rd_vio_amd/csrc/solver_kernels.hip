@@ -1159,13 +1159,13 @@ PHASE_FN double gauss_newton_step_and_model(LdsWs &w, Shared &sh, int &phase, do
 // ---------------------------------------------------------------------------------------------
 DM size_t candidates_lds_doubles(int nfr, int nl, int npre) { return 4 * ((size_t)28 * nfr + nl + 15 * npre); }
 
-PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int &phase, int K, const double (&ca4)[4],
-                                  const double (&cb4)[4], double (&cost_out)[4], double (&sn2_out)[4]) {
+// Trial-step coefficients arrive by value and the eight results leave through sh.blk[0..7] (cost, then squared step
+// norm, per candidate): arrays handed over by reference would live in scratch memory on both sides of the call.
+PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int &phase, int K, double ca0, double ca1, double ca2,
+                                  double ca3, double cb0, double cb1, double cb2, double cb3, unsigned long long &prof_last) {
     const int t = threadIdx.x, nfr = w.nfr, nl = w.nl, npre = w.npre, D = w.D;
     lds_double *stK = lds, *camK = stK + 4 * nfr * 16, *xdK = camK + 4 * nfr * 12, *epK = xdK + 4 * nl;
-    double ca[4], cb[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { ca[k] = ca4[k]; cb[k] = cb4[k]; }
+    const double ca[4] = {ca0, ca1, ca2, ca3}, cb[4] = {cb0, cb1, cb2, cb3};
     double cost[4] = {0.0, 0.0, 0.0, 0.0}, sn2[4] = {0.0, 0.0, 0.0, 0.0};
     // the candidate loops below are real loops (the bodies are large: four unrolled copies overflow the instruction
     // cache); the per-candidate accumulators are selected with compares so that they stay in registers
@@ -1258,6 +1258,7 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int &ph
     }
     for (int i = t; i < nfr * 6; i += T) sh.ub[i] = w.user[16 * (i / 6) + ST_BG + (i % 6)];
     __syncthreads();
+    STAMP(31);
     const double *W = RDVIO_GEN(sh.ext) + 14, *extr = RDVIO_GEN(sh.ext);
     constexpr int TF = T - 64;
     if (t < TF) {
@@ -1318,7 +1319,9 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int &ph
             for (int a = 0; a < 15; ++a) epK[(k * npre + f) * 15 + a] = e15[a];
         }
     }
+    STAMP(20);
     __syncthreads();
+    STAMP(21);
     for (int o = t; o < npre * 15; o += T) {
         const int f = o / 15, row = o - 15 * f;
         const double *Sic = w.preint + (size_t)RDVIO_PREINT_SIZE * f + PRE_SIC;
@@ -1334,6 +1337,7 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int &ph
             cost[k] += 0.5 * acc * acc;
         }
     }
+    STAMP(22);
     if (w.np > 0) {
         for (int base = 0; base < D; base += T / 4) {
             const int row = base + (t >> 2), part = t & 3;
@@ -1351,8 +1355,10 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int &ph
     }
     double v8[8] = {cost[0], cost[1], cost[2], cost[3], sn2[0], sn2[1], sn2[2], sn2[3]};
     block_sum_n<T, 8>(sh, v8, phase);
+    if (t == 0)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { cost_out[k] = v8[k]; sn2_out[k] = v8[4 + k]; }
+        for (int k = 0; k < 8; ++k) sh.blk[k] = v8[k];
+    __syncthreads();
 }
 
 // x <- speculative candidate k (still in the LDS buffer evaluate_candidates filled)
@@ -1472,35 +1478,46 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             if (radius <= 1e-32) { term = 0; break; }
             if (speculate && prev_rejected && reuse) {
                 // the trial steps the next iterations would take one by one, as long as each is a valid step within the limits
-                double ca4[4] = {0.0, 0.0, 0.0, 0.0}, cb4[4] = {0.0, 0.0, 0.0, 0.0}, dsn4[4], mcc4[4];
+                // (static indices throughout: these small arrays must stay in registers)
+                double ca4[4] = {0.0, 0.0, 0.0, 0.0}, cb4[4] = {0.0, 0.0, 0.0, 0.0}, dsn4[4] = {0.0, 0.0, 0.0, 0.0}, mcc4[4] = {1.0, 1.0, 1.0, 1.0};
                 int Kc = 0;
-                double rk = radius;
-                while (Kc < 4 && iteration + Kc < w.max_iter && rk > 1e-32) {
-                    if (!dogleg_step(rk, ca4[Kc], cb4[Kc], dsn4[Kc], mcc4[Kc])) break;
-                    ++Kc;
-                    rk *= 0.5;
+                {
+                    double rk = radius;
+                    bool open = true;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (open && iteration + k < w.max_iter && rk > 1e-32 && dogleg_step(rk, ca4[k], cb4[k], dsn4[k], mcc4[k])) {
+                            Kc = k + 1;
+                            rk *= 0.5;
+                        } else {
+                            open = false;
+                        }
+                    }
                 }
                 if (Kc >= 2) {
-                    double cost4[4], sn24[4];
-                    evaluate_candidates(wl, sh, RDVIO_LDS(lds_chol_buf), phase, Kc, ca4, cb4, cost4, sn24);
+                    evaluate_candidates(wl, sh, RDVIO_LDS(lds_chol_buf), phase, Kc, ca4[0], ca4[1], ca4[2], ca4[3], cb4[0], cb4[1], cb4[2], cb4[3], prof_last);
                     STAMP(9);
-                    int accepted = -1, finished = 0;
-                    double rel_acc = 0.0;
-                    for (int k = 0; k < Kc; ++k) {  // replay: exactly the decisions of Kc sequential iterations
-                        iteration++;
-                        last_successful = 0;
-                        invalid_steps = 0;
-                        const double cand_cost = isfinite(cost4[k]) ? cost4[k] : 1.7976931348623157e308;
-                        if (sqrt(sn24[k]) <= 1e-8 * (x_norm + 1e-8)) { term = 0; finished = 1; break; }
-                        if (fabs(x_cost - cand_cost) <= 1e-6 * x_cost) { term = 0; finished = 1; break; }
-                        const double rel = (cand_cost >= 1.7976931348623157e308) ? -1.7976931348623157e308 : (x_cost - cand_cost) / mcc4[k];
-                        if (rel > 1e-3) { accepted = k; rel_acc = rel; break; }
-                        radius *= 0.5;
+                    int accepted = -1, finished = 0, live = 1;
+                    double rel_acc = 0.0, dsn_acc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {  // replay: exactly the decisions of Kc sequential iterations
+                        if (live && k < Kc) {
+                            iteration++;
+                            last_successful = 0;
+                            invalid_steps = 0;
+                            const double ck = sh.blk[k], sk = sh.blk[4 + k];
+                            const double cand_cost = isfinite(ck) ? ck : 1.7976931348623157e308;
+                            const double rel = (cand_cost >= 1.7976931348623157e308) ? -1.7976931348623157e308 : (x_cost - cand_cost) / mcc4[k];
+                            if (sqrt(sk) <= 1e-8 * (x_norm + 1e-8)) { term = 0; finished = 1; live = 0; }
+                            else if (fabs(x_cost - cand_cost) <= 1e-6 * x_cost) { term = 0; finished = 1; live = 0; }
+                            else if (rel > 1e-3) { accepted = k; rel_acc = rel; dsn_acc = dsn4[k]; live = 0; }
+                            else radius *= 0.5;
+                        }
                     }
                     if (finished) break;
                     if (accepted >= 0) {
                         accept_speculative(wl, RDVIO_LDS(lds_chol_buf), accepted);
-                        dogleg_step_norm = dsn4[accepted];
+                        dogleg_step_norm = dsn_acc;
                         accepted_step(rel_acc);
                     }
                     continue;
