@@ -277,7 +277,7 @@ __device__ __attribute__((noinline)) void helper_loop(LdsWs &w, Shared &sh) {
 // squared ambient step norm -- instead of being written to global memory, fenced and read back (a rejected trust-region
 // iteration is a chain of such 1-5 us phases); *sn2_out receives the step norm squared.
 template <bool LIN, bool CAND = false>
-__device__ __attribute__((noinline)) double evaluate(LdsWs &w, Shared &sh, int &phase, const double *states, const double *invd, unsigned long long &prof_last,
+__device__ __attribute__((noinline)) double evaluate(LdsWs &w, Shared &sh, int phase, const double *states, const double *invd, unsigned long long &prof_last,
                                                      double *sn2_out = nullptr, double ca = 0.0, double cb = 0.0) {
     const int t = threadIdx.x;
     double sn2 = 0.0;
@@ -735,7 +735,7 @@ DM void model_products(const WS &w, Shared &sh, int &phase, const double *xp, co
 // (Gauss-Newton), both in unscaled-J coordinates:  q_xy = (J x)^T (J y),  l_x = (J x)^T r.  Every dogleg step is
 // delta = ca u + cb v, so |J delta|^2 and (J delta).r follow from these five numbers for ANY trust-region radius:
 // a rejected step re-interpolates without touching H again.
-__device__ __attribute__((noinline)) void model_scalars(LdsWs &w, Shared &sh, int &phase, double (&out)[5]) {
+__device__ __attribute__((noinline)) void model_scalars(LdsWs &w, Shared &sh, int phase, double (&out)[5]) {
     const int t = threadIdx.x;
     const int N = w.N, NA = 6 * w.nfree;
     double *u = RDVIO_GEN(sh.xv), *v = RDVIO_GEN(sh.xv) + 256;
@@ -790,7 +790,7 @@ __device__ __attribute__((noinline)) void model_scalars(LdsWs &w, Shared &sh, in
     for (int i = 0; i < 5; ++i) out[i] = a5[i];
 }
 
-__device__ __attribute__((noinline)) double x_norm_of(LdsWs &w, Shared &sh, int &phase, const double *st, const double *dep) {
+__device__ __attribute__((noinline)) double x_norm_of(LdsWs &w, Shared &sh, int phase, const double *st, const double *dep) {
     const int t = threadIdx.x;
     double s = 0.0;
     for (int o = t; o < w.nfr * 16; o += T)
@@ -801,7 +801,7 @@ __device__ __attribute__((noinline)) double x_norm_of(LdsWs &w, Shared &sh, int 
 }
 
 // gradient_max_norm = || x - Plus(x, -g) ||_inf  (TrustRegionMinimizer::EvaluateGradientAndJacobian)
-__device__ __attribute__((noinline)) double grad_max_norm(LdsWs &w, Shared &sh, int &phase) {
+__device__ __attribute__((noinline)) double grad_max_norm(LdsWs &w, Shared &sh, int phase) {
     const int t = threadIdx.x;
     double m = 0.0;
     for (int i = t; i < w.nfr; i += T) {
@@ -916,7 +916,7 @@ PHASE_FN void publish_user_state(LdsWs &w) {
 }
 
 // dogleg diagonal and scaled gradient; returns |scaled gradient|^2
-PHASE_FN double dogleg_prepare(LdsWs &w, Shared &sh, int &phase) {
+PHASE_FN double dogleg_prepare(LdsWs &w, Shared &sh, int phase) {
     const int t = threadIdx.x, N = w.N, nl = w.nl;
     double gsq = 0.0;
     for (int i = t; i < N; i += T) {
@@ -1014,7 +1014,7 @@ PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap
 }
 
 // landmark part of the Gauss-Newton solve from the frame part in yp; returns > 0 when a component is not finite
-PHASE_FN double back_substitute(LdsWs &w, Shared &sh, int &phase, double mu) {
+PHASE_FN double back_substitute(LdsWs &w, Shared &sh, int phase, double mu) {
     const int t = threadIdx.x;
     const int N = w.N, nl = w.nl, nfree = w.nfree, NAs = 6 * nfree + 2;
     double bad = 0.0;
@@ -1045,7 +1045,7 @@ PHASE_FN double back_substitute(LdsWs &w, Shared &sh, int &phase, double mu) {
 }
 
 // Gauss-Newton step in dogleg coordinates and the three norms the step selection needs: |g|^2, |gn|^2, g . gn
-PHASE_FN void gauss_newton_norms(LdsWs &w, Shared &sh, int &phase, double (&a3)[3]) {
+PHASE_FN void gauss_newton_norms(LdsWs &w, Shared &sh, int phase, double (&a3)[3]) {
     const int t = threadIdx.x, N = w.N, nl = w.nl;
     a3[0] = a3[1] = a3[2] = 0.0;
     for (int i = t; i < N; i += T) {
@@ -1069,7 +1069,7 @@ PHASE_FN void gauss_newton_norms(LdsWs &w, Shared &sh, int &phase, double (&a3)[
 // operand: 3 N <= 512): every landmark's coupling row is read once instead of twice, the pose vectors are staged once,
 // and the nine scalars share one reduction.  out = {|g|^2, |gn|^2, g.gn, q_uu, q_uv, q_vv, l_u, l_v}; returns > 0 when a
 // component of the solve is not finite.  Per-thread accumulation order is that of the three separate routines.
-PHASE_FN double gauss_newton_step_and_model(LdsWs &w, Shared &sh, int &phase, double mu, double (&out)[8]) {
+PHASE_FN double gauss_newton_step_and_model(LdsWs &w, Shared &sh, int phase, double mu, double (&out)[8]) {
     const int t = threadIdx.x;
     const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
     double *y = RDVIO_GEN(sh.xv), *u = y + N, *v = y + 2 * N;
@@ -1161,7 +1161,7 @@ DM size_t candidates_lds_doubles(int nfr, int nl, int npre) { return 4 * ((size_
 
 // Trial-step coefficients arrive by value and the eight results leave through sh.blk[0..7] (cost, then squared step
 // norm, per candidate): arrays handed over by reference would live in scratch memory on both sides of the call.
-PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int &phase, int K, double ca0, double ca1, double ca2,
+PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int phase, int K, double ca0, double ca1, double ca2,
                                   double ca3, double cb0, double cb1, double cb2, double cb3, unsigned long long &prof_last) {
     const int t = threadIdx.x, nfr = w.nfr, nl = w.nl, npre = w.npre, D = w.D;
     lds_double *stK = lds, *camK = stK + 4 * nfr * 16, *xdK = camK + 4 * nfr * 12, *epK = xdK + 4 * nl;
@@ -1441,12 +1441,15 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     // bookkeeping of an accepted step (x already holds the candidate): new linearisation, radius and damping updates
     auto accepted_step = [&](double rel) {
         x_norm = x_norm_of(wl, sh, phase, w.x, w.xd);
+        phase ^= 1;  // (one reduction inside)
         STAMP(10);
         x_cost = evaluate<true>(wl, sh, phase, w.x, w.xd, prof_last);  // `user` still holds the previous point here
+        phase ^= 1;  // (one reduction inside)
         STAMP(1);
         build_normal_equations(wl, sh, prof_last);
         STAMP(2);
         grad_max = grad_max_norm(wl, sh, phase);
+        phase ^= 1;  // (one reduction inside)
         STAMP(11);
         last_successful = 1;
         n_success++;
@@ -1461,13 +1464,16 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                            4 * w.D <= 512 && 4 * w.npre <= 64;
 
     x_norm = x_norm_of(wl, sh, phase, w.x, w.xd);
+    phase ^= 1;  // (one reduction inside)
     x_cost = evaluate<true>(wl, sh, phase, w.x, w.xd, prof_last);
+    phase ^= 1;  // (one reduction inside)
     STAMP(1);
     const double initial_cost = x_cost;
     build_normal_equations(wl, sh, prof_last);
     STAMP(2);
     jacobi_scaling(wl);
     grad_max = grad_max_norm(wl, sh, phase);
+    phase ^= 1;  // (one reduction inside)
 
     if (N == 0 && w.n_lfree_hint == 0) term = 0;
     else
@@ -1496,6 +1502,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                 }
                 if (Kc >= 2) {
                     evaluate_candidates(wl, sh, RDVIO_LDS(lds_chol_buf), phase, Kc, ca4[0], ca4[1], ca4[2], ca4[3], cb4[0], cb4[1], cb4[2], cb4[3], prof_last);
+                    phase ^= 1;  // (one reduction inside)
                     STAMP(9);
                     int accepted = -1, finished = 0, live = 1;
                     double rel_acc = 0.0, dsn_acc = 0.0;
@@ -1531,6 +1538,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             if (!reuse) {
                 reuse = 1;
                 gsq_keep = dogleg_prepare(wl, sh, phase);
+                phase ^= 1;  // (one reduction inside)
                 STAMP(3);
                 // Gauss-Newton step: (H_s + mu D^2) y = g_s with the landmarks eliminated
                 solve_ok = 0;
@@ -1548,6 +1556,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     const bool fused = 3 * N <= 512;
                     double pm[8];
                     const double bad = !ok ? 0.0 : fused ? gauss_newton_step_and_model(wl, sh, phase, mu, pm) : back_substitute(wl, sh, phase, mu);
+                    if (ok) phase ^= 1;  // (the phase function above ran one reduction)
                     if (!ok || bad > 0.0) {
                         mu *= 10.0;
                         continue;
@@ -1561,10 +1570,12 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     } else {
                         double a3[3];
                         gauss_newton_norms(wl, sh, phase, a3);
+                        phase ^= 1;  // (one reduction inside)
                         gnorm = sqrt(a3[0]);
                         gn_norm = sqrt(a3[1]);
                         gdotgn = a3[2];
                         model_scalars(wl, sh, phase, msc);
+                        phase ^= 1;  // (one reduction inside)
                     }
                     solve_ok = 1;
                     break;
@@ -1588,6 +1599,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             STAMP(28);
             double sn2 = 0.0;
             double cand_cost = evaluate<false, true>(wl, sh, phase, w.xc, w.xdc, prof_last, &sn2, step_ca, step_cb);
+            phase ^= 1;  // (one reduction inside)
             if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
             STAMP(9);
             const double step_norm = sqrt(sn2);
@@ -1636,6 +1648,7 @@ __global__ __launch_bounds__(T) void marginalize_kernel(SolverWs w) {
     solver_setup(wl, sh, RDVIO_LDS(lds_buf), sizeof(lds_buf) / sizeof(double), prof_last);
     STAMP(0);
     (void)evaluate<true>(wl, sh, phase, w.x, w.xd, prof_last);
+    phase ^= 1;  // (one reduction inside)
     STAMP(1);
     build_normal_equations(wl, sh, prof_last);
     STAMP(2);
