@@ -122,12 +122,46 @@ DM M3 hat(const V3 &w) {
     H.m[6] = -w.y; H.m[7] = w.x;  H.m[8] = 0;
     return H;
 }
+// sin and cos for the rotation algebra.  The arguments here are rotation increments and residual angles -- almost always
+// far inside [-pi/4, pi/4], where the two kernel polynomials of fdlibm (k_sin.c / k_cos.c, < 1 ulp) need no argument
+// reduction.  The library routines carry a Payne-Hanek
+// reduction that is never taken here but is executed around (two calls, sin and cos, each with its own reduction and
+// range tests); they remain the path for larger arguments.  (Inlined: a call would turn the caller into a non-leaf
+// function that saves its callee-saved registers to scratch.)
+DM double sin_large(double x) { return sin(x); }
+DM double cos_large(double x) { return cos(x); }
+DM void sincos_rot(double x, double &sn, double &cs) {
+    if (fabs(x) <= 0.7853981633974483) {
+        const double z = x * x;
+        {
+            const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                         S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+            const double v = z * x;
+            const double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+            sn = x + v * (S1 + z * r);
+        }
+        {
+            const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                         C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+            const double w = z * z;
+            const double r = z * (C1 + z * (C2 + z * C3)) + (w * w) * (C4 + z * (C5 + z * C6));
+            const double hz = 0.5 * z, a = 1.0 - hz;
+            cs = a + (((1.0 - a) - hz) + z * r);
+        }
+    } else {
+        sn = sin_large(x);
+        cs = cos_large(x);
+    }
+}
+
 // lie_algebra.h:11-16
 DM Q4 expmap(const V3 &w) {
     double n = norm(w);
     if (n > 0) {
-        double s = sin(0.5 * n) / n;
-        return Q4{w.x * s, w.y * s, w.z * s, cos(0.5 * n)};
+        double sh, ch;
+        sincos_rot(0.5 * n, sh, ch);
+        const double s = sh / n;
+        return Q4{w.x * s, w.y * s, w.z * s, ch};
     }
     return q_identity();
 }
@@ -151,7 +185,8 @@ DM M3 right_jacobian(const V3 &w) {
     const double sqrt24 = 4.898979485566356;
     const double sqrt120 = 10.954451150103322;
     double angle = norm(w);
-    double cangle = cos(angle), sangle = sin(angle);
+    double cangle, sangle;
+    sincos_rot(angle, sangle, cangle);
     double angle2 = angle * angle;
     double cos_term, sin_term;
     if (angle > root4_eps * qdrt720) {

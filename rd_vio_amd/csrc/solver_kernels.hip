@@ -1159,6 +1159,39 @@ PHASE_FN double gauss_newton_step_and_model(LdsWs &w, Shared &sh, int phase, dou
 // ---------------------------------------------------------------------------------------------
 DM size_t candidates_lds_doubles(int nfr, int nl, int npre) { return 4 * ((size_t)28 * nfr + nl + 15 * npre); }
 
+// one candidate state: Plus(x_i, delta_i) for the trial step (ca, cb) of frame i, its camera pose, and the squared ambient
+// step; written to the candidate's LDS slots.  Out of line: its ~100 live doubles (state, step, four scaling vectors,
+// quaternion algebra) would otherwise be spilled inside evaluate_candidates.
+PHASE_FN double form_candidate_state(LdsWs &w, Shared &sh, lds_double *st_out, lds_double *cam_out, int i, double cak, double cbk) {
+    const int c = sh.fcol[i];
+    double x16[16], o[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) x16[a] = w.x[16 * i + a];
+    double e2 = 0.0;
+    if (c < 0) {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) o[a] = x16[a];
+    } else {
+        double d15[15];
+#pragma unroll
+        for (int a = 0; a < 15; ++a) d15[a] = w.sig_p[15 * c + a] * ((cak * w.grad_p[15 * c + a] + cbk * w.gn_p[15 * c + a]) / w.diag_p[15 * c + a]);
+        state_plus(x16, d15, o);
+        if (sh.pfix[i])
+#pragma unroll
+            for (int a = 0; a < 7; ++a) o[a] = x16[a];  // constant pose block
+#pragma unroll
+        for (int a = 0; a < 16; ++a)
+            if (!(sh.pfix[i] && a < 7)) { const double e = x16[a] - o[a]; e2 += e * e; }
+    }
+#pragma unroll
+    for (int a = 0; a < 16; ++a) st_out[a] = o[a];
+    double cam[12];
+    camera_pose_of(o, w.extr, cam);
+#pragma unroll
+    for (int a = 0; a < 12; ++a) cam_out[a] = cam[a];
+    return e2;
+}
+
 // Trial-step coefficients arrive by value and the eight results leave through sh.blk[0..7] (cost, then squared step
 // norm, per candidate): arrays handed over by reference would live in scratch memory on both sides of the call.
 PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int phase, int K, double ca0, double ca1, double ca2,
@@ -1185,36 +1218,7 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int pha
     // step of frame i is then handed to the lane that owns frame i in the one-candidate evaluation, so that the step
     // norm is reduced from the same lanes, in the same order
     auto candidate_state = [&](int k, int i, double cak, double cbk, double &e2) {
-        const int c = sh.fcol[i];
-        double x16[16], o[16];
-#pragma unroll
-        for (int a = 0; a < 16; ++a) x16[a] = w.x[16 * i + a];
-        e2 = 0.0;
-        if (c < 0) {
-#pragma unroll
-            for (int a = 0; a < 16; ++a) o[a] = x16[a];
-        } else {
-            double d15[15], sg[15], gr[15], gn[15], dg[15];
-#pragma unroll
-            for (int a = 0; a < 15; ++a) {
-                sg[a] = w.sig_p[15 * c + a]; gr[a] = w.grad_p[15 * c + a]; gn[a] = w.gn_p[15 * c + a]; dg[a] = w.diag_p[15 * c + a];
-            }
-#pragma unroll
-            for (int a = 0; a < 15; ++a) d15[a] = sg[a] * ((cak * gr[a] + cbk * gn[a]) / dg[a]);
-            state_plus(x16, d15, o);
-            if (sh.pfix[i])
-#pragma unroll
-                for (int a = 0; a < 7; ++a) o[a] = x16[a];  // constant pose block
-#pragma unroll
-            for (int a = 0; a < 16; ++a)
-                if (!(sh.pfix[i] && a < 7)) { const double e = x16[a] - o[a]; e2 += e * e; }
-        }
-#pragma unroll
-        for (int a = 0; a < 16; ++a) stK[(k * nfr + i) * 16 + a] = o[a];
-        double cam[12];
-        camera_pose_of(o, w.extr, cam);
-#pragma unroll
-        for (int a = 0; a < 12; ++a) camK[(k * nfr + i) * 12 + a] = cam[a];
+        e2 = form_candidate_state(w, sh, stK + (k * nfr + i) * 16, camK + (k * nfr + i) * 12, i, cak, cbk);
     };
     if (nfr <= 16) {
         if (t >= T - 64) {
