@@ -927,7 +927,7 @@ PHASE_FN double dogleg_prepare(LdsWs &w, Shared &sh, int phase) {
         w.grad_p[i] = gv;
         gsq += gv * gv;
     }
-    for (int l = t; l < nl; l += T) {
+    for (int l = t; l < nl && w.n_lfree_hint > 0; l += T) {  // (no free landmark: diag_l / grad_l are never read)
         double d = 1.0, gv = 0.0;
         if (w.lfree[l]) {
             const double s = w.sig_l[l];
@@ -948,15 +948,17 @@ PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap
     const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
     const bool has_lm = nl > 0 && w.n_lfree_hint > 0;
     lds_double *Sl = lds;
-    for (int l = t; l < nl; l += T) {
-        double lw = 0.0;
-        if (w.lfree[l]) {
-            const double s2 = w.sig_l[l] * w.sig_l[l];
-            lw = s2 / (s2 * w.lm_m[l] + mu * w.diag_l[l] * w.diag_l[l]);
+    if (has_lm) {
+        for (int l = t; l < nl; l += T) {
+            double lw = 0.0;
+            if (w.lfree[l]) {
+                const double s2 = w.sig_l[l] * w.sig_l[l];
+                lw = s2 / (s2 * w.lm_m[l] + mu * w.diag_l[l] * w.diag_l[l]);
+            }
+            w.lm_w[l] = lw;
         }
-        w.lm_w[l] = lw;
+        __syncthreads();
     }
-    __syncthreads();
     // The operand is first staged into the (currently idle) LDS Cholesky buffer with one batch of coalesced loads: a
     // K-loop over global memory is a chain of ~nl/16 dependent L2 round trips per tile.
     if (NA > 0 && has_lm) {
