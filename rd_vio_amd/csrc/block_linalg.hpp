@@ -529,8 +529,13 @@ DM void cholesky_diag_block(LdsShared<T> &sh, lds_double *Lp, int k0, double tol
             a[j + 1] = __builtin_fma(-lj, readlane_d(lj, j + 1), a[j + 1]);
             piv = readlane_d(a[j + 1], j + 1);
         }
+        // the remaining multipliers L[c][j], c >= j + 2, are off the pivot chain: the column goes through LDS once (one
+        // write, then broadcast reads -- one instruction per multiplier instead of two v_readlane; the step is issue-bound)
+        if (j + 2 < 15) {
+            if (lane < 16) sh.blk[16 * j + lane] = lj;  // (16 slots per column; nobody else touches sh.blk during the factorisation)
 #pragma unroll
-        for (int c = j + 2; c < 15; ++c) a[c] = __builtin_fma(-lj, readlane_d(lj, c), a[c]);
+            for (int c = j + 2; c < 15; ++c) a[c] = __builtin_fma(-lj, sh.blk[16 * j + c], a[c]);
+        }
     }
     if (bad && lane == 0) sh.flag = 0;
     if (lane < 15) {
