@@ -280,35 +280,32 @@ __device__ __attribute__((noinline)) void marginalize_tail(LdsWs &w, LdsShared<T
     }
     __syncthreads();
     if (t < 64) {
+        // in registers: lane r holds row r of [M | I]; pivot rows and multipliers travel through v_readlane, so the 15
+        // dependent elimination steps never wait for LDS (the LDS version of this loop was ~2 us per column).  Rows are
+        // not swapped physically: the lane that supplied the pivot of column c ends up holding row c of the inverse.
+        double a[30];
+#pragma unroll
+        for (int c = 0; c < 30; ++c) a[c] = (lane < 15) ? sM[lane * 30 + c] : 0.0;
+        bool used = lane >= 15;
+        int mycol = -1;
+#pragma unroll
         for (int c = 0; c < 15; ++c) {
-            int piv = c;
-            double best = fabs(sM[c * 30 + c]);
-            for (int r = c + 1; r < 15; ++r) {
-                const double v = fabs(sM[r * 30 + c]);
-                if (v > best) { best = v; piv = r; }
+            const double v = used ? -1.0 : fabs(a[c]);
+            const double m = wave_max(v);
+            const unsigned long long tie = __ballot(v == m && !used);
+            const int piv = __builtin_amdgcn_readfirstlane(tie ? (int)__builtin_ctzll(tie) : 0);
+            const double inv_d = 1.0 / readlane_d(a[c], piv);  // one divide per column; the row is scaled by the reciprocal
+            const double f = a[c];
+#pragma unroll
+            for (int k = 0; k < 30; ++k) {
+                const double pr = readlane_d(a[k], piv) * inv_d;
+                a[k] = (lane == piv) ? pr : a[k] - f * pr;
             }
-            __builtin_amdgcn_wave_barrier();
-            if (piv != c && t < 30) {
-                const double tmp = sM[c * 30 + t];
-                sM[c * 30 + t] = sM[piv * 30 + t];
-                sM[piv * 30 + t] = tmp;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const double d = sM[c * 30 + c];
-            __builtin_amdgcn_wave_barrier();
-            if (t < 30) sM[c * 30 + t] /= d;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const double pc = (t < 30) ? sM[c * 30 + t] : 0.0;
-            for (int r = 0; r < 15; ++r) {
-                if (r == c) continue;
-                const double f = sM[r * 30 + c];
-                __builtin_amdgcn_wave_barrier();
-                if (t < 30) sM[r * 30 + t] -= f * pc;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
+            if (lane == piv) { used = true; mycol = c; }
+        }
+        if (mycol >= 0) {
+#pragma unroll
+            for (int k = 0; k < 15; ++k) sM[mycol * 30 + 15 + k] = a[15 + k];
         }
     }
     __syncthreads();
