@@ -257,14 +257,29 @@ __device__ __attribute__((noinline)) void marginalize_tail(LdsWs &w, LdsShared<T
     }
     __syncthreads();
     // Hs = H - C (full, natural frame order) into Sm; gs = g - Cg into yp
-    for (int o = t; o < N * N; o += T) {
-        const int i = o / N, j = o - i * N, fi = i / 15, a = i - 15 * fi, fj = j / 15, b = j - 15 * fj;
-        double v = w.H[o];
-        if (a < 6 && b < 6 && nl > 0) {
-            const int ri = 6 * fi + a, cj = 6 * fj + b;
-            v -= (ri >= cj) ? w.Cm[(size_t)ri * NAs + cj] : w.Cm[(size_t)cj * NAs + ri];
+    // (eight entries per trip with all their loads issued first: the stores to Sm may alias H / Cm as far as the
+    // compiler knows, so a one-entry loop is a chain of N^2 / T dependent round trips)
+    for (int o0 = t; o0 < N * N; o0 += 8 * T) {
+        double hv[8], cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int o = o0 + u * T;
+            hv[u] = 0.0;
+            cv[u] = 0.0;
+            if (o < N * N) {
+                const int i = o / N, j = o - i * N, fi = i / 15, a = i - 15 * fi, fj = j / 15, b = j - 15 * fj;
+                hv[u] = w.H[o];
+                if (a < 6 && b < 6 && nl > 0) {
+                    const int ri = 6 * fi + a, cj = 6 * fj + b;
+                    cv[u] = (ri >= cj) ? w.Cm[(size_t)ri * NAs + cj] : w.Cm[(size_t)cj * NAs + ri];
+                }
+            }
         }
-        w.Sm[o] = v;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int o = o0 + u * T;
+            if (o < N * N) w.Sm[o] = hv[u] - cv[u];
+        }
     }
     for (int i = t; i < N; i += T) {
         const int fi = i / 15, a = i - 15 * fi;
