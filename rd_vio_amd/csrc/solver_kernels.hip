@@ -1,3 +1,4 @@
+#include <cstdlib>
 // The non-linear solve behind rdvio::Solver::solve on gfx950 (FP64), as ONE persistent single-workgroup
 // kernel: the whole trust-region loop (Ceres TrustRegionMinimizer + DoglegStrategy + landmark-Schur normal
 // equations, as restated in DESIGN.md "Solver") runs on the device without host round trips.
@@ -1466,7 +1467,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
         prev_rejected = 0;
     };
     // a run of rejections is evaluated four trial radii at a time (evaluate_candidates) when the candidates fit the LDS
-    const bool speculate = w.n_wg == 1 && w.lds_chol && candidates_lds_doubles(w.nfr, w.nl, w.npre) <= LDS_CAP &&
+    const bool speculate = !w.no_speculation && w.n_wg == 1 && w.lds_chol && candidates_lds_doubles(w.nfr, w.nl, w.npre) <= LDS_CAP &&
                            4 * w.D <= 512 && 4 * w.npre <= 64;
 
     x_norm = x_norm_of(wl, sh, phase, w.x, w.xd);
@@ -1668,6 +1669,9 @@ void rdvio_launch_marginalize(hipStream_t stream, const SolverWs &w) {
     hipLaunchKernelGGL(marginalize_kernel, dim3(1), dim3(T), 0, stream, w);
 }
 
-void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w) {
+void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w0) {
+    SolverWs w = w0;
+    const char *ns = getenv("RDVIO_NO_SPECULATION");
+    w.no_speculation = (ns && ns[0] == '1') ? 1 : 0;
     hipLaunchKernelGGL(ba_solve_kernel, dim3(w.n_wg > 1 ? w.n_wg : 1), dim3(T), 0, stream, w);
 }

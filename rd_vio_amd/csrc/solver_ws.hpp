@@ -60,6 +60,7 @@ struct SolverWs {
     // ---- marginalisation mode (rdvio_hip_marginalize): the same linearisation + normal equations without the robust
     // loss, then the victim frame's Schur complement and the new sqrt prior (marg_tail.hpp)
     int no_loss, marg_force_eigen;
+    int no_speculation, pad_;           // diagnostic switch (RDVIO_NO_SPECULATION): trial steps one by one, for the equivalence test
     double *m_Tm, *m_Lr, *m_er, *m_Wk, *m_V, *m_cs, *m_yv;
     int32_t *m_nz;
     double *S_out, *f_out, *lin_out, *Lambda_out, *eta_out, *m_info;

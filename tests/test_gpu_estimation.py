@@ -233,3 +233,21 @@ def test_ba_solve_large_problem_uses_helper_workgroups(ctx, oracle):
     assert np.abs(got_s - ref_s).max() < 1e-6 and np.abs(got_d - ref_d).max() < 1e-6
     again_s, again_d, _ = ctx.ba_solve(pb, 6)
     assert (again_s == got_s).all() and (again_d == got_d).all()     # fixed reduction order across workgroups: reproducible
+
+
+def test_speculative_trial_steps_replay_the_sequential_loop(ctx, oracle, monkeypatch):
+    """A run of rejected trial steps is evaluated four radii at a time and the decisions are replayed in order
+    (solver_kernels.hip, evaluate_candidates); that must give exactly -- bit for bit -- what the one-trial-per-iteration
+    loop gives.  RDVIO_NO_SPECULATION=1 switches the batching off for the comparison.  The window problem runs to the
+    iteration limit with 27 rejections, so the speculative path is exercised seven times."""
+    for nfr, nl, seed in ((9, 150, 648), (11, 300, 649)):
+        pb = synth.make_window_problem(nfr, nl, seed, preintegrate=_oracle_pre(oracle))
+        monkeypatch.setenv("RDVIO_NO_SPECULATION", "1")
+        s_seq, d_seq, sm_seq = ctx.ba_solve(pb, 30)
+        monkeypatch.setenv("RDVIO_NO_SPECULATION", "0")
+        s_spec, d_spec, sm_spec = ctx.ba_solve(pb, 30)
+        assert sm_seq.iterations == sm_spec.iterations and sm_seq.successful_steps == sm_spec.successful_steps
+        assert sm_seq.termination == sm_spec.termination
+        assert sm_seq.final_cost == sm_spec.final_cost
+        assert np.array_equal(s_seq, s_spec) and np.array_equal(d_seq, d_spec)
+        assert sm_seq.iterations - sm_seq.successful_steps >= 5   # there was a run of rejections to batch
