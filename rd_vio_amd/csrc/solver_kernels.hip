@@ -1369,20 +1369,38 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int pha
 }
 
 // x <- speculative candidate k (still in the LDS buffer evaluate_candidates filled)
-PHASE_FN void accept_speculative(LdsWs &w, lds_double *lds, int k) {
+PHASE_FN double accept_speculative(LdsWs &w, Shared &sh, int phase, lds_double *lds, int k) {
     const int t = threadIdx.x, nfr = w.nfr, nl = w.nl;
     const lds_double *stK = lds + (size_t)k * nfr * 16, *xdK = lds + 4 * nfr * 28 + (size_t)k * nl;
-    for (int o = t; o < nfr * 16; o += T) w.x[o] = stK[o];
-    for (int l = t; l < nl; l += T) w.xd[l] = xdK[l];
-    __syncthreads();
+    double s = 0.0;  // |x|^2 of the accepted point, accumulated exactly as x_norm_of accumulates it
+    for (int o = t; o < nfr * 16; o += T) {
+        const double v = stK[o];
+        w.x[o] = v;
+        if (sh.fcol[o / 16] >= 0 && !(sh.pfix[o / 16] && (o & 15) < 7)) s += v * v;
+    }
+    for (int l = t; l < nl; l += T) {
+        const double v = xdK[l];
+        w.xd[l] = v;
+        if (w.lfree[l]) s += v * v;
+    }
+    return sqrt(block_sum(sh, s, phase));  // (the reduction's barrier also publishes the copies)
 }
 
 // x <- candidate
-PHASE_FN void accept_candidate(LdsWs &w) {
+PHASE_FN double accept_candidate(LdsWs &w, Shared &sh, int phase) {
     const int t = threadIdx.x;
-    for (int o = t; o < w.nfr * 16; o += T) w.x[o] = w.xc[o];
-    for (int l = t; l < w.nl; l += T) w.xd[l] = w.xdc[l];
-    __syncthreads();
+    double s = 0.0;
+    for (int o = t; o < w.nfr * 16; o += T) {
+        const double v = w.xc[o];
+        w.x[o] = v;
+        if (sh.fcol[o / 16] >= 0 && !(sh.pfix[o / 16] && (o & 15) < 7)) s += v * v;
+    }
+    for (int l = t; l < w.nl; l += T) {
+        const double v = w.xdc[l];
+        w.xd[l] = v;
+        if (w.lfree[l]) s += v * v;
+    }
+    return sqrt(block_sum(sh, s, phase));
 }
 
 __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
@@ -1446,9 +1464,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     int prev_rejected = 0;
     double x_norm = 0.0, x_cost = 0.0, grad_max = 0.0;
     // bookkeeping of an accepted step (x already holds the candidate): new linearisation, radius and damping updates
-    auto accepted_step = [&](double rel) {
-        x_norm = x_norm_of(wl, sh, phase, w.x, w.xd);
-        phase ^= 1;  // (one reduction inside)
+    auto accepted_step = [&](double rel) {  // (x_norm was set by the accept function)
         STAMP(10);
         x_cost = evaluate<true>(wl, sh, phase, w.x, w.xd, prof_last);  // `user` still holds the previous point here
         phase ^= 1;  // (one reduction inside)
@@ -1530,7 +1546,8 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     }
                     if (finished) break;
                     if (accepted >= 0) {
-                        accept_speculative(wl, RDVIO_LDS(lds_chol_buf), accepted);
+                        x_norm = accept_speculative(wl, sh, phase, RDVIO_LDS(lds_chol_buf), accepted);
+                        phase ^= 1;  // (one reduction inside)
                         dogleg_step_norm = dsn_acc;
                         accepted_step(rel_acc);
                     }
@@ -1615,7 +1632,8 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             if (fabs(cost_change) <= 1e-6 * x_cost) { term = 0; break; }
             const double rel = (cand_cost >= 1.7976931348623157e308) ? -1.7976931348623157e308 : (x_cost - cand_cost) / model_cost_change;
             if (rel > 1e-3) {
-                accept_candidate(wl);
+                x_norm = accept_candidate(wl, sh, phase);
+                phase ^= 1;  // (one reduction inside)
                 accepted_step(rel);
             } else {
                 radius *= 0.5;
