@@ -190,11 +190,29 @@ __device__ __attribute__((noinline)) void preintegration_translation_blocks(cons
     blk3_set(Gj, 15, ES_V, ES_V, RiT, 1.0);
 }
 
+// translation block group + the bias columns (the preintegration's own Jacobians and identities): everything of the
+// Jacobian that does not depend on the residual
+__device__ __attribute__((noinline)) void preintegration_translation_bias_blocks(const double *si, const double *sj, const double *pre,
+                                                                                const double *extr, double *Gi, double *Gj) {
+    preintegration_translation_blocks(si, sj, extr, pre[PRE_T], Gi, Gj);
+    const M3 I3 = m3_identity();
+    blk3_set(Gi, 15, ES_P, ES_BG, m3_load(pre + PRE_JAC + 9), -1.0);
+    blk3_set(Gi, 15, ES_V, ES_BG, m3_load(pre + PRE_JAC + 27), -1.0);
+    blk3_set(Gi, 15, ES_BG, ES_BG, I3, -1.0);
+    blk3_set(Gi, 15, ES_P, ES_BA, m3_load(pre + PRE_JAC + 18), -1.0);
+    blk3_set(Gi, 15, ES_V, ES_BA, m3_load(pre + PRE_JAC + 36), -1.0);
+    blk3_set(Gi, 15, ES_BA, ES_BA, I3, -1.0);
+    blk3_set(Gj, 15, ES_BG, ES_BG, I3, 1.0);
+    blk3_set(Gj, 15, ES_BA, ES_BA, I3, 1.0);
+}
+
 // CeresPreIntegrationErrorFactor::Evaluate, UNWHITENED part
 // (src/rdvio_estimation/include/rdvio/estimation/ceres/preintegration_factor.h:19-153):
 // e (15) and, if requested, the 15x15 blocks Gi, Gj (tangent columns; must be zero-initialised by the caller)
 // before the left multiplication by delta.sqrt_inv_cov (:155 and the per-block products).
-template <bool WITH_JAC>
+// ROT_ONLY: the translation / bias block groups are left to preintegration_translation_bias_blocks (the solver runs them
+// on otherwise idle lanes of another wavefront, in parallel with this function's residual and rotation rows).
+template <bool WITH_JAC, bool ROT_ONLY = false>
 __device__ __attribute__((noinline)) void preintegration_unwhitened(const double *si, const double *sj, const double *pre, const double *bias_lin,
                                   const double *extr, double *e, double *Gi, double *Gj) {
     const V3 g = v3(0, 0, -9.80665);
@@ -234,17 +252,7 @@ __device__ __attribute__((noinline)) void preintegration_unwhitened(const double
     // LDS-resident): a factor is evaluated by ONE lane, so the live set of the whole Jacobian -- ~100 doubles of
     // rotations, translations and trigonometric temporaries -- does not fit the register file in one piece.
     preintegration_rotation_blocks(si, sj, pre, extr, th, r_th, Gi, Gj);
-    preintegration_translation_blocks(si, sj, extr, dt, Gi, Gj);
-    // bias columns: the preintegration's own Jacobians and identities
-    const M3 I3 = m3_identity();
-    blk3_set(Gi, 15, ES_P, ES_BG, m3_load(pre + PRE_JAC + 9), -1.0);
-    blk3_set(Gi, 15, ES_V, ES_BG, m3_load(pre + PRE_JAC + 27), -1.0);
-    blk3_set(Gi, 15, ES_BG, ES_BG, I3, -1.0);
-    blk3_set(Gi, 15, ES_P, ES_BA, m3_load(pre + PRE_JAC + 18), -1.0);
-    blk3_set(Gi, 15, ES_V, ES_BA, m3_load(pre + PRE_JAC + 36), -1.0);
-    blk3_set(Gi, 15, ES_BA, ES_BA, I3, -1.0);
-    blk3_set(Gj, 15, ES_BG, ES_BG, I3, 1.0);
-    blk3_set(Gj, 15, ES_BA, ES_BA, I3, 1.0);
+    if (!ROT_ONLY) preintegration_translation_bias_blocks(si, sj, pre, extr, Gi, Gj);
 }
 
 // CeresMarginalizationFactor::Evaluate, per-frame part

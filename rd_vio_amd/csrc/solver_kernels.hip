@@ -322,6 +322,8 @@ __device__ __attribute__((noinline)) double evaluate(LdsWs &w, Shared &sh, int p
             for (int i = T - 1 - t; i < w.nfr; i += T) camera_pose_of(states + 16 * i, w.extr, RDVIO_GEN(sh.cam) + 12 * i);
     }
     for (int i = t; i < w.nfr * 6; i += T) sh.ub[i] = w.user[16 * (i / 6) + ST_BG + (i % 6)];
+    if (LIN)  // the preintegration Jacobian blocks are sparse: cleared here, ahead of the two wavefronts that fill them
+        for (int i = t; i < w.npre * 450; i += T) w.G[i] = 0.0;
     __syncthreads();
     STAMP(LIN ? 30 : 31);
     states = RDVIO_GEN(sh.st);
@@ -350,14 +352,21 @@ __device__ __attribute__((noinline)) double evaluate(LdsWs &w, Shared &sh, int p
             if (LIN)
                 for (int q = 0; q < 9; ++q) sh.Jri[9 * i + q] = Jri.m[q];
         }
+        // the residual-independent block groups of the preintegration Jacobians on lanes 16..63 of the same (last factor)
+        // wavefront -- its threads carry the fewest reprojection factors -- while the last wavefront evaluates the residuals
+        // and the rotation rows: the one-lane-per-factor chain there was the longest pole of the linearisation
+        if (LIN)
+            for (int k = t - (TF - 64) - 16; k >= 0 && k < w.npre; k += 48) {
+                double *G = w.G + 450 * k;
+                preintegration_translation_bias_blocks(states + 16 * w.pre_i[k], states + 16 * w.pre_j[k],
+                                                       w.preint + (size_t)RDVIO_PREINT_SIZE * k, extr, G, G + 225);
+            }
     } else {
         const int j = t - TF;  // last wave: the (long, serial) preintegration factors, one per lane
-        if (LIN)  // the Jacobian blocks are sparse: clear them with the whole wave (coalesced) before the per-lane evaluation
-            for (int i = j; i < w.npre * 450; i += 64) w.G[i] = 0.0;
         for (int k = j; k < w.npre; k += 64) {
             double *G = w.G + 450 * k;
-            preintegration_unwhitened<LIN>(states + 16 * w.pre_i[k], states + 16 * w.pre_j[k], w.preint + (size_t)RDVIO_PREINT_SIZE * k,
-                                           RDVIO_GEN(sh.ub) + 6 * w.pre_i[k], extr, w.e_p + 15 * k, G, G + 225);
+            preintegration_unwhitened<LIN, true>(states + 16 * w.pre_i[k], states + 16 * w.pre_j[k], w.preint + (size_t)RDVIO_PREINT_SIZE * k,
+                                                 RDVIO_GEN(sh.ub) + 6 * w.pre_i[k], extr, w.e_p + 15 * k, G, G + 225);
         }
     }
     STAMP(LIN ? 17 : 20);
