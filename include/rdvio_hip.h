@@ -35,6 +35,7 @@ extern "C" {
 #define RDVIO_ERR_INVALID 1   /* bad argument / shape mismatch (checked on the host before any launch) */
 #define RDVIO_ERR_HIP 2       /* a HIP runtime call failed; see rdvio_hip_last_error() */
 #define RDVIO_ERR_CAPACITY 3  /* problem larger than the context was created for */
+#define RDVIO_ERR_TIMEOUT 4   /* a device-side bounded wait expired (multi-workgroup solve); outputs hold the last accepted point */
 
 #define RDVIO_MAX_LEVELS 4    /* OpenCvImage::level_num() == 3 -> levels 0..3 (opencv_image.h:19) */
 #define RDVIO_LK_WIN 21       /* Size(21,21), opencv_image.cpp:96 */
@@ -163,6 +164,11 @@ typedef struct {
  * The J pointers may be NULL. */
 int rdvio_hip_reprojection_eval(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, double *r, double *Jt,
                                 double *Jr, double *Jd);
+
+/* CeresRotationPriorFactor::Evaluate for every rotation prior of the problem (ceres/rotation_factor.h:22-58;
+ * created by refine_subwindow for valid untriangulated tracks, sliding_window_tracker.cpp:389-404).
+ * r: n_rot x 2; J: n_rot x 2 x 3 (theta of the target frame; the reference's 2 x 4 block has a zero last column) or NULL. */
+int rdvio_hip_rotation_prior_eval(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, double *r, double *J);
 
 /* Solver::solve (solver.cpp:180-194): ceres::Solve with TRUST_REGION/DOGLEG, SPARSE_SCHUR (landmarks
  * eliminated), max_num_iterations = solver.iteration_limit.  The whole trust-region loop runs on the device.

@@ -18,14 +18,19 @@ EXPORTS = [
     "rdvio_hip_image_download", "rdvio_hip_track_keypoints", "rdvio_hip_track_keypoints_dev", "rdvio_hip_lk_flow",
     "rdvio_hip_detect_keypoints", "rdvio_hip_harris_response", "rdvio_hip_image_release", "rdvio_hip_preintegrate",
     "rdvio_hip_preintegrate_dev",
-    "rdvio_hip_reprojection_eval", "rdvio_hip_ba_solve", "rdvio_hip_ba_upload", "rdvio_hip_ba_solve_resident",
+    "rdvio_hip_reprojection_eval", "rdvio_hip_rotation_prior_eval", "rdvio_hip_ba_solve", "rdvio_hip_ba_upload", "rdvio_hip_ba_solve_resident",
     "rdvio_hip_ba_fetch", "rdvio_hip_marginalize", "rdvio_hip_marginalize_upload", "rdvio_hip_marginalize_resident",
     "rdvio_hip_marginalize_fetch",
 ]
 
 
 class RdvioError(RuntimeError):
-    pass
+    """code: the RDVIO_ERR_* value; summary: the solver summary when the failing call filled one (RDVIO_ERR_TIMEOUT)"""
+    code = None
+    summary = None
+
+
+ERR_TIMEOUT = 4
 
 
 class PyrLayout(ctypes.Structure):
@@ -118,6 +123,7 @@ def load_library():
     lib.rdvio_hip_preintegrate.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6 + [
         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.rdvio_hip_reprojection_eval.argtypes = [ctypes.c_void_p, ctypes.POINTER(BaProblem)] + [ctypes.c_void_p] * 4
+    lib.rdvio_hip_rotation_prior_eval.argtypes = [ctypes.c_void_p, ctypes.POINTER(BaProblem), ctypes.c_void_p, ctypes.c_void_p]
     lib.rdvio_hip_ba_solve.argtypes = [ctypes.c_void_p, ctypes.POINTER(BaProblem), ctypes.c_int, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.POINTER(BaSummary)]
     lib.rdvio_hip_ba_upload.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(BaProblem)]
@@ -186,9 +192,11 @@ class Context:
     def __exit__(self, *a):
         self.close()
 
-    def _check(self, rc):
+    def _check(self, rc, summary=None):
         if rc != 0:
-            raise RdvioError(f"rdvio_hip error {rc}: {self._lib.rdvio_hip_last_error(self._h).decode()}")
+            e = RdvioError(f"rdvio_hip error {rc}: {self._lib.rdvio_hip_last_error(self._h).decode()}")
+            e.code, e.summary = rc, summary
+            raise e
 
     def sync(self):
         self._check(self._lib.rdvio_hip_sync(self._h))
@@ -248,7 +256,7 @@ class Context:
         invd = np.zeros(c.n_landmarks)
         sm = BaSummary()
         self._check(self._lib.rdvio_hip_ba_solve(self._h, ctypes.byref(c), int(max_iterations), states.ctypes.data,
-                                                 invd.ctypes.data, ctypes.byref(sm)))
+                                                 invd.ctypes.data, ctypes.byref(sm)), sm)
         return states, invd, sm
 
     def ba_upload(self, pb, slot=0):
@@ -266,7 +274,7 @@ class Context:
         n, nl = self._ba_shape[int(slot)]
         states, invd, sm = np.zeros((n, 16)), np.zeros(nl), BaSummary()
         self._check(self._lib.rdvio_hip_ba_fetch(self._h, int(slot), states.ctypes.data, invd.ctypes.data,
-                                                 ctypes.byref(sm)))
+                                                 ctypes.byref(sm)), sm)
         return states, invd, sm
 
     def _marg_problem(self, states, extr, W, prior_frames, lin, S, f, preint01, tgt, ref, lm, tangent, z_ref, inv_depth):
@@ -319,6 +327,19 @@ class Context:
             self._h, ctypes.byref(c), r.ctypes.data, Jt.ctypes.data if jac else None,
             Jr.ctypes.data if jac else None, Jd.ctypes.data if jac else None))
         return r, Jt, Jr, Jd
+
+
+def _rotation_prior_eval(self, pb, jac=True):
+    """CeresRotationPriorFactor::Evaluate over the rotation priors of a BA problem dict -> (r (n,2), J (n,2,3) or None)"""
+    c, keep = self._ba_problem(pb)
+    n = c.n_rot
+    r = np.zeros((n, 2))
+    J = np.zeros((n, 2, 3)) if jac else None
+    self._check(self._lib.rdvio_hip_rotation_prior_eval(self._h, ctypes.byref(c), r.ctypes.data, J.ctypes.data if jac else None))
+    return r, J
+
+
+Context.rotation_prior_eval = _rotation_prior_eval
 
 
 class HipImage:

@@ -45,6 +45,27 @@ __global__ __launch_bounds__(256) void reprojection_eval_kernel(int nf, const in
     r_out[2 * (size_t)k + 1] = r[1];
 }
 
+// CeresRotationPriorFactor::Evaluate for a batch (unit-parity entry; inside a solve the same device routine runs in
+// ba_solve_kernel).  /root/reference/src/rdvio_estimation/include/rdvio/estimation/ceres/rotation_factor.h:22-58
+__global__ __launch_bounds__(256) void rotation_prior_eval_kernel(int n, const int32_t *__restrict__ tgt, const int32_t *__restrict__ ref,
+                                                                 const double *__restrict__ zref, const double *__restrict__ tangent,
+                                                                 const double *__restrict__ states, const double *__restrict__ extr,
+                                                                 const double *__restrict__ W, double *__restrict__ r_out,
+                                                                 double *__restrict__ J_out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double r[2], J[6];
+    if (J_out) {
+        rotation_prior_factor<true>(states + 16 * tgt[k], states + 16 * ref[k], zref + 3 * (size_t)k, tangent + 9 * (size_t)k, extr, W, r, J);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) J_out[6 * (size_t)k + i] = J[i];
+    } else {
+        rotation_prior_factor<false>(states + 16 * tgt[k], states + 16 * ref[k], zref + 3 * (size_t)k, tangent + 9 * (size_t)k, extr, W, r, J);
+    }
+    r_out[2 * (size_t)k] = r[0];
+    r_out[2 * (size_t)k + 1] = r[1];
+}
+
 // ---------------------------------------------------------------------------------------------
 // IMU preintegration, one wavefront per segment.
 //  phase 1 (data-parallel over samples): lane k computes its sample's increment
@@ -354,6 +375,15 @@ int rdvio_launch_reprojection(rdvio_hip_ctx *ctx, int nf, int with_jac) {
     hipLaunchKernelGGL(reprojection_eval_kernel, dim3((nf + 255) / 256), dim3(256), 0, ctx->stream, nf, tgt, ref, lm,
                        ctx->ba_tangent, ctx->ba_zref, ctx->ba_invd, ctx->ba_states, ctx->ba_extr, ctx->ba_extr + 14,
                        ctx->ba_r, with_jac ? ctx->ba_Jt : nullptr, ctx->ba_Jr, ctx->ba_Jd);
+    RDVIO_HIP_CHECK(ctx, hipGetLastError());
+    return RDVIO_OK;
+}
+
+int rdvio_launch_rotation_prior(rdvio_hip_ctx *ctx, int n, int with_jac) {
+    if (n <= 0) return RDVIO_OK;
+    const int32_t *tgt = ctx->ba_idx, *ref = ctx->ba_idx + ctx->max_factors;
+    hipLaunchKernelGGL(rotation_prior_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, tgt, ref, ctx->ba_zref,
+                       ctx->ba_tangent, ctx->ba_states, ctx->ba_extr, ctx->ba_extr + 14, ctx->ba_r, with_jac ? ctx->ba_Jt : nullptr);
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
     return RDVIO_OK;
 }

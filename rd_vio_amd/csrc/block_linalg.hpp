@@ -20,14 +20,14 @@ struct BlockShared {
     double blk[15 * 16];
     double vec[16];
     int flag;
-    int red_phase;
+    int lost;  // set when a helper workgroup did not answer in time (solver)
     int seq;  // command sequence number of the helper-workgroup protocol (solver)
     // small per-problem index tables (solver): frame -> free column block, column block -> prior frame, preintegration sources
     // per frame (up to RDVIO_SOLVER_MAX_FRAMES = 64, most of them constant anchors) / per free column block (<= 32)
     int fcol[64], pcol[32], band_src[32 * 6], g_src[32 * 2];
     int pfix[64], pfixc[32];  // pose-constant flag per frame / per free column block
     double Jri[32 * 9];  // Jr^-1(e_theta) of the prior frames at the current linearisation
-    double xv[512];      // staged vector operand (pose step / prior error)
+    double xv[512];      // staged vector operand (pose step / prior error); = RDVIO_SOLVER_XV, bounds checked in rdvio_ba_prepare
     double st[64 * 16];  // frame states being evaluated (x or the candidate)
     double ub[64 * 6];   // user-state biases (bias linearisation of the preintegration factors)
     double ext[18];      // extrinsics (14) + sqrt_inv_cov (4)

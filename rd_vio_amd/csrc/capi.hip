@@ -406,4 +406,31 @@ int rdvio_hip_reprojection_eval(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, 
     return RDVIO_OK;
 }
 
+int rdvio_hip_rotation_prior_eval(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, double *r, double *J) {
+    if (!ctx || !r) return RDVIO_ERR_INVALID;
+    if (!pb || pb->n_frames <= 0 || pb->n_rot < 0) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "bad BA problem");
+    if (pb->n_frames > ctx->max_window + 2) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d frames exceed window capacity", pb->n_frames);
+    if (pb->n_rot > ctx->max_factors) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d rotation priors exceed capacity %d", pb->n_rot, ctx->max_factors);
+    if (!pb->states || !pb->extr || !pb->sqrt_inv_cov) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null BA arrays");
+    const int n = pb->n_rot;
+    if (n == 0) return RDVIO_OK;
+    if (!pb->rot_tgt || !pb->rot_ref || !pb->rot_zref || !pb->rot_tangent) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null rotation-prior arrays");
+    for (int k = 0; k < n; ++k)
+        if (pb->rot_tgt[k] < 0 || pb->rot_tgt[k] >= pb->n_frames || pb->rot_ref[k] < 0 || pb->rot_ref[k] >= pb->n_frames)
+            return rdvio_fail(ctx, RDVIO_ERR_INVALID, "rotation prior %d indexes out of range", k);
+    hipStream_t st = ctx->stream;
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_states, pb->states, (size_t)pb->n_frames * 16 * sizeof(double), hipMemcpyHostToDevice, st));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_extr, pb->extr, 14 * sizeof(double), hipMemcpyHostToDevice, st));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_extr + 14, pb->sqrt_inv_cov, 4 * sizeof(double), hipMemcpyHostToDevice, st));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_idx, pb->rot_tgt, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_idx + ctx->max_factors, pb->rot_ref, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_zref, pb->rot_zref, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->ba_tangent, pb->rot_tangent, (size_t)n * 9 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (int rc = rdvio_launch_rotation_prior(ctx, n, J != nullptr)) return rc;
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(r, ctx->ba_r, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (J) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(J, ctx->ba_Jt, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    return RDVIO_OK;
+}
+
 }  // extern "C"

@@ -106,5 +106,6 @@ int rdvio_launch_lk_flow(rdvio_hip_ctx *ctx, int slot_prev, int slot_next, int n
 int rdvio_launch_harris(rdvio_hip_ctx *ctx, int slot);
 int rdvio_launch_harris_candidates(rdvio_hip_ctx *ctx, int slot, double quality);
 int rdvio_launch_reprojection(rdvio_hip_ctx *ctx, int nf, int with_jac);
+int rdvio_launch_rotation_prior(rdvio_hip_ctx *ctx, int n, int with_jac);
 int rdvio_launch_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *off, const double *imu, const double *par,
                               const double *noise, int cj, int cc, double *out);

@@ -46,6 +46,8 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     if (nf > ctx->max_factors || nl > ctx->max_factors || nrot > ctx->max_factors)
         return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d factors / %d landmarks exceed capacity %d", nf, nl, ctx->max_factors);
     if (npre > nfr + 8 || np > nfr) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "too many preintegration factors / prior frames");
+    // the prior error vector e (15 per prior frame) is staged in the kernel's LDS operand xv[RDVIO_SOLVER_XV]
+    if (15 * np > RDVIO_SOLVER_XV) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "at most %d frames in the marginalisation prior", RDVIO_SOLVER_XV / 15);
     if (!pb->states || !pb->frame_fixed || !pb->extr || !pb->sqrt_inv_cov) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null frame arrays");
     if (nl > 0 && (!pb->z_ref || !pb->inv_depth || !pb->lm_fixed)) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null landmark arrays");
     if (nf > 0 && (!pb->tgt || !pb->ref || !pb->lm || !pb->tangent)) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null factor arrays");
@@ -61,11 +63,11 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     // a track is anchored in ONE frame (Track::first_frame) and observed at most once per frame (track.h keypoint_refs)
     for (int k = 0; k < nf;) {
         int e = k;
-        uint32_t seen = 0;
+        uint64_t seen = 0;  // one bit per frame (nfr <= 64)
         while (e < nf && pb->lm[e] == pb->lm[k]) {
             if (pb->ref[e] != pb->ref[k]) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "landmark %d has two anchor frames", pb->lm[k]);
-            if (pb->tgt[e] == pb->ref[e] || (seen >> pb->tgt[e]) & 1u) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "landmark %d observed twice in one frame", pb->lm[k]);
-            seen |= 1u << pb->tgt[e];
+            if (pb->tgt[e] == pb->ref[e] || (seen >> pb->tgt[e]) & 1ull) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "landmark %d observed twice in one frame", pb->lm[k]);
+            seen |= 1ull << pb->tgt[e];
             ++e;
         }
         k = e;
@@ -331,6 +333,9 @@ int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double 
         summary->final_cost = sum[3];
         summary->termination = (int32_t)sum[4];
     }
+    // a helper workgroup that never answered (solver_kernels.hip, collect_partials): the outputs hold the last accepted
+    // point and termination FAILURE, and the caller is told
+    if (sum[5] != 0.0) return rdvio_fail(ctx, RDVIO_ERR_TIMEOUT, "a solver helper workgroup did not answer within the spin limit");
     return RDVIO_OK;
 }
 

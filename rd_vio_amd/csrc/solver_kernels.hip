@@ -132,8 +132,9 @@ DM double linearize_factor(const WS &w, Shared &sh, int k, const double *states,
 //   sync[1] completion counter                  (release-incremented by each helper, acquire-polled by the leader)
 // partial[g] is written with a plain store before the helper's release-increment and read with an atomic load (never
 // through the scalar cache).
-// Every wait is bounded (RDVIO_SPIN_LIMIT polls of ~0.2 us): a helper that never hears from the leader exits, a leader
-// that never hears from a helper reports failure -- the grid always drains.  The launch assumes the workgroups are
+// Every wait is bounded (RDVIO_SPIN_LIMIT polls of ~0.2 us): a helper that never hears from the leader exits; a leader
+// that never hears from a helper sets sh.lost, leaves the loop with termination FAILURE (2) and flags summary[5], which
+// rdvio_hip_ba_fetch turns into RDVIO_ERR_TIMEOUT -- the grid always drains and the caller always hears about it.  The launch assumes the workgroups are
 // co-resident (one per CU on an otherwise idle stream), which is what a <= 16-workgroup grid on 256 CUs gets.
 // ---------------------------------------------------------------------------------------------
 #define RDVIO_SPIN_LIMIT 1000000
@@ -161,6 +162,7 @@ DM double collect_partials(const WS &w, Shared &sh) {
         int spins = 0;
         while (sync_load(w.sync + 1) != (unsigned)G && ++spins < RDVIO_SPIN_LIMIT) __builtin_amdgcn_s_sleep(4);
         sh.flag = spins < RDVIO_SPIN_LIMIT ? 1 : 0;
+        if (spins >= RDVIO_SPIN_LIMIT) sh.lost = 1;  // the trust-region loop stops with FAILURE at its next check
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -745,10 +747,15 @@ DM void model_products(const WS &w, Shared &sh, int &phase, const double *xp, co
 // (Gauss-Newton), both in unscaled-J coordinates:  q_xy = (J x)^T (J y),  l_x = (J x)^T r.  Every dogleg step is
 // delta = ca u + cb v, so |J delta|^2 and (J delta).r follow from these five numbers for ANY trust-region radius:
 // a rejected step re-interpolates without touching H again.
-__device__ __attribute__((noinline)) void model_scalars(LdsWs &w, Shared &sh, int phase, double (&out)[5]) {
+// Only windows with 3 N > RDVIO_SOLVER_XV come here (the others take the fused gauss_newton_step_and_model): those are
+// exactly the windows with more than RDVIO_LDS_CHOL_MAX_FRAMES free frames, whose reduced system is factored in global
+// memory -- so u and v (2 N <= 960 doubles) live in the idle LDS Cholesky buffer, not in sh.xv (512 doubles).
+static_assert(3 * 15 * RDVIO_LDS_CHOL_MAX_FRAMES <= RDVIO_SOLVER_XV && 3 * 15 * (RDVIO_LDS_CHOL_MAX_FRAMES + 1) > RDVIO_SOLVER_XV,
+              "fused post-solve pass <=> LDS-resident Cholesky");
+__device__ __attribute__((noinline)) void model_scalars(LdsWs &w, Shared &sh, lds_double *lds, int phase, double (&out)[5]) {
     const int t = threadIdx.x;
     const int N = w.N, NA = 6 * w.nfree;
-    double *u = RDVIO_GEN(sh.xv), *v = RDVIO_GEN(sh.xv) + 256;
+    double *u = RDVIO_GEN(lds), *v = RDVIO_GEN(lds) + N;
     for (int i = t; i < N; i += T) {
         const double sd = w.sig_p[i] / w.diag_p[i];
         u[i] = sd * w.grad_p[i];
@@ -839,7 +846,7 @@ __device__ __attribute__((noinline)) double grad_max_norm(LdsWs &w, Shared &sh, 
 __device__ __attribute__((noinline)) void solver_setup(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap, unsigned long long &prof_last) {
     const int t = threadIdx.x;
     const int nl = w.nl, nfree = w.nfree, NAs = 6 * nfree + 2;
-    if (t == 0) sh.seq = 0;
+    if (t == 0) { sh.seq = 0; sh.lost = 0; }
     for (int i = t; i < w.nfr * 16; i += T) {
         const double v = w.x0[i];
         w.x[i] = v;
@@ -1428,6 +1435,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     __syncthreads();
     LdsWs &wl = *(LdsWs *)&w_lds;
     if (blockIdx.x > 0) {  // helper workgroup: factor evaluation on request
+        if (w.mute_helpers) return;  // test switch: the leader's bounded wait must turn this into FAILURE
         helper_loop(wl, sh);
         return;
     }
@@ -1493,7 +1501,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     };
     // a run of rejections is evaluated four trial radii at a time (evaluate_candidates) when the candidates fit the LDS
     const bool speculate = !w.no_speculation && w.n_wg == 1 && w.lds_chol && candidates_lds_doubles(w.nfr, w.nl, w.npre) <= LDS_CAP &&
-                           4 * w.D <= 512 && 4 * w.npre <= 64;
+                           4 * w.D <= RDVIO_SOLVER_XV && 4 * w.npre <= 64;
 
     x_norm = x_norm_of(wl, sh, phase, w.x, w.xd);
     phase ^= 1;  // (one reduction inside)
@@ -1510,6 +1518,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     if (N == 0 && w.n_lfree_hint == 0) term = 0;
     else
         for (;;) {
+            if (w.n_wg > 1 && sh.lost) { term = 2; break; }  // a helper workgroup went silent: FAILURE, x = last accepted point
             if (last_successful) publish_user_state(wl);
             if (iteration >= w.max_iter) { term = 1; break; }
             if (grad_max <= 1e-10) { term = 0; break; }
@@ -1586,7 +1595,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                         else cholesky_solve(sh, w.Sm, N, w.yp);
                     }
                     STAMP(6);
-                    const bool fused = 3 * N <= 512;
+                    const bool fused = 3 * N <= RDVIO_SOLVER_XV;
                     double pm[8];
                     const double bad = !ok ? 0.0 : fused ? gauss_newton_step_and_model(wl, sh, phase, mu, pm) : back_substitute(wl, sh, phase, mu);
                     if (ok) phase ^= 1;  // (the phase function above ran one reduction)
@@ -1607,7 +1616,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                         gnorm = sqrt(a3[0]);
                         gn_norm = sqrt(a3[1]);
                         gdotgn = a3[2];
-                        model_scalars(wl, sh, phase, msc);
+                        model_scalars(wl, sh, RDVIO_LDS(lds_chol_buf), phase, msc);
                         phase ^= 1;  // (one reduction inside)
                     }
                     solve_ok = 1;
@@ -1657,6 +1666,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
         w.summary[2] = initial_cost;
         w.summary[3] = x_cost;
         w.summary[4] = (double)term;
+        w.summary[5] = (w.n_wg > 1 && sh.lost) ? 1.0 : 0.0;
     }
 }
 
@@ -1700,5 +1710,7 @@ void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w0) {
     SolverWs w = w0;
     const char *ns = getenv("RDVIO_NO_SPECULATION");
     w.no_speculation = (ns && ns[0] == '1') ? 1 : 0;
+    const char *mh = getenv("RDVIO_TEST_MUTE_HELPERS");
+    w.mute_helpers = (mh && mh[0] == '1') ? 1 : 0;
     hipLaunchKernelGGL(ba_solve_kernel, dim3(w.n_wg > 1 ? w.n_wg : 1), dim3(T), 0, stream, w);
 }

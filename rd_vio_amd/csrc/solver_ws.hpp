@@ -8,6 +8,8 @@
 #define RDVIO_REC_STRIDE 26
 #define RDVIO_LDS_CHOL_MAX_FRAMES 11
 #define RDVIO_MAX_SOLVER_WGS 16
+// doubles of the LDS vector operand BlockShared::xv: bounds 15 * n_prior (prior error), N = 15 * free frames (<= 480)
+#define RDVIO_SOLVER_XV 512
 #define RDVIO_HELPER_MIN_FACTORS 4096
 
 struct SolverWs {
@@ -60,7 +62,8 @@ struct SolverWs {
     // ---- marginalisation mode (rdvio_hip_marginalize): the same linearisation + normal equations without the robust
     // loss, then the victim frame's Schur complement and the new sqrt prior (marg_tail.hpp)
     int no_loss, marg_force_eigen;
-    int no_speculation, pad_;           // diagnostic switch (RDVIO_NO_SPECULATION): trial steps one by one, for the equivalence test
+    int no_speculation;                  // diagnostic switch (RDVIO_NO_SPECULATION): trial steps one by one, for the equivalence test
+    int mute_helpers;                    // test switch (RDVIO_TEST_MUTE_HELPERS): helper workgroups exit at once
     double *m_Tm, *m_Lr, *m_er, *m_Wk, *m_V, *m_cs, *m_yv;
     int32_t *m_nz;
     double *S_out, *f_out, *lin_out, *Lambda_out, *eta_out, *m_info;

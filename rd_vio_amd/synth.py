@@ -313,6 +313,53 @@ def make_window_problem(n_frames=9, n_landmarks=150, seed=648, with_prior=True, 
     return pb
 
 
+def add_rotation_priors(pb, n_rot=40, tgt=None, seed=77, K=EUROC_K, pix_noise=0.5):
+    """Rotation-prior factors (CeresRotationPriorFactor, ceres/rotation_factor.h:11-67) as refine_subwindow adds them for
+    the valid but untriangulated tracks of the last subframe (sliding_window_tracker.cpp:389-404): per factor the target
+    frame, the frame of the track's first observation, that observation's bearing (rot_zref) and the tangent frame
+    [b1 b2 z] of the bearing observed in the target frame.  The 3-D points are far away (bearing-only information)."""
+    rng = np.random.default_rng(seed)
+    n = len(pb["states"])
+    tgt = n - 1 if tgt is None else tgt
+    ex = pb["extr"]
+    Rcs, pcs = q_to_mat(ex[0:4]), ex[4:7]
+    st = pb.get("states_true", pb["states"])
+
+    def cam(i):
+        R = q_to_mat(st[i, 0:4])
+        return R @ Rcs, st[i, 4:7] + R @ pcs
+    w_img, h_img = 2 * K[0, 2], 2 * K[1, 2]
+    rt, rr, rz, rT = [], [], [], []
+    tries = 0
+    while len(rt) < n_rot and tries < 100 * n_rot:
+        tries += 1
+        ref = int(rng.integers(0, n))
+        if ref == tgt:
+            continue
+        Rr, pr = cam(ref)
+        u = np.array([rng.uniform(40, w_img - 40), rng.uniform(40, h_img - 40)])
+        ray = np.array([(u[0] - K[0, 2]) / K[0, 0], (u[1] - K[1, 2]) / K[1, 1], 1.0])
+        X = pr + Rr @ (ray / np.linalg.norm(ray) * rng.uniform(15.0, 60.0))
+        Rt, pt = cam(tgt)
+        y = Rt.T @ (X - pt)
+        if y[2] < 0.5:
+            continue
+        px = np.array([K[0, 0] * y[0] / y[2] + K[0, 2], K[1, 1] * y[1] / y[2] + K[1, 2]])
+        if not (20 <= px[0] < w_img - 20 and 20 <= px[1] < h_img - 20):
+            continue
+        px = px + rng.normal(0, pix_noise, 2)
+        b = np.array([(px[0] - K[0, 2]) / K[0, 0], (px[1] - K[1, 2]) / K[1, 1], 1.0])
+        rt.append(tgt)
+        rr.append(ref)
+        rz.append(ray / np.linalg.norm(ray))
+        rT.append(tangent_frame(b / np.linalg.norm(b)).ravel())
+    pb["rot_tgt"] = np.array(rt, dtype=np.int32)
+    pb["rot_ref"] = np.array(rr, dtype=np.int32)
+    pb["rot_zref"] = np.array(rz).reshape(-1, 3)
+    pb["rot_tangent"] = np.array(rT).reshape(-1, 9)
+    return pb
+
+
 def make_marg_inputs(pb, with_full_prior=False, seed=9):
     """What Map::marginalize_frame(0) hands to marginalize() for a window problem: the current prior, the
     preintegration between frames 0 and 1 and the reprojection factors of the tracks the victim (frame 0)
@@ -436,15 +483,35 @@ def render_room(q_wb, p_wb, K, w, h, extr=EUROC_EXTR, seed=648, mover_t=None):
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
+def _render_job(job):
+    (q, p), K, w, h, seed, mover_t = job
+    return render_room(q, p, K, w, h, seed=seed, mover_t=mover_t)
+
+
+def _render_frames(jobs, workers=None):
+    """render_room for every job; frames are independent pure functions of their pose, so long streams are rendered by a
+    pool of forked workers (numpy only in the children; results do not depend on the number of workers)."""
+    import os
+
+    if workers is None:
+        workers = int(os.environ.get("RDVIO_SYNTH_WORKERS", min(8, os.cpu_count() or 1)))
+    if workers <= 1 or len(jobs) < 8:
+        return np.stack([_render_job(j) for j in jobs])
+    import multiprocessing as mp
+
+    with mp.get_context("fork").Pool(workers) as pool:
+        return np.stack(pool.map(_render_job, jobs, chunksize=1))
+
+
 def make_stream(n_frames, w=752, h=480, K=EUROC_K, t0=1.0, cam_rate=20.0, imu_rate=200.0, seed=648, imu_noise=True, pose_fn=None,
-                mover=False):
+                mover=False, workers=None):
     """A synthetic EuRoC-shaped stream on the SURVEY.md 8d trajectory: images (n_frames x h x w u8), frame times, IMU rows
     (t, gyro, acc) covering the frames with the constant biases TRUE_BG / TRUE_BA added, and the ground-truth body
     states at the frame times as rows (t, q, p, v, bg, ba)."""
     rng = np.random.default_rng(seed + 1)
     ts = t0 + np.arange(n_frames) / cam_rate
     pose_fn = pose_fn or traj_pose
-    frames = np.stack([render_room(*pose_fn(t), K, w, h, seed=seed, mover_t=(t if mover else None)) for t in ts])
+    frames = _render_frames([(pose_fn(t), K, w, h, seed, (t if mover else None)) for t in ts], workers)
     imu = make_imu_segment(t0 - 0.5 / imu_rate - 2.0 / imu_rate, ts[-1] + 3.0 / imu_rate, rate=imu_rate, rng=rng if imu_noise else None,
                            noise=imu_noise, bg=TRUE_BG, ba=TRUE_BA, pose_fn=pose_fn)
     gt = np.zeros((n_frames, 17))

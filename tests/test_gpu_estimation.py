@@ -160,6 +160,14 @@ def test_ba_solve_rejects_bad_problems(ctx, oracle):
         ctx.ba_solve(bad)
 
 
+def _scaled_err(A, B, d):
+    """max | D^-1/2 (A - B) D^-1/2 | with D = diag(d): every entry is measured against the information of ITS OWN rows, so
+    a wrong low-information block (velocity / bias rows, ~1..1e3) cannot hide behind the 1e10-1e30 pose entries."""
+    s = 1.0 / np.sqrt(d)
+    E = (A - B) * s[:, None] * s[None, :] if A.ndim == 2 else (A - B) * s
+    return float(np.abs(E).max()) if E.size else 0.0
+
+
 def _check_marg(oracle, args, got, lam_tol=1e-9):
     S2, f2, lin2, Lam, eta, fast = got
     So, fo, lino, Lamo, etao = oracle.marginalize(*args)
@@ -171,10 +179,29 @@ def _check_marg(oracle, args, got, lam_tol=1e-9):
     # Tolerance 1e-7 relative: the clamp at 1e-8 and sqrt/square round trip of entries up to ~1e10.
     assert np.abs(S2.T @ S2 - So.T @ So).max() <= 1e-7 * scale
     assert np.abs(S2.T @ f2 - So.T @ fo).max() <= 1e-6 * max(np.abs(etao).max(), 1.0)
+    # Diagonally scaled, per 15 x 15 block (ceres/marginalization_factor.h:440-474 rebuilds the prior from Lambda's
+    # eigen-decomposition with eigenvalues <= 1e-8 dropped; the kernel's pivoted / plain Cholesky factor must encode the same
+    # information block by block, not just in the largest entries).  D = diag(Lambda_oracle), rows with no information
+    # (d <= 1e-8, the reference's own clamp) are measured absolutely.  Bounds: the reduced information itself 1e-7 (two
+    # Schur complements through 1e15-pinned pivots); S^T S against the oracle's S^T S 1e-6 (both sides drop what lies
+    # under the clamp, which shows up at 1e-8 / d); S^T f against eta 1e-6 of |eta| scaled the same way.
+    d = np.maximum(np.diag(Lamo), 1e-8)
+    assert _scaled_err(Lam, Lamo, d) <= 1e-7, _scaled_err(Lam, Lamo, d)
+    SS, SSo = S2.T @ S2, So.T @ So
+    R = len(d)
+    worst = 0.0
+    for bi in range(0, R, 15):
+        for bj in range(0, bi + 15, 15):
+            di, dj = d[bi:bi + 15], d[bj:bj + 15]
+            E = (SS[bi:bi + 15, bj:bj + 15] - SSo[bi:bi + 15, bj:bj + 15]) / np.sqrt(di[:, None] * dj[None, :])
+            worst = max(worst, float(np.abs(E).max()))
+    assert worst <= 1e-6, worst
+    e_sc = np.abs(S2.T @ f2 - So.T @ fo) / np.sqrt(d)
+    assert e_sc.max() <= 1e-6 * max(1.0, (np.abs(etao) / np.sqrt(d)).max()), e_sc.max()
     return fast
 
 
-@pytest.mark.parametrize("nfr,nl,seed", [(9, 150, 648), (11, 300, 649), (5, 40, 3)])
+@pytest.mark.parametrize("nfr,nl,seed", [(9, 150, 648), (11, 300, 649), (5, 40, 3), (17, 1000, 656)])
 def test_marginalize_parity_initial_prior(ctx, oracle, nfr, nl, seed):
     # first marginalisation: the prior is the 1e15 pin of frame 0 (marginalization_factor.h:27-31); most rows of the
     # reduced information are structurally zero (no v/bias information on frames >= 2)
@@ -192,6 +219,15 @@ def test_marginalize_parity_dense_prior(ctx, oracle):
     fast = _check_marg(oracle, args, ctx.marginalize(*args))
     assert fast  # full-rank information: the Cholesky path must have produced the factor
     _check_marg(oracle, args, ctx.marginalize(*args, force_eigen=True))
+
+
+@pytest.mark.parametrize("nfr,nl,seed", [(9, 150, 657), (17, 1000, 658)])
+def test_marginalize_parity_steady_state_prior(ctx, oracle, nfr, nl, seed):
+    # every marginalisation of a session but the first: the prior the previous one left behind (positive definite on the
+    # retained rows) -- the plain blocked Cholesky road of the kernel; config 2 and config 5 sizes
+    pb = synth.make_window_problem(nfr, nl, seed, preintegrate=_oracle_pre(oracle))
+    args = synth.steady_state_marg_inputs(pb, oracle.marginalize)
+    _check_marg(oracle, args, ctx.marginalize(*args))
 
 
 def test_marginalize_chain_feeds_solver(ctx, oracle):
@@ -251,3 +287,139 @@ def test_speculative_trial_steps_replay_the_sequential_loop(ctx, oracle, monkeyp
         assert sm_seq.final_cost == sm_spec.final_cost
         assert np.array_equal(s_seq, s_spec) and np.array_equal(d_seq, d_spec)
         assert sm_seq.iterations - sm_seq.successful_steps >= 5   # there was a run of rejections to batch
+
+
+# ---------------------------------------------------------------------------------------------- row A10
+def test_rotation_prior_eval_parity(ctx, oracle):
+    """CeresRotationPriorFactor::Evaluate (ceres/rotation_factor.h:22-58) on the device against the oracle, 1e-11 relative
+    (same bound as the reprojection factor)."""
+    pb = synth.make_window_problem(9, 150, 660, preintegrate=_oracle_pre(oracle))
+    synth.add_rotation_priors(pb, 200)
+    r, J = ctx.rotation_prior_eval(pb)
+    r_ref, J_ref = np.zeros_like(r), np.zeros_like(J)
+    for k in range(len(r)):
+        r_ref[k], J_ref[k] = oracle.rotation_prior_eval(pb["states"][pb["rot_tgt"][k], :4], pb["states"][pb["rot_ref"][k], :4],
+                                                         pb["rot_zref"][k], pb["rot_tangent"][k].reshape(3, 3), pb["extr"], pb["sqrt_inv_cov"])
+    _close(r, r_ref, what="rotation prior r")
+    _close(J, J_ref, what="rotation prior J")
+    assert (ctx.rotation_prior_eval(pb, jac=False)[0] == r).all()
+    empty = dict(pb, rot_tgt=pb["rot_tgt"][:0], rot_ref=pb["rot_ref"][:0], rot_zref=pb["rot_zref"][:0], rot_tangent=pb["rot_tangent"][:0])
+    assert ctx.rotation_prior_eval(empty)[0].shape == (0, 2)
+    bad = dict(pb, rot_tgt=pb["rot_tgt"].copy())
+    bad["rot_tgt"][3] = 50
+    with pytest.raises(rd_vio_amd.RdvioError):
+        ctx.rotation_prior_eval(bad)
+
+
+@pytest.mark.parametrize("shape", ["window", "subwindow", "pose_fixed_target"])
+def test_ba_solve_with_rotation_priors(ctx, oracle, shape):
+    """Solves whose problem carries rot_tgt / rot_ref / rot_zref / rot_tangent (solver.cpp:134-141, CauchyLoss(1.0)):
+    same accept / reject path, costs and states as the oracle."""
+    if shape == "window":
+        pb = synth.make_window_problem(9, 150, 661, preintegrate=_oracle_pre(oracle))
+        synth.add_rotation_priors(pb, 60)
+    elif shape == "pose_fixed_target":
+        pb = synth.make_window_problem(6, 60, 663, preintegrate=_oracle_pre(oracle), with_prior=False)
+        pb["frame_fixed"][0] = 1
+        pb["frame_fixed"][5] = 2           # pose constant, motion free: the rotation priors' Jacobians are zeroed
+        synth.add_rotation_priors(pb, 30)
+    else:
+        # refine_subwindow's rotation-only branch (sliding_window_tracker.cpp:366-409): the keyframe is constant, the
+        # subframes are free and chained by preintegration factors, the last subframe carries reprojection priors
+        # (anchor and landmark constant) for triangulated tracks and rotation priors for the others
+        pb = synth.make_window_problem(5, 80, 662, preintegrate=_oracle_pre(oracle), with_prior=False, dt_frame=0.05)
+        pb["frame_fixed"][0] = 1
+        pb["lm_fixed"][:] = 1
+        keep = (pb["tgt"] == 4) & (pb["ref"] == 0)
+        for k in ("tgt", "ref", "lm", "tangent"):
+            pb[k] = pb[k][keep]
+        synth.add_rotation_priors(pb, 50, tgt=4)
+        pb["rot_ref"][:] = 0
+    assert len(pb["rot_tgt"]) >= 30
+    ref_s, ref_d, ref_sm = oracle.ba_solve(pb, 30)
+    got_s, got_d, got_sm = ctx.ba_solve(pb, 30)
+    assert (got_sm.iterations, got_sm.successful_steps, got_sm.termination) == (ref_sm.iterations, ref_sm.successful_steps, ref_sm.termination)
+    assert abs(got_sm.initial_cost - ref_sm.initial_cost) <= 1e-9 * abs(ref_sm.initial_cost)
+    assert abs(got_sm.final_cost - ref_sm.final_cost) <= 1e-6 * abs(ref_sm.final_cost)
+    assert np.abs(got_s - ref_s).max() < 1e-6 and np.abs(got_d - ref_d).max() < 1e-6
+    # the priors were really part of the objective
+    no_rot = dict(pb, rot_tgt=pb["rot_tgt"][:0], rot_ref=pb["rot_ref"][:0], rot_zref=pb["rot_zref"][:0], rot_tangent=pb["rot_tangent"][:0])
+    assert ctx.ba_solve(no_rot, 0)[2].initial_cost < got_sm.initial_cost
+
+
+# ---------------------------------------------------------------------------------------------- size limits
+@pytest.fixture(scope="module")
+def big_ctx():
+    c = rd_vio_amd.Context(max_width=752, max_height=480, max_features=1024, max_window=62, max_factors=20000)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("nfr,nl,seed", [(21, 250, 670), (25, 300, 671)])
+def test_ba_solve_many_free_frames(big_ctx, oracle, nfr, nl, seed):
+    """20 and 24 free frames (N = 300 / 360 pose columns): the global-memory Cholesky road and the separate
+    back-substitution / model-scalar passes whose vector operands live in the idle LDS Cholesky buffer (2 N doubles do not
+    fit the 512-double operand of the smaller windows)."""
+    pb = synth.make_window_problem(nfr, nl, seed, preintegrate=_oracle_pre(oracle))
+    pb["frame_fixed"][0] = 1
+    ref_s, ref_d, ref_sm = oracle.ba_solve(pb, 8)
+    got_s, got_d, got_sm = big_ctx.ba_solve(pb, 8)
+    assert (got_sm.iterations, got_sm.successful_steps, got_sm.termination) == (ref_sm.iterations, ref_sm.successful_steps, ref_sm.termination)
+    assert abs(got_sm.initial_cost - ref_sm.initial_cost) <= 1e-9 * abs(ref_sm.initial_cost)
+    assert abs(got_sm.final_cost - ref_sm.final_cost) <= 1e-6 * abs(ref_sm.final_cost)
+    assert np.abs(got_s - ref_s).max() < 1e-6 and np.abs(got_d - ref_d).max() < 1e-6
+    assert ref_sm.successful_steps >= 1
+
+
+def test_ba_solve_more_than_32_frames(big_ctx, oracle):
+    """Up to 64 frames per solve (32 free): a landmark observed in frames i and i + 32 is a valid problem (the duplicate
+    observation check keeps one bit per frame), a real duplicate across that distance is refused."""
+    pb = synth.make_window_problem(40, 200, 672, preintegrate=_oracle_pre(oracle), with_prior=False, dt_frame=0.05, obs_prob=0.5)
+    pb["frame_fixed"][:] = 1
+    pb["frame_fixed"][30:] = 0
+    span = [np.ptp(pb["tgt"][pb["lm"] == l]) for l in np.unique(pb["lm"])]
+    assert max(span) >= 32
+    keepp = pb["pre_i"] >= 30
+    pb["pre_i"], pb["pre_j"], pb["preint"] = pb["pre_i"][keepp], pb["pre_j"][keepp], pb["preint"][keepp]
+    ref_s, ref_d, ref_sm = oracle.ba_solve(pb, 6)
+    got_s, got_d, got_sm = big_ctx.ba_solve(pb, 6)
+    assert (got_sm.iterations, got_sm.successful_steps, got_sm.termination) == (ref_sm.iterations, ref_sm.successful_steps, ref_sm.termination)
+    assert np.abs(got_s - ref_s).max() < 1e-6 and np.abs(got_d - ref_d).max() < 1e-6
+    # a genuine duplicate: landmark l observed twice in a frame 32+ frames after another observation
+    l = int(np.unique(pb["lm"])[int(np.argmax(span))])
+    idx = np.flatnonzero(pb["lm"] == l)
+    dup = int(idx[-1])
+    bad = {k: (np.insert(pb[k], dup + 1, pb[k][dup], axis=0) if k in ("tgt", "ref", "lm", "tangent") else pb[k]) for k in pb}
+    with pytest.raises(rd_vio_amd.RdvioError):
+        big_ctx.ba_solve(bad, 6)
+
+
+def test_ba_solve_rejects_oversized_prior(big_ctx, oracle):
+    # 15 * n_prior must fit the kernel's 512-double LDS operand (RDVIO_SOLVER_XV): 35 prior frames are refused on the host
+    pb = synth.make_window_problem(40, 100, 673, preintegrate=_oracle_pre(oracle), with_prior=False, dt_frame=0.05)
+    pb["frame_fixed"][:] = 1
+    pb["frame_fixed"][35:] = 0
+    npf = 35
+    pb["prior_frames"] = np.arange(npf, dtype=np.int32)
+    pb["lin"] = pb["states"][:npf].copy()
+    pb["S"] = np.eye(15 * npf)
+    pb["f"] = np.zeros(15 * npf)
+    with pytest.raises(rd_vio_amd.RdvioError) as e:
+        big_ctx.ba_solve(pb, 2)
+    assert e.value.code == 3   # RDVIO_ERR_CAPACITY
+
+
+def test_helper_timeout_is_reported_as_failure(ctx, oracle, monkeypatch):
+    """A helper workgroup that never answers (here: all of them exit at once, RDVIO_TEST_MUTE_HELPERS) must not hang the
+    launch nor pass for convergence: the leader's bounded wait expires, the loop ends with termination FAILURE (2), the
+    outputs hold the last accepted point (the initial values here) and rdvio_hip_ba_fetch returns RDVIO_ERR_TIMEOUT."""
+    pb = synth.make_window_problem(17, 1000, 655, preintegrate=_oracle_pre(oracle))
+    assert len(pb["tgt"]) >= 4096
+    monkeypatch.setenv("RDVIO_TEST_MUTE_HELPERS", "1")
+    with pytest.raises(rd_vio_amd.RdvioError) as e:
+        ctx.ba_solve(pb, 6)
+    assert e.value.code == rd_vio_amd.binding.ERR_TIMEOUT
+    assert e.value.summary.termination == 2 and e.value.summary.successful_steps == 0
+    monkeypatch.setenv("RDVIO_TEST_MUTE_HELPERS", "0")
+    _, _, sm = ctx.ba_solve(pb, 6)     # the context is usable afterwards
+    assert sm.termination in (0, 1) and np.isfinite(sm.final_cost)

@@ -14,12 +14,25 @@ OVER = dict(sliding_window_size=8, feature_tracker_max_keypoint_detection=150, f
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["translation_full_res", "rotation_phase_half_res", "full_initializer_half_res", "dynamic_object_parsac"])
+@pytest.mark.parametrize("case", ["translation_full_res", "rotation_phase_half_res", "full_initializer_half_res", "dynamic_object_parsac",
+                                  "dynamic_object_parsac_300_w10", "synthetic_720p_1000_w16"])
 def test_hip_pipeline_reproduces_the_cpu_path(case):
     if case == "translation_full_res":
         W, H, K = 752, 480, synth.EUROC_K
         frames, ts, imu, gt = synth.make_stream(36, W, H, K)
         pose_fn = synth.traj_pose
+    elif case == "synthetic_720p_1000_w16":
+        # BASELINE config 5: 1280x720, 1000 features, window 16 -- long enough for the window to fill and marginalise
+        # (solves of up to 23 frames / > 4096 factors: the helper-workgroup launch shape runs inside the pipeline)
+        W, H = 1280, 720
+        K = np.array([[900.0, 0.0, 640.0], [0.0, 900.0, 360.0], [0.0, 0.0, 1.0]])
+        pose_fn = synth.traj_pose
+        frames, ts, imu, gt = synth.make_stream(64, W, H, K)
+    elif case == "dynamic_object_parsac_300_w10":
+        # BASELINE config 3 (MH_03 shape): 300 features, window 10, RD path on
+        W, H, K = 752, 480, synth.EUROC_K
+        pose_fn = synth.traj_pose
+        frames, ts, imu, gt = synth.make_stream(80, W, H, K, mover=True)
     elif case == "dynamic_object_parsac":
         # row A19: a mapped object starts to move at t = 2.6 s; parsac_flag enables judge_track_status / update_track_status
         # (IMU-PARSAC over EPnP hypotheses, PARSAC essential checks)
@@ -46,11 +59,16 @@ def test_hip_pipeline_reproduces_the_cpu_path(case):
     over = dict(OVER, initializer_keyframe_gap=3, initializer_min_parallax=5.0, initializer_min_triangulation=20) if case == "full_initializer_half_res" else OVER
     if case == "dynamic_object_parsac":
         over = dict(OVER, parsac_flag=1, parsac_keyframe_check_size=1)
+    if case == "dynamic_object_parsac_300_w10":
+        over = dict(OVER, parsac_flag=1, parsac_keyframe_check_size=1, sliding_window_size=10, feature_tracker_max_keypoint_detection=300)
+    if case == "synthetic_720p_1000_w16":
+        over = dict(OVER, sliding_window_size=16, feature_tracker_max_keypoint_detection=1000)
+    max_kp = 4096
     cfg = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **over)
-    cpu = pu.run_stream(lib, pu.oracle_pipeline_factory(lib, shim, cfg), frames, ts, imu, gt)
-    ctx = rd_vio_amd.Context(max_width=W, max_height=H, max_features=1024, max_window=16, max_factors=20000)
+    cpu = pu.run_stream(lib, pu.oracle_pipeline_factory(lib, shim, cfg), frames, ts, imu, gt, max_kp=max_kp)
+    ctx = rd_vio_amd.Context(max_width=W, max_height=H, max_features=4096, max_window=over["sliding_window_size"] + 8, max_factors=20000)
     try:
-        gpu = pu.run_stream(lib, pu.hip_pipeline_factory(lib, ctx, cfg), frames, ts, imu, gt)
+        gpu = pu.run_stream(lib, pu.hip_pipeline_factory(lib, ctx, cfg), frames, ts, imu, gt, max_kp=max_kp)
     finally:
         ctx.close()
     assert (gpu["counters"][:11] == cpu["counters"][:11]).all(), (gpu["counters"], cpu["counters"])   # [11:] are timers
@@ -78,10 +96,16 @@ def test_hip_pipeline_reproduces_the_cpu_path(case):
     p_gt = np.array([pose_fn(t)[1] for t in sc[ok, 0]])
     if case == "rotation_phase_half_res":
         assert cpu["counters"][25] >= 10                        # the rotation-only branch was really exercised
-    if case == "dynamic_object_parsac":
+        # row A10: rotation-prior factors (refine_subwindow, sliding_window_tracker.cpp:389-404) were emitted and went through
+        # the HIP solver -- the same number on both paths
+        assert gpu["counters"][26] > 0 and gpu["counters"][26] == cpu["counters"][26], (gpu["counters"][26], cpu["counters"][26])
+    if case == "synthetic_720p_1000_w16":
+        assert cpu["counters"][1] >= 10 and cpu["counters"][3] >= 3      # window solves and marginalisations at config-5 size
+        assert cpu["counters"][8] >= 17 and cpu["counters"][9] >= 4096   # a solve large enough for the helper workgroups
+    if case.startswith("dynamic_object_parsac"):
         assert cpu["counters"][27] >= 30 and cpu["counters"][28] >= 20   # judgements ran, tracks were switched to non-static
         off = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **dict(over, parsac_flag=0))
-        ref = pu.run_stream(lib, pu.oracle_pipeline_factory(lib, shim, off), frames, ts, imu, gt)
+        ref = pu.run_stream(lib, pu.oracle_pipeline_factory(lib, shim, off), frames, ts, imu, gt, max_kp=max_kp)
         so = ref["states"]
         oo = ~np.isnan(so[:, 0])
         e_on = np.linalg.norm(sc[ok, 5:8] - p_gt, axis=1).mean()

@@ -294,3 +294,51 @@ def test_sym_eig_via_marginalize_threshold(oracle):
     ev2 = np.linalg.eigvalsh(S2.T @ S2)
     assert np.isfinite(S2).all() and np.isfinite(f2).all()
     assert np.allclose(np.where(ev > 1e-8, ev, 0), ev2, rtol=1e-6, atol=1e-6 * ev.max())
+
+
+def test_rotation_prior_matches_numpy_restatement_and_fd(oracle):
+    """Row A10, CeresRotationPriorFactor::Evaluate (ceres/rotation_factor.h:22-58): the C oracle against an independent
+    numpy restatement of the same lines (incl. the translation added to a bearing, :34) and its Jacobian against central
+    differences of the right-multiplicative update q <- q exp(d) (quaternion_parameterization.h:11-17)."""
+    pb = synth.make_window_problem(6, 40, 31, preintegrate=lambda imu, t, bg, ba: oracle.preintegrate(imu, t, bg, ba, synth.EUROC_NOISE))
+    synth.add_rotation_priors(pb, 25)
+    assert len(pb["rot_tgt"]) == 25
+    ex, W = pb["extr"], pb["sqrt_inv_cov"]
+    Rcs, pcs = synth.q_to_mat(ex[0:4]), ex[4:7]
+
+    def numpy_r(q_t, q_r, z, T):
+        z_rc = Rcs @ z + pcs
+        z_tc = synth.q_to_mat(q_t).T @ (synth.q_to_mat(q_r) @ z_rc)
+        z_t = Rcs.T @ (z_tc - pcs)
+        u = T.T @ z_t
+        return W @ (u[:2] / u[2])
+
+    h = 1e-6
+    for k in range(len(pb["rot_tgt"])):
+        q_t, q_r = pb["states"][pb["rot_tgt"][k], :4], pb["states"][pb["rot_ref"][k], :4]
+        z, T = pb["rot_zref"][k], pb["rot_tangent"][k].reshape(3, 3)
+        r, J = oracle.rotation_prior_eval(q_t, q_r, z, T, ex, W)
+        assert np.allclose(r, numpy_r(q_t, q_r, z, T), rtol=1e-12, atol=1e-10)
+        for c in range(3):
+            d = np.zeros(3)
+            d[c] = h
+            qp = synth.q_mul(q_t, synth.q_exp(d))
+            qm = synth.q_mul(q_t, synth.q_exp(-d))
+            num = (numpy_r(qp / np.linalg.norm(qp), q_r, z, T) - numpy_r(qm / np.linalg.norm(qm), q_r, z, T)) / (2 * h)
+            assert np.allclose(J[:, c], num, rtol=1e-5, atol=1e-4 * max(1.0, np.abs(num).max()))
+
+
+def test_rotation_priors_enter_the_solve(oracle):
+    """The oracle's solver uses the rotation priors (solver.cpp:134-141: CauchyLoss(1.0)): the initial cost grows by
+    exactly the sum of 0.5 log(1 + |r|^2) over them, and they pull the free target frame's orientation."""
+    pre = lambda imu, t, bg, ba: oracle.preintegrate(imu, t, bg, ba, synth.EUROC_NOISE)  # noqa: E731
+    pb = synth.make_window_problem(6, 40, 32, preintegrate=pre)
+    base = oracle.ba_solve(pb, 0)[2].initial_cost
+    synth.add_rotation_priors(pb, 30)
+    sm = oracle.ba_solve(pb, 0)[2]
+    extra = 0.0
+    for k in range(30):
+        r, _ = oracle.rotation_prior_eval(pb["states"][pb["rot_tgt"][k], :4], pb["states"][pb["rot_ref"][k], :4], pb["rot_zref"][k],
+                                          pb["rot_tangent"][k].reshape(3, 3), pb["extr"], pb["sqrt_inv_cov"])
+        extra += 0.5 * np.log1p(r @ r)
+    assert abs(sm.initial_cost - (base + extra)) <= 1e-9 * sm.initial_cost
