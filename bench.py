@@ -156,8 +156,11 @@ def build_workload(cfg, ctx, torch, dev, seed=648):
     return wl
 
 
-def cpu_baseline(cfg, wl, budget_s=12.0, max_frames=400):
-    """The CPU oracle (single thread) on the same per-frame workload; bounded sample."""
+CPU_STAGES = ["preprocess", "lk_track", "detect", "preintegrate", "ba_localize", "ba_window", "marginalize"]
+
+
+def cpu_baseline_loop(cfg, wl, budget_s, max_frames):
+    """The CPU oracle (single thread) on the same per-frame workload; bounded sample; per-stage wall time."""
     import oracle
     from rd_vio_amd import synth
 
@@ -166,27 +169,97 @@ def cpu_baseline(cfg, wl, budget_s=12.0, max_frames=400):
     kp = wl["kp_host"]
     pyr = oracle.preprocess(frames[0])
     n = 0
+    stage = np.zeros(len(CPU_STAGES))
     t0 = time.perf_counter()
     while True:
         img = frames[(n + 1) % len(frames)]
+        a = time.perf_counter()
         nxt = oracle.preprocess(img)
+        b = time.perf_counter()
         oracle.track_keypoints(pyr[0], (pyr[1], pyr[2]), (nxt[1], nxt[2]), kp)
+        c = time.perf_counter()
         lvl0 = np.ascontiguousarray(oracle.level_view(nxt[0], nxt[1], 0))
         oracle.detect_keypoints(lvl0, np.zeros((0, 2)), cfg["features"], 10.0)
+        d = time.perf_counter()
         for i, s in enumerate(wl["imu_segs"]):
             p = wl["imu_par"][i]
             oracle.preintegrate(s, p[0], p[1:4], p[4:7], synth.EUROC_NOISE, jac=i > 0, cov=i > 0)
+        e = time.perf_counter()
         oracle.ba_solve(wl["localize_pb"], cfg["iters"])
+        f = time.perf_counter()
         oracle.ba_solve(wl["window_pb"], cfg["iters"])
+        g = time.perf_counter()
         oracle.marginalize(*wl["marg_args"])
+        h = time.perf_counter()
+        stage += np.diff([a, b, c, d, e, f, g, h])
         pyr = nxt
         n += 1
         el = time.perf_counter() - t0
         if el >= budget_s or n >= max_frames:
             break
-    return dict(value=n / el, unit="frames/s", cores=1, kind="port",
-                sample=f"{n} frames of the same synthetic stream through the CPU oracle (oracle/*.c, gcc -O2, 1 thread), "
-                       f"{el:.1f} s")
+    return n, el, stage / n * 1e3
+
+
+def cpu_baseline_worker(args):
+    """child process of cpu_baseline(): loads the oracle build named by RDVIO_ORACLE_LIB (set by the parent), runs the
+    bounded loop on the pickled workload, prints one JSON line.  Never touches the GPU."""
+    import pickle
+
+    with open(args.cpu_baseline_worker, "rb") as fh:
+        cfg, wl = pickle.load(fh)
+    n, el, stage = cpu_baseline_loop(cfg, wl, args.cpu_budget, 400)
+    print(json.dumps({"frames": n, "seconds": el, "stage_ms": [float(x) for x in stage]}))
+
+
+def cpu_baseline(cfg, wl, budget_s=10.0):
+    """SURVEY.md 8(d) / BASELINE.md section 3: the CPU restatement of the same per-frame work on one pinned host core, in the
+    two builds the survey names -- `-O3 -march=native` (strong baseline; the >= 200x target is quoted against it) and the
+    reference's own flags `-Og -msse -msse2 -msse3 -ffast-math -mtune=native` (/root/reference/CMakeLists.txt:10,17-18) --
+    each compiled on THIS host and timed in a child process (one thread, pinned to one core), with per-stage milliseconds.
+    The parity build (-O2, no contraction, no fast-math) is timed too, for continuity with round 1."""
+    import pickle
+    import subprocess
+    import tempfile
+
+    import oracle
+
+    keep = ("frames_host", "kp_host", "imu_segs", "imu_par", "localize_pb", "window_pb", "marg_args")
+    with tempfile.NamedTemporaryFile(suffix=".pkl", delete=False) as fh:
+        pickle.dump((cfg, {k: wl[k] for k in keep}), fh)
+        path = fh.name
+    builds = {}
+    try:
+        for name in ("O3_native", "Og_fastmath", "O2_parity"):
+            env = dict(os.environ)
+            if name == "O2_parity":
+                env.pop("RDVIO_ORACLE_LIB", None)
+                flags = "-O2 -ffp-contract=off -fno-fast-math"
+            else:
+                env["RDVIO_ORACLE_LIB"] = oracle.build_variant(name)
+                flags = " ".join(oracle.VARIANTS[name])
+            cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", path, "--cpu-budget", str(budget_s)]
+            try:
+                core = sorted(os.sched_getaffinity(0))[-1]
+                cmd = ["taskset", "-c", str(core)] + cmd
+            except (AttributeError, OSError):
+                pass
+            out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=20 * budget_s + 120)
+            if out.returncode != 0:
+                builds[name] = {"error": (out.stderr or out.stdout)[-300:], "flags": flags}
+                continue
+            rep = json.loads(out.stdout.strip().splitlines()[-1])
+            builds[name] = {"value": round(rep["frames"] / rep["seconds"], 3), "unit": "frames/s", "flags": "gcc " + flags,
+                            "frames": rep["frames"], "seconds": round(rep["seconds"], 2),
+                            "stage_ms": {k: round(v, 4) for k, v in zip(CPU_STAGES, rep["stage_ms"])}}
+    finally:
+        os.unlink(path)
+    head = builds.get("O3_native", {})
+    if "value" not in head:
+        head = builds.get("O2_parity", {})
+    return dict(value=head.get("value"), unit="frames/s", cores=1, kind="port",
+                sample=f"{head.get('frames')} frames of the same synthetic per-frame work through the CPU oracle (oracle/*.c), gcc -O3 "
+                       f"-march=native, 1 thread pinned to one core, {head.get('seconds')} s; other builds under `builds`",
+                stage_ms=head.get("stage_ms"), builds=builds)
 
 
 def end_to_end(cfg, ctx, n_frames, with_cpu_path):
@@ -271,7 +344,7 @@ def end_to_end(cfg, ctx, n_frames, with_cpu_path):
     return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -279,7 +352,72 @@ def main():
     ap.add_argument("--config", default="euroc_v101", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--end-to-end-frames", type=int, default=100, help="frames of the pipeline run (0 = skip)")
-    args = ap.parse_args()
+    ap.add_argument("--serial", action="store_true", help="one stream, stages back to back (the round-1 step); default: frontend / estimator streams overlapped")
+    # internal modes
+    ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-budget", type=float, default=10.0, help=argparse.SUPPRESS)
+    ap.add_argument("--stub-step-ms", type=float, default=None,
+                    help="test mode: no GPU, a step is a sleep of this many ms (exercises the replica launcher and the timing protocol on CPU)")
+    return ap.parse_args(argv)
+
+
+def launch_replicas(args, argv):
+    """`bench.py --gpus N` outside torchrun: N independent replicas, one child process and one GPU each (SURVEY.md 8e:
+    replicas only, no data-path collective).  This parent never imports torch and never touches HIP; each child sees
+    exactly one device (HIP_VISIBLE_DEVICES=i), rendezvous is gloo on 127.0.0.1, rank 0's JSON line (the aggregate over
+    all replicas, with the per-replica rates) is relayed to stdout."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   RDVIO_BENCH_DEVICE="0")
+        if args.stub_step_ms is None:
+            env["HIP_VISIBLE_DEVICES"] = str(r)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(rcs):
+        sys.stderr.write(f"bench.py: replica exit codes {rcs}\n")
+        sys.stdout.write(out0 or "")
+        raise SystemExit(1)
+    line = [l for l in (out0 or "").splitlines() if l.startswith("{")][-1]
+    print(line)
+
+
+def run_stub(args):
+    """test mode (no GPU): the launcher, the gloo rendezvous, the barrier-bracketed timed region and the aggregate"""
+    from rd_vio_amd import replica
+
+    rank, local_rank, world, dist = replica.init_distributed("gloo")
+    for _ in range(args.warmup):
+        time.sleep(args.stub_step_ms * 1e-3)
+    elapsed, per_rank = replica.timed_region(lambda k: time.sleep(args.stub_step_ms * 1e-3 * (1 + rank)), args.steps, sync=lambda: None,
+                                             dist=dist, first_index=args.warmup, per_rank=True)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": round(world * args.steps / elapsed, 3), "unit": "steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+                          "per_replica_steps_per_s": [round(args.steps / e, 3) for e in per_rank]}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker(args)
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # torchrun (the driver's N > 1 launch) or launch_replicas
+    if args.gpus > 1 and not under_launcher:
+        return launch_replicas(args, argv)
+    if args.stub_step_ms is not None:
+        return run_stub(args)
     cfg = CONFIGS[args.config]
 
     import torch
@@ -288,11 +426,13 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # torchrun: one process per GPU, device = LOCAL_RANK; launch_replicas: each child sees one device (index 0)
+    local_rank = int(os.environ.get("RDVIO_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # one process per GPU; "nccl" is RCCL on ROCm and is used for the barrier / max-over-ranks only
-    rank, local_rank, world, dist = replica.init_distributed("nccl", device_id=dev)
+    # one process per GPU, replicas only: the only distributed traffic is the barrier and the max-over-ranks of a timer,
+    # which gloo carries on the host -- no RCCL communicator is created for a path that has no collective
+    rank, _lr, world, dist = replica.init_distributed("gloo")
 
     from rd_vio_amd import build as rbuild
     import rd_vio_amd
@@ -348,8 +488,8 @@ def main():
     for k in range(args.warmup):
         step(k)
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(NS + 1)] for _ in range(args.steps)]
-    elapsed = replica.timed_region(lambda k: step(k, evs[k - args.warmup]), args.steps, sync=torch.cuda.synchronize,
-                                   dist=dist, device=dev, first_index=args.warmup)
+    elapsed, per_rank = replica.timed_region(lambda k: step(k, evs[k - args.warmup]), args.steps, sync=torch.cuda.synchronize,
+                                             dist=dist, first_index=args.warmup, per_rank=True)
     stage_ms = np.zeros(NS)
     for e in evs:
         for i in range(NS):

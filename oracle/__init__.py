@@ -13,7 +13,43 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# RDVIO_ORACLE_LIB: load another build of the same sources (bench.py's cpu_baseline timing variants, see build_variant);
+# the parity checker is always the default liboracle.so (-O2, no contraction, no fast-math)
+_LIB_PATH = os.environ.get("RDVIO_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
+
+# CPU-baseline timing builds (SURVEY.md 8d / BASELINE.md section 3).  Timing only -- never used as the parity checker:
+# -march=native ties the binary to the host it was compiled on, fast-math changes low bits.
+VARIANTS = {
+    # strong baseline: what the >= 200x target is quoted against
+    "O3_native": ["-O3", "-march=native"],
+    # the reference's own flags, /root/reference/CMakeLists.txt:10,17-18 (Debug: -Og; -msse -msse2 -msse3 -ffast-math -mtune=native)
+    "Og_fastmath": ["-Og", "-msse", "-msse2", "-msse3", "-ffast-math", "-mtune=native"],
+}
+
+
+def _host_tag():
+    """short hash of this host's CPU model + flags: a -march=native build must never run on another machine"""
+    import hashlib
+
+    try:
+        txt = open("/proc/cpuinfo").read()
+        key = "".join(l for l in txt.splitlines() if l.startswith(("model name", "flags")))[:20000]
+    except OSError:
+        key = "unknown"
+    return hashlib.sha1(key.encode()).hexdigest()[:10]
+
+
+def build_variant(name):
+    """gcc the oracle sources with VARIANTS[name] into oracle/_build/ (on THIS host); returns the .so path"""
+    flags = VARIANTS[name]
+    out_dir = os.path.join(_HERE, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, f"liboracle_{name}_{_host_tag()}.so")
+    srcs = sorted(os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c"))
+    deps = srcs + [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["gcc", "-std=c99", "-fPIC", "-shared", "-Wall", "-Wno-unused-parameter"] + flags + ["-o", out] + srcs + ["-lm"])
+    return out
 
 STATE_SIZE = 16
 PREINT_SIZE = 506
@@ -22,6 +58,8 @@ PREINT_T, PREINT_Q, PREINT_P, PREINT_V, PREINT_COV, PREINT_SIC, PREINT_JAC = 0, 
 
 def build(force=False):
     """Compile liboracle.so with gcc (oracle/Makefile)."""
+    if os.environ.get("RDVIO_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
         for f in os.listdir(_HERE)

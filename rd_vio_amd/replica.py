@@ -24,8 +24,9 @@ def init_distributed(backend=None, device_id=None):
     return rank, local_rank, world, dist
 
 
-def timed_region(step, steps, sync, dist=None, device=None, first_index=0):
-    """barrier + sync, EXACTLY `steps` calls of step(k), sync + barrier; returns the MAX elapsed seconds over ranks."""
+def timed_region(step, steps, sync, dist=None, device=None, first_index=0, per_rank=False):
+    """barrier + sync, EXACTLY `steps` calls of step(k), sync + barrier; returns the MAX elapsed seconds over ranks
+    (with per_rank: also every rank's own time between the barriers' release and its own last sync, rank order)."""
     import torch
 
     sync()
@@ -35,14 +36,21 @@ def timed_region(step, steps, sync, dist=None, device=None, first_index=0):
     for k in range(steps):
         step(first_index + k)
     sync()
+    own = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    own_all = [own]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed
+        if per_rank:
+            mine = torch.tensor([own], dtype=torch.float64, device=device if device is not None else "cpu")
+            every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(every, mine)
+            own_all = [float(x.item()) for x in every]
+    return (elapsed, own_all) if per_rank else elapsed
 
 
 def aggregate_rate(world, steps, elapsed):
