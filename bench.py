@@ -71,18 +71,42 @@ def ba_algorithmic_flops(pb, iterations, successful_steps):
     return (successful_steps + 1) * lin + iterations * cost
 
 
+PMC_TAG = "r02"
+
+
+def kernel_source_hash():
+    """sha256 over the HIP library's sources (rd_vio_amd/csrc/*, include/rdvio_hip.h): the PMC summary under profiles/ is only
+    valid for the kernels it was taken from."""
+    import hashlib
+
+    hsh = hashlib.sha256()
+    d = os.path.join(ROOT, "rd_vio_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp", ".h")):
+            hsh.update(f.encode())
+            hsh.update(open(os.path.join(d, f), "rb").read())
+    hsh.update(open(os.path.join(ROOT, "include", "rdvio_hip.h"), "rb").read())
+    return hsh.hexdigest()
+
+
 def pmc_traffic_bytes():
     """HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate
-    runs of this script; profiles/r01_e_pmc_fetch_write.csv).  FETCH_SIZE + WRITE_SIZE in KB, RAW: the gfx950 x2
-    FETCH_SIZE correction of MI355X_MICROARCH.md is calibrated for 16-B-per-lane streaming reads only, these kernels
-    read bytes / shorts / scattered doubles, so no correction is applied (the guide calls such widths uncalibrated)."""
-    path = os.path.join(ROOT, "profiles", "r01_e_pmc_fetch_write.csv")
+    runs of this script, scripts/refresh_profiles.sh -> profiles/<tag>_pmc_fetch_write.csv + .meta.json).  Counters cannot be
+    collected inside a timed run, so the figure is looked up -- but only while the kernel sources still hash to what the
+    summary was taken from; otherwise traffic is reported as null with the reason.  FETCH_SIZE + WRITE_SIZE in KB, RAW: the
+    gfx950 x2 FETCH_SIZE correction of MI355X_MICROARCH.md is calibrated for 16-B-per-lane streaming reads only; these
+    kernels read bytes / shorts / scattered doubles (widths the guide calls uncalibrated), so the figure is a LOWER BOUND."""
+    path = os.path.join(ROOT, "profiles", f"{PMC_TAG}_pmc_fetch_write.csv")
+    meta = os.path.join(ROOT, "profiles", f"{PMC_TAG}_pmc_fetch_write.meta.json")
+    if not (os.path.exists(path) and os.path.exists(meta)):
+        return {}, f"no PMC summary profiles/{PMC_TAG}_pmc_fetch_write.csv for this round yet"
+    if json.load(open(meta)).get("kernel_source_sha256") != kernel_source_hash():
+        return {}, f"stale: profiles/{PMC_TAG}_pmc_fetch_write.csv was taken from other kernel sources (scripts/refresh_profiles.sh)"
     out = {}
-    if os.path.exists(path):
-        for line in open(path).read().strip().splitlines()[1:]:
-            k, _n, f, w = line.split(",")
-            out[k] = int((float(f) + float(w)) * 1024)
-    return out
+    for line in open(path).read().strip().splitlines()[1:]:
+        k, _n, f, w = line.split(",")
+        out[k] = int((float(f) + float(w)) * 1024)
+    return out, f"bytes per launch, FETCH_SIZE + WRITE_SIZE raw = lower bound (profiles/{PMC_TAG}_pmc_fetch_write.csv, sources verified by hash)"
 
 
 def build_workload(cfg, ctx, torch, dev, seed=648):
@@ -438,12 +462,19 @@ def main(argv=None):
     import rd_vio_amd
 
     rbuild.build()
-    # an explicit (non-default) stream: the context enqueues on it and torch.cuda.Event records on it, so the
-    # HIP events below bracket exactly the kernels of each stage
+    # explicit (non-default) streams: the context enqueues on them and torch.cuda.Event records on them, so the HIP events
+    # below bracket exactly the kernels of each stage.  Lanes (include/rdvio_hip.h): the frontend (image side +
+    # preintegration), the solver and the marginalisation each get their own stream unless --serial.
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx = rd_vio_amd.Context(max_width=cfg["width"], max_height=cfg["height"], max_features=max(1024, 4 * cfg["features"]),
                              max_window=cfg["window"], max_factors=20000, device=local_rank, stream=stream.cuda_stream)
+    overlap = not args.serial
+    s_front, s_solve, s_marg = stream, stream, stream
+    if overlap:
+        s_solve, s_marg = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        ctx.set_lane_stream(rd_vio_amd.binding.LANE_SOLVER, s_solve.cuda_stream)
+        ctx.set_lane_stream(rd_vio_amd.binding.LANE_MARG, s_marg.cuda_stream)
     wl = build_workload(cfg, ctx, torch, dev)
     lib, h = ctx._lib, ctx._h
     w, hh, nfeat, iters = cfg["width"], cfg["height"], cfg["features"], cfg["iters"]
@@ -454,19 +485,39 @@ def main(argv=None):
     n_out = ctypes.c_int(0)
     stage_names = ["preprocess", "lk_track", "detect", "preintegrate", "ba_localize", "ba_window", "marginalize"]
     NS = len(stage_names)
+    LF, LS, LM = rd_vio_amd.binding.LANE_FRONTEND, rd_vio_amd.binding.LANE_SOLVER, rd_vio_amd.binding.LANE_MARG
+    # event pairs per stage: (start, end) indices into the per-step event list
+    EV_PAIRS = [(0, 1), (1, 2), (2, 3), (3, 4), (5, 6), (7, 8), (9, 10)]
+    N_EV = 11
 
-    def step(k, ev=None):
+    def estimator(ev):
+        """frame k's estimation on the solver / marginalisation lanes: localize_newframe, refine_window (reads the prior the
+        previous marginalisation wrote: device-side wait on the marginalisation lane), then slide_window ->
+        Map::marginalize_frame(0) (reads the window solve's states: device-side wait on the solver lane)."""
+        if ev: ev[5].record(s_solve)
+        ctx._check(lib.rdvio_hip_ba_solve_resident(h, 1, iters))
+        if ev: ev[6].record(s_solve)
+        ctx.lane_wait(LS, LM)
+        if ev: ev[7].record(s_solve)
+        ctx._check(lib.rdvio_hip_ba_solve_resident(h, 0, iters))
+        if ev: ev[8].record(s_solve)
+        ctx.lane_wait(LM, LS)
+        if ev: ev[9].record(s_marg)
+        ctx._check(lib.rdvio_hip_marginalize_resident(h, 0))
+        if ev: ev[10].record(s_marg)
+
+    def frontend(k, ev):
         cur, prv = k % 2, (k + 1) % 2
         img = wl["frames"][k % len(wl["frames"])]
-        if ev: ev[0].record()
+        if ev: ev[0].record(s_front)
         ctx._check(lib.rdvio_hip_image_preprocess_dev(h, cur, img.data_ptr(), w, hh, w, 6.0, 8, 8))
-        if ev: ev[1].record()
+        if ev: ev[1].record(s_front)
         ctx._check(lib.rdvio_hip_track_keypoints_dev(h, prv, cur, nfeat, wl["curr"].data_ptr(), wl["next"].data_ptr(),
                                                      0, wl["status"].data_ptr()))
-        if ev: ev[2].record()
+        if ev: ev[2].record(s_front)
         ctx._check(lib.rdvio_hip_detect_keypoints(h, cur, kp_buf.ctypes.data, 0, len(kp_buf), nfeat, 10.0,
                                                   ctypes.byref(n_out)))
-        if ev: ev[3].record()
+        if ev: ev[3].record(s_front)
         # frame segment without covariance, keyframe segments with (two launches, as the reference's two call sites)
         ctx._check(lib.rdvio_hip_preintegrate_dev(h, 1, wl["imu_off"].data_ptr(), wl["imu"].data_ptr(),
                                                   wl["imu_par_dev"].data_ptr(), wl["noise"].data_ptr(), 0, 0,
@@ -474,26 +525,34 @@ def main(argv=None):
         ctx._check(lib.rdvio_hip_preintegrate_dev(h, nseg - 1, wl["imu_off"].data_ptr() + 4, wl["imu"].data_ptr(),
                                                   wl["imu_par_dev"].data_ptr() + 56, wl["noise"].data_ptr(), 1, 1,
                                                   wl["pre_out"].data_ptr() + 8 * rd_vio_amd.PREINT_SIZE))
-        if ev: ev[4].record()
-        ctx._check(lib.rdvio_hip_ba_solve_resident(h, 1, iters))
-        if ev: ev[5].record()
-        ctx._check(lib.rdvio_hip_ba_solve_resident(h, 0, iters))
-        if ev: ev[6].record()
-        ctx._check(lib.rdvio_hip_marginalize_resident(h, 0))  # slide_window -> Map::marginalize_frame(0)
-        if ev: ev[7].record()
-        # the frame's results are consumed by host logic before the next frame
-        ctx.sync()
+        if ev: ev[4].record(s_front)
+
+    def step(k, ev=None):
+        """One camera frame.  Overlapped (default): while the solver lane works on frame k's localisation and window solve
+        and the marginalisation lane on its slide_window, the frontend lane runs frame k+1's image side and preintegration
+        -- the reference's tracker-thread / frontend-thread split (handler.cpp:35-50).  The host waits once per frame for what
+        host logic consumes before the next frame: the frontend's keypoints and the solver's states; the new prior stays on
+        the device for the next window solve.  --serial: every stage back to back on one stream (round 1's step)."""
+        if overlap:
+            estimator(ev)
+            frontend(k, ev)
+            ctx.lane_sync(LF)
+            ctx.lane_sync(LS)
+        else:
+            frontend(k, ev)
+            estimator(ev)
+            ctx.sync()
 
     # slot 1 holds frame 0 (build_workload); warm up
     for k in range(args.warmup):
         step(k)
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(NS + 1)] for _ in range(args.steps)]
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(N_EV)] for _ in range(args.steps)]
     elapsed, per_rank = replica.timed_region(lambda k: step(k, evs[k - args.warmup]), args.steps, sync=torch.cuda.synchronize,
                                              dist=dist, first_index=args.warmup, per_rank=True)
     stage_ms = np.zeros(NS)
     for e in evs:
-        for i in range(NS):
-            stage_ms[i] += e[i].elapsed_time(e[i + 1])
+        for i, (a, b) in enumerate(EV_PAIRS):
+            stage_ms[i] += e[a].elapsed_time(e[b])
     stage_ms /= args.steps
     _, _, sm_win = ctx.ba_fetch(0)
     _, _, sm_loc = ctx.ba_fetch(1)
@@ -515,10 +574,10 @@ def main(argv=None):
               + ba_algorithmic_flops(wl["localize_pb"], sm_loc.iterations, sm_loc.successful_steps))
         ba_ms = stage_ms[4] + stage_ms[5]
         tfl = fl / (ba_ms * 1e-3) / 1e12
-        pmc = pmc_traffic_bytes() if args.config == "euroc_v101" else {}
+        pmc, pmc_note = pmc_traffic_bytes() if args.config == "euroc_v101" else ({}, "PMC passes are taken on the default config only")
         roof = dict(kernel="ba_solve_kernel", bound="mfma", achieved=round(tfl, 5), peak=FP64_PEAK_TFLOPS,
                     unit="TFLOP/s", frac=round(tfl / FP64_PEAK_TFLOPS, 7), traffic=pmc.get("ba_solve_kernel"),
-                    traffic_unit="bytes per launch, FETCH_SIZE + WRITE_SIZE raw (profiles/r01_e_pmc_fetch_write.csv)",
+                    traffic_unit=pmc_note,
                     algorithmic_flops_per_launch=int(fl / 2), avg_launch_us=round(float(ba_ms) * 1e3 / 2, 2),
                     launches_per_frame=2, dominant_stage=stage_names[dom],
                     note="single-workgroup latency-bound trust-region loop; see DESIGN.md section 4 for the phase table")
@@ -538,10 +597,17 @@ def main(argv=None):
             "vs_baseline": None, "dtype": "u8/int64 (image, LK) + f64 (estimation)", "data": "synthetic",
             "config": {"workload": cfg["name"], "features": nfeat, "window": cfg["window"],
                        "solver_iteration_limit": iters, "replicas": world,
+                       "schedule": ("frontend lane (image side + preintegration of frame k+1) overlapped with the solver lane (localisation + "
+                                    "window solve of frame k) and the marginalisation lane; one host wait per frame on frontend + solver"
+                                    if overlap else "serial: all stages back to back on one stream, one host wait per frame"),
+                       "fixed_problem_note": "every frame is a keyframe whose window solve runs to the iteration limit (27 of 30 trial steps "
+                                             "rejected through the reference's live bias-linearisation, DESIGN.md section 2) -- a reading of "
+                                             "Ceres that no reference fixture pins",
                        "ba_window": {"factors": int(len(wl["window_pb"]["tgt"])), "iterations": int(sm_win.iterations),
                                      "successful_steps": int(sm_win.successful_steps)},
                        "ba_localize": {"factors": int(len(wl["localize_pb"]["tgt"])), "iterations": int(sm_loc.iterations)}},
             "stages_ms": stages,
+            "per_replica_fps": [round(args.steps / e, 2) for e in per_rank],
             "roofline": roof,
             "image_kernels_roofline": image_roof,
         }

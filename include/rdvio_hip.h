@@ -66,6 +66,23 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_width, int max
 void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx);
 const char *rdvio_hip_last_error(const rdvio_hip_ctx *ctx);
 int rdvio_hip_sync(rdvio_hip_ctx *ctx);
+/* Lanes.  The reference runs the feature tracker and the frontend (sliding-window tracker) on two worker threads
+ * (src/rdvio/src/handler.cpp:35-50); here each gets a HIP stream, and marginalisation -- whose result is first read by the
+ * NEXT refine_window (sliding_window_tracker.cpp:339-347, 226-300) -- a third.  Every entry point enqueues on the lane of
+ * its seam and touches only that lane's staging buffers:
+ *   RDVIO_LANE_FRONTEND  Image::preprocess / track_keypoints / detect_keypoints, PreIntegrator::integrate, unit entries
+ *   RDVIO_LANE_SOLVER    rdvio_hip_ba_*            (Solver::solve)
+ *   RDVIO_LANE_MARG      rdvio_hip_marginalize*    (MarginalizationFactor::marginalize)
+ * All lanes are the context's stream (everything serial, in call order) until a lane gets a stream of its own with
+ * rdvio_hip_ctx_set_lane_stream (stream == NULL: the context creates and owns one).  Host entry points synchronise only
+ * their own lane; rdvio_hip_lane_wait(lane, on_lane) makes work enqueued on `lane` from now on wait for everything enqueued
+ * on `on_lane` so far (a device-side dependency, no host wait); rdvio_hip_sync waits for all lanes. */
+#define RDVIO_LANE_FRONTEND 0
+#define RDVIO_LANE_SOLVER 1
+#define RDVIO_LANE_MARG 2
+int rdvio_hip_ctx_set_lane_stream(rdvio_hip_ctx *ctx, int lane, void *stream);
+int rdvio_hip_lane_wait(rdvio_hip_ctx *ctx, int lane, int on_lane);
+int rdvio_hip_lane_sync(rdvio_hip_ctx *ctx, int lane);
 int rdvio_hip_pyr_layout_init(int width, int height, int max_level, rdvio_pyr_layout *out);
 const char *rdvio_hip_version(void);
 

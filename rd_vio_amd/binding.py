@@ -14,7 +14,7 @@ MAX_LEVELS = 4
 # every symbol include/rdvio_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "rdvio_hip_version", "rdvio_hip_pyr_layout_init", "rdvio_hip_ctx_create", "rdvio_hip_ctx_destroy",
-    "rdvio_hip_last_error", "rdvio_hip_sync", "rdvio_hip_image_preprocess", "rdvio_hip_image_preprocess_dev",
+    "rdvio_hip_last_error", "rdvio_hip_sync", "rdvio_hip_ctx_set_lane_stream", "rdvio_hip_lane_wait", "rdvio_hip_lane_sync", "rdvio_hip_image_preprocess", "rdvio_hip_image_preprocess_dev",
     "rdvio_hip_image_download", "rdvio_hip_track_keypoints", "rdvio_hip_track_keypoints_dev", "rdvio_hip_lk_flow",
     "rdvio_hip_detect_keypoints", "rdvio_hip_harris_response", "rdvio_hip_image_release", "rdvio_hip_preintegrate",
     "rdvio_hip_preintegrate_dev",
@@ -31,6 +31,7 @@ class RdvioError(RuntimeError):
 
 
 ERR_TIMEOUT = 4
+LANE_FRONTEND, LANE_SOLVER, LANE_MARG = 0, 1, 2
 
 
 class PyrLayout(ctypes.Structure):
@@ -103,6 +104,9 @@ def load_library():
     lib.rdvio_hip_ctx_destroy.argtypes = [ctypes.c_void_p]
     lib.rdvio_hip_ctx_destroy.restype = None
     lib.rdvio_hip_sync.argtypes = [ctypes.c_void_p]
+    lib.rdvio_hip_ctx_set_lane_stream.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.rdvio_hip_lane_wait.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    lib.rdvio_hip_lane_sync.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.rdvio_hip_pyr_layout_init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(PyrLayout)]
     img_args = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                 ctypes.c_double, ctypes.c_int, ctypes.c_int]
@@ -200,6 +204,16 @@ class Context:
 
     def sync(self):
         self._check(self._lib.rdvio_hip_sync(self._h))
+
+    def set_lane_stream(self, lane, stream=None):
+        """give the solver (1) or marginalisation (2) lane a stream of its own (None: context-owned)"""
+        self._check(self._lib.rdvio_hip_ctx_set_lane_stream(self._h, int(lane), stream))
+
+    def lane_wait(self, lane, on_lane):
+        self._check(self._lib.rdvio_hip_lane_wait(self._h, int(lane), int(on_lane)))
+
+    def lane_sync(self, lane):
+        self._check(self._lib.rdvio_hip_lane_sync(self._h, int(lane)))
 
     # ---------------------------------------------------------------- seam 2: estimation
     def preintegrate(self, segments, t_end, bg, ba, noise, jac=True, cov=True):

@@ -81,6 +81,7 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
         }
         ctx->own_stream = true;
     }
+    for (int l = 0; l < 3; ++l) ctx->lane[l] = ctx->stream;
     rdvio_hip_pyr_layout_init(max_w, max_h, RDVIO_MAX_LEVELS - 1, &ctx->maxL);
     for (int s = 0; s < RDVIO_NUM_SLOTS; ++s) {
         CTX_ALLOC(ctx->slots[s].pyr_img, (size_t)ctx->maxL.img_bytes);
@@ -155,7 +156,7 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
 void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    for (int l = 0; l < 3; ++l) (void)hipStreamSynchronize(ctx->lane[l]);
     for (int s = 0; s < RDVIO_NUM_SLOTS; ++s) {
         (void)hipFree(ctx->slots[s].pyr_img);
         (void)hipFree(ctx->slots[s].pyr_deriv);
@@ -172,6 +173,10 @@ void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
         if (ctx->ba[s].host) (void)hipHostFree(ctx->ba[s].host);
         (void)hipFree(ctx->ba[s].arena);
     }
+    for (int l = 0; l < 3; ++l) {
+        if (ctx->lane_ev[l]) (void)hipEventDestroy(ctx->lane_ev[l]);
+        if (ctx->own_lane[l]) (void)hipStreamDestroy(ctx->lane[l]);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -180,7 +185,44 @@ const char *rdvio_hip_last_error(const rdvio_hip_ctx *ctx) { return ctx ? ctx->e
 
 int rdvio_hip_sync(rdvio_hip_ctx *ctx) {
     if (!ctx) return RDVIO_ERR_INVALID;
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int l = 0; l < 3; ++l)
+        if (l == 0 || ctx->lane[l] != ctx->lane[0]) RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane[l]));
+    return RDVIO_OK;
+}
+
+static bool bad_lane(int lane) { return lane < 0 || lane > 2; }
+
+int rdvio_hip_ctx_set_lane_stream(rdvio_hip_ctx *ctx, int lane, void *stream) {
+    if (!ctx || bad_lane(lane)) return RDVIO_ERR_INVALID;
+    if (lane == RDVIO_LANE_FRONTEND) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "the frontend lane is the context's stream (rdvio_hip_ctx_create)");
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane[lane]));
+    if (ctx->own_lane[lane]) {
+        RDVIO_HIP_CHECK(ctx, hipStreamDestroy(ctx->lane[lane]));
+        ctx->own_lane[lane] = false;
+    }
+    if (stream) {
+        ctx->lane[lane] = (hipStream_t)stream;
+    } else {
+        hipStream_t s = nullptr;
+        RDVIO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        ctx->lane[lane] = s;
+        ctx->own_lane[lane] = true;
+    }
+    return RDVIO_OK;
+}
+
+int rdvio_hip_lane_wait(rdvio_hip_ctx *ctx, int lane, int on_lane) {
+    if (!ctx || bad_lane(lane) || bad_lane(on_lane)) return RDVIO_ERR_INVALID;
+    if (ctx->lane[lane] == ctx->lane[on_lane]) return RDVIO_OK;  // same stream: already ordered
+    if (!ctx->lane_ev[on_lane]) RDVIO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->lane_ev[on_lane], hipEventDisableTiming));
+    RDVIO_HIP_CHECK(ctx, hipEventRecord(ctx->lane_ev[on_lane], ctx->lane[on_lane]));
+    RDVIO_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->lane[lane], ctx->lane_ev[on_lane], 0));
+    return RDVIO_OK;
+}
+
+int rdvio_hip_lane_sync(rdvio_hip_ctx *ctx, int lane) {
+    if (!ctx || bad_lane(lane)) return RDVIO_ERR_INVALID;
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane[lane]));
     return RDVIO_OK;
 }
 

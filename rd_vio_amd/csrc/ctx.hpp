@@ -29,8 +29,14 @@ struct HarrisCand {
 
 struct rdvio_hip_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // lane 0 (frontend): Image::*, PreIntegrator::integrate, unit-parity entry points
     bool own_stream = false;
+    // lanes: [0] frontend (= stream), [1] solver (Solver::solve), [2] marginalisation.  All three are `stream` until
+    // rdvio_hip_ctx_set_lane_stream gives a lane a stream of its own; each lane has its own staging buffers, so calls on
+    // different lanes never share mutable state.
+    hipStream_t lane[3] = {nullptr, nullptr, nullptr};
+    bool own_lane[3] = {false, false, false};
+    hipEvent_t lane_ev[3] = {nullptr, nullptr, nullptr};
     int max_w = 0, max_h = 0, max_feat = 0, max_window = 0, max_factors = 0;
     int solver_wgs = 8;  // workgroups per solver launch for problems with >= RDVIO_HELPER_MIN_FACTORS factors (env RDVIO_SOLVER_WGS)
     rdvio_pyr_layout maxL{};

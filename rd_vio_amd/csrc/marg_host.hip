@@ -50,9 +50,9 @@ extern "C" {
 int rdvio_hip_marginalize_upload(rdvio_hip_ctx *ctx, const rdvio_marg_problem *pb) {
     if (!ctx) return RDVIO_ERR_INVALID;
     ctx->marg.ready = false;
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane[RDVIO_LANE_MARG]));
     if (int rc = marg_prepare(ctx, pb)) return rc;
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->marg.arena, ctx->marg.host, ctx->marg.in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->marg.arena, ctx->marg.host, ctx->marg.in_bytes, hipMemcpyHostToDevice, ctx->lane[RDVIO_LANE_MARG]));
     return RDVIO_OK;
 }
 
@@ -62,7 +62,7 @@ int rdvio_hip_marginalize_resident(rdvio_hip_ctx *ctx, int force_eigen) {
     if (!S.ready) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "no marginalisation problem uploaded");
     SolverWs &w = S.ws;
     w.marg_force_eigen = force_eigen ? 1 : 0;
-    rdvio_launch_marginalize(ctx->stream, w);
+    rdvio_launch_marginalize(ctx->lane[RDVIO_LANE_MARG], w);
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
     return RDVIO_OK;
 }
@@ -73,7 +73,7 @@ int rdvio_hip_marginalize_fetch(rdvio_hip_ctx *ctx, double *S_out, double *f_out
     if (!ctx->marg.ready) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "no marginalisation problem uploaded");
     const SolverWs &w = ctx->marg.ws;
     const size_t R = (size_t)15 * (w.nfr - 1);
-    hipStream_t st = ctx->stream;
+    hipStream_t st = ctx->lane[RDVIO_LANE_MARG];
     const rdvio_hip_ctx::BaSlot &slot = ctx->marg;
     // S | f | lin | info in one device-to-host copy into the slot's pinned blob (behind the uploaded inputs)
     const size_t n_out = (size_t)(w.m_info + 4 - w.S_out);

@@ -291,9 +291,9 @@ int rdvio_hip_ba_upload(rdvio_hip_ctx *ctx, int slot, const rdvio_ba_problem *pb
     rdvio_hip_ctx::BaSlot &S = ctx->ba[slot];
     S.ready = false;
     // the pinned blob may still be in flight from a previous upload on this stream
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane[RDVIO_LANE_SOLVER]));
     if (int rc = rdvio_ba_prepare(ctx, S, pb, ctx->ba_arena_bytes, false)) return rc;
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(S.arena, S.host, S.in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(S.arena, S.host, S.in_bytes, hipMemcpyHostToDevice, ctx->lane[RDVIO_LANE_SOLVER]));
     return RDVIO_OK;
 }
 
@@ -305,8 +305,8 @@ int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int slot, int max_iterations
     SolverWs &w = S.ws;
     w.max_iter = max_iterations;
     // the kernel (re)starts from the uploaded initial values (SolverWs::x0 / xd0): no host traffic, no extra copies
-    if (w.n_wg > 1) RDVIO_HIP_CHECK(ctx, hipMemsetAsync(w.sync, 0, 8 * sizeof(double), ctx->stream));
-    rdvio_launch_ba_solve(ctx->stream, w);
+    if (w.n_wg > 1) RDVIO_HIP_CHECK(ctx, hipMemsetAsync(w.sync, 0, 8 * sizeof(double), ctx->lane[RDVIO_LANE_SOLVER]));
+    rdvio_launch_ba_solve(ctx->lane[RDVIO_LANE_SOLVER], w);
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
     return RDVIO_OK;
 }
@@ -321,8 +321,8 @@ int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double 
     const size_t host_off = (S.in_bytes + 63) & ~(size_t)63;
     if (host_off + n_out * sizeof(double) > S.host_bytes) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "result does not fit the pinned blob");
     double *down = (double *)((uint8_t *)S.host + host_off);
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, w.x, n_out * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, w.x, n_out * sizeof(double), hipMemcpyDeviceToHost, ctx->lane[RDVIO_LANE_SOLVER]));
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane[RDVIO_LANE_SOLVER]));
     if (states_out) memcpy(states_out, down, (size_t)w.nfr * 16 * sizeof(double));
     if (inv_depth_out && w.nl > 0) memcpy(inv_depth_out, down + (w.xd - w.x), (size_t)w.nl * sizeof(double));
     const double *sum = down + (w.summary - w.x);
@@ -342,8 +342,8 @@ int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double 
 // diagnostic (RDVIO_PROF builds): per-phase ticks / counts of the last solve in a slot; not part of the public header
 int rdvio_hip_debug_ba_prof(rdvio_hip_ctx *ctx, int slot, double *out64) {
     if (!ctx || bad_slot(slot) || !ctx->ba[slot].ready) return RDVIO_ERR_INVALID;
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(out64, ctx->ba[slot].ws.summary + 8, 64 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(out64, ctx->ba[slot].ws.summary + 8, 64 * sizeof(double), hipMemcpyDeviceToHost, ctx->lane[RDVIO_LANE_SOLVER]));
+    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane[RDVIO_LANE_SOLVER]));
     return RDVIO_OK;
 }
 
