@@ -1419,6 +1419,16 @@ PHASE_FN double accept_candidate(LdsWs &w, Shared &sh, int phase) {
     return sqrt(block_sum(sh, s, phase));
 }
 
+// Test switch RDVIO_TEST_POISON_LDS: LDS is not cleared between workgroups, so a field that some path reads before
+// anybody wrote it holds whatever the previous kernel left there -- the mechanism behind the round-1 hang of the
+// helper-workgroup launch (helper workgroups never run solver_setup).  With the switch on, every
+// workgroup first fills its shared block and scratch buffer with 0xFF bytes (NaN doubles, -1 integers): any dependence on
+// uninitialised LDS then shows up in the parity tests instead of depending on what ran before.
+DM void poison_lds(void *p, size_t bytes) {
+    __attribute__((address_space(3))) unsigned *q = (__attribute__((address_space(3))) unsigned *)p;
+    for (size_t i = threadIdx.x; i < bytes / 4; i += T) q[i] = 0xffffffffu;
+}
+
 __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     __shared__ BlockShared<T> sh_store;
     Shared &sh = *(Shared *)&sh_store;
@@ -1430,6 +1440,11 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     double *Sl = lds_chol_buf, *Dinv = lds_chol_buf + (w.N + 1) * (w.N + 2) / 2;
     const int t = threadIdx.x;
     __shared__ SolverWs w_lds;
+    if (w.poison_lds) {
+        poison_lds(&sh_store, sizeof(sh_store));
+        poison_lds(lds_chol_buf, sizeof(lds_chol_buf));
+        __syncthreads();
+    }
     for (int i = t; i < (int)(sizeof(SolverWs) / 8); i += T)
         ((__attribute__((address_space(3))) unsigned long long *)&w_lds)[i] = ((const unsigned long long *)&w)[i];
     __syncthreads();
@@ -1660,7 +1675,16 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             }
         }
     if (w.n_wg > 1) post_command(w, sh, CMD_EXIT);
+    // Every thread carries its own copy of the loop's scalars and branches on it; they are computed from identical inputs in
+    // identical order, so all copies must agree.  Checked once per launch (one LDS word per wavefront): a disagreement means
+    // wavefronts took different paths through the loop -- reported as summary[6] -> RDVIO_ERR_HIP from rdvio_hip_ba_fetch.
+    __syncthreads();
+    if ((t & 63) == 0) sh.red[0][0][t >> 6] = (double)(iteration * 8 + n_success * 2048 + term);
+    __syncthreads();
+    int disagree = 0;
+    for (int q = 1; q < NW; ++q) disagree |= sh.red[0][0][q] != sh.red[0][0][0];
     if (t == 0) {
+        w.summary[6] = disagree ? 1.0 : 0.0;
         w.summary[0] = (double)iteration;
         w.summary[1] = (double)n_success;
         w.summary[2] = initial_cost;
@@ -1679,6 +1703,11 @@ __global__ __launch_bounds__(T) void marginalize_kernel(SolverWs w) {
     constexpr int NMAX = 15 * RDVIO_LDS_CHOL_MAX_FRAMES;
     __shared__ __attribute__((aligned(16))) double lds_buf[NMAX * (NMAX + 1) / 2 + 225 * RDVIO_LDS_CHOL_MAX_FRAMES];
     __shared__ SolverWs w_lds;
+    if (w.poison_lds) {
+        poison_lds(&sh_store, sizeof(sh_store));
+        poison_lds(lds_buf, sizeof(lds_buf));
+        __syncthreads();
+    }
     for (int i = threadIdx.x; i < (int)(sizeof(SolverWs) / 8); i += T)
         ((__attribute__((address_space(3))) unsigned long long *)&w_lds)[i] = ((const unsigned long long *)&w)[i];
     __syncthreads();
@@ -1702,7 +1731,10 @@ __global__ __launch_bounds__(T) void marginalize_kernel(SolverWs w) {
 
 }  // namespace
 
-void rdvio_launch_marginalize(hipStream_t stream, const SolverWs &w) {
+void rdvio_launch_marginalize(hipStream_t stream, const SolverWs &w0) {
+    SolverWs w = w0;
+    const char *pl = getenv("RDVIO_TEST_POISON_LDS");
+    w.poison_lds = (pl && pl[0] == '1') ? 1 : 0;
     hipLaunchKernelGGL(marginalize_kernel, dim3(1), dim3(T), 0, stream, w);
 }
 
@@ -1712,5 +1744,7 @@ void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w0) {
     w.no_speculation = (ns && ns[0] == '1') ? 1 : 0;
     const char *mh = getenv("RDVIO_TEST_MUTE_HELPERS");
     w.mute_helpers = (mh && mh[0] == '1') ? 1 : 0;
+    const char *pl = getenv("RDVIO_TEST_POISON_LDS");
+    w.poison_lds = (pl && pl[0] == '1') ? 1 : 0;
     hipLaunchKernelGGL(ba_solve_kernel, dim3(w.n_wg > 1 ? w.n_wg : 1), dim3(T), 0, stream, w);
 }

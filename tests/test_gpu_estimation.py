@@ -423,3 +423,24 @@ def test_helper_timeout_is_reported_as_failure(ctx, oracle, monkeypatch):
     monkeypatch.setenv("RDVIO_TEST_MUTE_HELPERS", "0")
     _, _, sm = ctx.ba_solve(pb, 6)     # the context is usable afterwards
     assert sm.termination in (0, 1) and np.isfinite(sm.final_cost)
+
+
+def test_results_do_not_depend_on_initial_lds_contents(ctx, oracle, monkeypatch):
+    """LDS is not cleared between workgroups.  RDVIO_TEST_POISON_LDS=1 makes every workgroup of the solver / marginalisation
+    kernels fill its LDS with 0xFF bytes (NaN doubles, -1 integers) before anything else: results must be bit-identical
+    with and without it -- for the single-workgroup solve, for the helper-workgroup launch (whose helpers never run the
+    leader's setup: the round-1 hang) and for the marginalisation."""
+    small = synth.make_window_problem(9, 150, 648, preintegrate=_oracle_pre(oracle))
+    large = synth.make_window_problem(17, 1000, 655, preintegrate=_oracle_pre(oracle))
+    margs = synth.make_marg_inputs(small)
+    out = {}
+    for poison in ("0", "1", "0"):
+        monkeypatch.setenv("RDVIO_TEST_POISON_LDS", poison)
+        res = (ctx.ba_solve(small, 30), ctx.ba_solve(large, 6), ctx.marginalize(*margs))
+        out.setdefault(poison, []).append(res)
+    for a in out["0"]:
+        b = out["1"][0]
+        for k in (0, 1):
+            assert np.array_equal(a[k][0], b[k][0]) and np.array_equal(a[k][1], b[k][1])
+            assert (a[k][2].iterations, a[k][2].successful_steps, a[k][2].final_cost) == (b[k][2].iterations, b[k][2].successful_steps, b[k][2].final_cost)
+        assert np.array_equal(a[2][0], b[2][0]) and np.array_equal(a[2][1], b[2][1])
