@@ -10,6 +10,7 @@
 
 #include "ctx.hpp"
 #include "host_select.hpp"
+#include "select_caps.hpp"
 
 extern "C" {
 
@@ -93,11 +94,16 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
     CTX_ALLOC(ctx->harris_scalars, 4 * sizeof(uint32_t));
     ctx->harris_cand_cap = (max_w * max_h) / 4 + 1024;  // 3x3 strict local maxima cannot exceed 1/4 of the pixels
     CTX_ALLOC(ctx->harris_cand, (size_t)ctx->harris_cand_cap * sizeof(HarrisCand));
+    CTX_ALLOC(ctx->sel_hdr, 64 + (size_t)RDVIO_SEL_CORNERS_MAX * 2 * sizeof(double));
+    ctx->sel_new = (double *)(ctx->sel_hdr + 16);
+    CTX_ALLOC(ctx->sel_corners, (size_t)RDVIO_SEL_CORNERS_MAX * 2 * sizeof(float));
+    CTX_ALLOC(ctx->sel_existing, (size_t)RDVIO_SEL_PTS_MAX * 2 * sizeof(double));
     CTX_ALLOC(ctx->lk_curr, (size_t)max_feat * (4 * sizeof(double) + 1) + 64);  // curr | next | status for the host entry point
     CTX_ALLOC(ctx->lk_next, (size_t)max_feat * 2 * sizeof(double));
     CTX_ALLOC(ctx->lk_prevf, (size_t)max_feat * 2 * sizeof(float));
     CTX_ALLOC(ctx->lk_nextf, (size_t)max_feat * 2 * sizeof(float));
     CTX_ALLOC(ctx->lk_status, (size_t)max_feat);
+    if (const char *e = getenv("RDVIO_HOST_SELECT")) ctx->force_host_select = e[0] == '1';  // diagnostic: keypoint selection on the host road
     if (const char *e = getenv("RDVIO_SOLVER_WGS")) ctx->solver_wgs = std::min(std::max(atoi(e), 1), RDVIO_MAX_SOLVER_WGS);
     const int nfr = max_window + 2;
     const int max_lm = max_factors;  // every factor could belong to its own landmark
@@ -161,7 +167,7 @@ void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
         (void)hipFree(ctx->slots[s].pyr_img);
         (void)hipFree(ctx->slots[s].pyr_deriv);
     }
-    void *bufs[] = {ctx->gray, ctx->clahe_lut, ctx->harris, ctx->harris_scalars, ctx->harris_cand, ctx->lk_curr,
+    void *bufs[] = {ctx->gray, ctx->clahe_lut, ctx->harris, ctx->harris_scalars, ctx->harris_cand, ctx->sel_hdr, ctx->sel_corners, ctx->sel_existing, ctx->lk_curr,
                     ctx->lk_next, ctx->lk_prevf, ctx->lk_nextf, ctx->lk_status, ctx->ba_states, ctx->ba_extr,
                     ctx->ba_zref, ctx->ba_invd, ctx->ba_tangent, ctx->ba_idx, ctx->ba_r, ctx->ba_Jt, ctx->ba_Jr,
                     ctx->ba_Jd, ctx->pre_out, ctx->pre_blob};
@@ -330,8 +336,26 @@ int rdvio_hip_detect_keypoints(rdvio_hip_ctx *ctx, int slot, double *keypoints, 
     // GFTTDetector::create(max_points, 1.0e-3, 20, 3, true): opencv_image.cpp:184-188
     if (int rc = rdvio_launch_harris(ctx, slot)) return rc;
     if (int rc = rdvio_launch_harris_candidates(ctx, slot, 1.0e-3)) return rc;
-    // one round trip in the common case: the counters and a 4096-candidate prefix travel together into pinned memory
-    // (a second copy only if the image produced more local maxima than that)
+    // Selection on the device (select_kernels.hip): sort, greedy minDistance, Poisson-disk thinning against the existing
+    // keypoints, border test.  Up: the existing keypoints; down: a 64-byte header + the accepted new keypoints, one copy.
+    const double gftt_min_dist = 20.0;
+    const bool device_road = !ctx->force_host_select && n_existing <= RDVIO_SEL_PTS_MAX && max_points <= RDVIO_SEL_CORNERS_MAX;
+    if (device_road) {
+        if (n_existing > 0)
+            RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->sel_existing, keypoints, (size_t)n_existing * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        if (int rc = rdvio_launch_select(ctx, slot, max_points, gftt_min_dist, min_distance, n_existing)) return rc;
+        int32_t *hdr = (int32_t *)ctx->pinned;
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(hdr, ctx->sel_hdr, 64 + (size_t)max_points * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (hdr[1] == 0) {
+            const int n_new = hdr[3];
+            if (n_existing + n_new > capacity) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "keypoint capacity %d too small", capacity);
+            memcpy(keypoints + 2 * (size_t)n_existing, (const uint8_t *)hdr + 64, (size_t)n_new * 2 * sizeof(double));
+            *n_out = n_existing + n_new;
+            return RDVIO_OK;
+        }
+        // beyond the kernels' LDS capacities (e.g. > 8192 local maxima on a noise image): the host road below
+    }
     uint32_t *scalars = (uint32_t *)ctx->pinned;
     HarrisCand *cand = (HarrisCand *)((uint8_t *)ctx->pinned + 64);
     const int prefix = std::min(ctx->harris_cand_cap, 4096);

@@ -38,6 +38,7 @@ struct rdvio_hip_ctx {
     bool own_lane[3] = {false, false, false};
     hipEvent_t lane_ev[3] = {nullptr, nullptr, nullptr};
     int max_w = 0, max_h = 0, max_feat = 0, max_window = 0, max_factors = 0;
+    bool force_host_select = false;  // env RDVIO_HOST_SELECT=1 (read at context creation)
     int solver_wgs = 8;  // workgroups per solver launch for problems with >= RDVIO_HELPER_MIN_FACTORS factors (env RDVIO_SOLVER_WGS)
     rdvio_pyr_layout maxL{};
 
@@ -48,6 +49,12 @@ struct rdvio_hip_ctx {
     uint32_t *harris_scalars = nullptr;  // [0] ordered-uint max, [1] candidate count
     HarrisCand *harris_cand = nullptr;
     int harris_cand_cap = 0;
+    // device-side selection (select_kernels.hip): header + accepted new keypoints in one buffer (one D2H), corner list,
+    // uploaded existing keypoints
+    int32_t *sel_hdr = nullptr;      // [0] candidates, [1] capacity flags (host road when != 0), [2] corners, [3] new keypoints
+    double *sel_new = nullptr;       // = (double *)(sel_hdr + 16)
+    float *sel_corners = nullptr;
+    double *sel_existing = nullptr;
 
     // LK device buffers
     double *lk_curr = nullptr, *lk_next = nullptr;
@@ -111,6 +118,7 @@ int rdvio_launch_lk_flow(rdvio_hip_ctx *ctx, int slot_prev, int slot_next, int n
                          float *next_dev, uint8_t *status_dev, int max_iter, double eps);
 int rdvio_launch_harris(rdvio_hip_ctx *ctx, int slot);
 int rdvio_launch_harris_candidates(rdvio_hip_ctx *ctx, int slot, double quality);
+int rdvio_launch_select(rdvio_hip_ctx *ctx, int slot, int max_corners, double gftt_min_dist, double poisson_radius, int n_existing);
 int rdvio_launch_reprojection(rdvio_hip_ctx *ctx, int nf, int with_jac);
 int rdvio_launch_rotation_prior(rdvio_hip_ctx *ctx, int n, int with_jac);
 int rdvio_launch_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *off, const double *imu, const double *par,

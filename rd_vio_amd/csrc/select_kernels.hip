@@ -1,0 +1,270 @@
+// Keypoint selection on gfx950: what cv::goodFeaturesToTrack does after the response map (sort by response, greedy
+// minDistance selection, maxCorners cut) and what OpenCvImage::detect_keypoints does with the result
+// (/root/reference/src/rdvio_extra/src/opencv_image.cpp:44-72: response order, PoissonDiskFilter<2> seeded with the existing
+// keypoints, 20-px border test) -- order-exact with the host restatement in host_select.cpp, which stays as the road for
+// inputs beyond this file's LDS capacities (it is product host code, not the oracle).
+//
+// Two single-workgroup kernels (everything lives in LDS; the candidate list is a few thousand entries):
+//   gftt_select_kernel    bitonic sort of the Harris local maxima by (response desc, pixel index desc) = cv::greaterThanPtr;
+//                         then the greedy minDistance pass.  The greedy pass is sequential as written ("accept a
+//                         candidate unless an ALREADY ACCEPTED corner is closer than minDistance"), but its result is the
+//                         lexicographically-first maximal independent set of the "closer than minDistance" graph in
+//                         priority order, which has a parallel fixed-point form: a candidate is rejected as soon as one
+//                         higher-priority neighbour is accepted and accepted as soon as all of them are rejected.  Rounds of
+//                         that rule over chunks of 1024 candidates in priority order (a chunk only depends on earlier ones)
+//                         reproduce the sequential loop exactly, including the stop at maxCorners accepted.
+//   poisson_filter_kernel PoissonDiskFilter<2>::preset_points / insert_points, kept literally: ONE point index per grid
+//                         cell (a later preset overwrites an earlier one in the same cell), the reference's neighbourhood
+//                         walk that skips the first cell of the 5x5 block and visits one cell past its end
+//                         (poisson_disk_filter.h:77-92), points compared in double.  The inserts are sequential in the
+//                         reference and stay sequential here: one wavefront, one corner per trip, the 25 visited cells on
+//                         25 lanes, one ballot.
+#include "ctx.hpp"
+#include "select_caps.hpp"
+
+namespace {
+
+constexpr int ST = 1024;
+
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__restrict__ cand, const uint32_t *__restrict__ scalars, int cap,
+                                                        int w, int h, int max_corners, int cell, float md2, float *__restrict__ corners_out,
+                                                        int32_t *__restrict__ hdr) {
+    __shared__ unsigned long long keys[RDVIO_SEL_NC_MAX];   // 64 KB: (ordered response << 32) | pixel index, sorted descending
+    __shared__ unsigned short clist[RDVIO_SEL_NC_MAX];      // 16 KB: candidate ranks grouped by grid cell
+    __shared__ unsigned char state[RDVIO_SEL_NC_MAX];       //  8 KB: 0 undecided, 1 accepted, 2 rejected
+    __shared__ int coff[RDVIO_SEL_GCELLS_MAX + 1];          // 16 KB: first clist entry of a cell
+    __shared__ int ccur[RDVIO_SEL_GCELLS_MAX];              // 16 KB: per-cell counters / fill cursors
+    __shared__ int wsum[ST / 64];
+    __shared__ int s_flag, s_total;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int nc = (int)min(scalars[1], (uint32_t)cap);
+    const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell, ncell = gw * gh;
+    if (t == 0) {
+        hdr[0] = nc;
+        hdr[1] = (nc > RDVIO_SEL_NC_MAX || ncell > RDVIO_SEL_GCELLS_MAX || max_corners > RDVIO_SEL_CORNERS_MAX) ? 1 : 0;  // beyond capacity: host road
+        hdr[2] = 0;
+    }
+    if (nc > RDVIO_SEL_NC_MAX || ncell > RDVIO_SEL_GCELLS_MAX || max_corners > RDVIO_SEL_CORNERS_MAX) return;
+    // ---- sort (bitonic, descending).  Keys are unique (the pixel index is part of them), padding keys (0) sink to the end.
+    int P = 2;
+    while (P < nc) P <<= 1;
+    for (int i = t; i < P; i += ST) {
+        unsigned long long k = 0;
+        if (i < nc) k = ((unsigned long long)f2ord(cand[i].v) << 32) | (uint32_t)cand[i].idx;
+        keys[i] = k;
+        if (i < RDVIO_SEL_NC_MAX) state[i] = 0;
+    }
+    for (int i = t; i < ncell; i += ST) ccur[i] = 0;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < P; i += ST) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = keys[i], b = keys[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? a < b : a > b) {
+                        keys[i] = b;
+                        keys[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    // ---- candidates grouped by grid cell (counting sort; the order inside a cell does not matter)
+    for (int i = t; i < nc; i += ST) {
+        const int idx = (int)(uint32_t)keys[i];
+        const int y = idx / w, x = idx - y * w;
+        atomicAdd(&ccur[(y / cell) * gw + x / cell], 1);
+    }
+    __syncthreads();
+    {
+        // exclusive scan over the cells: four consecutive cells per thread, wave scan, wave totals through LDS
+        int v[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 4 * t + q;
+            v[q] = c < ncell ? ccur[c] : 0;
+            sum += v[q];
+        }
+        int inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int n = __shfl_up(inc, off);
+            if (lane >= off) inc += n;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int q = 0; q < wave; ++q) base += wsum[q];
+        int run = base + inc - sum;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 4 * t + q;
+            if (c < ncell) coff[c] = run;
+            run += v[q];
+        }
+        if (t == ST - 1) coff[ncell] = run;
+    }
+    __syncthreads();
+    for (int i = t; i < ncell; i += ST) ccur[i] = 0;
+    if (t == 0) s_total = 0;
+    __syncthreads();
+    for (int i = t; i < nc; i += ST) {
+        const int idx = (int)(uint32_t)keys[i];
+        const int y = idx / w, x = idx - y * w, c = (y / cell) * gw + x / cell;
+        clist[coff[c] + atomicAdd(&ccur[c], 1)] = (unsigned short)i;
+    }
+    __syncthreads();
+    // ---- greedy minDistance selection, a chunk of 1024 ranks at a time
+    for (int base = 0; base < nc; base += ST) {
+        if (s_total >= max_corners) break;  // (uniform: s_total is only written between barriers)
+        const int i = base + t;
+        const bool mine = i < nc;
+        int x = 0, y = 0;
+        if (mine) {
+            const int idx = (int)(uint32_t)keys[i];
+            y = idx / w;
+            x = idx - y * w;
+        }
+        const int xc = x / cell, yc = y / cell;
+        const int x1 = max(0, xc - 1), y1 = max(0, yc - 1), x2 = min(gw - 1, xc + 1), y2 = min(gh - 1, yc + 1);
+        for (;;) {
+            __syncthreads();
+            if (t == 0) s_flag = 0;
+            __syncthreads();
+            if (mine && state[i] == 0) {
+                bool any_acc = false, any_und = false;
+                for (int yy = y1; yy <= y2 && !any_acc; ++yy)
+                    for (int xx = x1; xx <= x2 && !any_acc; ++xx) {
+                        const int cc = yy * gw + xx;
+                        for (int e = coff[cc]; e < coff[cc + 1]; ++e) {
+                            const int j = clist[e];
+                            if (j >= i) continue;
+                            const int jdx = (int)(uint32_t)keys[j];
+                            const int jy = jdx / w, jx = jdx - jy * w;
+                            const float dx = (float)x - (float)jx, dy = (float)y - (float)jy;
+                            if (!(dx * dx + dy * dy < md2)) continue;
+                            const int sj = state[j];
+                            if (sj == 1) {
+                                any_acc = true;
+                                break;
+                            }
+                            if (sj == 0) any_und = true;
+                        }
+                    }
+                if (any_acc) state[i] = 2;
+                else if (!any_und) state[i] = 1;
+                else s_flag = 1;
+            }
+            __syncthreads();
+            if (!s_flag) break;
+        }
+        // accepted candidates of the chunk in rank order -> their positions in the corner list
+        const bool acc = mine && state[i] == 1;
+        const unsigned long long bal = __ballot(acc);
+        const int before_me = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int off = s_total, chunk = 0;
+        for (int q = 0; q < ST / 64; ++q) {
+            if (q < wave) off += wsum[q];
+            chunk += wsum[q];
+        }
+        if (acc && off + before_me < max_corners) {
+            corners_out[2 * (off + before_me)] = (float)x;
+            corners_out[2 * (off + before_me) + 1] = (float)y;
+        }
+        __syncthreads();
+        if (t == 0) s_total += chunk;
+        __syncthreads();
+    }
+    if (t == 0) hdr[2] = min(s_total, max_corners);
+}
+
+// PoissonDiskFilter<2> (poisson_disk_filter.h) + the 20-px border test of opencv_image.cpp:61-68.
+// existing: n_existing x 2 doubles; corners: hdr[2] x 2 floats (response order); new_out: accepted corners inside the
+// border, in order; hdr[3] = their count; hdr[1] |= 2 when the grid or the point table would not fit (host road).
+__global__ __launch_bounds__(256) void poisson_filter_kernel(const double *__restrict__ existing, int n_existing, const float *__restrict__ corners,
+                                                            int w, int h, double radius, double *__restrict__ new_out, int32_t *__restrict__ hdr) {
+    __shared__ int grid[RDVIO_SEL_PGRID_MAX];                                  // 88 KB: point index per cell or -1
+    __shared__ __attribute__((aligned(16))) double pts[2 * RDVIO_SEL_PTS_MAX];  // 64 KB
+    const int t = threadIdx.x;
+    if (hdr[1] != 0) return;
+    const int ncorn = hdr[2];
+    const double cellp = radius / sqrt(2.0), r2 = radius * radius;
+    // cells touched by any corner inside the image, widened by the walk's reach (2 left / up, 2 right, 3 down) -> 3 all round
+    constexpr int M = 3;
+    const int gx = (int)floor((double)(w - 1) / cellp) + 1 + 2 * M, gy = (int)floor((double)(h - 1) / cellp) + 1 + 2 * M;
+    if ((long long)gx * gy > RDVIO_SEL_PGRID_MAX || n_existing + ncorn > RDVIO_SEL_PTS_MAX) {
+        if (t == 0) hdr[1] |= 2;
+        return;
+    }
+    for (int i = t; i < gx * gy; i += 256) grid[i] = -1;
+    __syncthreads();
+    // presets: "grid_[cell] = index" in order, i.e. the LAST preset of a cell stays (atomicMax of the index)
+    for (int i = t; i < n_existing; i += 256) {
+        const double x = existing[2 * i], y = existing[2 * i + 1];
+        pts[2 * i] = x;
+        pts[2 * i + 1] = y;
+        const double fx = floor(x / cellp), fy = floor(y / cellp);
+        // a preset further out than the margin can never be visited from a corner inside the image
+        if (fx >= -M && fy >= -M && fx < gx - M && fy < gy - M) atomicMax(&grid[((int)fy + M) * gx + (int)fx + M], i);
+    }
+    __syncthreads();
+    if (t >= 64) return;
+    int npts = n_existing, total = 0;
+    for (int k = 0; k < ncorn; ++k) {
+        const double x = (double)corners[2 * k], y = (double)corners[2 * k + 1];
+        const int cx = (int)floor(x / cellp), cy = (int)floor(y / cellp);
+        // the reference's walk over the block [cx-2, cx+2] x [cy-2, cy+2]: it steps BEFORE it looks, so it never visits
+        // the first cell (cx-2, cy-2) and ends on (cx-2, cy+3)
+        bool conflict = false;
+        if (t < 25) {
+            const int pos = t + 1, vx = cx - 2 + pos % 5, vy = cy - 2 + pos / 5;
+            const int ax = vx + M, ay = vy + M;
+            if (ax >= 0 && ay >= 0 && ax < gx && ay < gy) {
+                const int p = grid[ay * gx + ax];
+                if (p >= 0) {
+                    const double dx = x - pts[2 * p], dy = y - pts[2 * p + 1];
+                    conflict = dx * dx + dy * dy < r2;
+                }
+            }
+        }
+        if (__ballot(conflict) != 0ull) continue;
+        if (t == 0) {
+            grid[(cy + M) * gx + cx + M] = npts;
+            pts[2 * npts] = x;
+            pts[2 * npts + 1] = y;
+        }
+        npts++;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (x < 20 || y < 20 || x >= w - 20 || y >= h - 20) continue;
+        if (t == 0) {
+            new_out[2 * total] = x;
+            new_out[2 * total + 1] = y;
+        }
+        total++;
+    }
+    if (t == 0) hdr[3] = total;
+}
+
+}  // namespace
+
+int rdvio_launch_select(rdvio_hip_ctx *ctx, int slot, int max_corners, double gftt_min_dist, double poisson_radius, int n_existing) {
+    ImageSlot &S = ctx->slots[slot];
+    const int cell = (int)lrint(gftt_min_dist);
+    const float md2 = (float)(gftt_min_dist * gftt_min_dist);
+    hipLaunchKernelGGL(gftt_select_kernel, dim3(1), dim3(ST), 0, ctx->stream, ctx->harris_cand, ctx->harris_scalars, ctx->harris_cand_cap, S.w,
+                       S.h, max_corners, cell, md2, ctx->sel_corners, ctx->sel_hdr);
+    hipLaunchKernelGGL(poisson_filter_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->sel_existing, n_existing, ctx->sel_corners, S.w, S.h,
+                       poisson_radius, ctx->sel_new, ctx->sel_hdr);
+    RDVIO_HIP_CHECK(ctx, hipGetLastError());
+    return RDVIO_OK;
+}

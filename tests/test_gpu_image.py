@@ -128,6 +128,56 @@ def test_harris_and_detect_bit_exact(ctx, oracle, size, seed):
             assert len(ref_kp) > len(existing)
 
 
+@pytest.mark.parametrize("kind", ["room_752", "room_1280", "fractional_existing", "radius_above_min_distance", "noise_host_road", "flat"])
+def test_device_keypoint_selection_is_order_exact(ctx, oracle, kind, monkeypatch):
+    """Device-side GFTT ordering + greedy minDistance + Poisson-disk thinning + border test (select_kernels.hip) against the
+    oracle AND against the product's own host road (RDVIO_HOST_SELECT=1, host_select.cpp): same keypoints, same order, bit
+    for bit.  Cases: ray-cast room frames, existing keypoints at fractional (tracked) positions incl. two in one Poisson cell,
+    a Poisson radius above GFTT's minDistance (the inserts then depend on each other), a noise image with > 8192 local maxima
+    (beyond the kernels' LDS capacity: the entry point must take the host road and still be exact), a flat image."""
+    rng = np.random.default_rng(5)
+    w, h, maxp, dist = 752, 480, 150, 10.0
+    if kind == "room_1280":
+        w, h, maxp = 1280, 720, 1000
+        K = np.array([[900.0, 0, 640.0], [0, 900.0, 360.0], [0, 0, 1.0]])
+        img = synth.make_stream(1, w, h, K)[0][0]
+    elif kind == "noise_host_road":
+        img = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    elif kind == "flat":
+        img = np.full((h, w), 77, np.uint8)
+    else:
+        img = synth.make_stream(2, w, h, synth.EUROC_K)[0][1]
+    Lo, pi, pd = oracle.preprocess(img)
+    lvl0 = np.ascontiguousarray(oracle.level_view(Lo, pi, 0))
+    g = rd_vio_amd.HipImage(ctx, 0, img)
+    g.preprocess()
+    existing = np.zeros((0, 2))
+    if kind == "fractional_existing":
+        first = oracle.detect_keypoints(lvl0, np.zeros((0, 2)), 60, 20.0)
+        existing = first + rng.uniform(-3.0, 3.0, first.shape)
+        existing = np.concatenate([existing, existing[:5] + 0.5, [[-4.0, 100.25], [w + 3.0, 50.0]]])   # same-cell pairs, points off the image
+    if kind == "radius_above_min_distance":
+        dist = 33.0
+    ref_kp = oracle.detect_keypoints(lvl0, existing, maxp, dist)
+    got_kp = g.detect_keypoints(existing, maxp, dist)
+    assert ref_kp.shape == got_kp.shape and (ref_kp == got_kp).all()
+    if kind == "flat":
+        assert len(got_kp) == len(existing)
+    else:
+        assert len(got_kp) > len(existing)
+    # the product's host road gives the same answer
+    host_ctx_env = dict(RDVIO_HOST_SELECT="1")
+    monkeypatch.setenv("RDVIO_HOST_SELECT", "1")
+    hc = rd_vio_amd.Context(max_width=w, max_height=h, max_features=64)
+    try:
+        gh = rd_vio_amd.HipImage(hc, 0, img)
+        gh.preprocess()
+        host_kp = gh.detect_keypoints(existing, maxp, dist)
+    finally:
+        hc.close()
+    assert host_kp.shape == got_kp.shape and (host_kp == got_kp).all()
+
+
 def test_capacity_and_argument_errors(ctx):
     small = rd_vio_amd.Context(max_width=128, max_height=96, max_features=8)
     img = synth.render_scene(752, 480, seed=1)
