@@ -235,6 +235,44 @@ int rdvio_hip_marginalize_resident(rdvio_hip_ctx *ctx, int force_eigen);
 int rdvio_hip_marginalize_fetch(rdvio_hip_ctx *ctx, double *S_out, double *f_out, double *lin_out,
                                 double *Lambda_out, double *eta_out, int *used_fast_path);
 
+/* ------------------------------------------------------------------ RD path: PARSAC hypothesis scoring (row A19 / N2) */
+/* The inner loop of Parsac<>::solve / IMU_Parsac<>::solve (src/rdvio_util/include/rdvio/util/parsac.h:128-160, 215-262;
+ * imu_parsac.h:93-150, 233-280) for a batch of hypotheses: per model the error test of every correspondence, the inlier
+ * mask, the number of inliers (and of inliers the IMU prior model shares), the inlier count of every occupied grid bin and
+ * the coverage-weighted score -- float arithmetic in the reference's order, so scores compare bit for bit.  Sampling
+ * (rand()-ordered) and model generation (5-point essential / EPnP) stay with the caller.
+ *   kind 0  model = essential matrix E (9, row-major); pa = p1, pb = p2 (n x 2, normalised image points);
+ *           error = d(E, p1, p2) + d(E^T, p2, p1)          (src/rdvio_geometry/src/stereo.cpp:137-141, essential.h:14-19)
+ *   kind 1  model = [R | t] (R row-major 9, then t 3); pa = X (n x 3), pb = x (n x 2);
+ *           error = |x - proj(R X + t)|^2                  (src/rdvio_geometry/include/rdvio/geometry/pnp.h:89-93, 187-189)
+ * The grid of the solve is passed flattened: data_to_valid (point -> occupied bin), valid_sizes, bin_xy (centre of each
+ * occupied bin), lens_weight (1 - dynamic_probability^(0.1 mean track length) per occupied bin, NULL for plain PARSAC),
+ * prior_mask (inliers of the IMU prior model, NULL for plain PARSAC).  Runs on RDVIO_LANE_SOLVER. */
+#define RDVIO_PARSAC_MAX_BINS 400
+#define RDVIO_PARSAC_MAX_MODELS 128
+typedef struct {
+    int32_t kind, n_points;
+    int32_t points_changed;        /* != 0: pa / pb / grid / prior_mask differ from the previous call (re-upload) */
+    const double *pa, *pb;
+    double threshold;
+    int32_t n_valid;
+    const int32_t *data_to_valid, *valid_sizes;
+    const double *bin_xy;          /* n_valid x 2 */
+    const float *lens_weight;      /* n_valid or NULL */
+    const uint8_t *prior_mask;     /* n_points or NULL */
+    int32_t n_models;
+    const double *models;          /* n_models x 9 (kind 0) or x 12 (kind 1) */
+} rdvio_parsac_batch;
+typedef struct {
+    int32_t count;                 /* inliers */
+    int32_t effective;             /* inliers shared with the prior model (= count without a prior) */
+    float score;
+    int32_t pad_;
+} rdvio_parsac_result;
+int rdvio_hip_parsac_score(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *batch, rdvio_parsac_result *results);
+/* inlier mask (n_points) and per-occupied-bin inlier counts (n_valid) of model `model` of the last scored batch */
+int rdvio_hip_parsac_fetch(rdvio_hip_ctx *ctx, int model, uint8_t *mask, int32_t *bin_inliers);
+
 #ifdef __cplusplus
 }
 #endif

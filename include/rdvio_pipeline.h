@@ -58,6 +58,10 @@ typedef struct rdvio_backend {
     int (*marginalize)(void *user, const rdvio_marg_problem *pb, double *S_out, double *f_out, double *lin_out);
     const char *(*last_error)(void *user);
     void (*destroy)(void *user); /* optional: called by rdvio_pipeline_destroy */
+    /* optional (NULL = the orchestration scores on the host, parsac.hpp): PARSAC / IMU-PARSAC hypothesis scoring of a
+     * batch of models and the mask / bin counts of one of them (rdvio_hip_parsac_score / _fetch) */
+    int (*parsac_score)(void *user, const rdvio_parsac_batch *batch, rdvio_parsac_result *results);
+    int (*parsac_fetch)(void *user, int model, uint8_t *mask, int32_t *bin_inliers);
 } rdvio_backend;
 
 /* rdvio::Config (types.h:85-151) with the defaults of src/rdvio/src/config.cpp; rdvio_pipeline_config_default fills

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librdvio_hip.so")
-SOURCES = ["capi.hip", "image_kernels.hip", "lk_kernels.hip", "ba_kernels.hip", "select_kernels.hip", "solver_kernels.hip", "solver_host.hip", "marg_host.hip",
+SOURCES = ["capi.hip", "image_kernels.hip", "lk_kernels.hip", "ba_kernels.hip", "select_kernels.hip", "parsac_kernels.hip", "solver_kernels.hip", "solver_host.hip", "marg_host.hip",
            "host_select.cpp"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # No FMA contraction anywhere: the image / LK arithmetic must round exactly like the oracle (bit-exact feature

@@ -148,6 +148,20 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
             return RDVIO_ERR_HIP;
         }
     }
+    {
+        ctx->ps_max_points = std::max(4096, 4 * max_feat);
+        const size_t n = (size_t)ctx->ps_max_points;
+        ctx->ps_in_bytes = (n * (5 * 8 + 4 + 1) + RDVIO_PARSAC_MAX_BINS * 24 + (size_t)RDVIO_PARSAC_MAX_MODELS * 12 * 8 + 4096 + 15) & ~(size_t)15;
+        CTX_ALLOC(ctx->ps_dev, ctx->ps_in_bytes);
+        CTX_ALLOC(ctx->ps_masks, (size_t)RDVIO_PARSAC_MAX_MODELS * n);
+        CTX_ALLOC(ctx->ps_bins, (size_t)RDVIO_PARSAC_MAX_MODELS * RDVIO_PARSAC_MAX_BINS * sizeof(int32_t));
+        CTX_ALLOC(ctx->ps_results, (size_t)RDVIO_PARSAC_MAX_MODELS * sizeof(rdvio_parsac_result));
+        if (hipHostMalloc(&ctx->ps_host, ctx->ps_in_bytes + n + 65536, hipHostMallocDefault) != hipSuccess) {
+            rdvio_fail(ctx, RDVIO_ERR_HIP, "hipHostMalloc(parsac blob) failed");
+            *out = ctx;
+            return RDVIO_ERR_HIP;
+        }
+    }
     ctx->pinned_bytes = std::max<size_t>((size_t)ctx->harris_cand_cap * sizeof(HarrisCand) + 64, 1 << 20);
     ctx->pinned_bytes = std::max<size_t>(ctx->pinned_bytes, ((size_t)ctx->pre_max_seg * (7 + RDVIO_PREINT_SIZE + 1) + 64 + (size_t)ctx->pre_max_samples * 7) * sizeof(double));
     if (hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
@@ -167,12 +181,14 @@ void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
         (void)hipFree(ctx->slots[s].pyr_img);
         (void)hipFree(ctx->slots[s].pyr_deriv);
     }
-    void *bufs[] = {ctx->gray, ctx->clahe_lut, ctx->harris, ctx->harris_scalars, ctx->harris_cand, ctx->sel_hdr, ctx->sel_corners, ctx->sel_existing, ctx->lk_curr,
+    void *bufs[] = {ctx->gray, ctx->clahe_lut, ctx->harris, ctx->harris_scalars, ctx->harris_cand, ctx->sel_hdr, ctx->sel_corners, ctx->sel_existing, ctx->ps_dev, ctx->ps_masks, ctx->ps_bins, ctx->ps_results,
+                    ctx->lk_curr,
                     ctx->lk_next, ctx->lk_prevf, ctx->lk_nextf, ctx->lk_status, ctx->ba_states, ctx->ba_extr,
                     ctx->ba_zref, ctx->ba_invd, ctx->ba_tangent, ctx->ba_idx, ctx->ba_r, ctx->ba_Jt, ctx->ba_Jr,
                     ctx->ba_Jd, ctx->pre_out, ctx->pre_blob};
     for (void *b : bufs) (void)hipFree(b);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->ps_host) (void)hipHostFree(ctx->ps_host);
     if (ctx->marg.host) (void)hipHostFree(ctx->marg.host);
     (void)hipFree(ctx->marg.arena);
     for (int s = 0; s < RDVIO_BA_SLOTS; ++s) {

@@ -80,6 +80,16 @@ struct rdvio_hip_ctx {
     BaSlot marg;
     size_t marg_bytes = 0;
 
+    // PARSAC hypothesis scoring (parsac_kernels.hip; solver lane): pinned blob (inputs | results), device mirror, outputs
+    void *ps_host = nullptr, *ps_dev = nullptr;
+    size_t ps_in_bytes = 0;
+    int ps_max_points = 0;
+    uint8_t *ps_masks = nullptr;           // RDVIO_PARSAC_MAX_MODELS x ps_max_points
+    int32_t *ps_bins = nullptr;            // RDVIO_PARSAC_MAX_MODELS x RDVIO_PARSAC_MAX_BINS
+    rdvio_parsac_result *ps_results = nullptr;
+    int ps_n = 0, ps_kind = -1, ps_nv = 0, ps_nm = 0;
+    bool ps_has_prior = false, ps_has_lens = false;
+
     // pinned host staging
     void *pinned = nullptr;
     size_t pinned_bytes = 0;

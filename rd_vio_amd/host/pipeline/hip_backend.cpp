@@ -77,6 +77,14 @@ int marginalize(void *user, const rdvio_marg_problem *pb, double *S, double *f, 
     return rdvio_hip_marginalize(static_cast<HipBackend *>(user)->ctx, pb, 0, S, f, lin, nullptr, nullptr, nullptr);
 }
 
+int parsac_score(void *user, const rdvio_parsac_batch *batch, rdvio_parsac_result *results) {
+    return rdvio_hip_parsac_score(static_cast<HipBackend *>(user)->ctx, batch, results);
+}
+
+int parsac_fetch(void *user, int model, uint8_t *mask, int32_t *bin_inliers) {
+    return rdvio_hip_parsac_fetch(static_cast<HipBackend *>(user)->ctx, model, mask, bin_inliers);
+}
+
 const char *last_error(void *user) { return rdvio_hip_last_error(static_cast<HipBackend *>(user)->ctx); }
 
 void destroy(void *user) { delete static_cast<HipBackend *>(user); }
@@ -99,6 +107,8 @@ extern "C" int rdvio_pipeline_create_hip(rdvio_pipeline **out, const rdvio_pipel
     fn.marginalize = marginalize;
     fn.last_error = last_error;
     fn.destroy = destroy;
+    fn.parsac_score = parsac_score;
+    fn.parsac_fetch = parsac_fetch;
     const int rc = rdvio_pipeline_create(out, cfg, &fn);
     if (rc != RDVIO_OK) delete b;
     return rc;

@@ -21,6 +21,9 @@
 #include <cfloat>
 #include <cstdlib>
 
+#include <stdexcept>
+
+#include "../../../include/rdvio_pipeline.h"
 #include "geom.hpp"
 
 namespace rdvio_pipe {
@@ -396,9 +399,36 @@ struct ParsacGrid {
     }
 };
 
+// Hypothesis scoring behind the backend (rdvio_backend::parsac_score / parsac_fetch; the HIP product implements them,
+// rdvio_hip_parsac_score).  kind / pa / pb are the flattened correspondences of the call site; flatten(model, out) writes
+// the model as 9 (essential) or 12 ([R | t]) doubles.  fn == nullptr: the scoring below runs on the host.
+struct ParsacDeviceScorer {
+    int (*score)(void *user, const rdvio_parsac_batch *batch, rdvio_parsac_result *results) = nullptr;
+    int (*fetch)(void *user, int model, uint8_t *mask, int32_t *bin_inliers) = nullptr;
+    void *user = nullptr;
+    int kind = 0;
+    const double *pa = nullptr, *pb = nullptr;
+};
+inline void parsac_flatten(const M3 &E, double *out) {
+    for (int q = 0; q < 9; ++q) out[q] = E.m[q];
+}
+inline void parsac_flatten(const Pose4 &T, double *out) {
+    for (int q = 0; q < 9; ++q) out[q] = T.R.m[q];
+    out[9] = T.t.x; out[10] = T.t.y; out[11] = T.t.z;
+}
+
 // Parsac<DoF>::solve (parsac.h:74-171) / IMU_Parsac<DoF>::solve (imu_parsac.h:28-163).
 // solve(sample indices) -> models, error(model, i) -> double, pts2 = the image points that are bucketed.
 // imu != nullptr selects the IMU variant: prior model inliers (error <= 2 threshold), overlap counting, lens weighting.
+//
+// The loop is evaluated a batch of iterations at a time: sampling and model generation do not depend on the scores (the
+// samplers are seeded per solve and draw in a fixed order), only the NUMBER of iterations does, through the adaptive
+// iter_max.  So the hypotheses of the next PARSAC_BATCH iterations are generated up front, scored together -- on the device
+// when the backend offers the hook, on the host otherwise -- and the reference's accept / early-exit decisions are then
+// replayed on the results in iteration order; hypotheses beyond the iteration at which the loop ends are simply ignored.
+// Both roads run this same control flow and produce bit-identical scores, masks and bin confidences.
+constexpr size_t PARSAC_BATCH = 8;
+
 template <size_t DoF, class Model, class SolveFn, class ErrorFn>
 struct ParsacResult {
     Model model;
@@ -410,7 +440,8 @@ template <size_t DoF, class Model, class SolveFn, class ErrorFn>
 ParsacResult<DoF, Model, SolveFn, ErrorFn> parsac_solve(size_t size, const std::vector<V2> &pts2, double threshold, double confidence, size_t max_iteration,
                                                        int seed, std::vector<float> &binConfidences, SolveFn solve, ErrorFn error, Model identity,
                                                        double norm_scale = 1.0, const Model *imu_prior = nullptr,
-                                                       const std::vector<size_t> *lens = nullptr, double dynamic_probability = 0.0) {
+                                                       const std::vector<size_t> *lens = nullptr, double dynamic_probability = 0.0,
+                                                       const ParsacDeviceScorer *dev = nullptr) {
     ParsacResult<DoF, Model, SolveFn, ErrorFn> out;
     out.model = identity;
     LotBox lotbox(size);
@@ -443,42 +474,131 @@ ParsacResult<DoF, Model, SolveFn, ErrorFn> parsac_solve(size_t size, const std::
             return out;
         }
     }
+    const bool on_device = dev && dev->score && dev->fetch;
+    // flattened grid for the device road (uploaded with the first batch)
+    std::vector<int32_t> d2v, vsizes;
+    std::vector<double> bin_xy;
+    std::vector<float> lens_w;
+    std::vector<uint8_t> prior_u8;
+    constexpr int MD = sizeof(Model) == sizeof(M3) ? 9 : 12;
+    if (on_device) {
+        d2v.assign(grid.mapDataToValid.begin(), grid.mapDataToValid.end());
+        vsizes.assign(grid.validSizes.begin(), grid.validSizes.end());
+        bin_xy.resize(2 * grid.nValidBins);
+        for (size_t iv = 0; iv < grid.nValidBins; ++iv) {
+            bin_xy[2 * iv] = grid.binLocations[grid.mapValidToBin[iv]].x;
+            bin_xy[2 * iv + 1] = grid.binLocations[grid.mapValidToBin[iv]].y;
+        }
+        if (grid.use_lens) {  // the track-length factor of imu_parsac.h:243-246 is a per-bin constant of the solve
+            lens_w.resize(grid.nValidBins);
+            for (size_t iv = 0; iv < grid.nValidBins; ++iv) lens_w[iv] = (float)(1 - std::pow(dynamic_probability, 0.10 * grid.validLens[iv]));
+        }
+        if (imu_prior) prior_u8.assign(prior_mask.begin(), prior_mask.end());
+    }
     std::vector<size_t> bestBinInliers(grid.nValidBins, 0);
     size_t iter_max = max_iteration;
     float scoreMax = imu_prior ? -FLT_MAX : 0.0f;
-    for (size_t iter = 0; iter < iter_max; ++iter) {
-        std::array<size_t, DoF> sample;
-        lotbox.refill_all();
-        sampler.refill_all();
-        for (size_t si = 0; si < DoF; ++si)
-            sample[si] = grid.nValidBins > 20 ? sampler.draw_by_weight() : lotbox.draw_without_replacement();  // (bin index used as data index)
-        const std::vector<Model> models = solve(sample);
-        for (const Model &current : models) {
-            size_t count = 0;
-            std::vector<char> mask(size, 0);
-            for (size_t i = 0; i < size; ++i)
-                if (error(current, i) <= threshold) {
-                    count++;
-                    mask[i] = 1;
-                }
-            size_t effective = count;
-            if (imu_prior) {
-                effective = 0;
-                for (size_t i = 0; i < size; ++i)
-                    if (prior_mask[i] && mask[i]) effective++;
-                if (effective < DoF) continue;
+    bool first_batch = true;
+    for (size_t iter0 = 0; iter0 < iter_max; iter0 += PARSAC_BATCH) {
+        // ---- hypotheses of iterations iter0 .. iter0 + B - 1
+        const size_t B = std::min(PARSAC_BATCH, iter_max - iter0);
+        std::vector<Model> models;
+        std::vector<size_t> first_of(B + 1, 0);
+        for (size_t b = 0; b < B; ++b) {
+            std::array<size_t, DoF> sample;
+            lotbox.refill_all();
+            sampler.refill_all();
+            for (size_t si = 0; si < DoF; ++si)
+                sample[si] = grid.nValidBins > 20 ? sampler.draw_by_weight() : lotbox.draw_without_replacement();  // (bin index used as data index)
+            const std::vector<Model> ms = solve(sample);
+            models.insert(models.end(), ms.begin(), ms.end());
+            first_of[b + 1] = models.size();
+        }
+        const size_t nm = models.size();
+        // ---- scores
+        std::vector<size_t> counts(nm, 0), effs(nm, 0);
+        std::vector<float> scores(nm, 0.0f);
+        std::vector<std::vector<char>> masks;           // host road only
+        std::vector<std::vector<size_t>> bin_inl;       // host road only
+        if (on_device && nm > 0) {
+            std::vector<double> flat(nm * MD);
+            for (size_t k = 0; k < nm; ++k) parsac_flatten(models[k], &flat[k * MD]);
+            // the device kernel takes at most RDVIO_PARSAC_MAX_MODELS hypotheses per launch (8 iterations x 10 essential
+            // matrices = 80 at most)
+            rdvio_parsac_batch pb{};
+            pb.kind = dev->kind;
+            pb.n_points = (int32_t)size;
+            pb.points_changed = first_batch ? 1 : 0;
+            pb.pa = dev->pa;
+            pb.pb = dev->pb;
+            pb.threshold = threshold;
+            pb.n_valid = (int32_t)grid.nValidBins;
+            pb.data_to_valid = d2v.data();
+            pb.valid_sizes = vsizes.data();
+            pb.bin_xy = bin_xy.data();
+            pb.lens_weight = grid.use_lens ? lens_w.data() : nullptr;
+            pb.prior_mask = imu_prior ? prior_u8.data() : nullptr;
+            pb.n_models = (int32_t)nm;
+            pb.models = flat.data();
+            std::vector<rdvio_parsac_result> res(nm);
+            if (dev->score(dev->user, &pb, res.data()) != RDVIO_OK) throw std::runtime_error("backend parsac_score failed");
+            first_batch = false;
+            for (size_t k = 0; k < nm; ++k) {
+                counts[k] = (size_t)res[k].count;
+                effs[k] = (size_t)res[k].effective;
+                scores[k] = res[k].score;
             }
-            const std::vector<size_t> binInliers = grid.inliers_per_valid_bin(mask);
-            const float score = grid.score(binInliers);
-            if (score > scoreMax || (score == scoreMax && effective > inlier_count)) {
-                scoreMax = score;
-                out.model = current;
-                inlier_count = effective;
-                bestBinInliers = binInliers;
-                out.inlier_mask.swap(mask);
-                const double ratio = inlier_count / (double)size;
-                const double N = K / std::log(1 - std::pow(ratio, 5));
-                if (N < (double)iter_max) iter_max = (size_t)std::ceil(N);
+        } else {
+            masks.resize(nm);
+            bin_inl.resize(nm);
+            for (size_t k = 0; k < nm; ++k) {
+                std::vector<char> &mask = masks[k];
+                mask.assign(size, 0);
+                size_t count = 0;
+                for (size_t i = 0; i < size; ++i)
+                    if (error(models[k], i) <= threshold) {
+                        count++;
+                        mask[i] = 1;
+                    }
+                size_t effective = count;
+                if (imu_prior) {
+                    effective = 0;
+                    for (size_t i = 0; i < size; ++i)
+                        if (prior_mask[i] && mask[i]) effective++;
+                }
+                counts[k] = count;
+                effs[k] = effective;
+                bin_inl[k] = grid.inliers_per_valid_bin(mask);
+                scores[k] = grid.score(bin_inl[k]);
+            }
+        }
+        // ---- replay of the reference's loop body on the results, in iteration order
+        long best_in_batch = -1;
+        for (size_t b = 0; b < B && iter0 + b < iter_max; ++b)
+            for (size_t k = first_of[b]; k < first_of[b + 1]; ++k) {
+                const size_t effective = effs[k];
+                if (imu_prior && effective < DoF) continue;
+                const float score = scores[k];
+                if (score > scoreMax || (score == scoreMax && effective > inlier_count)) {
+                    scoreMax = score;
+                    out.model = models[k];
+                    inlier_count = effective;
+                    best_in_batch = (long)k;
+                    const double ratio = inlier_count / (double)size;
+                    const double N = K / std::log(1 - std::pow(ratio, 5));
+                    if (N < (double)iter_max) iter_max = (size_t)std::ceil(N);
+                }
+            }
+        if (best_in_batch >= 0) {
+            if (on_device) {
+                std::vector<uint8_t> m8(size);
+                std::vector<int32_t> bi(grid.nValidBins);
+                if (dev->fetch(dev->user, (int)best_in_batch, m8.data(), bi.data()) != RDVIO_OK) throw std::runtime_error("backend parsac_fetch failed");
+                out.inlier_mask.assign(m8.begin(), m8.end());
+                bestBinInliers.assign(bi.begin(), bi.end());
+            } else {
+                out.inlier_mask.swap(masks[(size_t)best_in_batch]);
+                bestBinInliers = bin_inl[(size_t)best_in_batch];
             }
         }
     }
@@ -495,7 +615,8 @@ ParsacResult<DoF, Model, SolveFn, ErrorFn> parsac_solve(size_t size, const std::
 
 // stereo.cpp:126-157
 inline M3 find_essential_matrix_parsac(const std::vector<V2> &p1, const std::vector<V2> &p2, std::vector<char> &mask, std::vector<float> &binConfidences,
-                                       double threshold = 1.0, double confidence = 0.999, size_t max_iteration = 1000, int seed = 0) {
+                                       double threshold = 1.0, double confidence = 0.999, size_t max_iteration = 1000, int seed = 0,
+                                       ParsacDeviceScorer *dev = nullptr) {
     const double t1 = 3.84;
     auto solve = [&](const std::array<size_t, 5> &s) {
         std::array<V2, 5> a, b;
@@ -505,7 +626,15 @@ inline M3 find_essential_matrix_parsac(const std::vector<V2> &p1, const std::vec
     auto err = [&](const M3 &E, size_t i) {
         return essential_geometric_error(E, p1[i], p2[i]) + essential_geometric_error(transpose(E), p2[i], p1[i]);
     };
-    auto res = parsac_solve<5, M3>(p1.size(), p2, 2.0 * t1 * threshold * threshold, confidence, max_iteration, seed, binConfidences, solve, err, M3{});
+    std::vector<double> fa, fb;
+    if (dev) {
+        fa.resize(2 * p1.size());
+        fb.resize(2 * p2.size());
+        for (size_t i = 0; i < p1.size(); ++i) { fa[2 * i] = p1[i].x; fa[2 * i + 1] = p1[i].y; fb[2 * i] = p2[i].x; fb[2 * i + 1] = p2[i].y; }
+        dev->kind = 0; dev->pa = fa.data(); dev->pb = fb.data();
+    }
+    auto res = parsac_solve<5, M3>(p1.size(), p2, 2.0 * t1 * threshold * threshold, confidence, max_iteration, seed, binConfidences, solve, err, M3{},
+                                   1.0, (const M3 *)nullptr, nullptr, 0.0, dev);
     mask.swap(res.inlier_mask);
     return res.model;
 }
@@ -513,7 +642,8 @@ inline M3 find_essential_matrix_parsac(const std::vector<V2> &p1, const std::vec
 // pnp.h:167-206
 inline Pose4 find_pnp_matrix_parsac_imu(const std::vector<V3> &Xs, const std::vector<V2> &xs, const std::vector<size_t> &lens, const M3 &R, const V3 &t,
                                         double dynamic_prob, double scale, std::vector<char> &mask, std::vector<float> &binConfidences,
-                                        double threshold = 1.0, double confidence = 0.999, size_t max_iteration = 1000, int seed = 0) {
+                                        double threshold = 1.0, double confidence = 0.999, size_t max_iteration = 1000, int seed = 0,
+                                        ParsacDeviceScorer *dev = nullptr) {
     const double t2 = 5.99;
     auto solve = [&](const std::array<size_t, 6> &s) {
         std::array<V3, 6> a;
@@ -523,8 +653,15 @@ inline Pose4 find_pnp_matrix_parsac_imu(const std::vector<V3> &Xs, const std::ve
     };
     auto err = [&](const Pose4 &T, size_t i) { return pnp_reproject_error(T, Xs[i], xs[i]); };
     const Pose4 prior{R, t};
+    std::vector<double> fa, fb;
+    if (dev) {
+        fa.resize(3 * Xs.size());
+        fb.resize(2 * xs.size());
+        for (size_t i = 0; i < Xs.size(); ++i) { fa[3 * i] = Xs[i].x; fa[3 * i + 1] = Xs[i].y; fa[3 * i + 2] = Xs[i].z; fb[2 * i] = xs[i].x; fb[2 * i + 1] = xs[i].y; }
+        dev->kind = 1; dev->pa = fa.data(); dev->pb = fb.data();
+    }
     auto res = parsac_solve<6, Pose4>(Xs.size(), xs, 2.0 * t2 * threshold * threshold, confidence, max_iteration, seed, binConfidences, solve, err,
-                                      Pose4{}, scale, &prior, &lens, dynamic_prob);
+                                      Pose4{}, scale, &prior, &lens, dynamic_prob, dev);
     mask.swap(res.inlier_mask);
     return res.model;
 }

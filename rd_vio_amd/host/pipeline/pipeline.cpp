@@ -825,7 +825,9 @@ bool SlidingWindowTracker::filter_parsac_2d2d(Frame *frame_i, Frame *frame_j, st
             }
         }
     if (pts1.size() < 10) return false;
-    (void)find_essential_matrix_parsac(pts1, pts2, mask, sh.essential_bin_confidences, m_th / frame_i->K[0]);
+    ParsacDeviceScorer dev{sh.backend.fn.parsac_score, sh.backend.fn.parsac_fetch, sh.backend.fn.user};
+    (void)find_essential_matrix_parsac(pts1, pts2, mask, sh.essential_bin_confidences, m_th / frame_i->K[0], 0.999, 1000, 0,
+                                       sh.backend.fn.parsac_score ? &dev : nullptr);
     return true;
 }
 
@@ -854,7 +856,9 @@ bool SlidingWindowTracker::judge_track_status() {
     std::vector<char> mask;
     const M3 Rcw = to_mat(conj(pose.q));
     const V3 tcw = -(Rcw * pose.p);
-    (void)find_pnp_matrix_parsac_imu(P3D, P2D, lens, Rcw, tcw, 0.20, 1.0, mask, sh.pnp_bin_confidences, 1.0 / curr_frame->K[0]);
+    ParsacDeviceScorer dev{sh.backend.fn.parsac_score, sh.backend.fn.parsac_fetch, sh.backend.fn.user};
+    (void)find_pnp_matrix_parsac_imu(P3D, P2D, lens, Rcw, tcw, 0.20, 1.0, mask, sh.pnp_bin_confidences, 1.0 / curr_frame->K[0], 0.999, 1000, 0,
+                                     sh.backend.fn.parsac_score ? &dev : nullptr);
     mask.resize(P2D.size(), 0);
     sh.counters.parsac_judgements++;
 

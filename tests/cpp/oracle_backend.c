@@ -135,4 +135,6 @@ void rdvio_oracle_backend_fill(rdvio_backend *b) {
     b->marginalize = ob_marginalize;
     b->last_error = ob_last_error;
     b->destroy = NULL;
+    b->parsac_score = NULL; /* the CPU path scores hypotheses with the orchestration's own host code (parsac.hpp) */
+    b->parsac_fetch = NULL;
 }

@@ -55,3 +55,29 @@ def test_odometry_mirror_runs_on_gpu():
     out = subprocess.run([ODO_EXE], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.startswith("OK")
+
+
+PARSAC_SRC = os.path.join(ROOT, "tests", "cpp", "parsac_device_test.cpp")
+PARSAC_EXE = os.path.join(ROOT, "tests", "cpp", "parsac_device_test.bin")
+
+
+def _compile_parsac():
+    rbuild.build()
+    libdir = os.path.join(ROOT, "rd_vio_amd")
+    # -ffp-contract=off like librdvio_pipeline.so: the host scoring must round exactly like the device kernel
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-ffp-contract=off", "-o", PARSAC_EXE, PARSAC_SRC, "-L", libdir, "-lrdvio_hip",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
+
+
+def test_parsac_device_test_compiles_and_links():
+    _compile_parsac()
+    assert os.path.exists(PARSAC_EXE)
+
+
+@pytest.mark.gpu
+def test_parsac_device_scoring_matches_host_scoring():
+    """row N2: rdvio_hip_parsac_score / _fetch against the host road of parsac.hpp -- masks, models, bin confidences bit-identical"""
+    _compile_parsac()
+    out = subprocess.run([PARSAC_EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith("OK")
