@@ -44,9 +44,27 @@ def build_pipeline(force=False, verbose=False):
     return PIPE_LIB
 
 
+EUROC_EXE = os.path.join(HERE, "test_euroc")
+
+
+def build_test_euroc(force=False, verbose=False):
+    """rd_vio_amd/test_euroc: the C++ EuRoC replay (host/test_euroc.cpp; the reference's examples/test_euroc.cpp headless)"""
+    hdir = os.path.join(HERE, "host")
+    deps = [os.path.join(hdir, f) for f in ("test_euroc.cpp", "rdvio_odometry.hpp", "rdvio_yaml.hpp", "rdvio_png.hpp")] + [PIPE_LIB, LIB]
+    if not force and os.path.exists(EUROC_EXE) and all(os.path.getmtime(d) <= os.path.getmtime(EUROC_EXE) for d in deps):
+        return EUROC_EXE
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-Wextra", "-ffp-contract=off", "-o", EUROC_EXE, os.path.join(hdir, "test_euroc.cpp"),
+           "-L" + HERE, "-lrdvio_pipeline", "-lrdvio_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return EUROC_EXE
+
+
 def build(force=False, verbose=False):
     lib = _build_hip(force, verbose)
     build_pipeline(force, verbose)
+    build_test_euroc(force, verbose)
     return lib
 
 

@@ -17,12 +17,18 @@
 #include <vector>
 
 #include "../../include/rdvio_pipeline.h"
+#include "rdvio_yaml.hpp"
 
 namespace rdvio_hip {
 
 class Odometry {
   public:
-    // cfg: rdvio::Config values (rdvio_pipeline_config_default + calibration); the reference reads them from two YAML files
+    // rdvio::Odometry(calib, config) (rdvio.hpp:27-37): the sensor calibration file (configs/euroc_sensor.yaml) and the
+    // SLAM settings file (configs/setting.yaml), read like rdvio::extra::YamlConfig(config, calib) reads them; throws the
+    // Yaml*Exception kinds of rdvio_yaml.hpp for unreadable files, missing mandatory keys and wrongly typed values
+    Odometry(const std::string &calib, const std::string &config, int device = 0, int max_features = 4096, int max_factors = 40000)
+        : Odometry(load_yaml_config(config, calib), device, max_features, max_factors) {}
+    // cfg: rdvio::Config values (rdvio_pipeline_config_default + calibration) already in the pipeline's struct
     explicit Odometry(const rdvio_pipeline_config &cfg, int device = 0, int max_features = 4096, int max_factors = 40000) : cfg_(cfg) {
         int rc = rdvio_hip_ctx_create(&ctx_, device, cfg.width, cfg.height, max_features, cfg.sliding_window_size > 16 ? cfg.sliding_window_size : 16,
                                       max_factors, nullptr);

@@ -25,8 +25,12 @@ imu:
     cov_bg: [3.7608844899999997e-10, 0.0, 0.0, 0.0, 3.7608844899999997e-10, 0.0, 0.0, 0.0, 3.7608844899999997e-10]
     cov_ba: [9.0e-6, 0.0, 0.0, 0.0, 9.0e-6, 0.0, 0.0, 0.0, 9.0e-6]
 cam0:
-  resolution: [%d, %d]
-  intrinsics: [%r, %r, %r, %r]
+  resolution: [%d, %d]        # resolution of camera
+  camera_model: pinhole
+  intrinsics: [%r, %r, %r, %r] # fu, fv, cu, cv
+  camera_distortion_flag: 0
+  distortion: [0.0, 0.0, 0.0, 0.0] # k1, k2, p1, p2
+  time_offset: 0.0
   extrinsic:
     q_bc: [ -7.7071797555374275e-03, 1.0499323370587278e-02, 7.0175280029197162e-01, 7.1230146066895372e-01 ]
     p_bc: [ -0.0216401454975, -0.064676986768, 0.00981073058949 ]
@@ -134,3 +138,169 @@ def test_replay_tum_and_ate(mav, tmp_path):
     # ATE is invariant to a rigid motion of the estimate
     Rz = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]])
     assert abs(euroc.ate_rmse(traj[:, 1:4] @ Rz.T + [1, 2, 3], p_gt) - euroc.ate_rmse(traj[:, 1:4], p_gt)) < 1e-9
+
+
+# ------------------------------------------------------------------------------------------------ C++ boundary
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _yaml_tool():
+    import subprocess
+
+    exe = os.path.join(ROOT, "tests", "cpp", "yaml_config_test.bin")
+    src = os.path.join(ROOT, "tests", "cpp", "yaml_config_test.cpp")
+    libdir = os.path.join(ROOT, "rd_vio_amd")
+    from rd_vio_amd import build as rbuild
+
+    rbuild.build()
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-o", exe, src, "-L", libdir, "-lrdvio_pipeline", "-lrdvio_hip", f"-Wl,-rpath,{libdir}",
+                           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
+    return lambda config, calib: subprocess.run([exe, str(config), str(calib)], capture_output=True, text=True, timeout=60).stdout.strip()
+
+
+def test_cpp_yaml_loader_matches_the_python_mapping(mav):
+    """rdvio_hip::load_yaml_config (rd_vio_amd/host/rdvio_yaml.hpp; yaml_config.cpp:83-338 without yaml-cpp) against the Python
+    mapping of the same two files, field by field, incl. the defaults of rdvio::Config for keys the files omit."""
+    import json
+
+    d, *_ = mav
+    tool = _yaml_tool()
+    got = json.loads(tool(d / "setting.yaml", d / "sensor.yaml"))
+    lib = pu.load_pipeline_lib()
+    Kc, w, h, extr, noise, over = euroc.config_overrides(str(d / "sensor.yaml"), str(d / "setting.yaml"))
+    cfg = euroc.apply_overrides(pu.default_config(lib, Kc, w, h, extr, noise), over)
+    for name, v in got.items():
+        if name == "extras":
+            continue
+        want = getattr(cfg, name)
+        if isinstance(v, list):
+            assert list(want) == v, name
+        else:
+            assert want == v, (name, want, v)
+    assert got["sliding_window_size"] == 8 and got["feature_tracker_max_keypoint_detection"] == 150 and got["parsac_flag"] == 0
+    assert got["parsac_keyframe_check_size"] == 3 and got["feature_tracker_clahe_width"] == 8      # rdvio::Config defaults
+    assert got["extras"]["solver_time_limit"] == 1.0e6 and got["extras"]["camera_distortion_flag"] == 0
+
+
+def test_cpp_yaml_loader_reference_layout_and_errors(tmp_path):
+    """files laid out like configs/euroc_sensor.yaml / configs/setting.yaml (multi-line flow sequences, comments, unused keys,
+    a nested T_BS block, `true` / scientific notation) and the four exception kinds with the reference's messages
+    (yaml_config.h:10-27)."""
+    import json
+
+    tool = _yaml_tool()
+    sensor = tmp_path / "sensor.yaml"
+    setting = tmp_path / "setting.yaml"
+    sensor.write_text("""%YAML:1.0
+imu:
+  # inertial sensor noise model parameters (static)
+  gyroscope_noise_density: 0.01       # [ rad / s / sqrt(Hz) ]
+  accelerometer_bias: [0.0, 0.0, 0.0] # acc bias prior
+  extrinsic:
+    q_bi: [ 0.0, 0.0, 0.0, 1.0 ] # x y z w
+    p_bi: [ 0.0, 0.0, 0.0 ] # x y z [m]
+  noise:
+    cov_g: [
+      2.5e-08, 0.0, 0.0,
+      0.0, 2.5e-08, 0.0,
+      0.0, 0.0, 2.5e-08]
+    cov_a: [
+      4.0e-6, 0.0, 0.0,
+      0.0, 4.0e-6, 0.0,
+      0.0, 0.0, 4.0e-6]
+    cov_bg: [1e-10, 0, 0, 0, 1e-10, 0, 0, 0, 1e-10]
+    cov_ba: [9.0e-6, 0.0, 0.0, 0.0, 9.0e-6, 0.0, 0.0, 0.0, 9.0e-6]
+
+cam0:
+  # camera0 wrt. body frame
+  T_BS:
+    cols: 4
+    rows: 4
+    data: [1.0, 0.0, 0.0, 0.5,
+           0.0, 1.0, 0.0, 0.25,
+           0.0, 0.0, 1.0, 0.125,
+           0.0, 0.0, 0.0, 1.0]
+  resolution: [752, 480]        # resolution of camera
+  camera_model: pinhole         # camera model
+  intrinsics: [458.654, 457.296, 367.215, 248.375] # fu, fv, cu, cv
+  camera_distortion_flag: 1     # use distortion model or not
+  distortion: [-0.28, 0.07, 0.0002, 1.76e-05] # k1, k2, p1, p2, xi
+  time_offset: 0.0              # camera time delay wrt. IMU
+  extrinsic:
+    q_bc: [ 0.0, 0.0, 0.7071067811865476, 0.7071067811865476 ] # x y z w
+    p_bc: [ -0.02, -0.06, 0.01 ] # x y z [m]
+  noise: [
+    0.5, 0.0,
+    0.0, 0.5] # [pixel^2]
+""")
+    setting.write_text("""%YAML:1.0
+output:
+  q_bo: [ 0.0, 0.0, 0.0, 1.0 ] # x y z w
+  p_bo: [ 0.0, 0.0, 0.0 ] # x y z [m]
+
+sliding_window:
+  size: 12 # 10 by default
+  subframe_size: 5 # 3 by default
+
+feature_tracker:
+  max_keypoint_detection: 200
+  predict_keypoints: true
+  clahe_clip_limit: 6.0
+
+solver:
+  iteration_limit: 30
+  time_limit: 1.0e6 # [s]
+
+parsac:
+  parsac_flag: true
+  dynamic_probability: 0.15
+  keyframe_check_size: 1
+""")
+    got = json.loads(tool(setting, sensor))
+    assert (got["width"], got["height"]) == (752, 480) and got["K"] == [458.654, 0, 367.215, 0, 457.296, 248.375, 0, 0, 1]
+    assert got["gyroscope_noise_cov"][0] == 2.5e-08 and got["gyroscope_noise_cov"][8] == 2.5e-08 and got["gyroscope_bias_noise_cov"][4] == 1e-10
+    assert got["q_bc"][2] == 0.7071067811865476 and got["p_bc"] == [-0.02, -0.06, 0.01] and got["keypoint_noise_cov"] == [0.5, 0, 0, 0.5]
+    assert got["sliding_window_size"] == 12 and got["sliding_window_subframe_size"] == 5 and got["solver_iteration_limit"] == 30
+    assert got["parsac_flag"] == 1 and got["parsac_keyframe_check_size"] == 1 and got["extras"]["parsac_dynamic_probability"] == 0.15
+    assert got["extras"]["camera_distortion"][0] == -0.28 and got["extras"]["camera_distortion_flag"] == 1
+    assert got["sliding_window_force_keyframe_landmarks"] == 35 and got["initializer_keyframe_num"] == 8     # config.cpp defaults
+    # the four exception kinds
+    assert tool(setting, tmp_path / "nope.yaml") == f"EXCEPTION load: cannot load config {tmp_path / 'nope.yaml'}"
+    broken = tmp_path / "missing.yaml"
+    broken.write_text(sensor.read_text().replace("  intrinsics: [458.654, 457.296, 367.215, 248.375] # fu, fv, cu, cv\n", ""))
+    assert tool(setting, broken) == 'EXCEPTION missing: config "cam0.intrinsics" is mandatory'
+    broken.write_text(sensor.read_text().replace("[752, 480]", "[752, 480, 3]"))
+    assert tool(setting, broken) == 'EXCEPTION type: config "cam0.resolution" has wrong type'
+    bad_setting = tmp_path / "bad_setting.yaml"
+    bad_setting.write_text(setting.read_text().replace("size: 12", "size: [12]"))
+    assert tool(bad_setting, sensor) == 'EXCEPTION type: config "sliding_window.size" has wrong type'
+    bad_setting.write_text("sliding_window:\n    size: 3\n  subframe_size: 2\n")
+    assert tool(bad_setting, sensor).startswith("EXCEPTION parse:")
+
+
+@pytest.mark.gpu
+def test_cpp_test_euroc_matches_run_euroc(mav, tmp_path):
+    """rd_vio_amd/test_euroc (C++: rdvio_hip::Odometry(calib, config) + the mav0 reader of host/test_euroc.cpp, i.e. the
+    reference's examples/test_euroc.cpp loop) and scripts/run_euroc.py (Python harness) over the same synthetic mav0 tree:
+    the two TUM trajectory files must be identical byte for byte."""
+    import json
+    import subprocess
+    import sys
+
+    d, frames, ts, imu, gt = mav
+    exe = os.path.join(ROOT, "rd_vio_amd", "test_euroc")
+    assert os.path.exists(exe)
+    a = subprocess.run([exe, str(d), str(d / "sensor.yaml"), str(d / "setting.yaml"), "--out", str(tmp_path / "cpp.txt"), "--bootstrap-from-groundtruth"],
+                       capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0, a.stdout + a.stderr
+    rep = json.loads(a.stdout.strip().splitlines()[-1])
+    b = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_euroc.py"), str(d), "--sensor", str(d / "sensor.yaml"), "--setting",
+                        str(d / "setting.yaml"), "--out", str(tmp_path / "py.txt"), "--bootstrap-from-groundtruth"], capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stdout + b.stderr
+    rep_py = json.loads(b.stdout.strip().splitlines()[-1])
+    assert rep["frames"] == len(ts) and rep["poses"] == rep_py["poses"] >= 10 and rep["state"] == 1
+    assert (tmp_path / "cpp.txt").read_bytes() == (tmp_path / "py.txt").read_bytes()
+    assert rep_py["ate_rmse_m"] < 0.05
+    # the constructor's failure modes surface as the reference's exception messages
+    c = subprocess.run([exe, str(d), str(d / "nope.yaml"), str(d / "setting.yaml")], capture_output=True, text=True, timeout=60)
+    assert c.returncode == 1 and "cannot load config" in c.stderr
