@@ -164,7 +164,7 @@ class EurocDataset:
             if np.dot(q0, q1) < 0:
                 q1 = -q1
             q = (1 - a) * q0 + a * q1
-            row[1:5] = q / np.linalg.norm(q)
+            row[1:5] = q / np.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3])   # (sequential sum: the C++ harness does the same)
             row[0] = t
             out[i] = row
         return out

@@ -9,7 +9,7 @@
 //
 // --bootstrap-from-groundtruth hands the ground-truth states of the first keyframes to the pipeline instead of running the
 // SfM / IMU-alignment stages (rdvio_pipeline_set_init_states); the Python harness scripts/run_euroc.py offers the same
-// switch, and both produce the same file byte for byte (tests/test_euroc_harness.py).
+// switch, and both produce the same trajectory to the file's 9 decimals (tests/test_euroc_harness.py).
 #include <algorithm>
 #include <chrono>
 #include <cmath>
