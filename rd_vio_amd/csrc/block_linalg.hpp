@@ -21,9 +21,7 @@ struct BlockShared {
     double vec[16];
     int flag;
     int lost;  // set when a helper workgroup did not answer in time (solver)
-    int seq;
-    int cflag[4];          // wave-level hand-off counters of the pipelined LDS Cholesky
-    double rinv2[2][16];   // reciprocal pivots of the diagonal block, double-buffered by block parity  // command sequence number of the helper-workgroup protocol (solver)
+    int seq;  // command sequence number of the helper-workgroup protocol (solver)
     // small per-problem index tables (solver): frame -> free column block, column block -> prior frame, preintegration sources
     // per frame (up to RDVIO_SOLVER_MAX_FRAMES = 64, most of them constant anchors) / per free column block (<= 32)
     int fcol[64], pcol[32], band_src[32 * 6], g_src[32 * 2];
@@ -619,195 +617,6 @@ __device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_doub
         }
         __syncthreads();
     }
-    __syncthreads();
-    // inverses of the diagonal blocks: column c of L_kk^-1 by forward substitution, one thread per (block, column)
-    for (int o = t; want_dinv && o < nb * 15; o += T) {
-        const int kb = o / 15, c = o - 15 * kb;
-        double x[15];
-#pragma unroll
-        for (int r = 0; r < 15; ++r) {
-            const lds_double *Lr = Lp + tri(15 * kb + r) + 15 * kb;
-            double s = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-            for (int q = 0; q < 15; ++q)
-                if (q < r) s = __builtin_fma(-Lr[q], x[q], s);
-            x[r] = (r >= c) ? s / Lr[r] : 0.0;
-        }
-#pragma unroll
-        for (int r = 0; r < 15; ++r) Dinv[225 * kb + 15 * r + c] = x[r];
-    }
-    __syncthreads();
-    return sh.flag;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Pipelined LDS Cholesky (same packed layout, same extra right-hand-side row, same results up to rounding order of the
-// MFMA trailing products).  The blocked factorisation above is bounded by its dependent chain -- 15 pivots per diagonal
-// block, then the panel, then the trailing update, two workgroup barriers per block column -- while most of the
-// workgroup waits.  Here the chain gets a wavefront of its own and nobody waits on a workgroup barrier:
-//   wavefront 0      diag block k  ->  panel rows of block row k+1 only (15 rows)  ->  the one trailing 15 x 15 block that
-//                    becomes diag block k+1  ->  diag block k+1 ...   (everything the next pivot depends on, nothing else)
-//   wavefronts 1..7  for every block column: the rest of the panel, then all other trailing blocks.
-// Hand-offs are monotone counters in LDS (release / acquire at workgroup scope, s_sleep polling); every wavefront runs
-// the same number of trips, every counter value waited for is eventually published, so the waits always end:
-//   cflag[0]  diag blocks factored (+ reciprocal pivots in rinv2[k & 1])         written by wavefront 0
-//   cflag[1]  panel rows of block row k+1 written for block columns < value      written by wavefront 0
-//   cflag[2]  arrivals at the barriers among wavefronts 1..7 (two per block column: panel done, trailing done)
-// Trailing blocks are 15 x 15 (one MFMA tile each, K = 15), so block ownership and tile ownership coincide.
-// ---------------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) int lds_int;
-DM void lds_wait_ge(lds_int *p, int v) {
-    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-DM void lds_publish(lds_int *p, int v) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if ((threadIdx.x & 63) == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-DM void lds_arrive(lds_int *p) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// row i of the panel behind diagonal block k0: x L_kk^T = row (forward substitution with reciprocal pivots)
-DM void cholesky_panel_row(lds_double *Lp, int k0, int i, const lds_double *rinv) {
-    lds_double *row = Lp + tri(i) + k0;
-    double x[15];
-#pragma unroll
-    for (int c = 0; c < 15; ++c) x[c] = row[c];
-#pragma unroll
-    for (int c = 0; c < 15; ++c) {
-        const lds_double *Lc = Lp + tri(k0 + c) + k0;
-        double s = x[c];
-#pragma unroll
-        for (int q = 0; q < 15; ++q)
-            if (q < c) s = __builtin_fma(-x[q], Lc[q], s);
-        x[c] = s * rinv[c];
-    }
-#pragma unroll
-    for (int c = 0; c < 15; ++c) row[c] = x[c];
-}
-
-// diagonal block at k0 in the registers of one wavefront (see cholesky_diag_block); reciprocal pivots to rinv[0..14]
-template <int T>
-DM void cholesky_diag_block_p(LdsShared<T> &sh, lds_double *Lp, int k0, double tol, lds_double *rinv) {
-    const int lane = threadIdx.x & 63;
-    const int r = lane < 15 ? lane : 14;
-    const lds_double *row = Lp + tri(k0 + r) + k0;
-    double a[15];
-#pragma unroll
-    for (int c = 0; c < 15; ++c) a[c] = (lane < 15 && c <= lane) ? row[c] : 0.0;
-    bool bad = false;
-    double piv = readlane_d(a[0], 0);
-#pragma unroll
-    for (int j = 0; j < 15; ++j) {
-        if (!(piv > tol) || !isfinite(piv)) bad = true;
-        const double rs = rsqrt_nr(piv);
-        const double lj = (lane == j) ? piv * rs : a[j] * rs;
-        a[j] = lj;
-        if (lane == j) rinv[j] = rs;
-        if (j + 1 < 15) {
-            a[j + 1] = __builtin_fma(-lj, readlane_d(lj, j + 1), a[j + 1]);
-            piv = readlane_d(a[j + 1], j + 1);
-        }
-        if (j + 2 < 15) {
-            if (lane < 16) sh.blk[16 * j + lane] = lj;
-#pragma unroll
-            for (int c = j + 2; c < 15; ++c) a[c] = __builtin_fma(-lj, sh.blk[16 * j + c], a[c]);
-        }
-    }
-    if (bad && lane == 0) sh.flag = 0;
-    if (lane < 15) {
-        lds_double *wrow = Lp + tri(k0 + lane) + k0;
-#pragma unroll
-        for (int c = 0; c < 15; ++c)
-            if (c <= lane) wrow[c] = a[c];
-    }
-}
-
-// one lower 15 x 15 block (bi, bj) of the trailing update C -= P P^T behind block column k0 (NR rows in the triangle)
-DM void cholesky_trailing_block15(lds_double *Lp, int k0, int NR, int bi, int bj) {
-    const int lane = threadIdx.x & 63;
-    const int i = lane & 15, kk = lane >> 4;
-    const int ra = k0 + 15 + 15 * bi + i, rb = k0 + 15 + 15 * bj + i;
-    const bool va = i < 15 && ra < NR, vb = i < 15 && rb < NR;
-    const lds_double *pa = Lp + tri(va ? ra : NR - 1) + k0, *pb = Lp + tri(vb ? rb : NR - 1) + k0;
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int q = 4 * u + kk;
-        const double av = (va && q < 15) ? pa[q] : 0.0, bv = (vb && q < 15) ? pb[q] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-    }
-    const int cl = lane & 15, col = k0 + 15 + 15 * bj + cl;
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-        const int rl = (lane >> 4) + 4 * r4, rowi = k0 + 15 + 15 * bi + rl;
-        if (rl < 15 && cl < 15 && rowi < NR && col <= rowi) Lp[tri(rowi) + col] -= acc[r4];
-    }
-}
-
-// the chain wavefront and the other wavefronts as separate out-of-line functions: each keeps (and saves) only its own
-// registers -- in one body the prologue saved a hundred callee-saved VGPRs on the chain wavefront's critical path
-template <int T>
-__device__ __attribute__((noinline)) void cholesky_chain_wave(LdsShared<T> &sh, lds_double *Lp, int N, double tol) {
-    constexpr int NO = T / 64 - 1;
-    const int lane = threadIdx.x & 63, nb = N / 15, NR = N + 1;
-    lds_int *f_diag = (lds_int *)&sh.cflag[0], *f_panel = (lds_int *)&sh.cflag[1], *f_arr = (lds_int *)&sh.cflag[2];
-    if (nb > 0) {
-        cholesky_diag_block_p<T>(sh, Lp, 0, tol, (lds_double *)&sh.rinv2[0][0]);
-        lds_publish(f_diag, 1);
-    }
-    for (int kb = 0; kb < nb; ++kb) {
-        const int k0 = 15 * kb;
-        // the rows read below carry the trailing updates of block column kb - 1: barrier 2 kb of the other wavefronts
-        lds_wait_ge(f_arr, NO * 2 * kb);
-        const int i = k0 + 15 + lane;
-        if (lane < 15 && i < NR) cholesky_panel_row(Lp, k0, i, (const lds_double *)&sh.rinv2[kb & 1][0]);
-        lds_publish(f_panel, kb + 1);
-        if (kb + 1 < nb) {
-            cholesky_trailing_block15(Lp, k0, NR, 0, 0);
-            cholesky_diag_block_p<T>(sh, Lp, k0 + 15, tol, (lds_double *)&sh.rinv2[(kb + 1) & 1][0]);
-            lds_publish(f_diag, kb + 2);
-        }
-    }
-}
-template <int T>
-__device__ __attribute__((noinline)) void cholesky_other_waves(LdsShared<T> &sh, lds_double *Lp, int N) {
-    constexpr int NO = T / 64 - 1;
-    const int t = threadIdx.x, wave = t >> 6, nb = N / 15, NR = N + 1;
-    lds_int *f_diag = (lds_int *)&sh.cflag[0], *f_panel = (lds_int *)&sh.cflag[1], *f_arr = (lds_int *)&sh.cflag[2];
-    const int ot = t - 64;  // 0 .. 64 NO - 1
-    for (int kb = 0; kb < nb; ++kb) {
-        const int k0 = 15 * kb;
-        lds_wait_ge(f_diag, kb + 1);
-        lds_wait_ge(f_arr, NO * 2 * kb);   // trailing updates of block column kb - 1 complete on every wavefront
-        for (int i = k0 + 30 + ot; i < NR; i += 64 * NO) cholesky_panel_row(Lp, k0, i, (const lds_double *)&sh.rinv2[kb & 1][0]);
-        lds_arrive(f_arr);
-        lds_wait_ge(f_arr, NO * (2 * kb + 1));
-        lds_wait_ge(f_panel, kb + 1);      // block row 0 of the panel comes from wavefront 0
-        const int rem = NR - (k0 + 15), nbr = (rem + 14) / 15;
-        int idx = 0;
-        for (int bi = 1; bi < nbr; ++bi)
-            for (int bj = 0; bj <= bi; ++bj, ++idx)
-                if (idx % NO == wave - 1) cholesky_trailing_block15(Lp, k0, NR, bi, bj);
-        lds_arrive(f_arr);
-    }
-}
-
-template <int T>
-__device__ __attribute__((noinline)) int cholesky_lds_pipelined(LdsShared<T> &sh, lds_double *Lp, lds_double *Dinv, int N, double tol = 0.0,
-                                                                bool want_dinv = true) {
-    static_assert(T / 64 >= 3, "needs the chain wavefront and at least two others");
-    const int t = threadIdx.x, wave = t >> 6;
-    const int nb = N / 15;
-    if (t == 0) {
-        sh.flag = 1;
-        sh.cflag[0] = sh.cflag[1] = sh.cflag[2] = 0;
-    }
-    __syncthreads();
-    if (wave == 0) cholesky_chain_wave<T>(sh, Lp, N, tol);
-    else cholesky_other_waves<T>(sh, Lp, N);
     __syncthreads();
     // inverses of the diagonal blocks: column c of L_kk^-1 by forward substitution, one thread per (block, column)
     for (int o = t; want_dinv && o < nb * 15; o += T) {

@@ -1603,9 +1603,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     schur_reduce(wl, sh, RDVIO_LDS(lds_chol_buf), LDS_CAP, mu, prof_last);
                     STAMP(4);
                     int ok = 1;
-                    if (N > 0)
-                        ok = !w.lds_chol ? cholesky_blocked(sh, w.Sm, N)
-                                         : (w.chol_serial ? cholesky_lds(sh, RDVIO_LDS(Sl), RDVIO_LDS(Dinv), N) : cholesky_lds_pipelined(sh, RDVIO_LDS(Sl), RDVIO_LDS(Dinv), N));
+                    if (N > 0) ok = w.lds_chol ? cholesky_lds(sh, RDVIO_LDS(Sl), RDVIO_LDS(Dinv), N) : cholesky_blocked(sh, w.Sm, N);
                     STAMP(5);
                     if (ok && N > 0) {
                         if (w.lds_chol) cholesky_solve_lds(sh, RDVIO_LDS(Sl), RDVIO_LDS(Dinv), N, w.yp);
@@ -1748,7 +1746,5 @@ void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w0) {
     w.mute_helpers = (mh && mh[0] == '1') ? 1 : 0;
     const char *pl = getenv("RDVIO_TEST_POISON_LDS");
     w.poison_lds = (pl && pl[0] == '1') ? 1 : 0;
-    const char *cs = getenv("RDVIO_CHOL_SERIAL");
-    w.chol_serial = (cs && cs[0] == '1') ? 1 : 0;
     hipLaunchKernelGGL(ba_solve_kernel, dim3(w.n_wg > 1 ? w.n_wg : 1), dim3(T), 0, stream, w);
 }
