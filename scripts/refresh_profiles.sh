@@ -23,7 +23,11 @@ cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_all.csv
 python $R/bench.py > $O/bench.json 2> $O/bench.err
 echo "bench done"
-python $R/bench.py --config synthetic_720p --no-cpu-baseline --steps 30 --warmup 5 > $O/bench_synthetic_720p.json 2>> $O/bench.err
-python $R/bench.py --config euroc_mh03_rd --no-cpu-baseline --steps 50 --warmup 5 > $O/bench_euroc_mh03_rd.json 2>> $O/bench.err
+# configs 3 and 5 WITH the CPU legs: feature_indices_identical / ate_rmse_gpu_vs_cpu_path_mm exist for every config
+python $R/bench.py --config synthetic_720p --steps 30 --warmup 5 > $O/bench_synthetic_720p.json 2>> $O/bench.err
+echo "720p done"
+python $R/bench.py --config euroc_mh03_rd --steps 50 --warmup 5 > $O/bench_euroc_mh03_rd.json 2>> $O/bench.err
+echo "mh03 done"
+python $R/bench.py --serial --no-cpu-baseline --end-to-end-frames 0 > $O/bench_serial.json 2>> $O/bench.err
 python $R/bench.py --no-cpu-baseline --end-to-end-frames 400 --steps 50 --warmup 5 > $O/bench_long_400_frames.json 2>> $O/bench.err
 echo "all done"
