@@ -39,6 +39,7 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
     __shared__ unsigned char state[RDVIO_SEL_NC_MAX];       //  8 KB: 0 undecided, 1 accepted, 2 rejected
     __shared__ int coff[RDVIO_SEL_GCELLS_MAX + 1];          // 16 KB: first clist entry of a cell
     __shared__ int ccur[RDVIO_SEL_GCELLS_MAX];              // 16 KB: per-cell counters / fill cursors
+    __shared__ unsigned short cx_[RDVIO_SEL_NC_MAX], cy_[RDVIO_SEL_NC_MAX];  // 32 KB: pixel coordinates by rank (decoded once)
     __shared__ int wsum[ST / 64];
     __shared__ int s_flag, s_total;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -46,10 +47,10 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell, ncell = gw * gh;
     if (t == 0) {
         hdr[0] = nc;
-        hdr[1] = (nc > RDVIO_SEL_NC_MAX || ncell > RDVIO_SEL_GCELLS_MAX || max_corners > RDVIO_SEL_CORNERS_MAX) ? 1 : 0;  // beyond capacity: host road
+        hdr[1] = (nc > RDVIO_SEL_NC_MAX || ncell > RDVIO_SEL_GCELLS_MAX || max_corners > RDVIO_SEL_CORNERS_MAX || w > 65535 || h > 65535) ? 1 : 0;  // host road
         hdr[2] = 0;
     }
-    if (nc > RDVIO_SEL_NC_MAX || ncell > RDVIO_SEL_GCELLS_MAX || max_corners > RDVIO_SEL_CORNERS_MAX) return;
+    if (nc > RDVIO_SEL_NC_MAX || ncell > RDVIO_SEL_GCELLS_MAX || max_corners > RDVIO_SEL_CORNERS_MAX || w > 65535 || h > 65535) return;
     // ---- sort (bitonic, descending).  Keys are unique (the pixel index is part of them), padding keys (0) sink to the end.
     int P = 2;
     while (P < nc) P <<= 1;
@@ -80,6 +81,8 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
     for (int i = t; i < nc; i += ST) {
         const int idx = (int)(uint32_t)keys[i];
         const int y = idx / w, x = idx - y * w;
+        cx_[i] = (unsigned short)x;
+        cy_[i] = (unsigned short)y;
         atomicAdd(&ccur[(y / cell) * gw + x / cell], 1);
     }
     __syncthreads();
@@ -116,8 +119,7 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
     if (t == 0) s_total = 0;
     __syncthreads();
     for (int i = t; i < nc; i += ST) {
-        const int idx = (int)(uint32_t)keys[i];
-        const int y = idx / w, x = idx - y * w, c = (y / cell) * gw + x / cell;
+        const int x = cx_[i], y = cy_[i], c = (y / cell) * gw + x / cell;
         clist[coff[c] + atomicAdd(&ccur[c], 1)] = (unsigned short)i;
     }
     __syncthreads();
@@ -128,9 +130,8 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
         const bool mine = i < nc;
         int x = 0, y = 0;
         if (mine) {
-            const int idx = (int)(uint32_t)keys[i];
-            y = idx / w;
-            x = idx - y * w;
+            x = cx_[i];
+            y = cy_[i];
         }
         const int xc = x / cell, yc = y / cell;
         const int x1 = max(0, xc - 1), y1 = max(0, yc - 1), x2 = min(gw - 1, xc + 1), y2 = min(gh - 1, yc + 1);
@@ -146,9 +147,7 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
                         for (int e = coff[cc]; e < coff[cc + 1]; ++e) {
                             const int j = clist[e];
                             if (j >= i) continue;
-                            const int jdx = (int)(uint32_t)keys[j];
-                            const int jy = jdx / w, jx = jdx - jy * w;
-                            const float dx = (float)x - (float)jx, dy = (float)y - (float)jy;
+                            const float dx = (float)x - (float)cx_[j], dy = (float)y - (float)cy_[j];
                             if (!(dx * dx + dy * dy < md2)) continue;
                             const int sj = state[j];
                             if (sj == 1) {
@@ -191,7 +190,8 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
 // existing: n_existing x 2 doubles; corners: hdr[2] x 2 floats (response order); new_out: accepted corners inside the
 // border, in order; hdr[3] = their count; hdr[1] |= 2 when the grid or the point table would not fit (host road).
 __global__ __launch_bounds__(256) void poisson_filter_kernel(const double *__restrict__ existing, int n_existing, const float *__restrict__ corners,
-                                                            int w, int h, double radius, double *__restrict__ new_out, int32_t *__restrict__ hdr) {
+                                                            int w, int h, double radius, double gftt_md2, double *__restrict__ new_out,
+                                                            int32_t *__restrict__ hdr) {
     __shared__ int grid[RDVIO_SEL_PGRID_MAX];                                  // 88 KB: point index per cell or -1
     __shared__ __attribute__((aligned(16))) double pts[2 * RDVIO_SEL_PTS_MAX];  // 64 KB
     const int t = threadIdx.x;
@@ -216,26 +216,58 @@ __global__ __launch_bounds__(256) void poisson_filter_kernel(const double *__res
         // a preset further out than the margin can never be visited from a corner inside the image
         if (fx >= -M && fy >= -M && fx < gx - M && fy < gy - M) atomicMax(&grid[((int)fy + M) * gx + (int)fx + M], i);
     }
+    // cell coordinates of every corner (two double divisions each) in parallel, ahead of the sequential pass
+    __shared__ short ccx[RDVIO_SEL_CORNERS_MAX], ccy[RDVIO_SEL_CORNERS_MAX];
+    __shared__ unsigned char keep[RDVIO_SEL_CORNERS_MAX];
+    for (int k = t; k < ncorn; k += 256) {
+        ccx[k] = (short)(int)floor((double)corners[2 * k] / cellp);
+        ccy[k] = (short)(int)floor((double)corners[2 * k + 1] / cellp);
+    }
     __syncthreads();
+    // does corner (x, y) in cell (cx, cy) conflict with a resident point of the grid?  the reference's walk over the block
+    // [cx-2, cx+2] x [cy-2, cy+2]: it steps BEFORE it looks, so it never visits (cx-2, cy-2) and ends on (cx-2, cy+3)
+    auto conflict_at = [&](double x, double y, int cx, int cy, int pos) {
+        const int vx = cx - 2 + pos % 5, vy = cy - 2 + pos / 5;
+        const int ax = vx + M, ay = vy + M;
+        if (ax < 0 || ay < 0 || ax >= gx || ay >= gy) return false;
+        const int p = grid[ay * gx + ax];
+        if (p < 0) return false;
+        const double dx = x - pts[2 * p], dy = y - pts[2 * p + 1];
+        return dx * dx + dy * dy < r2;
+    };
+    if (gftt_md2 >= r2) {
+        // The corners are at least minDistance apart, so with radius <= minDistance no accepted corner can reject another
+        // one (their distance is never < radius) and an accepted corner never lands in an occupied cell: every insert
+        // only depends on the presets -- decided in parallel, one corner per thread, order restored by a prefix count.
+        for (int k = t; k < ncorn; k += 256) {
+            const double x = (double)corners[2 * k], y = (double)corners[2 * k + 1];
+            bool c = false;
+            for (int pos = 1; pos <= 25 && !c; ++pos) c = conflict_at(x, y, ccx[k], ccy[k], pos);
+            keep[k] = (!c && !(x < 20 || y < 20 || x >= w - 20 || y >= h - 20)) ? 1 : 0;
+        }
+        __syncthreads();
+        if (t >= 64) return;
+        int total = 0;
+        for (int base = 0; base < ncorn; base += 64) {
+            const int k = base + t;
+            const bool kp = k < ncorn && keep[k];
+            const unsigned long long bal = __ballot(kp);
+            if (kp) {
+                const int o = total + __popcll(bal & ((1ull << t) - 1ull));
+                new_out[2 * o] = (double)corners[2 * k];
+                new_out[2 * o + 1] = (double)corners[2 * k + 1];
+            }
+            total += __popcll(bal);
+        }
+        if (t == 0) hdr[3] = total;
+        return;
+    }
     if (t >= 64) return;
     int npts = n_existing, total = 0;
     for (int k = 0; k < ncorn; ++k) {
         const double x = (double)corners[2 * k], y = (double)corners[2 * k + 1];
-        const int cx = (int)floor(x / cellp), cy = (int)floor(y / cellp);
-        // the reference's walk over the block [cx-2, cx+2] x [cy-2, cy+2]: it steps BEFORE it looks, so it never visits
-        // the first cell (cx-2, cy-2) and ends on (cx-2, cy+3)
-        bool conflict = false;
-        if (t < 25) {
-            const int pos = t + 1, vx = cx - 2 + pos % 5, vy = cy - 2 + pos / 5;
-            const int ax = vx + M, ay = vy + M;
-            if (ax >= 0 && ay >= 0 && ax < gx && ay < gy) {
-                const int p = grid[ay * gx + ax];
-                if (p >= 0) {
-                    const double dx = x - pts[2 * p], dy = y - pts[2 * p + 1];
-                    conflict = dx * dx + dy * dy < r2;
-                }
-            }
-        }
+        const int cx = ccx[k], cy = ccy[k];
+        const bool conflict = t < 25 && conflict_at(x, y, cx, cy, t + 1);
         if (__ballot(conflict) != 0ull) continue;
         if (t == 0) {
             grid[(cy + M) * gx + cx + M] = npts;
@@ -264,7 +296,7 @@ int rdvio_launch_select(rdvio_hip_ctx *ctx, int slot, int max_corners, double gf
     hipLaunchKernelGGL(gftt_select_kernel, dim3(1), dim3(ST), 0, ctx->stream, ctx->harris_cand, ctx->harris_scalars, ctx->harris_cand_cap, S.w,
                        S.h, max_corners, cell, md2, ctx->sel_corners, ctx->sel_hdr);
     hipLaunchKernelGGL(poisson_filter_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->sel_existing, n_existing, ctx->sel_corners, S.w, S.h,
-                       poisson_radius, ctx->sel_new, ctx->sel_hdr);
+                       poisson_radius, gftt_min_dist >= 1 ? gftt_min_dist * gftt_min_dist : 0.0, ctx->sel_new, ctx->sel_hdr);
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
     return RDVIO_OK;
 }
