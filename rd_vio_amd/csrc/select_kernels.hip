@@ -10,9 +10,10 @@
 //                         candidate unless an ALREADY ACCEPTED corner is closer than minDistance"), but its result is the
 //                         lexicographically-first maximal independent set of the "closer than minDistance" graph in
 //                         priority order, which has a parallel fixed-point form: a candidate is rejected as soon as one
-//                         higher-priority neighbour is accepted and accepted as soon as all of them are rejected.  Rounds of
-//                         that rule over chunks of 1024 candidates in priority order (a chunk only depends on earlier ones)
-//                         reproduce the sequential loop exactly, including the stop at maxCorners accepted.
+//                         higher-priority neighbour is accepted and accepted as soon as all of them are rejected.  Every
+//                         candidate of a chunk of 1024 (in priority order; a chunk only depends on earlier ones) polls its
+//                         handful of higher-priority neighbours until that rule fires: the sequential loop's result exactly,
+//                         including the stop at maxCorners accepted.
 //   poisson_filter_kernel PoissonDiskFilter<2>::preset_points / insert_points, kept literally: ONE point index per grid
 //                         cell (a later preset overwrites an earlier one in the same cell), the reference's neighbourhood
 //                         walk that skips the first cell of the 5x5 block and visits one cell past its end
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
     __shared__ int ccur[RDVIO_SEL_GCELLS_MAX];              // 16 KB: per-cell counters / fill cursors
     __shared__ unsigned short cx_[RDVIO_SEL_NC_MAX], cy_[RDVIO_SEL_NC_MAX];  // 32 KB: pixel coordinates by rank (decoded once)
     __shared__ int wsum[ST / 64];
-    __shared__ int s_flag, s_total;
+    __shared__ int s_total;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int nc = (int)min(scalars[1], (uint32_t)cap);
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell, ncell = gw * gh;
@@ -135,35 +136,70 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
         }
         const int xc = x / cell, yc = y / cell;
         const int x1 = max(0, xc - 1), y1 = max(0, yc - 1), x2 = min(gw - 1, xc + 1), y2 = min(gh - 1, yc + 1);
-        for (;;) {
-            __syncthreads();
-            if (t == 0) s_flag = 0;
-            __syncthreads();
-            if (mine && state[i] == 0) {
-                bool any_acc = false, any_und = false;
-                for (int yy = y1; yy <= y2 && !any_acc; ++yy)
-                    for (int xx = x1; xx <= x2 && !any_acc; ++xx) {
-                        const int cc = yy * gw + xx;
-                        for (int e = coff[cc]; e < coff[cc + 1]; ++e) {
-                            const int j = clist[e];
-                            if (j >= i) continue;
-                            const float dx = (float)x - (float)cx_[j], dy = (float)y - (float)cy_[j];
-                            if (!(dx * dx + dy * dy < md2)) continue;
-                            const int sj = state[j];
-                            if (sj == 1) {
-                                any_acc = true;
-                                break;
-                            }
-                            if (sj == 0) any_und = true;
+        // higher-priority candidates closer than minDistance, collected once (typically a handful)
+        constexpr int NBMAX = 12;
+        int nb[NBMAX], nn = 0;
+        bool overflow = false;
+        if (mine)
+            for (int yy = y1; yy <= y2; ++yy)
+                for (int xx = x1; xx <= x2; ++xx) {
+                    const int cc = yy * gw + xx;
+                    for (int e = coff[cc]; e < coff[cc + 1]; ++e) {
+                        const int j = clist[e];
+                        if (j >= i) continue;
+                        const float dx = (float)x - (float)cx_[j], dy = (float)y - (float)cy_[j];
+                        if (!(dx * dx + dy * dy < md2)) continue;
+                        if (nn < NBMAX) {
+#pragma unroll
+                            for (int q = 0; q < NBMAX; ++q)
+                                if (q == nn) nb[q] = j;   // (static indices: the list stays in registers)
+                            ++nn;
+                        } else {
+                            overflow = true;
                         }
                     }
-                if (any_acc) state[i] = 2;
-                else if (!any_und) state[i] = 1;
-                else s_flag = 1;
+                }
+        // Resolution without rounds: a candidate only ever waits for higher-priority ones, so the highest-priority
+        // undecided candidate can always decide -- every thread polls its own neighbours (states only move from
+        // undecided to final) until its own state is final.  No barrier inside: all wavefronts keep running.
+        volatile unsigned char *vstate = state;
+        if (mine) {
+            for (;;) {
+                bool any_acc = false, any_und = false;
+#pragma unroll
+                for (int q = 0; q < NBMAX; ++q)
+                    if (q < nn) {
+                        const int sj = vstate[nb[q]];
+                        any_acc |= sj == 1;
+                        any_und |= sj == 0;
+                    }
+                if (overflow && !any_acc) {  // (rare: more than NBMAX close neighbours) the full walk
+                    for (int yy = y1; yy <= y2; ++yy)
+                        for (int xx = x1; xx <= x2; ++xx) {
+                            const int cc = yy * gw + xx;
+                            for (int e = coff[cc]; e < coff[cc + 1]; ++e) {
+                                const int j = clist[e];
+                                if (j >= i) continue;
+                                const float dx = (float)x - (float)cx_[j], dy = (float)y - (float)cy_[j];
+                                if (!(dx * dx + dy * dy < md2)) continue;
+                                const int sj = vstate[j];
+                                any_acc |= sj == 1;
+                                any_und |= sj == 0;
+                            }
+                        }
+                }
+                if (any_acc) {
+                    vstate[i] = 2;
+                    break;
+                }
+                if (!any_und) {
+                    vstate[i] = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
             }
-            __syncthreads();
-            if (!s_flag) break;
         }
+        __syncthreads();
         // accepted candidates of the chunk in rank order -> their positions in the corner list
         const bool acc = mine && state[i] == 1;
         const unsigned long long bal = __ballot(acc);
