@@ -42,7 +42,7 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
     __shared__ int ccur[RDVIO_SEL_GCELLS_MAX];              // 16 KB: per-cell counters / fill cursors
     __shared__ unsigned short cx_[RDVIO_SEL_NC_MAX], cy_[RDVIO_SEL_NC_MAX];  // 32 KB: pixel coordinates by rank (decoded once)
     __shared__ int wsum[ST / 64];
-    __shared__ int s_total;
+    __shared__ int s_total, s_fail;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int nc = (int)min(scalars[1], (uint32_t)cap);
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell, ncell = gw * gh;
@@ -117,7 +117,10 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
     }
     __syncthreads();
     for (int i = t; i < ncell; i += ST) ccur[i] = 0;
-    if (t == 0) s_total = 0;
+    if (t == 0) {
+        s_total = 0;
+        s_fail = 0;
+    }
     __syncthreads();
     for (int i = t; i < nc; i += ST) {
         const int x = cx_[i], y = cy_[i], c = (y / cell) * gw + x / cell;
@@ -159,12 +162,18 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
                         }
                     }
                 }
-        // Resolution without rounds: a candidate only ever waits for higher-priority ones, so the highest-priority
-        // undecided candidate can always decide -- every thread polls its own neighbours (states only move from
-        // undecided to final) until its own state is final.  No barrier inside: all wavefronts keep running.
-        volatile unsigned char *vstate = state;
-        if (mine) {
-            for (;;) {
+        // Resolution by polling: a candidate only ever waits for higher-priority ones, so the highest-priority undecided
+        // candidate can always decide.  Every thread polls its own neighbours (states only move from undecided to final).
+        // The loop is WAVE-UNIFORM (it runs until every lane of the wavefront is done) and the state is stored inside its
+        // body: a divergent `store; break` would be moved behind the loop by the compiler's control-flow structurisation,
+        // i.e. published only when the whole wavefront has left the loop -- a lane waiting for another lane of its own
+        // wavefront would then wait forever.  The trip count is bounded; running out of trips hands the frame to the host road.
+        typedef volatile __attribute__((address_space(3))) unsigned char lds_vu8;  // (volatile AND LDS-typed: ds_read / ds_write, re-read every trip)
+        lds_vu8 *vstate = (lds_vu8 *)state;
+        bool done = !mine;
+        int trips = 0;
+        while (__ballot(!done) != 0ull) {
+            if (!done) {
                 bool any_acc = false, any_und = false;
 #pragma unroll
                 for (int q = 0; q < NBMAX; ++q)
@@ -188,18 +197,22 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
                             }
                         }
                 }
-                if (any_acc) {
-                    vstate[i] = 2;
-                    break;
+                if (any_acc || !any_und) {
+                    vstate[i] = any_acc ? 2 : 1;
+                    done = true;
                 }
-                if (!any_und) {
-                    vstate[i] = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
             }
+            if (++trips > 200000) {  // (never reached by a consistent candidate list: ~0.1 s of polling)
+                if (!done) s_fail = 1;
+                done = true;
+            }
+            __builtin_amdgcn_s_sleep(1);
         }
         __syncthreads();
+        if (s_fail) {
+            if (t == 0) hdr[1] = 4;
+            return;
+        }
         // accepted candidates of the chunk in rank order -> their positions in the corner list
         const bool acc = mine && state[i] == 1;
         const unsigned long long bal = __ballot(acc);
