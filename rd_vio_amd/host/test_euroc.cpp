@@ -233,8 +233,19 @@ int main(int argc, char **argv) {
             std::fprintf(fo, "\n");
         }
         std::fclose(fo);
-        std::printf("{\"frames\": %ld, \"poses\": %zu, \"pipeline_seconds\": %.3f, \"state\": %d, \"trajectory\": \"%s\"}\n", n_img, traj.size(), spent,
-                    vio.state(), out_path.c_str());
+        // Odometry::local_map (rdvio.hpp:91-97): the window's valid triangulated landmarks with R_imu_to_cv = [1 0 0; 0 0 -1; 0 1 0]
+        // applied; the C entry point returns them in the world frame, the mirror class applies the swap
+        const std::vector<std::array<double, 3>> lm = vio.local_map();
+        std::vector<double> raw(3 * lm.size() + 3);
+        const int n_raw = rdvio_pipeline_local_map(vio.handle(), raw.data(), (int)lm.size());
+        bool swap_ok = n_raw == (int)lm.size();
+        for (size_t k = 0; swap_ok && k < lm.size(); ++k)
+            swap_ok = lm[k][0] == raw[3 * k] && lm[k][1] == -raw[3 * k + 2] && lm[k][2] == raw[3 * k + 1];
+        const std::array<double, 16> Twc = vio.transform_world_cam();
+        std::printf("{\"frames\": %ld, \"poses\": %zu, \"pipeline_seconds\": %.3f, \"state\": %d, \"local_map_points\": %zu, "
+                    "\"local_map_axis_swap_ok\": %s, \"transform_world_cam_last_row_ok\": %s, \"trajectory\": \"%s\"}\n",
+                    n_img, traj.size(), spent, vio.state(), lm.size(), swap_ok ? "true" : "false",
+                    (Twc[12] == 0 && Twc[13] == 0 && Twc[14] == 0 && Twc[15] == 1) ? "true" : "false", out_path.c_str());
     } catch (const std::exception &e) {
         std::fprintf(stderr, "test_euroc: %s\n", e.what());
         return 1;

@@ -300,6 +300,8 @@ def test_cpp_test_euroc_matches_run_euroc(mav, tmp_path):
     assert b.returncode == 0, b.stdout + b.stderr
     rep_py = json.loads(b.stdout.strip().splitlines()[-1])
     assert rep["frames"] == len(ts) and rep["poses"] == rep_py["poses"] >= 10 and rep["state"] == 1
+    # Odometry::local_map: landmarks of the window with the reference's axis swap applied by the mirror class (rdvio.hpp:91-97)
+    assert rep["local_map_points"] >= 20 and rep["local_map_axis_swap_ok"] and rep["transform_world_cam_last_row_ok"]
     ta, tb = np.loadtxt(str(tmp_path / "cpp.txt")), np.loadtxt(str(tmp_path / "py.txt"))
     assert ta.shape == tb.shape and (ta[:, 0] == tb[:, 0]).all()
     assert np.abs(ta - tb).max() <= 2.5e-9, np.abs(ta - tb).max()
