@@ -324,6 +324,92 @@ DM void block_gemm_tn_lds(double *__restrict__ C, int ldc, const lds_double *A, 
     else block_gemm_tn_g<T, const lds_double *, false>(C, ldc, A, lda, B, ldb, A, M, N, K, lower_only);
 }
 
+// C = A^T diag(w) A (lower tiles + a trailing extra column, like block_gemm_tn with lower_only) for an operand too large
+// for LDS as a whole: K is walked in chunks of rows that DO fit (A is row-major K x lda, so a chunk is one contiguous run of
+// memory: every thread keeps tens of coalesced loads in flight instead of one dependent L2 round trip per four rows of K),
+// every wavefront keeps the accumulators of its tiles in registers across the chunks.  Same MFMA sequence per tile as the
+// unstaged product (K ascending, four rows per instruction; chunks are multiples of four rows): bit-identical results.
+// lds: scratch of lds_cap doubles; M = rows of C, N = columns (M or M + 1), w = per-row weight (global, K entries).
+template <int T, int MAXT = 6>
+DM bool block_gemm_tn_chunked(double *__restrict__ C, int ldc, const double *__restrict__ A, int lda, const double *__restrict__ wgt, int M, int N,
+                              int K, lds_double *lds, size_t lds_cap) {
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, nw = T / 64;
+    const int tm = (M + 15) / 16, tn = (N + 15) / 16;
+    // this wavefront's tiles: walk the tile grid with the same skip rule as block_gemm_tn_g (strictly-upper tiles are
+    // skipped unless they belong to the trailing extra column)
+    int tbi[MAXT], tbj[MAXT], nt = 0, seen = 0;
+    for (int tile = 0; tile < tm * tn; ++tile) {
+        const int bi = tile / tn, bj = tile - bi * tn;
+        if (bj > bi && 16 * bj + 16 < N) continue;
+        if (seen++ % nw != wave) continue;
+        if (nt >= MAXT) return false;   // (uniform per wavefront count check; the caller sizes MAXT)
+#pragma unroll
+        for (int q = 0; q < MAXT; ++q)
+            if (q == nt) { tbi[q] = bi; tbj[q] = bj; }
+        ++nt;
+    }
+    double4_t acc[MAXT];
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
+    int kc = (int)(lds_cap / (size_t)(lda + 1));
+    kc &= ~3;
+    if (kc < 4) return false;
+    lds_double *As = lds, *ws = lds + (size_t)kc * lda;
+    const int i = lane & 15, kk = lane >> 4;
+    for (int k0 = 0; k0 < K; k0 += kc) {
+        const int kn = (K - k0 < kc) ? K - k0 : kc;
+        const double *src = A + (size_t)k0 * lda;
+        for (int o = t; o < kn * lda; o += T) As[o] = src[o];
+        for (int o = t; o < kn; o += T) ws[o] = wgt[k0 + o];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < MAXT; ++q) {
+            if (q < nt) {
+                const int m0 = 16 * tbi[q], n0 = 16 * tbj[q];
+                const bool am = (m0 + i) < M, bn = (n0 + i) < N;
+                const lds_double *ap = As + m0 + i, *bp = As + n0 + i;
+                double4_t a4 = acc[q];
+                int kq = 0;
+                for (; kq + 16 <= kn; kq += 16) {
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = kq + 4 * u + kk;
+                        av[u] = am ? ap[(size_t)k * lda] : 0.0;
+                        bv[u] = bn ? bp[(size_t)k * lda] : 0.0;
+                        av[u] *= ws[k];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], a4, 0, 0, 0);
+                }
+                for (; kq < kn; kq += 4) {
+                    const int k = kq + kk;
+                    double av = 0.0, bv = 0.0;
+                    if (k < kn) {
+                        av = am ? ap[(size_t)k * lda] : 0.0;
+                        bv = bn ? bp[(size_t)k * lda] : 0.0;
+                        av *= ws[k];
+                    }
+                    a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a4, 0, 0, 0);
+                }
+                acc[q] = a4;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q)
+        if (q < nt) {
+            const int col = 16 * tbj[q] + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * tbi[q] + (lane >> 4) + 4 * r;
+                if (row < M && col < N) C[(long)row * ldc + col] = acc[q][r];
+            }
+        }
+    return true;
+}
+
 // y[row] = sum_c Mx[row * ld + c] * x[c]  (+ add[row]) for row in [0, R): one wave per row, coalesced row reads.
 // Calls emit(row, value) on lane 0 of the owning wave.
 template <int T, class Emit>

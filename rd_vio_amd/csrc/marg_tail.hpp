@@ -252,7 +252,9 @@ __device__ __attribute__((noinline)) void marginalize_tail(LdsWs &w, LdsShared<T
             __syncthreads();
             block_gemm_tn_lds<T>(w.Cm, NAs, As, NAs, As, NAs, ws, true, NA, NA + 1, nl, true);
         } else {
-            block_gemm_tn<T>(w.Cm, NAs, w.A, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, true);
+            // (operand too large for LDS: staged a chunk of landmarks at a time; up to 8 x 5 = 40 tiles -- 32 free frames -- else the unstaged walk)
+            if (!block_gemm_tn_chunked<T>(w.Cm, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, lds, LDS_DOUBLES))
+                block_gemm_tn<T>(w.Cm, NAs, w.A, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, true);
         }
     }
     __syncthreads();

@@ -986,7 +986,9 @@ PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap
             __syncthreads();
             block_gemm_tn_lds<T>(w.Cm, NAs, As, NAs, As, NAs, ws, true, NA, NA + 1, nl, true);
         } else {
-            block_gemm_tn<T>(w.Cm, NAs, w.A, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, true);
+            // (operand too large for LDS: staged a chunk of landmarks at a time; up to 8 x 5 = 40 tiles -- 32 free frames -- else the unstaged walk)
+            if (!block_gemm_tn_chunked<T>(w.Cm, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, lds, lds_cap))
+                block_gemm_tn<T>(w.Cm, NAs, w.A, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, true);
         }
     }
     __syncthreads();
