@@ -330,7 +330,7 @@ DM void block_gemm_tn_lds(double *__restrict__ C, int ldc, const lds_double *A, 
 // every wavefront keeps the accumulators of its tiles in registers across the chunks.  Same MFMA sequence per tile as the
 // unstaged product (K ascending, four rows per instruction; chunks are multiples of four rows): bit-identical results.
 // lds: scratch of lds_cap doubles; M = rows of C, N = columns (M or M + 1), w = per-row weight (global, K entries).
-template <int T, int MAXT = 6>
+template <int T, int MAXT = 12>
 DM bool block_gemm_tn_chunked(double *__restrict__ C, int ldc, const double *__restrict__ A, int lda, const double *__restrict__ wgt, int M, int N,
                               int K, lds_double *lds, size_t lds_cap) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, nw = T / 64;
@@ -338,11 +338,18 @@ DM bool block_gemm_tn_chunked(double *__restrict__ C, int ldc, const double *__r
     // this wavefront's tiles: walk the tile grid with the same skip rule as block_gemm_tn_g (strictly-upper tiles are
     // skipped unless they belong to the trailing extra column)
     int tbi[MAXT], tbj[MAXT], nt = 0, seen = 0;
+    {   // workgroup-uniform capacity check BEFORE anything else: the chunk loop below contains barriers
+        int total = 0;
+        for (int tile = 0; tile < tm * tn; ++tile) {
+            const int bi = tile / tn, bj = tile - bi * tn;
+            if (!(bj > bi && 16 * bj + 16 < N)) ++total;
+        }
+        if ((total + nw - 1) / nw > MAXT) return false;
+    }
     for (int tile = 0; tile < tm * tn; ++tile) {
         const int bi = tile / tn, bj = tile - bi * tn;
         if (bj > bi && 16 * bj + 16 < N) continue;
         if (seen++ % nw != wave) continue;
-        if (nt >= MAXT) return false;   // (uniform per wavefront count check; the caller sizes MAXT)
 #pragma unroll
         for (int q = 0; q < MAXT; ++q)
             if (q == nt) { tbi[q] = bi; tbj[q] = bj; }
