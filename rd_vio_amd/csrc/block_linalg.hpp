@@ -40,6 +40,22 @@ using LdsShared = __attribute__((address_space(3))) BlockShared<T>;
 // a member array handed to an (inlined) routine that takes plain pointers: the cast folds away after inlining
 #define RDVIO_GEN(a) ((double *)(a))
 
+// dst[0..n) (LDS) = src[0..n) (global), all T threads, U loads per thread in flight.  The plain loop
+// `for (i = t; i < n; i += T) dst[i] = src[i]` compiles to load -> wait -> store per trip: one L2 round trip (~0.2 us) per
+// element and thread; batching makes a 16-element-per-thread copy two round trips instead of sixteen.
+template <int T, int U = 8>
+DM void stage_to_lds(lds_double *dst, const double *__restrict__ src, int n) {
+    const int t = threadIdx.x;
+    for (int o = t; o < n; o += T * U) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = (o + u * T < n) ? src[o + u * T] : 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (o + u * T < n) dst[o + u * T] = v[u];
+    }
+}
+
 // sum_i a[i * sa] * x[i * sx] with the loads of U iterations issued together (memory-level parallelism: a single
 // workgroup has little other latency hiding).  Summation order is fixed.
 template <int U = 8>
@@ -366,8 +382,8 @@ DM bool block_gemm_tn_chunked(double *__restrict__ C, int ldc, const double *__r
     for (int k0 = 0; k0 < K; k0 += kc) {
         const int kn = (K - k0 < kc) ? K - k0 : kc;
         const double *src = A + (size_t)k0 * lda;
-        for (int o = t; o < kn * lda; o += T) As[o] = src[o];
-        for (int o = t; o < kn; o += T) ws[o] = wgt[k0 + o];
+        stage_to_lds<T, 16>(As, src, kn * lda);
+        stage_to_lds<T, 1>(ws, wgt + k0, kn);
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < MAXT; ++q) {

@@ -247,7 +247,7 @@ __device__ __attribute__((noinline)) void marginalize_tail(LdsWs &w, LdsShared<T
         constexpr size_t LDS_DOUBLES = (size_t)(15 * RDVIO_LDS_CHOL_MAX_FRAMES) * (15 * RDVIO_LDS_CHOL_MAX_FRAMES + 1) / 2 + 225 * RDVIO_LDS_CHOL_MAX_FRAMES;
         if (w.lds_chol && (size_t)nl * NAs + nl <= LDS_DOUBLES) {
             lds_double *As = lds, *ws = lds + nl * NAs;
-            for (int i = t; i < nl * NAs; i += T) As[i] = w.A[i];
+            stage_to_lds<T, 16>(As, w.A, nl * NAs);
             for (int l = t; l < nl; l += T) ws[l] = w.lm_w[l];
             __syncthreads();
             block_gemm_tn_lds<T>(w.Cm, NAs, As, NAs, As, NAs, ws, true, NA, NA + 1, nl, true);

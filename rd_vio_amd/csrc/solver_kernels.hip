@@ -500,10 +500,16 @@ __device__ __attribute__((noinline)) void build_normal_equations(LdsWs &w, Share
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v[u] : 0.0, v[u], acc, 0, 0, 0);
         }
-        for (; it < n; it += 2) {
-            const int item = it + item_off;
-            const double v = (has && item < n) ? rec[RDVIO_REC_STRIDE * (size_t)item] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v : 0.0, v, acc, 0, 0, 0);
+        if (it < n) {  // the remainder as ONE masked trip of eight loads (a two-item loop here is one L2 round trip per MFMA)
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int item = it + 2 * u + item_off;
+                v[u] = (has && item < n) ? rec[RDVIO_REC_STRIDE * (size_t)item] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (it + 2 * u < n) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v[u] : 0.0, v[u], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[16 * ((lane >> 4) + 4 * r) + (lane & 15)] = acc[r];
@@ -876,7 +882,7 @@ __device__ __attribute__((noinline)) void solver_setup(LdsWs &w, Shared &sh, lds
         // first (one batch of coalesced loads): the K-loops of the GEMM and of S^T f then run at LDS latency.
         if ((size_t)D * D + D <= lds_cap) {
             lds_double *Sl = lds, *fl = Sl + D * D;
-            for (int o = t; o < D * D; o += T) Sl[o] = w.S[o];
+            stage_to_lds<T, 16>(Sl, w.S, D * D);
             for (int q = t; q < D; q += T) fl[q] = w.f[q];
             __syncthreads();
             for (int o = t; o < D * D; o += T) w.ST[o] = Sl[(o % D) * D + o / D];
@@ -981,7 +987,7 @@ PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap
     if (NA > 0 && has_lm) {
         if (w.lds_chol && (size_t)nl * NAs + nl <= lds_cap) {
             lds_double *As = lds, *ws = lds + nl * NAs;
-            for (int i = t; i < nl * NAs; i += T) As[i] = w.A[i];
+            stage_to_lds<T, 16>(As, w.A, nl * NAs);
             for (int l = t; l < nl; l += T) ws[l] = w.lm_w[l];
             __syncthreads();
             block_gemm_tn_lds<T>(w.Cm, NAs, As, NAs, As, NAs, ws, true, NA, NA + 1, nl, true);
