@@ -446,77 +446,132 @@ DM void block_matvec_rows(const double *__restrict__ Mx, int ld, int R, int C, c
     }
 }
 
-// blocked (15-wide) in-place Cholesky of the N x N matrix M (lower triangle), N a multiple of 15.
-// Diagonal block: LDS, first wave.  Panel: one thread per row.  Trailing update: MFMA tiles.
+// ---------------------------------------------------------------------------------------------------------
+// Global-memory blocked Cholesky (windows whose packed triangle does not fit LDS: more than RDVIO_LDS_CHOL_MAX_FRAMES free
+// frames, i.e. BASELINE config 5).  Every access to M is an L2 round trip (~0.2 us), so the routine is organised around
+// the number of DEPENDENT round trips, not around flops:
+//   * the diagonal block is staged into LDS (packed) and factored by the register routine of the LDS Cholesky
+//     (cholesky_diag_block: v_readlane pivots, no memory on the pivot chain);
+//   * the panel is one thread per row with its fifteen loads issued together;
+//   * the trailing update walks TWO 16 x 16 tiles per trip with all operand and target loads (24-32 per lane) in flight
+//     before the first MFMA -- one round trip per pair of tiles instead of five per tile;
+//   * optionally (NR = N + 1) the right-hand side rides along as row N of the matrix (ld stays N) and leaves the
+//     factorisation as L^-1 b: the forward substitution is free, as in the LDS version.
 // Returns 0 on a non-positive / non-finite pivot.
+// ---------------------------------------------------------------------------------------------------------
+DM int tri(int r) { return r * (r + 1) / 2; }
+
+
+// broadcast a double from a (wave-uniform) lane through SGPRs
+DM double readlane_d(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+// 1/sqrt(x) to full double precision: hardware estimate + two Newton steps (no FP64 divide / sqrt sequence)
+DM double rsqrt_nr(double x) {
+    // (explicit FMAs: the factorisation is not compared bit for bit with anything, and on the pivot chain -- which is
+    // instruction-issue bound -- a fused step is one instruction instead of two)
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);
+    y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);
+    return y;
+}
+
+template <int T> DM void cholesky_diag_block(LdsShared<T> &sh, lds_double *Lp, int k0, double tol);
+
+DM void cholesky_trailing_pair_global(double *__restrict__ M, int N, int NR, int k0, int bi0, int bj0, int bi1, int bj1, bool two) {
+    const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
+    const int base = k0 + 15;
+    const int ra[2] = {base + 16 * bi0 + i, base + 16 * bi1 + i}, rb[2] = {base + 16 * bj0 + i, base + 16 * bj1 + i};
+    double a[2][4], b[2][4], c[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const bool on = p == 0 || two;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = 4 * u + kk;
+            a[p][u] = (on && ra[p] < NR && q < 15) ? M[(size_t)ra[p] * N + k0 + q] : 0.0;
+            b[p][u] = (on && rb[p] < NR && q < 15) ? M[(size_t)rb[p] * N + k0 + q] : 0.0;
+        }
+        const int bi = p == 0 ? bi0 : bi1, bj = p == 0 ? bj0 : bj1;
+        const int col = base + 16 * bj + (lane & 15);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int row = base + 16 * bi + (lane >> 4) + 4 * r4;
+            c[p][r4] = (on && row < NR && col <= row && col < N) ? M[(size_t)row * N + col] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[p][u], b[p][u], acc, 0, 0, 0);
+        const bool on = p == 0 || two;
+        const int bi = p == 0 ? bi0 : bi1, bj = p == 0 ? bj0 : bj1;
+        const int col = base + 16 * bj + (lane & 15);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int row = base + 16 * bi + (lane >> 4) + 4 * r4;
+            if (on && row < NR && col <= row && col < N) M[(size_t)row * N + col] = c[p][r4] - acc[r4];
+        }
+    }
+}
+
 template <int T>
-__device__ __attribute__((noinline)) int cholesky_blocked(LdsShared<T> &sh, double *M, int N) {
-    const int t = threadIdx.x;
+__device__ __attribute__((noinline)) int cholesky_blocked(LdsShared<T> &sh, double *M, int N, int NR = -1) {
+    const int t = threadIdx.x, wave = t >> 6, nw = T / 64;
     const int nb = N / 15;
+    if (NR < 0) NR = N;
+    lds_double *Pk = RDVIO_LDS(sh.xv);   // the diagonal block, packed (entry (r, c) at tri(r) + c); xv is idle during a factorisation
     if (t == 0) sh.flag = 1;
     __syncthreads();
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = 15 * kb;
-        for (int i = t; i < 225; i += T) sh.blk[(i / 15) * 16 + (i % 15)] = M[(size_t)(k0 + i / 15) * N + k0 + (i % 15)];
-        __syncthreads();
-        if (t < 64) {
-            for (int j = 0; j < 15; ++j) {
-                double d = sh.blk[j * 16 + j];
-                if (!(d > 0.0) || !isfinite(d)) {
-                    if (t == 0) sh.flag = 0;
-                    d = 1.0;
-                }
-                d = sqrt(d);
-                __builtin_amdgcn_wave_barrier();
-                if (t == j) sh.blk[j * 16 + j] = d;
-                if (t > j && t < 15) sh.blk[t * 16 + j] /= d;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                for (int e = t; e < 225; e += 64) {
-                    const int r = e / 15, c = e - 15 * r;
-                    if (c > j && r >= c) sh.blk[r * 16 + c] -= sh.blk[r * 16 + j] * sh.blk[c * 16 + j];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
+        if (t < 225) {
+            const int r = t / 15, c = t - 15 * r;
+            if (c <= r) Pk[r * (r + 1) / 2 + c] = M[(size_t)(k0 + r) * N + k0 + c];
         }
         __syncthreads();
-        for (int i = t; i < 225; i += T) {
-            const int r = i / 15, c = i - 15 * r;
-            if (c <= r) M[(size_t)(k0 + r) * N + k0 + c] = sh.blk[r * 16 + c];
+        if (wave == 0) cholesky_diag_block<T>(sh, Pk, 0, 0.0);   // factor -> Pk, reciprocal pivots -> sh.vec, sh.flag on a bad pivot
+        __syncthreads();
+        if (t < 225) {
+            const int r = t / 15, c = t - 15 * r;
+            if (c <= r) M[(size_t)(k0 + r) * N + k0 + c] = Pk[r * (r + 1) / 2 + c];
         }
-        // panel below: row i solves x L_kk^T = M[i, k0:k0+15]
-        for (int i = k0 + 15 + t; i < N; i += T) {
+        // panel below (and the right-hand-side row): row i solves x L_kk^T = M[i, k0:k0+15]
+        for (int i = k0 + 15 + t; i < NR; i += T) {
             double x[15];
 #pragma unroll
+            for (int c = 0; c < 15; ++c) x[c] = M[(size_t)i * N + k0 + c];
+#pragma unroll
             for (int c = 0; c < 15; ++c) {
-                double s = M[(size_t)i * N + k0 + c];
+                double s = x[c];
 #pragma unroll
                 for (int q = 0; q < 15; ++q)
-                    if (q < c) s -= x[q] * sh.blk[c * 16 + q];
-                x[c] = s / sh.blk[c * 16 + c];
+                    if (q < c) s = __builtin_fma(-x[q], Pk[c * (c + 1) / 2 + q], s);
+                x[c] = s * sh.vec[c];
             }
 #pragma unroll
             for (int c = 0; c < 15; ++c) M[(size_t)i * N + k0 + c] = x[c];
         }
         __syncthreads();
-        // trailing update of the lower triangle: C[r][c] -= sum_q P[r][q] P[c][q], 16x16 MFMA tiles
-        const int rem = N - (k0 + 15);
-        if (rem > 0) {
-            const int wave = t >> 6, lane = t & 63, nw = T / 64;
-            const int tn = (rem + 15) / 16;
-            const double *P = M + (size_t)(k0 + 15) * N + k0;  // panel: rem x 15, row stride N
-            double *Cb = M + (size_t)(k0 + 15) * N + k0 + 15;
-            for (int tile = wave; tile < tn * tn; tile += nw) {
-                const int bi = tile / tn, bj = tile - bi * tn;
-                if (bj > bi) continue;
-                const double4_t acc = mfma_tile_f64(P, 1, N, P, 1, N, nullptr, 15, 16 * bi, 16 * bj, rem, rem);
-                const int col = 16 * bj + (lane & 15);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * bi + (lane >> 4) + 4 * r;
-                    if (row < rem && col <= row) Cb[(size_t)row * N + col] -= acc[r];
+        // trailing update of the lower triangle (and of the right-hand-side row): C[r][c] -= sum_q P[r][q] P[c][q]
+        const int rem = NR - (k0 + 15);
+        if (rem > 0 && k0 + 15 < N) {
+            const int tn = (rem + 15) / 16, ntile = tn * (tn + 1) / 2;
+            for (int p = 2 * wave; p < ntile; p += 2 * nw) {
+                int bi0 = 0;
+                while ((bi0 + 1) * (bi0 + 2) / 2 <= p) ++bi0;
+                const int bj0 = p - bi0 * (bi0 + 1) / 2;
+                const bool two = p + 1 < ntile;
+                int bi1 = bi0, bj1 = bj0 + 1;
+                if (bj1 > bi1) {
+                    ++bi1;
+                    bj1 = 0;
                 }
+                cholesky_trailing_pair_global(M, N, NR, k0, bi0, bj0, two ? bi1 : bi0, two ? bj1 : bj0, two);
             }
         }
         __syncthreads();
@@ -524,25 +579,53 @@ __device__ __attribute__((noinline)) int cholesky_blocked(LdsShared<T> &sh, doub
     return sh.flag;
 }
 
-// solve L L^T y = b in place (y overwrites b), blocked like the factorisation; the 15x15 diagonal block is
-// staged in LDS so the sequential triangular solve never waits on global memory
+// L_kk y = z (forward) or L_kk^T y = z (backward) for one 15 x 15 diagonal block staged in sh.blk (row r at 16 r), z in
+// sh.vec[0..14], on ONE wavefront with every operand in registers: lane r keeps row r (forward) or column r (backward) of the
+// block, the solved component travels through v_readlane -- fifteen short steps instead of a 105-term chain on one thread.
 template <int T>
-__device__ __attribute__((noinline)) void cholesky_solve(LdsShared<T> &sh, const double *M, int N, double *b, bool forward = true, bool backward = true) {
+DM void block_triangular_solve(LdsShared<T> &sh, bool forward) {
+    const int lane = threadIdx.x & 63, r = lane < 15 ? lane : 14;
+    double l[15], z = sh.vec[r];
+#pragma unroll
+    for (int c = 0; c < 15; ++c) l[c] = forward ? sh.blk[r * 16 + c] : sh.blk[c * 16 + r];   // row r / column r
+    double y = 0.0;
+    if (forward) {
+#pragma unroll
+        for (int c = 0; c < 15; ++c) {
+            const double yc = readlane_d(z, c) / readlane_d(l[c], c);   // z_c / L_cc (uniform)
+            if (lane == c) y = yc;
+            if (lane > c) z = __builtin_fma(-l[c], yc, z);
+        }
+    } else {
+#pragma unroll
+        for (int c = 14; c >= 0; --c) {
+            const double yc = readlane_d(z, c) / readlane_d(l[c], c);   // lane c's l[c] = L_cc in both layouts
+            if (lane == c) y = yc;
+            if (lane < c) z = __builtin_fma(-l[c], yc, z);             // column r, entry c: L[c][r]
+        }
+    }
+    if (lane < 15) sh.vec[lane] = y;
+}
+
+// solve L L^T y = b in place (y overwrites b), blocked like the factorisation; M's row stride is N.
+// rhs_row: b is first taken from row N of M, where cholesky_blocked(.., NR = N + 1) left L^-1 b -- then forward = false and
+// only the backward substitution runs.
+template <int T>
+__device__ __attribute__((noinline)) void cholesky_solve(LdsShared<T> &sh, const double *M, int N, double *b, bool forward = true, bool backward = true,
+                                                         bool rhs_row = false) {
     const int t = threadIdx.x;
     const int nb = N / 15;
+    if (rhs_row) {
+        for (int i = t; i < N; i += T) b[i] = M[(size_t)N * N + i];
+        __syncthreads();
+    }
     if (forward)
         for (int kb = 0; kb < nb; ++kb) {
             const int k0 = 15 * kb;
             for (int i = t; i < 225; i += T) sh.blk[(i / 15) * 16 + (i % 15)] = M[(size_t)(k0 + i / 15) * N + k0 + (i % 15)];
             if (t < 15) sh.vec[t] = b[k0 + t];
             __syncthreads();
-            if (t == 0) {
-                for (int c = 0; c < 15; ++c) {
-                    double s = sh.vec[c];
-                    for (int q = 0; q < c; ++q) s -= sh.blk[c * 16 + q] * sh.vec[q];
-                    sh.vec[c] = s / sh.blk[c * 16 + c];
-                }
-            }
+            if (t < 64) block_triangular_solve<T>(sh, true);
             __syncthreads();
             if (t < 15) b[k0 + t] = sh.vec[t];
             for (int i = k0 + 15 + t; i < N; i += T) {
@@ -559,13 +642,7 @@ __device__ __attribute__((noinline)) void cholesky_solve(LdsShared<T> &sh, const
             for (int i = t; i < 225; i += T) sh.blk[(i / 15) * 16 + (i % 15)] = M[(size_t)(k0 + i / 15) * N + k0 + (i % 15)];
             if (t < 15) sh.vec[t] = b[k0 + t];
             __syncthreads();
-            if (t == 0) {
-                for (int c = 14; c >= 0; --c) {
-                    double s = sh.vec[c];
-                    for (int q = c + 1; q < 15; ++q) s -= sh.blk[q * 16 + c] * sh.vec[q];
-                    sh.vec[c] = s / sh.blk[c * 16 + c];
-                }
-            }
+            if (t < 64) block_triangular_solve<T>(sh, false);
             __syncthreads();
             if (t < 15) b[k0 + t] = sh.vec[t];
             for (int i = t; i < k0; i += T) {
@@ -588,26 +665,6 @@ __device__ __attribute__((noinline)) void cholesky_solve(LdsShared<T> &sh, const
 // step is ~500 cycles (LDS bandwidth: N^3/6 entry updates x 4 LDS operations) instead of several L2 round trips.
 // Dinv receives the inverses of the 15 x 15 diagonal blocks of L so the triangular solves are small mat-vecs.
 // ---------------------------------------------------------------------------------------------------------
-DM int tri(int r) { return r * (r + 1) / 2; }
-
-
-// broadcast a double from a (wave-uniform) lane through SGPRs
-DM double readlane_d(double v, int src_lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-    return __hiloint2double(hi, lo);
-}
-// 1/sqrt(x) to full double precision: hardware estimate + two Newton steps (no FP64 divide / sqrt sequence)
-DM double rsqrt_nr(double x) {
-    // (explicit FMAs: the factorisation is not compared bit for bit with anything, and on the pivot chain -- which is
-    // instruction-issue bound -- a fused step is one instruction instead of two)
-    double y = __builtin_amdgcn_rsq(x);
-    const double h = 0.5 * x;
-    y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);
-    y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);
-    return y;
-}
-
 // Blocked (15-wide) right-looking Cholesky on the LDS-resident packed matrix.  Per block column:
 //   (1) the 15 x 15 diagonal block is factored by ONE wavefront entirely in registers: lane r holds row r, pivots and
 //       multipliers travel through v_readlane (no LDS round trips in the 15-step dependent chain);

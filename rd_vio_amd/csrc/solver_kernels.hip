@@ -1036,6 +1036,7 @@ PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap
         v *= w.sig_p[i];
         w.yp[i] = v;
         if (w.lds_chol) Sl[tri(N) + i] = v;  // right-hand-side row of the packed triangle
+        else w.Sm[(size_t)N * N + i] = v;   // ... or row N of the global-memory matrix (ld N)
     }
     __syncthreads();
 }
@@ -1611,11 +1612,11 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     schur_reduce(wl, sh, RDVIO_LDS(lds_chol_buf), LDS_CAP, mu, prof_last);
                     STAMP(4);
                     int ok = 1;
-                    if (N > 0) ok = w.lds_chol ? cholesky_lds(sh, RDVIO_LDS(Sl), RDVIO_LDS(Dinv), N) : cholesky_blocked(sh, w.Sm, N);
+                    if (N > 0) ok = w.lds_chol ? cholesky_lds(sh, RDVIO_LDS(Sl), RDVIO_LDS(Dinv), N) : cholesky_blocked(sh, w.Sm, N, N + 1);
                     STAMP(5);
                     if (ok && N > 0) {
                         if (w.lds_chol) cholesky_solve_lds(sh, RDVIO_LDS(Sl), RDVIO_LDS(Dinv), N, w.yp);
-                        else cholesky_solve(sh, w.Sm, N, w.yp);
+                        else cholesky_solve(sh, w.Sm, N, w.yp, false, true, true);   // (row N holds L^-1 b)
                     }
                     STAMP(6);
                     const bool fused = 3 * N <= RDVIO_SOLVER_XV;
