@@ -140,32 +140,47 @@ DM double linearize_factor(const WS &w, Shared &sh, int k, const double *states,
 #define RDVIO_SPIN_LIMIT 1000000
 enum { CMD_LIN = 1, CMD_CAND = 2, CMD_EXIT = 0x100 };
 
-DM unsigned sync_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
-DM void sync_store(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+// Hand-off forms (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"):
+//   producer: plain stores -> every storing wavefront's s_waitcnt vmcnt(0) -> workgroup barrier -> ONE lane's agent-scope
+//             release fence (L2 write-back) -> s_waitcnt vmcnt(0) -> relaxed agent-scope flag store;
+//   consumer: relaxed (L1-bypassing) polls by one lane -> ONE agent-scope acquire (invalidates this CU's L1) ->
+//             s_waitcnt vmcnt(0) -> workgroup barrier -> plain loads.
+// A cost-only answer has no payload but the 8-byte partial sum, which travels as an agent-scope store / load itself:
+// no fence at all on that path.  (Round 1 fenced from every thread on both sides and polled with acquire loads: ~8 us
+// per command round trip.)
+DM unsigned sync_poll(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DM void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // leader: publish a command (all earlier global writes of the workgroup become visible to the helpers)
 template <class WS>
 DM void post_command(const WS &w, Shared &sh, unsigned cmd) {
-    __threadfence();
+    vm_drain();
     __syncthreads();
     if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        vm_drain();
         __hip_atomic_store(w.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vm_drain();   // the counter is reset before any helper can see the command
         sh.seq += 1;
-        sync_store(w.sync, ((unsigned)sh.seq << 12) | cmd);
+        __hip_atomic_store(w.sync, ((unsigned)sh.seq << 12) | cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-// leader: wait for all helpers; returns the sum of their partial costs in workgroup order (NaN on timeout)
+// leader: wait for all helpers; returns the sum of their partial costs in workgroup order (NaN on timeout).
+// with_payload: the helpers also wrote linearisation records that this workgroup reads with plain loads afterwards.
 template <class WS>
-DM double collect_partials(const WS &w, Shared &sh) {
+DM double collect_partials(const WS &w, Shared &sh, bool with_payload) {
     const int G = w.n_wg - 1;
     if (threadIdx.x == 0) {
         int spins = 0;
-        while (sync_load(w.sync + 1) != (unsigned)G && ++spins < RDVIO_SPIN_LIMIT) __builtin_amdgcn_s_sleep(4);
+        while (sync_poll(w.sync + 1) != (unsigned)G && ++spins < RDVIO_SPIN_LIMIT) __builtin_amdgcn_s_sleep(4);
         sh.flag = spins < RDVIO_SPIN_LIMIT ? 1 : 0;
         if (spins >= RDVIO_SPIN_LIMIT) sh.lost = 1;  // the trust-region loop stops with FAILURE at its next check
+        if (with_payload) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            vm_drain();
+        }
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     double extra = 0.0;
     if (threadIdx.x == 0) {
         if (!sh.flag) extra = __builtin_nan("");
@@ -229,12 +244,13 @@ __device__ __attribute__((noinline)) void helper_loop(LdsWs &w, Shared &sh) {
         if (t == 0) {
             int spins = 0;
             unsigned s;
-            while ((s = sync_load(w.sync)) == seen && ++spins < RDVIO_SPIN_LIMIT) __builtin_amdgcn_s_sleep(4);
+            while ((s = sync_poll(w.sync)) == seen && ++spins < RDVIO_SPIN_LIMIT) __builtin_amdgcn_s_sleep(4);
             sh.flag = (s == seen) ? -1 : (int)s;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // one acquire per CU: the command's data is read with plain loads below
+            vm_drain();
         }
         __syncthreads();
         const int s = sh.flag;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (s < 0) return;  // the leader went silent
         seen = (unsigned)s;
         const unsigned cmd = seen & 0xfffu;
@@ -261,12 +277,19 @@ __device__ __attribute__((noinline)) void helper_loop(LdsWs &w, Shared &sh) {
             cost += rotation_factors<false>(w, sh, RDVIO_GEN(sh.st), extr, W, gid, P);
         }
         cost = block_sum(sh, cost, phase);
-        __threadfence();
-        __syncthreads();
+        if (cmd & CMD_LIN) {   // the linearisation records this workgroup wrote must reach memory before the answer does
+            vm_drain();
+            __syncthreads();
+            if (t == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                vm_drain();
+            }
+        }
         if (t == 0) {
-            w.partial[blockIdx.x] = cost;
-            __threadfence();
-            __hip_atomic_fetch_add(w.sync + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((unsigned long long *)(w.partial + blockIdx.x), (unsigned long long)__double_as_longlong(cost), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            vm_drain();   // the partial sum is at memory scope before the arrival is counted
+            __hip_atomic_fetch_add(w.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -431,7 +454,7 @@ __device__ __attribute__((noinline)) double evaluate(LdsWs &w, Shared &sh, int p
             }
         }
     }
-    if (w.n_wg > 1) cost += collect_partials(w, sh);  // (thread 0 carries the helpers' partial sums into the reduction)
+    if (w.n_wg > 1) cost += collect_partials(w, sh, LIN);  // (thread 0 carries the helpers' partial sums into the reduction)
     if (CAND) {
         double v2[2] = {cost, sn2};
         block_sum_n<T, 2>(sh, v2, phase);
