@@ -1120,10 +1120,12 @@ PHASE_FN void gauss_newton_norms(LdsWs &w, Shared &sh, int phase, double (&a3)[3
 // operand: 3 N <= 512): every landmark's coupling row is read once instead of twice, the pose vectors are staged once,
 // and the nine scalars share one reduction.  out = {|g|^2, |gn|^2, g.gn, q_uu, q_uv, q_vv, l_u, l_v}; returns > 0 when a
 // component of the solve is not finite.  Per-thread accumulation order is that of the three separate routines.
-PHASE_FN double gauss_newton_step_and_model(LdsWs &w, Shared &sh, int phase, double mu, double (&out)[8]) {
+PHASE_FN double gauss_newton_step_and_model(LdsWs &w, Shared &sh, lds_double *big, int phase, double mu, double (&out)[8]) {
     const int t = threadIdx.x;
     const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
-    double *y = RDVIO_GEN(sh.xv), *u = y + N, *v = y + 2 * N;
+    // the three staged pose vectors: sh.xv for windows whose 3 N doubles fit it, the idle LDS Cholesky buffer otherwise
+    // (those windows factor in global memory)
+    double *y = (3 * N <= RDVIO_SOLVER_XV) ? RDVIO_GEN(sh.xv) : RDVIO_GEN(big), *u = y + N, *v = y + 2 * N;
     double r[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // r[8]: count of non-finite components
     for (int i = t; i < N; i += T) {
         const double yp = w.yp[i], sg = w.sig_p[i], dg = w.diag_p[i], gr = w.grad_p[i];
@@ -1642,9 +1644,9 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                         else cholesky_solve(sh, w.Sm, N, w.yp, false, true, true);   // (row N holds L^-1 b)
                     }
                     STAMP(6);
-                    const bool fused = 3 * N <= RDVIO_SOLVER_XV;
+                    const bool fused = 3 * N <= RDVIO_SOLVER_XV || !w.lds_chol;   // (3 N <= 1440 doubles always fit the LDS buffer)
                     double pm[8];
-                    const double bad = !ok ? 0.0 : fused ? gauss_newton_step_and_model(wl, sh, phase, mu, pm) : back_substitute(wl, sh, phase, mu);
+                    const double bad = !ok ? 0.0 : fused ? gauss_newton_step_and_model(wl, sh, RDVIO_LDS(lds_chol_buf), phase, mu, pm) : back_substitute(wl, sh, phase, mu);
                     if (ok) phase ^= 1;  // (the phase function above ran one reduction)
                     if (!ok || bad > 0.0) {
                         mu *= 10.0;
