@@ -347,7 +347,7 @@ DM void block_gemm_tn_lds(double *__restrict__ C, int ldc, const lds_double *A, 
 // unstaged product (K ascending, four rows per instruction; chunks are multiples of four rows): bit-identical results.
 // lds: scratch of lds_cap doubles; M = rows of C, N = columns (M or M + 1), w = per-row weight (global, K entries).
 template <int T, int MAXT = 12>
-DM bool block_gemm_tn_chunked(double *__restrict__ C, int ldc, const double *__restrict__ A, int lda, const double *__restrict__ wgt, int M, int N,
+__device__ __attribute__((noinline)) bool block_gemm_tn_chunked(double *__restrict__ C, int ldc, const double *__restrict__ A, int lda, const double *__restrict__ wgt, int M, int N,
                               int K, lds_double *lds, size_t lds_cap) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, nw = T / 64;
     const int tm = (M + 15) / 16, tn = (N + 15) / 16;

@@ -124,7 +124,8 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
     {
         const size_t F = (size_t)max_factors, Lm = (size_t)max_factors, Nmax = 15 * (size_t)nfr, npre = (size_t)nfr + 8;
         size_t bytes = (1 << 16) + F * (520 + 3 * 26 * 8 + 12) + Lm * (192 + 48 * (size_t)nfr) + Nmax * Nmax * 8 * 7 + npre * 930 * 8 +
-                       npre * (RDVIO_PREINT_SIZE + 1400) * 8 + Nmax * 8 * 32;
+                       npre * (RDVIO_PREINT_SIZE + 1400) * 8 + Nmax * 8 * 32 +
+                       (size_t)RDVIO_MAX_SOLVER_WGS * (6 * (size_t)nfr + 2) * (6 * (size_t)nfr + 2) * 8;  // (per-workgroup partial Schur terms)
         bytes += bytes / 4;
         ctx->ba_arena_bytes = ctx->ba_host_bytes = bytes;
         for (int s = 0; s < RDVIO_BA_SLOTS; ++s) {

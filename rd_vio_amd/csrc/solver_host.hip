@@ -217,6 +217,8 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     const size_t s_em = dd(D), s_rm = dd(D), s_cm = dd(D), s_Jri = dd((size_t)np * 9), s_Lam = dd((size_t)D * D), s_eta0 = dd(D), s_le = dd(D), s_Ex = dd(D);
     const size_t s_H = dd((size_t)N * N), s_Sm = dd((size_t)(N + 1) * N), s_g = dd(N), s_yp = dd(N);  // Sm: + the right-hand-side row
     const size_t s_Cm = dd((size_t)(6 * nfree + 2) * (6 * nfree + 2));
+    const int n_wg = (!with_marg_tail && nf >= RDVIO_HELPER_MIN_FACTORS && ctx->solver_wgs > 1) ? ctx->solver_wgs : 1;
+    const size_t s_Cmp = dd(n_wg > 1 ? (size_t)n_wg * (6 * nfree + 2) * (6 * nfree + 2) : 1);
     const size_t s_lmm = dd(nl), s_lmg = dd(nl), s_lmw = dd(nl), s_A = dd((size_t)nl * (6 * nfree + 2)), s_yl = dd(nl);
     const size_t s_sigp = dd(N), s_sigl = dd(nl), s_dgp = dd(N), s_dgl = dd(nl), s_grp = dd(N), s_grl = dd(nl), s_gnp = dd(N), s_gnl = dd(nl), s_tp = dd(N), s_tl = dd(nl);
     // marginalisation tail (victim = frame 0): R = N - 15 retained rows
@@ -256,7 +258,7 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     w.fac = DP(s_fac); w.prec = DP(s_prec); w.GP = DP(s_GP); w.PP = DP(s_PP); w.Pg = DP(s_Pg); w.ST = DP(s_ST); w.r_r = DP(s_rr); w.Jro = DP(s_Jro);
     w.e_p = DP(s_ep); w.G = DP(s_G); w.r_p = DP(s_rp); w.c_p = DP(s_cp); w.Jp = DP(s_Jp);
     w.e_m = DP(s_em); w.r_m = DP(s_rm); w.c_m = DP(s_cm); w.Jri = DP(s_Jri); w.Lam = DP(s_Lam); w.eta0 = DP(s_eta0); w.le = DP(s_le); w.Ex = DP(s_Ex);
-    w.H = DP(s_H); w.Sm = DP(s_Sm); w.g = DP(s_g); w.yp = DP(s_yp); w.Cm = DP(s_Cm);
+    w.H = DP(s_H); w.Sm = DP(s_Sm); w.g = DP(s_g); w.yp = DP(s_yp); w.Cm = DP(s_Cm); w.Cmp = DP(s_Cmp);
     w.lm_m = DP(s_lmm); w.lm_g = DP(s_lmg); w.lm_w = DP(s_lmw); w.A = DP(s_A); w.yl = DP(s_yl);
     w.sig_p = DP(s_sigp); w.sig_l = DP(s_sigl); w.diag_p = DP(s_dgp); w.diag_l = DP(s_dgl); w.grad_p = DP(s_grp); w.grad_l = DP(s_grl);
     w.gn_p = DP(s_gnp); w.gn_l = DP(s_gnl); w.tp = DP(s_tp); w.tl = DP(s_tl);
@@ -265,7 +267,7 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     // helper workgroups: a command round trip costs ~8 us (L2 atomics, barriers, re-staging the states), one evaluation
     // of F factors on the leader alone ~F / 90 us -- measured break-even near 2000 factors; the marginalisation kernel
     // (a single linearisation) never uses them
-    w.n_wg = (!with_marg_tail && nf >= RDVIO_HELPER_MIN_FACTORS && ctx->solver_wgs > 1) ? ctx->solver_wgs : 1;
+    w.n_wg = n_wg;
     if (with_marg_tail) {
         w.no_loss = 1;
         w.m_Tm = DP(s_mTm); w.m_Lr = DP(s_mLr); w.m_er = DP(s_mer); w.m_Wk = DP(s_mWk); w.m_V = DP(s_mV); w.m_cs = DP(s_mcs);

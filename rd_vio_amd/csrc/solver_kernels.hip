@@ -128,7 +128,8 @@ DM double linearize_factor(const WS &w, Shared &sh, int k, const double *states,
 // with n_wg > 1 workgroups: workgroup 0 runs the trust-region loop, the others wait for "evaluate your share of the
 // factors" commands.  Protocol (all words in w.sync, agent-scope atomics):
 //   sync[0] (sequence number << 12) | command   (release-stored by the leader, acquire-polled by the helpers);
-//           command: bit 0 = with linearisation, bit 1 = candidate states (xc / xdc), 0x100 = exit
+//           command: bit 0 = with linearisation, bit 1 = candidate states (xc / xdc); 4 / 8 / 16 = this workgroup's share of
+//           the group products / the H blocks / the Schur product (normal equations of large windows); 0x100 = exit
 //   sync[1] completion counter                  (release-incremented by each helper, acquire-polled by the leader)
 // partial[g] is written with a plain store before the helper's release-increment and read with an atomic load (never
 // through the scalar cache).
@@ -138,7 +139,7 @@ DM double linearize_factor(const WS &w, Shared &sh, int k, const double *states,
 // co-resident (one per CU on an otherwise idle stream), which is what a <= 16-workgroup grid on 256 CUs gets.
 // ---------------------------------------------------------------------------------------------
 #define RDVIO_SPIN_LIMIT 1000000
-enum { CMD_LIN = 1, CMD_CAND = 2, CMD_EXIT = 0x100 };
+enum { CMD_LIN = 1, CMD_CAND = 2, CMD_PAIRS = 4, CMD_HBLK = 8, CMD_GEMM = 16, CMD_EXIT = 0x100 };
 
 // Hand-off forms (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"):
 //   producer: plain stores -> every storing wavefront's s_waitcnt vmcnt(0) -> workgroup barrier -> ONE lane's agent-scope
@@ -171,8 +172,8 @@ template <class WS>
 DM double collect_partials(const WS &w, Shared &sh, bool with_payload) {
     const int G = w.n_wg - 1;
     if (threadIdx.x == 0) {
-        int spins = 0;
-        while (sync_poll(w.sync + 1) != (unsigned)G && ++spins < RDVIO_SPIN_LIMIT) __builtin_amdgcn_s_sleep(4);
+        int spins = sh.lost ? RDVIO_SPIN_LIMIT : 0;   // (a helper already went silent: the solve is ending, do not wait again)
+        while (spins < RDVIO_SPIN_LIMIT && sync_poll(w.sync + 1) != (unsigned)G) { ++spins; __builtin_amdgcn_s_sleep(4); }
         sh.flag = spins < RDVIO_SPIN_LIMIT ? 1 : 0;
         if (spins >= RDVIO_SPIN_LIMIT) sh.lost = 1;  // the trust-region loop stops with FAILURE at its next check
         if (with_payload) {
@@ -233,8 +234,193 @@ DM double rotation_factors(const WS &w, Shared &sh, const double *states, const 
     return cost;
 }
 
+template <class WS>
+DM double prior_part(const WS &w, const Shared &sh, int pi, int a, int pj, int b) {
+    const int D = w.D;
+    if (a >= 3 && b >= 3) return w.Lam[(size_t)(15 * pi + a) * D + 15 * pj + b];
+    // rows {0,1,2} (a < 3) or {a}, columns {0,1,2} (b < 3) or {b}: fixed 3 x 3 trip counts with the unused terms masked, so
+    // that the (up to nine) loads are issued together instead of one per trip of a run-time loop; same summation order
+    double lam[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const bool valid = (a < 3 || i == 0) && (b < 3 || j == 0);
+            const int aa = a < 3 ? i : a, bb = b < 3 ? j : b;
+            lam[3 * i + j] = valid ? w.Lam[(size_t)(15 * pi + aa) * D + 15 * pj + bb] : 0.0;
+        }
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const bool valid = (a < 3 || i == 0) && (b < 3 || j == 0);
+            const int aa = a < 3 ? i : a, bb = b < 3 ? j : b;
+            if (valid) acc += prior_E(sh, pi, aa, a) * lam[3 * i + j] * prior_E(sh, pj, bb, b);
+        }
+    return acc;
+}
+
+// index of the frame pair (lo <= hi) in the host's enumeration
+DM int pair_id(int lo, int hi, int nfree) { return lo * nfree - lo * (lo - 1) / 2 + (hi - lo); }
+
+// per factor group, X^T X with X = [J_lo | J_hi | r] (2 n_g x 13) on the matrix cores, groups g0, g0 + gstride, ...
+// (one wavefront per group; lane l feeds A[i = l & 15][k] and B[k][j = l & 15] -- the same record element for i = j < 12 --,
+// k = (item, row))
+__device__ __attribute__((noinline)) void ne_pair_products(LdsWs &w, int g0, int gstride) {
+    const int lane = threadIdx.x & 63;
+    for (int g = g0; g < w.npairs; g += gstride) {
+        const int n = w.grp_off[g + 1] - w.grp_off[g];
+        double *out = w.GP + 256 * (size_t)g;
+        const int i = lane & 15, kk = lane >> 4;
+        const int item_off = kk >> 1, row = kk & 1;
+        // element of the record this lane supplies: i < 6: first[row][i]; 6 <= i < 12: second[row][i - 6]; i == 12: r[row]
+        const int eo = (i < 6) ? row * 6 + i : (i < 12 ? 12 + row * 6 + (i - 6) : 24 + row);
+        const bool has = i < 13;
+        const double *rec = w.prec + RDVIO_REC_STRIDE * (size_t)w.grp_off[g] + eo;
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        int it = 0;
+        for (; it + 16 <= n; it += 16) {  // 8 MFMAs (16 items) per trip, loads issued together
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = has ? rec[RDVIO_REC_STRIDE * (size_t)(it + 2 * u + item_off)] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v[u] : 0.0, v[u], acc, 0, 0, 0);
+        }
+        if (it < n) {  // the remainder as ONE masked trip of eight loads (a two-item loop here is one L2 round trip per MFMA)
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int item = it + 2 * u + item_off;
+                v[u] = (has && item < n) ? rec[RDVIO_REC_STRIDE * (size_t)item] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (it + 2 * u < n) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v[u] : 0.0, v[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[16 * ((lane >> 4) + 4 * r) + (lane & 15)] = acc[r];
+    }
+}
+
+// every entry of H, output-stationary: prior + preintegration band + reprojection groups.  One wavefront per 15 x 15 lower
+// block (block-level conditions are wave-uniform), four lane passes per block whose loads are independent and issued
+// together; wavefront p0 of pstride takes the lower blocks p0, p0 + 2 pstride, ... two at a time.
+__device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh, int p0, int pstride) {
+    const int lane = threadIdx.x & 63;
+    const int N = w.N, nfree = w.nfree;
+    auto block_entries = [&](int blk, double (&v)[4]) {
+        const int fi = blk / nfree, fj = blk - fi * nfree;
+        const int pi = sh.pcol[fi], pj = sh.pcol[fj];
+        const bool has_prior = pi >= 0 && pj >= 0;
+        const int which = fj - fi + 1;
+        const int src0 = (which >= 0 && which <= 2) ? sh.band_src[(fi * 3 + which) * 2] : -1;
+        const int src1 = (which >= 0 && which <= 2) ? sh.band_src[(fi * 3 + which) * 2 + 1] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = lane + 64 * u;
+            const int a = e / 15, b = e - 15 * a;
+            double acc = 0.0;
+            if (e < 225) {
+                if (has_prior && !((a < 6 && sh.pfixc[fi]) || (b < 6 && sh.pfixc[fj]))) acc += prior_part(w, sh, pi, a, pj, b);
+                if (src0 >= 0) acc += w.PP[900 * (size_t)(src0 >> 2) + 30 * (15 * ((src0 >> 1) & 1) + a) + 15 * (src0 & 1) + b];
+                if (src1 >= 0) acc += w.PP[900 * (size_t)(src1 >> 2) + 30 * (15 * ((src1 >> 1) & 1) + a) + 15 * (src1 & 1) + b];
+                if (a < 6 && b < 6) {
+                    if (fi == fj) {
+                        // the nfree group tiles that touch this frame, twelve loads in flight: one round trip covers a
+                        // window of up to 12 free frames (summed in f2 order)
+                        for (int f0 = 0; f0 < nfree; f0 += 12) {
+                            double gv[12];
+#pragma unroll
+                            for (int u4 = 0; u4 < 12; ++u4) {
+                                const int f2 = f0 + u4;
+                                const int lo = f2 < fi ? f2 : fi, hi = f2 < fi ? fi : f2;
+                                const int off = (fi == lo) ? 0 : 6;  // quadrant (lo,lo) or (hi,hi); the single group (f,f) uses (lo,lo)
+                                gv[u4] = f2 < nfree ? w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + off + b] : 0.0;
+                            }
+#pragma unroll
+                            for (int u4 = 0; u4 < 12; ++u4)
+                                if (f0 + u4 < nfree) acc += gv[u4];
+                        }
+                        if (a < 3 && b < 3)
+                            for (int k = 0; k < w.nrot; ++k)
+                                if (sh.fcol[w.rot_tgt[k]] == fi) acc += w.Jro[6 * k + a] * w.Jro[6 * k + b] + w.Jro[6 * k + 3 + a] * w.Jro[6 * k + 3 + b];
+                    } else if (fi < fj) {
+                        acc += w.GP[256 * (size_t)pair_id(fi, fj, nfree) + 16 * a + 6 + b];
+                    } else {
+                        acc += w.GP[256 * (size_t)pair_id(fj, fi, nfree) + 16 * b + 6 + a];
+                    }
+                }
+            }
+            v[u] = acc;
+        }
+    };
+    // H is symmetric: only the lower blocks are formed, an off-diagonal block is stored a second time transposed
+    // (the scattered stores cost nothing on the dependent path; forming the block again would be another trip)
+    auto block_store = [&](int blk, const double (&v)[4]) {
+        const int fi = blk / nfree, fj = blk - fi * nfree;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = lane + 64 * u;
+            if (e < 225) {
+                w.H[(size_t)(15 * fi + e / 15) * N + 15 * fj + e % 15] = v[u];
+                if (fi != fj) w.H[(size_t)(15 * fj + e % 15) * N + 15 * fi + e / 15] = v[u];
+            }
+        }
+    };
+    auto lower_block = [&](int p) {  // p-th lower block in row-major order -> fi * nfree + fj
+        int fi = 0;
+        while (tri(fi + 1) <= p) ++fi;
+        return fi * nfree + (p - tri(fi));
+    };
+    // two blocks per trip: their loads are independent, so twice as many are in flight per L2 round trip
+    const int n_lower = nfree * (nfree + 1) / 2;
+    for (int p = p0; p < n_lower; p += 2 * pstride) {
+        double v0[4], v1[4];
+        const bool two = p + pstride < n_lower;
+        const int b0 = lower_block(p), b1 = two ? lower_block(p + pstride) : 0;
+        block_entries(b0, v0);
+        if (two) block_entries(b1, v1);
+        block_store(b0, v0);
+        if (two) block_store(b1, v1);
+    }
+}
+
+// workgroup g's share of the Schur product [C | Cg] = A^T W [A | g] of a multi-workgroup launch: the landmarks are split
+// into n_wg runs (multiples of four rows: whole MFMA steps), every workgroup forms the product of ITS run -- one LDS-staged
+// chunk at config-5 size -- into its own partial w.Cmp[g]; the consumers (schur_cm) add the partials in workgroup order.
+__device__ __attribute__((noinline)) void schur_gemm_share(LdsWs &w, lds_double *lds, size_t lds_cap, int g) {
+    const int NA = 6 * w.nfree, NAs = NA + 2;
+    const int per = (((w.nl + w.n_wg - 1) / w.n_wg) + 3) & ~3;
+    const int k0 = g * per < w.nl ? g * per : w.nl, k1 = k0 + per < w.nl ? k0 + per : w.nl, K = k1 - k0;
+    double *C = w.Cmp + (size_t)g * NAs * NAs;
+    const double *A = w.A + (size_t)k0 * NAs;
+    if ((size_t)K * NAs + K <= lds_cap) {   // the whole run in one staged operand (config 5: 125 landmarks x 98 doubles)
+        lds_double *As = lds, *ws = lds + (size_t)K * NAs;
+        stage_to_lds<T, 16>(As, A, K * NAs);
+        stage_to_lds<T, 1>(ws, w.lm_w + k0, K);
+        __syncthreads();
+        block_gemm_tn_lds<T>(C, NAs, As, NAs, As, NAs, ws, true, NA, NA + 1, K, true);
+    } else if (!block_gemm_tn_chunked<T>(C, NAs, A, NAs, w.lm_w + k0, NA, NA + 1, K, lds, lds_cap)) {
+        block_gemm_tn<T>(C, NAs, A, NAs, A, NAs, w.lm_w + k0, NA, NA + 1, K, true);
+    }
+}
+// entry idx of the Schur product: one matrix, or the sum of the workgroups' partials (fixed order)
+template <class WS>
+DM double schur_cm(const WS &w, size_t idx, bool split, size_t stride) {
+    if (!split) return w.Cm[idx];
+    double v[RDVIO_MAX_SOLVER_WGS];
+#pragma unroll
+    for (int g = 0; g < RDVIO_MAX_SOLVER_WGS; ++g) v[g] = g < w.n_wg ? w.Cmp[g * stride + idx] : 0.0;
+    double acc = v[0];
+#pragma unroll
+    for (int g = 1; g < RDVIO_MAX_SOLVER_WGS; ++g)
+        if (g < w.n_wg) acc += v[g];
+    return acc;
+}
+
 // the helpers' side: serve evaluation commands until told to exit (or until the leader goes silent)
-__device__ __attribute__((noinline)) void helper_loop(LdsWs &w, Shared &sh) {
+__device__ __attribute__((noinline)) void helper_loop(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap) {
     const int t = threadIdx.x;
     constexpr int TFm = T - 64;
     const int P = TFm + (w.n_wg - 1) * T, gid = TFm + ((int)blockIdx.x - 1) * T + t;
@@ -255,13 +441,41 @@ __device__ __attribute__((noinline)) void helper_loop(LdsWs &w, Shared &sh) {
         seen = (unsigned)s;
         const unsigned cmd = seen & 0xfffu;
         if (cmd & CMD_EXIT) return;
+        if (cmd & (CMD_PAIRS | CMD_HBLK | CMD_GEMM)) {
+            // a share of the normal equations (the small tables were mirrored on the first command, an evaluation)
+            if (cmd & CMD_PAIRS) {
+                ne_pair_products(w, (int)blockIdx.x * NW + (t >> 6), w.n_wg * NW);
+            } else if (cmd & CMD_HBLK) {
+                for (int i = t; i < 9 * w.np; i += T) sh.Jri[i] = w.Jri[i];   // (the leader's linearisation left them in memory)
+                __syncthreads();
+                ne_h_blocks(w, sh, (int)blockIdx.x * NW + (t >> 6), w.n_wg * NW);
+            } else {
+                schur_gemm_share(w, lds, lds_cap, (int)blockIdx.x);
+            }
+            vm_drain();
+            __syncthreads();
+            if (t == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                vm_drain();
+                __hip_atomic_fetch_add(w.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            continue;
+        }
         const double *states = (cmd & CMD_CAND) ? w.xc : w.x, *invd = (cmd & CMD_CAND) ? w.xdc : w.xd;
         if ((seen >> 12) == 1) {  // first command: the leader's setup is complete, mirror the small tables
             for (int i = t; i < 64; i += T) {
                 sh.fcol[i] = (i < w.nfr) ? w.fcol[i] : -1;
                 sh.pfix[i] = (i < w.nfr && w.frame_fixed[i] == 2) ? 1 : 0;
+                if (i < 32) {
+                    sh.pcol[i] = (i < w.nfree) ? w.pcol[i] : -1;
+                    sh.pfixc[i] = 0;
+                }
             }
             for (int i = t; i < 18; i += T) sh.ext[i] = w.extr[i];
+            for (int i = t; i < w.nfree * 6; i += T) sh.band_src[i] = w.band_src[i];
+            __syncthreads();
+            for (int i = t; i < w.nfr; i += T)
+                if (w.fcol[i] >= 0) sh.pfixc[w.fcol[i]] = (w.frame_fixed[i] == 2) ? 1 : 0;
         }
         for (int i = t; i < w.nfr * 16; i += T) sh.st[i] = states[i];
         if (!(cmd & CMD_LIN))
@@ -375,7 +589,10 @@ __device__ __attribute__((noinline)) double evaluate(LdsWs &w, Shared &sh, int p
                 sh.xv[15 * i + a] = e15[a];
             }
             if (LIN)
-                for (int q = 0; q < 9; ++q) sh.Jri[9 * i + q] = Jri.m[q];
+                for (int q = 0; q < 9; ++q) {
+                    sh.Jri[9 * i + q] = Jri.m[q];
+                    if (w.n_wg > 1) w.Jri[9 * i + q] = Jri.m[q];   // (the helpers' share of the H blocks reads them)
+                }
         }
         // the residual-independent block groups of the preintegration Jacobians on lanes 16..63 of the same (last factor)
         // wavefront -- its threads carry the fewest reprojection factors -- while the last wavefront evaluates the residuals
@@ -470,73 +687,14 @@ __device__ __attribute__((noinline)) double evaluate(LdsWs &w, Shared &sh, int p
 // frame pair streaming that pair's contiguous records), landmark rows, per-factor preintegration products.
 // Phase 2: one output-stationary pass writes every H / g entry as prior + preintegration + reprojection part.
 // ---------------------------------------------------------------------------------------------
-template <class WS>
-DM double prior_part(const WS &w, const Shared &sh, int pi, int a, int pj, int b) {
-    const int D = w.D;
-    if (a >= 3 && b >= 3) return w.Lam[(size_t)(15 * pi + a) * D + 15 * pj + b];
-    // rows {0,1,2} (a < 3) or {a}, columns {0,1,2} (b < 3) or {b}: fixed 3 x 3 trip counts with the unused terms masked, so
-    // that the (up to nine) loads are issued together instead of one per trip of a run-time loop; same summation order
-    double lam[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const bool valid = (a < 3 || i == 0) && (b < 3 || j == 0);
-            const int aa = a < 3 ? i : a, bb = b < 3 ? j : b;
-            lam[3 * i + j] = valid ? w.Lam[(size_t)(15 * pi + aa) * D + 15 * pj + bb] : 0.0;
-        }
-    double acc = 0.0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const bool valid = (a < 3 || i == 0) && (b < 3 || j == 0);
-            const int aa = a < 3 ? i : a, bb = b < 3 ? j : b;
-            if (valid) acc += prior_E(sh, pi, aa, a) * lam[3 * i + j] * prior_E(sh, pj, bb, b);
-        }
-    return acc;
-}
-
-// index of the frame pair (lo <= hi) in the host's enumeration
-DM int pair_id(int lo, int hi, int nfree) { return lo * nfree - lo * (lo - 1) / 2 + (hi - lo); }
-
 __device__ __attribute__((noinline)) void build_normal_equations(LdsWs &w, Shared &sh, unsigned long long &prof_last) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int N = w.N, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
-    // ---- phase 1a: per factor group, X^T X with X = [J_lo | J_hi | r] (2 n_g x 13) on the matrix cores:
-    //      lane l feeds A[i = l & 15][k] and B[k][j = l & 15] (the same record element for i = j < 12), k = (item, row)
-    for (int g = wave; g < w.npairs; g += NW) {
-        const int n = w.grp_off[g + 1] - w.grp_off[g];
-        double *out = w.GP + 256 * (size_t)g;
-        const int i = lane & 15, kk = lane >> 4;
-        const int item_off = kk >> 1, row = kk & 1;
-        // element of the record this lane supplies: i < 6: first[row][i]; 6 <= i < 12: second[row][i - 6]; i == 12: r[row]
-        const int eo = (i < 6) ? row * 6 + i : (i < 12 ? 12 + row * 6 + (i - 6) : 24 + row);
-        const bool has = i < 13;
-        const double *rec = w.prec + RDVIO_REC_STRIDE * (size_t)w.grp_off[g] + eo;
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
-        int it = 0;
-        for (; it + 16 <= n; it += 16) {  // 8 MFMAs (16 items) per trip, loads issued together
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = has ? rec[RDVIO_REC_STRIDE * (size_t)(it + 2 * u + item_off)] : 0.0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v[u] : 0.0, v[u], acc, 0, 0, 0);
-        }
-        if (it < n) {  // the remainder as ONE masked trip of eight loads (a two-item loop here is one L2 round trip per MFMA)
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int item = it + 2 * u + item_off;
-                v[u] = (has && item < n) ? rec[RDVIO_REC_STRIDE * (size_t)item] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (it + 2 * u < n) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v[u] : 0.0, v[u], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[16 * ((lane >> 4) + 4 * r) + (lane & 15)] = acc[r];
-    }
+    // ---- phase 1a: the group products (ne_pair_products); large windows share them with the helper workgroups
+    const bool multi = w.n_wg > 1;
+    const int GW = multi ? w.n_wg * NW : NW;
+    if (multi) post_command(w, sh, CMD_PAIRS);
+    ne_pair_products(w, wave, GW);
     STAMP(12);
     // ---- phase 1b: landmarks (factors of one landmark are contiguous): scalars m, g and the anchor slot of the
     // coupling row (target slots were stored at linearisation time; untouched slots stay zero from the setup).
@@ -618,86 +776,12 @@ __device__ __attribute__((noinline)) void build_normal_equations(LdsWs &w, Share
         w.Pg[o] = acc;
     }
     STAMP(14);
-    __syncthreads();
+    if (multi) (void)collect_partials(w, sh, true);   // (ends with the workgroup barrier; the helpers' tiles are acquired)
+    else __syncthreads();
     STAMP(15);
-    // ---- phase 2: every entry of H, output-stationary: prior + preintegration band + reprojection groups.
-    // One wavefront per 15 x 15 block (block-level conditions are wave-uniform), four lane passes per block whose
-    // loads are independent and issued together.
-    auto block_entries = [&](int blk, double (&v)[4]) {
-        const int fi = blk / nfree, fj = blk - fi * nfree;
-        const int pi = sh.pcol[fi], pj = sh.pcol[fj];
-        const bool has_prior = pi >= 0 && pj >= 0;
-        const int which = fj - fi + 1;
-        const int src0 = (which >= 0 && which <= 2) ? sh.band_src[(fi * 3 + which) * 2] : -1;
-        const int src1 = (which >= 0 && which <= 2) ? sh.band_src[(fi * 3 + which) * 2 + 1] : -1;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = lane + 64 * u;
-            const int a = e / 15, b = e - 15 * a;
-            double acc = 0.0;
-            if (e < 225) {
-                if (has_prior && !((a < 6 && sh.pfixc[fi]) || (b < 6 && sh.pfixc[fj]))) acc += prior_part(w, sh, pi, a, pj, b);
-                if (src0 >= 0) acc += w.PP[900 * (size_t)(src0 >> 2) + 30 * (15 * ((src0 >> 1) & 1) + a) + 15 * (src0 & 1) + b];
-                if (src1 >= 0) acc += w.PP[900 * (size_t)(src1 >> 2) + 30 * (15 * ((src1 >> 1) & 1) + a) + 15 * (src1 & 1) + b];
-                if (a < 6 && b < 6) {
-                    if (fi == fj) {
-                        // the nfree group tiles that touch this frame, twelve loads in flight: one round trip covers a
-                        // window of up to 12 free frames (summed in f2 order)
-                        for (int f0 = 0; f0 < nfree; f0 += 12) {
-                            double gv[12];
-#pragma unroll
-                            for (int u4 = 0; u4 < 12; ++u4) {
-                                const int f2 = f0 + u4;
-                                const int lo = f2 < fi ? f2 : fi, hi = f2 < fi ? fi : f2;
-                                const int off = (fi == lo) ? 0 : 6;  // quadrant (lo,lo) or (hi,hi); the single group (f,f) uses (lo,lo)
-                                gv[u4] = f2 < nfree ? w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + off + b] : 0.0;
-                            }
-#pragma unroll
-                            for (int u4 = 0; u4 < 12; ++u4)
-                                if (f0 + u4 < nfree) acc += gv[u4];
-                        }
-                        if (a < 3 && b < 3)
-                            for (int k = 0; k < w.nrot; ++k)
-                                if (sh.fcol[w.rot_tgt[k]] == fi) acc += w.Jro[6 * k + a] * w.Jro[6 * k + b] + w.Jro[6 * k + 3 + a] * w.Jro[6 * k + 3 + b];
-                    } else if (fi < fj) {
-                        acc += w.GP[256 * (size_t)pair_id(fi, fj, nfree) + 16 * a + 6 + b];
-                    } else {
-                        acc += w.GP[256 * (size_t)pair_id(fj, fi, nfree) + 16 * b + 6 + a];
-                    }
-                }
-            }
-            v[u] = acc;
-        }
-    };
-    // H is symmetric: only the lower blocks are formed, an off-diagonal block is stored a second time transposed
-    // (the scattered stores cost nothing on the dependent path; forming the block again would be another trip)
-    auto block_store = [&](int blk, const double (&v)[4]) {
-        const int fi = blk / nfree, fj = blk - fi * nfree;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = lane + 64 * u;
-            if (e < 225) {
-                w.H[(size_t)(15 * fi + e / 15) * N + 15 * fj + e % 15] = v[u];
-                if (fi != fj) w.H[(size_t)(15 * fj + e % 15) * N + 15 * fi + e / 15] = v[u];
-            }
-        }
-    };
-    auto lower_block = [&](int p) {  // p-th lower block in row-major order -> fi * nfree + fj
-        int fi = 0;
-        while (tri(fi + 1) <= p) ++fi;
-        return fi * nfree + (p - tri(fi));
-    };
-    // two blocks per trip: their loads are independent, so twice as many are in flight per L2 round trip
-    const int n_lower = nfree * (nfree + 1) / 2;
-    for (int p = wave; p < n_lower; p += 2 * NW) {
-        double v0[4], v1[4];
-        const bool two = p + NW < n_lower;
-        const int b0 = lower_block(p), b1 = two ? lower_block(p + NW) : 0;
-        block_entries(b0, v0);
-        if (two) block_entries(b1, v1);
-        block_store(b0, v0);
-        if (two) block_store(b1, v1);
-    }
+    // ---- phase 2: the H blocks (ne_h_blocks), shared with the helper workgroups like phase 1a
+    if (multi) post_command(w, sh, CMD_HBLK);
+    ne_h_blocks(w, sh, wave, GW);
     STAMP(27);
     for (int o = t; o < N; o += T) {
         const int c = o / 15, a = o - 15 * c;
@@ -735,7 +819,8 @@ __device__ __attribute__((noinline)) void build_normal_equations(LdsWs &w, Share
         }
         w.g[o] = acc;
     }
-    __syncthreads();
+    if (multi) (void)collect_partials(w, sh, true);   // (the helpers' H blocks are acquired; ends with the workgroup barrier)
+    else __syncthreads();
     STAMP(16);
 }
 
@@ -993,6 +1078,8 @@ PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap
     const int t = threadIdx.x;
     const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
     const bool has_lm = nl > 0 && w.n_lfree_hint > 0;
+    const bool split = w.n_wg > 1 && !(w.lds_chol && (size_t)nl * NAs + nl <= lds_cap);   // Schur product shared with the helpers
+    const size_t cstride = (size_t)NAs * NAs;
     lds_double *Sl = lds;
     if (has_lm) {
         for (int l = t; l < nl; l += T) {
@@ -1016,7 +1103,11 @@ PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap
             block_gemm_tn_lds<T>(w.Cm, NAs, As, NAs, As, NAs, ws, true, NA, NA + 1, nl, true);
         } else {
             // (operand too large for LDS: staged a chunk of landmarks at a time; up to 8 x 5 = 40 tiles -- 32 free frames -- else the unstaged walk)
-            if (!block_gemm_tn_chunked<T>(w.Cm, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, lds, lds_cap))
+            if (split) {   // every workgroup forms the product of its run of landmarks (schur_gemm_share)
+                post_command(w, sh, CMD_GEMM);
+                schur_gemm_share(w, lds, lds_cap, 0);
+                (void)collect_partials(w, sh, true);
+            } else if (!block_gemm_tn_chunked<T>(w.Cm, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, lds, lds_cap))
                 block_gemm_tn<T>(w.Cm, NAs, w.A, NAs, w.A, NAs, w.lm_w, NA, NA + 1, nl, true);
         }
     }
@@ -1036,7 +1127,7 @@ PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap
             if (e < 225 && (fi != fj || b <= a)) {
                 const int i = 15 * fi + a, j = 15 * fj + b;
                 v = w.H[(size_t)i * N + j];
-                if (a < 6 && b < 6 && has_lm) v -= w.Cm[(size_t)(6 * fi + a) * NAs + 6 * fj + b];
+                if (a < 6 && b < 6 && has_lm) v -= schur_cm(w, (size_t)(6 * fi + a) * NAs + 6 * fj + b, split, cstride);
                 v *= sh.xv[i] * sh.xv[j];
                 if (i == j) v += mu * w.diag_p[i] * w.diag_p[i];
             }
@@ -1055,7 +1146,7 @@ PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap
     for (int i = t; i < N; i += T) {
         const int fi = i / 15, a = i - 15 * fi;
         double v = w.g[i];
-        if (a < 6 && has_lm) v -= w.Cm[(size_t)(6 * fi + a) * NAs + NA];
+        if (a < 6 && has_lm) v -= schur_cm(w, (size_t)(6 * fi + a) * NAs + NA, split, cstride);
         v *= w.sig_p[i];
         w.yp[i] = v;
         if (w.lds_chol) Sl[tri(N) + i] = v;  // right-hand-side row of the packed triangle
@@ -1485,7 +1576,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     LdsWs &wl = *(LdsWs *)&w_lds;
     if (blockIdx.x > 0) {  // helper workgroup: factor evaluation on request
         if (w.mute_helpers) return;  // test switch: the leader's bounded wait must turn this into FAILURE
-        helper_loop(wl, sh);
+        helper_loop(wl, sh, RDVIO_LDS(lds_chol_buf), LDS_CAP);
         return;
     }
     const int N = w.N;

@@ -56,6 +56,7 @@ struct SolverWs {
     double *e_m, *r_m, *c_m, *Jri, *Lam, *eta0, *le, *Ex;
     // ---- normal equations / step
     double *H, *Sm, *g, *yp, *Cm;        // Cm: (6 nfree + 2)^2 landmark Schur term A^T W [A | g] (gradient part in column 6 nfree)
+    double *Cmp;                         // n_wg > 1: n_wg partial Schur terms (one per workgroup's run of landmarks), summed by the consumers
     double *lm_m, *lm_g, *lm_w, *A, *yl;
     double *sig_p, *sig_l, *diag_p, *diag_l, *grad_p, *grad_l, *gn_p, *gn_l, *tp, *tl;
     double *summary;
