@@ -109,26 +109,31 @@ def pmc_traffic_bytes():
     return out, f"bytes per launch, FETCH_SIZE + WRITE_SIZE raw = lower bound (profiles/{PMC_TAG}_pmc_fetch_write.csv, sources verified by hash)"
 
 
-def build_workload(cfg, ctx, torch, dev, seed=648):
+def build_workload(cfg, ctx, torch, dev, seed=648, host=None):
+    """Synthetic per-frame inputs, resident on the device.  `host`: the workload of another context of the same config --
+    its host-side data (rendered frames, keypoints, IMU segments, BA problems) is reused and only the device side (frame
+    slot 1 preprocessed, uploads into THIS context's arenas) is built: the sequences of the multi-sequence leg."""
     import rd_vio_amd
     from rd_vio_amd import synth
 
     w, h, nfeat, W = cfg["width"], cfg["height"], cfg["features"], cfg["window"]
     wl = {}
     # a short loop of frames: the same planar scene under a small per-frame motion
-    n_img = 4
     offs = [(0.0, 0.0), (2.6, -1.4), (5.1, -2.9), (2.4, -1.2)]
-    frames = [synth.render_scene(w, h, seed=seed, offset=o, rot=0.002 * i) for i, o in enumerate(offs)]
+    frames = host["frames_host"] if host else [synth.render_scene(w, h, seed=seed, offset=o, rot=0.002 * i) for i, o in enumerate(offs)]
     wl["frames_host"] = frames
     wl["frames"] = [torch.from_numpy(f).to(dev) for f in frames]
     # features: what detect_keypoints finds on frame 0 (min distance as in configs/setting.yaml:12)
     img0 = rd_vio_amd.HipImage(ctx, 1, frames[0])
     img0.preprocess()
-    kp = img0.detect_keypoints(np.zeros((0, 2)), nfeat, 10.0)
-    if len(kp) < nfeat:  # top up from a jittered grid so the feature count matches the config
-        extra = synth.jittered_grid(w, h, 40, 25, seed=seed)[: nfeat - len(kp)]
-        kp = np.concatenate([kp, extra])
-    kp = kp[:nfeat]
+    if host:
+        kp = host["kp_host"]
+    else:
+        kp = img0.detect_keypoints(np.zeros((0, 2)), nfeat, 10.0)
+        if len(kp) < nfeat:  # top up from a jittered grid so the feature count matches the config
+            extra = synth.jittered_grid(w, h, 40, 25, seed=seed)[: nfeat - len(kp)]
+            kp = np.concatenate([kp, extra])
+        kp = kp[:nfeat]
     wl["kp_host"] = kp
     wl["curr"] = torch.from_numpy(kp.copy()).to(dev)
     wl["next"] = torch.zeros_like(wl["curr"])
@@ -137,12 +142,15 @@ def build_workload(cfg, ctx, torch, dev, seed=648):
     # Jacobians (sliding_window_tracker.cpp:294)
     rng = np.random.default_rng(seed + 1)
     segs, par = [], []
-    segs.append(synth.make_imu_segment(1.0, 1.05, rng=rng, bg=synth.TRUE_BG, ba=synth.TRUE_BA))
-    par.append([1.05, *synth.TRUE_BG, *synth.TRUE_BA])
-    for j in range(W):
-        t0 = 1.0 + 0.25 * j
-        segs.append(synth.make_imu_segment(t0, t0 + 0.25, rng=rng, bg=synth.TRUE_BG, ba=synth.TRUE_BA))
-        par.append([t0 + 0.25, *synth.TRUE_BG, *synth.TRUE_BA])
+    if host:
+        segs, par = host["imu_segs"], [list(p) for p in host["imu_par"]]
+    else:
+        segs.append(synth.make_imu_segment(1.0, 1.05, rng=rng, bg=synth.TRUE_BG, ba=synth.TRUE_BA))
+        par.append([1.05, *synth.TRUE_BG, *synth.TRUE_BA])
+        for j in range(W):
+            t0 = 1.0 + 0.25 * j
+            segs.append(synth.make_imu_segment(t0, t0 + 0.25, rng=rng, bg=synth.TRUE_BG, ba=synth.TRUE_BA))
+            par.append([t0 + 0.25, *synth.TRUE_BG, *synth.TRUE_BA])
     off = np.zeros(len(segs) + 1, dtype=np.int32)
     for i, s in enumerate(segs):
         off[i + 1] = off[i] + len(s)
@@ -157,27 +165,173 @@ def build_workload(cfg, ctx, torch, dev, seed=648):
     K = synth.EUROC_K.copy()
     if (w, h) != (752, 480):
         K = np.array([[900.0, 0, w / 2.0], [0, 900.0, h / 2.0], [0, 0, 1.0]])
-    pb = synth.make_window_problem(W + 1, cfg["landmarks"], seed, preintegrate=gpu_pre, K=K)
+    if host:
+        pb, loc = host["window_pb"], host["localize_pb"]
+    else:
+        pb = synth.make_window_problem(W + 1, cfg["landmarks"], seed, preintegrate=gpu_pre, K=K)
+        loc = dict(pb)
+        loc["frame_fixed"] = np.ones(W + 1, dtype=np.uint8)
+        loc["frame_fixed"][W] = 0
+        loc["lm_fixed"] = np.ones(len(pb["inv_depth"]), dtype=np.uint8)
+        keep = pb["tgt"] == W
+        for k in ("tgt", "ref", "lm", "tangent"):
+            loc[k] = pb[k][keep]
+        loc["pre_i"], loc["pre_j"], loc["preint"] = pb["pre_i"][-1:], pb["pre_j"][-1:], pb["preint"][-1:]
+        for k in ("prior_frames", "lin", "S", "f"):
+            loc.pop(k, None)
     wl["window_pb"] = pb
-    loc = dict(pb)
-    loc["frame_fixed"] = np.ones(W + 1, dtype=np.uint8)
-    loc["frame_fixed"][W] = 0
-    loc["lm_fixed"] = np.ones(len(pb["inv_depth"]), dtype=np.uint8)
-    keep = pb["tgt"] == W
-    for k in ("tgt", "ref", "lm", "tangent"):
-        loc[k] = pb[k][keep]
-    loc["pre_i"], loc["pre_j"], loc["preint"] = pb["pre_i"][-1:], pb["pre_j"][-1:], pb["preint"][-1:]
-    for k in ("prior_frames", "lin", "S", "f"):
-        loc.pop(k, None)
     wl["localize_pb"] = loc
     ctx.ba_upload(pb, slot=0)
     ctx.ba_upload(loc, slot=1)
     # marginalisation input: the steady-state prior (what the previous marginalisation leaves behind), as on every
     # marginalisation of a session but the first
-    wl["marg_args"] = synth.steady_state_marg_inputs(pb, ctx.marginalize)
+    wl["marg_args"] = host["marg_args"] if host else synth.steady_state_marg_inputs(pb, ctx.marginalize)
     ctx.marginalize_upload(*wl["marg_args"])
     wl["L"] = img0.L
     return wl
+
+
+class Sequence:
+    """One VIO sequence on the device: its own rdvio_hip context (arenas, staging, three lanes = three HIP streams), the
+    synthetic per-frame inputs resident in HBM, and step(k) = one camera frame of the hot path."""
+
+    STAGES = ["preprocess", "lk_track", "detect", "preintegrate", "ba_localize", "ba_window", "marginalize"]
+    # event pairs per stage: (start, end) indices into the per-step event list
+    EV_PAIRS = [(0, 1), (1, 2), (2, 3), (3, 4), (5, 6), (7, 8), (9, 10)]
+    N_EV = 11
+
+    def __init__(self, cfg, torch, dev, device_index, overlap=True, first_stream=None, host=None, max_factors=20000):
+        import ctypes
+
+        import rd_vio_amd
+
+        self.cfg, self.overlap, self.ctypes, self.rd = cfg, overlap, ctypes, rd_vio_amd
+        # explicit (non-default) streams: the context enqueues on them and torch.cuda.Event records on them, so the HIP events
+        # bracket exactly the kernels of each stage.  Lanes (include/rdvio_hip.h): the frontend (image side +
+        # preintegration), the solver and the marginalisation each get their own stream unless serial.
+        stream = first_stream if first_stream is not None else torch.cuda.Stream(device=dev)
+        self.ctx = ctx = rd_vio_amd.Context(max_width=cfg["width"], max_height=cfg["height"], max_features=max(1024, 4 * cfg["features"]),
+                                            max_window=cfg["window"], max_factors=max_factors, device=device_index, stream=stream.cuda_stream)
+        self.s_front = self.s_solve = self.s_marg = stream
+        if overlap:
+            self.s_solve, self.s_marg = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+            ctx.set_lane_stream(rd_vio_amd.binding.LANE_SOLVER, self.s_solve.cuda_stream)
+            ctx.set_lane_stream(rd_vio_amd.binding.LANE_MARG, self.s_marg.cuda_stream)
+        with torch.cuda.stream(stream):
+            self.wl = build_workload(cfg, ctx, torch, dev, host=host)
+        self.kp_buf = np.zeros((2 * cfg["features"], 2))
+        self.n_out = ctypes.c_int(0)
+        self.nseg = len(self.wl["imu_segs"])
+
+    def estimator(self, ev):
+        """frame k's estimation on the solver / marginalisation lanes: localize_newframe, refine_window (reads the prior the
+        previous marginalisation wrote: device-side wait on the marginalisation lane), then slide_window ->
+        Map::marginalize_frame(0) (reads the window solve's states: device-side wait on the solver lane)."""
+        ctx, lib, h, iters = self.ctx, self.ctx._lib, self.ctx._h, self.cfg["iters"]
+        LS, LM = self.rd.binding.LANE_SOLVER, self.rd.binding.LANE_MARG
+        if ev: ev[5].record(self.s_solve)
+        ctx._check(lib.rdvio_hip_ba_solve_resident(h, 1, iters))
+        if ev: ev[6].record(self.s_solve)
+        ctx.lane_wait(LS, LM)
+        if ev: ev[7].record(self.s_solve)
+        ctx._check(lib.rdvio_hip_ba_solve_resident(h, 0, iters))
+        if ev: ev[8].record(self.s_solve)
+        ctx.lane_wait(LM, LS)
+        if ev: ev[9].record(self.s_marg)
+        ctx._check(lib.rdvio_hip_marginalize_resident(h, 0))
+        if ev: ev[10].record(self.s_marg)
+
+    def frontend(self, k, ev):
+        ctx, lib, h, wl, cfg = self.ctx, self.ctx._lib, self.ctx._h, self.wl, self.cfg
+        w, hh, nfeat = cfg["width"], cfg["height"], cfg["features"]
+        cur, prv = k % 2, (k + 1) % 2
+        img = wl["frames"][k % len(wl["frames"])]
+        s_front = self.s_front
+        if ev: ev[0].record(s_front)
+        ctx._check(lib.rdvio_hip_image_preprocess_dev(h, cur, img.data_ptr(), w, hh, w, 6.0, 8, 8))
+        if ev: ev[1].record(s_front)
+        ctx._check(lib.rdvio_hip_track_keypoints_dev(h, prv, cur, nfeat, wl["curr"].data_ptr(), wl["next"].data_ptr(),
+                                                     0, wl["status"].data_ptr()))
+        if ev: ev[2].record(s_front)
+        ctx._check(lib.rdvio_hip_detect_keypoints(h, cur, self.kp_buf.ctypes.data, 0, len(self.kp_buf), nfeat, 10.0,
+                                                  self.ctypes.byref(self.n_out)))
+        if ev: ev[3].record(s_front)
+        # frame segment without covariance, keyframe segments with (two launches, as the reference's two call sites)
+        ctx._check(lib.rdvio_hip_preintegrate_dev(h, 1, wl["imu_off"].data_ptr(), wl["imu"].data_ptr(),
+                                                  wl["imu_par_dev"].data_ptr(), wl["noise"].data_ptr(), 0, 0,
+                                                  wl["pre_out"].data_ptr()))
+        ctx._check(lib.rdvio_hip_preintegrate_dev(h, self.nseg - 1, wl["imu_off"].data_ptr() + 4, wl["imu"].data_ptr(),
+                                                  wl["imu_par_dev"].data_ptr() + 56, wl["noise"].data_ptr(), 1, 1,
+                                                  wl["pre_out"].data_ptr() + 8 * self.rd.PREINT_SIZE))
+        if ev: ev[4].record(s_front)
+
+    def step(self, k, ev=None):
+        """One camera frame.  Overlapped (default): while the solver lane works on frame k's localisation and window solve
+        and the marginalisation lane on its slide_window, the frontend lane runs frame k+1's image side and preintegration
+        -- the reference's tracker-thread / frontend-thread split (handler.cpp:35-50).  The host waits once per frame for what
+        host logic consumes before the next frame: the frontend's keypoints and the solver's states; the new prior stays on
+        the device for the next window solve.  Serial: every stage back to back on one stream (round 1's step)."""
+        if self.overlap:
+            self.estimator(ev)
+            self.frontend(k, ev)
+            self.ctx.lane_sync(self.rd.binding.LANE_FRONTEND)
+            self.ctx.lane_sync(self.rd.binding.LANE_SOLVER)
+        else:
+            self.frontend(k, ev)
+            self.estimator(ev)
+            self.ctx.sync()
+
+
+def multi_sequence(cfg, torch, dev, device_index, host, n_seq, steps, warmup):
+    """n_seq independent sequences on ONE GPU, each with its own context and lanes, each driven by its own host thread (the
+    C ABI releases the GIL; a sequence is sequential in itself, so its thread mostly waits).  One sequence occupies one
+    compute unit for most of a frame (the persistent single-workgroup solver), so a GPU has room for many: this is what the
+    device sustains when it is kept busy.  NOT `value` (BASELINE's configs are one stream per GPU): reported beside it."""
+    import threading
+
+    mf = max(2048, 2 * len(host["window_pb"]["tgt"]))
+    seqs = [Sequence(cfg, torch, dev, device_index, overlap=True, host=host, max_factors=mf) for _ in range(n_seq)]
+    torch.cuda.synchronize()
+    gate = threading.Barrier(n_seq + 1)
+    t_done = [0.0] * n_seq
+    errors = []
+
+    def run(i):
+        try:
+            sq = seqs[i]
+            for k in range(warmup):
+                sq.step(k)
+            gate.wait()
+            for k in range(warmup, warmup + steps):
+                sq.step(k)
+            sq.ctx.sync()
+            t_done[i] = time.perf_counter()
+        except Exception as e:  # noqa: BLE001 -- reported by the caller
+            errors.append(repr(e))
+            try:
+                gate.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(n_seq)]
+    for t in threads:
+        t.start()
+    try:
+        gate.wait()
+    except threading.BrokenBarrierError:
+        pass
+    t0 = time.perf_counter()
+    for t in threads:
+        t.join()
+    for sq in seqs:
+        sq.ctx.close()
+    if errors:
+        return {"sequences": n_seq, "error": errors[0]}
+    elapsed = max(t_done) - t0
+    return {"sequences": n_seq, "frames_per_sequence": steps, "aggregate_fps": round(n_seq * steps / elapsed, 1),
+            "per_sequence_fps": round(steps / elapsed, 1), "ms_per_frame_per_sequence": round(1e3 * elapsed / steps, 4),
+            "note": "independent sequences sharing one GPU (one context, three HIP streams and one host thread each); the same per-frame "
+                    "step as `value`; wall time from the common start to the last sequence's last frame"}
 
 
 CPU_STAGES = ["preprocess", "lk_track", "detect", "preintegrate", "ba_localize", "ba_window", "marginalize"]
@@ -376,6 +530,8 @@ def parse_args(argv=None):
     ap.add_argument("--config", default="euroc_v101", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--end-to-end-frames", type=int, default=100, help="frames of the pipeline run (0 = skip)")
+    ap.add_argument("--sequences", type=int, default=16,
+                    help="extra leg (1 GPU, rank 0): this many independent sequences sharing the GPU, aggregate frames/s reported beside `value` (0 = skip)")
     ap.add_argument("--serial", action="store_true", help="one stream, stages back to back (the round-1 step); default: frontend / estimator streams overlapped")
     # internal modes
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
@@ -467,81 +623,10 @@ def main(argv=None):
     # preintegration), the solver and the marginalisation each get their own stream unless --serial.
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    ctx = rd_vio_amd.Context(max_width=cfg["width"], max_height=cfg["height"], max_features=max(1024, 4 * cfg["features"]),
-                             max_window=cfg["window"], max_factors=20000, device=local_rank, stream=stream.cuda_stream)
-    overlap = not args.serial
-    s_front, s_solve, s_marg = stream, stream, stream
-    if overlap:
-        s_solve, s_marg = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-        ctx.set_lane_stream(rd_vio_amd.binding.LANE_SOLVER, s_solve.cuda_stream)
-        ctx.set_lane_stream(rd_vio_amd.binding.LANE_MARG, s_marg.cuda_stream)
-    wl = build_workload(cfg, ctx, torch, dev)
-    lib, h = ctx._lib, ctx._h
-    w, hh, nfeat, iters = cfg["width"], cfg["height"], cfg["features"], cfg["iters"]
-    nseg = len(wl["imu_segs"])
-    kp_buf = np.zeros((nfeat + nfeat, 2))
-    import ctypes
-
-    n_out = ctypes.c_int(0)
-    stage_names = ["preprocess", "lk_track", "detect", "preintegrate", "ba_localize", "ba_window", "marginalize"]
-    NS = len(stage_names)
-    LF, LS, LM = rd_vio_amd.binding.LANE_FRONTEND, rd_vio_amd.binding.LANE_SOLVER, rd_vio_amd.binding.LANE_MARG
-    # event pairs per stage: (start, end) indices into the per-step event list
-    EV_PAIRS = [(0, 1), (1, 2), (2, 3), (3, 4), (5, 6), (7, 8), (9, 10)]
-    N_EV = 11
-
-    def estimator(ev):
-        """frame k's estimation on the solver / marginalisation lanes: localize_newframe, refine_window (reads the prior the
-        previous marginalisation wrote: device-side wait on the marginalisation lane), then slide_window ->
-        Map::marginalize_frame(0) (reads the window solve's states: device-side wait on the solver lane)."""
-        if ev: ev[5].record(s_solve)
-        ctx._check(lib.rdvio_hip_ba_solve_resident(h, 1, iters))
-        if ev: ev[6].record(s_solve)
-        ctx.lane_wait(LS, LM)
-        if ev: ev[7].record(s_solve)
-        ctx._check(lib.rdvio_hip_ba_solve_resident(h, 0, iters))
-        if ev: ev[8].record(s_solve)
-        ctx.lane_wait(LM, LS)
-        if ev: ev[9].record(s_marg)
-        ctx._check(lib.rdvio_hip_marginalize_resident(h, 0))
-        if ev: ev[10].record(s_marg)
-
-    def frontend(k, ev):
-        cur, prv = k % 2, (k + 1) % 2
-        img = wl["frames"][k % len(wl["frames"])]
-        if ev: ev[0].record(s_front)
-        ctx._check(lib.rdvio_hip_image_preprocess_dev(h, cur, img.data_ptr(), w, hh, w, 6.0, 8, 8))
-        if ev: ev[1].record(s_front)
-        ctx._check(lib.rdvio_hip_track_keypoints_dev(h, prv, cur, nfeat, wl["curr"].data_ptr(), wl["next"].data_ptr(),
-                                                     0, wl["status"].data_ptr()))
-        if ev: ev[2].record(s_front)
-        ctx._check(lib.rdvio_hip_detect_keypoints(h, cur, kp_buf.ctypes.data, 0, len(kp_buf), nfeat, 10.0,
-                                                  ctypes.byref(n_out)))
-        if ev: ev[3].record(s_front)
-        # frame segment without covariance, keyframe segments with (two launches, as the reference's two call sites)
-        ctx._check(lib.rdvio_hip_preintegrate_dev(h, 1, wl["imu_off"].data_ptr(), wl["imu"].data_ptr(),
-                                                  wl["imu_par_dev"].data_ptr(), wl["noise"].data_ptr(), 0, 0,
-                                                  wl["pre_out"].data_ptr()))
-        ctx._check(lib.rdvio_hip_preintegrate_dev(h, nseg - 1, wl["imu_off"].data_ptr() + 4, wl["imu"].data_ptr(),
-                                                  wl["imu_par_dev"].data_ptr() + 56, wl["noise"].data_ptr(), 1, 1,
-                                                  wl["pre_out"].data_ptr() + 8 * rd_vio_amd.PREINT_SIZE))
-        if ev: ev[4].record(s_front)
-
-    def step(k, ev=None):
-        """One camera frame.  Overlapped (default): while the solver lane works on frame k's localisation and window solve
-        and the marginalisation lane on its slide_window, the frontend lane runs frame k+1's image side and preintegration
-        -- the reference's tracker-thread / frontend-thread split (handler.cpp:35-50).  The host waits once per frame for what
-        host logic consumes before the next frame: the frontend's keypoints and the solver's states; the new prior stays on
-        the device for the next window solve.  --serial: every stage back to back on one stream (round 1's step)."""
-        if overlap:
-            estimator(ev)
-            frontend(k, ev)
-            ctx.lane_sync(LF)
-            ctx.lane_sync(LS)
-        else:
-            frontend(k, ev)
-            estimator(ev)
-            ctx.sync()
+    seq = Sequence(cfg, torch, dev, local_rank, overlap=not args.serial, first_stream=stream)
+    ctx, wl, step, overlap = seq.ctx, seq.wl, seq.step, seq.overlap
+    nfeat, iters = cfg["features"], cfg["iters"]
+    stage_names, NS, EV_PAIRS, N_EV = Sequence.STAGES, len(Sequence.STAGES), Sequence.EV_PAIRS, Sequence.N_EV
 
     # slot 1 holds frame 0 (build_workload); warm up
     for k in range(args.warmup):
@@ -616,6 +701,8 @@ def main(argv=None):
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 2)
         if world == 1 and args.end_to_end_frames > 0:
             out["end_to_end"] = end_to_end(cfg, ctx, args.end_to_end_frames, with_cpu_path=not args.no_cpu_baseline)
+        if world == 1 and args.sequences > 1 and not args.serial:
+            out["multi_sequence"] = multi_sequence(cfg, torch, dev, local_rank, wl, args.sequences, steps=min(args.steps, 100), warmup=10)
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

@@ -420,10 +420,10 @@ DM double schur_cm(const WS &w, size_t idx, bool split, size_t stride) {
 }
 
 // the helpers' side: serve evaluation commands until told to exit (or until the leader goes silent)
-__device__ __attribute__((noinline)) void helper_loop(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap) {
+__device__ __attribute__((noinline)) void helper_loop(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap, int rank) {
     const int t = threadIdx.x;
     constexpr int TFm = T - 64;
-    const int P = TFm + (w.n_wg - 1) * T, gid = TFm + ((int)blockIdx.x - 1) * T + t;
+    const int P = TFm + (w.n_wg - 1) * T, gid = TFm + (rank - 1) * T + t;
     int phase = 0;
     unsigned seen = 0;
     for (;;) {
@@ -444,13 +444,13 @@ __device__ __attribute__((noinline)) void helper_loop(LdsWs &w, Shared &sh, lds_
         if (cmd & (CMD_PAIRS | CMD_HBLK | CMD_GEMM)) {
             // a share of the normal equations (the small tables were mirrored on the first command, an evaluation)
             if (cmd & CMD_PAIRS) {
-                ne_pair_products(w, (int)blockIdx.x * NW + (t >> 6), w.n_wg * NW);
+                ne_pair_products(w, rank * NW + (t >> 6), w.n_wg * NW);
             } else if (cmd & CMD_HBLK) {
                 for (int i = t; i < 9 * w.np; i += T) sh.Jri[i] = w.Jri[i];   // (the leader's linearisation left them in memory)
                 __syncthreads();
-                ne_h_blocks(w, sh, (int)blockIdx.x * NW + (t >> 6), w.n_wg * NW);
+                ne_h_blocks(w, sh, rank * NW + (t >> 6), w.n_wg * NW);
             } else {
-                schur_gemm_share(w, lds, lds_cap, (int)blockIdx.x);
+                schur_gemm_share(w, lds, lds_cap, rank);
             }
             vm_drain();
             __syncthreads();
@@ -500,7 +500,7 @@ __device__ __attribute__((noinline)) void helper_loop(LdsWs &w, Shared &sh, lds_
             }
         }
         if (t == 0) {
-            __hip_atomic_store((unsigned long long *)(w.partial + blockIdx.x), (unsigned long long)__double_as_longlong(cost), __ATOMIC_RELAXED,
+            __hip_atomic_store((unsigned long long *)(w.partial + rank), (unsigned long long)__double_as_longlong(cost), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
             vm_drain();   // the partial sum is at memory scope before the arrival is counted
             __hip_atomic_fetch_add(w.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1564,6 +1564,12 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     __shared__ __attribute__((aligned(16))) double lds_chol_buf[LDS_CAP];
     double *Sl = lds_chol_buf, *Dinv = lds_chol_buf + (w.N + 1) * (w.N + 2) / 2;
     const int t = threadIdx.x;
+    // Workgroups of a multi-workgroup launch: the grid is wg_stride x n_wg blocks and only every wg_stride-th block takes part
+    // (the others end here).  Blocks are dealt round-robin over the 8 XCDs, so with wg_stride = 8 the team shares one XCD's L2:
+    // what one workgroup hands to another (records, tiles, coupling rows -- megabytes at config-5 size) is then read from that
+    // L2 instead of from memory.  Placement is a speed matter only: every hand-off keeps its agent-scope release / acquire.
+    const int rank = (int)blockIdx.x / w.wg_stride;
+    if ((int)blockIdx.x % w.wg_stride) return;
     __shared__ SolverWs w_lds;
     if (w.poison_lds) {
         poison_lds(&sh_store, sizeof(sh_store));
@@ -1574,9 +1580,9 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
         ((__attribute__((address_space(3))) unsigned long long *)&w_lds)[i] = ((const unsigned long long *)&w)[i];
     __syncthreads();
     LdsWs &wl = *(LdsWs *)&w_lds;
-    if (blockIdx.x > 0) {  // helper workgroup: factor evaluation on request
+    if (rank > 0) {  // helper workgroup: factor evaluation and shares of the normal equations on request
         if (w.mute_helpers) return;  // test switch: the leader's bounded wait must turn this into FAILURE
-        helper_loop(wl, sh, RDVIO_LDS(lds_chol_buf), LDS_CAP);
+        helper_loop(wl, sh, RDVIO_LDS(lds_chol_buf), LDS_CAP, rank);
         return;
     }
     const int N = w.N;
@@ -1871,5 +1877,7 @@ void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w0) {
     w.mute_helpers = (mh && mh[0] == '1') ? 1 : 0;
     const char *pl = getenv("RDVIO_TEST_POISON_LDS");
     w.poison_lds = (pl && pl[0] == '1') ? 1 : 0;
-    hipLaunchKernelGGL(ba_solve_kernel, dim3(w.n_wg > 1 ? w.n_wg : 1), dim3(T), 0, stream, w);
+    const char *sp = getenv("RDVIO_SOLVER_SPREAD");   // diagnostic: one team member per XCD (the round-robin placement of a plain grid)
+    w.wg_stride = (w.n_wg > 1 && !(sp && sp[0] == '1')) ? 8 : 1;
+    hipLaunchKernelGGL(ba_solve_kernel, dim3((w.n_wg > 1 ? w.n_wg : 1) * w.wg_stride), dim3(T), 0, stream, w);
 }

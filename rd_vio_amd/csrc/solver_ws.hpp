@@ -66,7 +66,7 @@ struct SolverWs {
     int no_speculation;                  // diagnostic switch (RDVIO_NO_SPECULATION): trial steps one by one, for the equivalence test
     int mute_helpers;                    // test switch (RDVIO_TEST_MUTE_HELPERS): helper workgroups exit at once
     int poison_lds;                      // test switch (RDVIO_TEST_POISON_LDS): every workgroup fills its LDS with 0xFF bytes first
-    int pad2_;
+    int wg_stride;                       // multi-workgroup launches: every wg_stride-th block of the grid is a team member (8: one XCD)
     double *m_Tm, *m_Lr, *m_er, *m_Wk, *m_V, *m_cs, *m_yv;
     int32_t *m_nz;
     double *S_out, *f_out, *lin_out, *Lambda_out, *eta_out, *m_info;
