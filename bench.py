@@ -282,7 +282,7 @@ class Sequence:
             self.ctx.sync()
 
 
-def multi_sequence(cfg, torch, dev, device_index, host, n_seq, steps, warmup):
+def multi_sequence(cfg, torch, dev, device_index, host, n_seq, steps, warmup, overlap=False):
     """n_seq independent sequences on ONE GPU, each with its own context and lanes, each driven by its own host thread (the
     C ABI releases the GIL; a sequence is sequential in itself, so its thread mostly waits).  One sequence occupies one
     compute unit for most of a frame (the persistent single-workgroup solver), so a GPU has room for many: this is what the
@@ -290,7 +290,7 @@ def multi_sequence(cfg, torch, dev, device_index, host, n_seq, steps, warmup):
     import threading
 
     mf = max(2048, 2 * len(host["window_pb"]["tgt"]))
-    seqs = [Sequence(cfg, torch, dev, device_index, overlap=True, host=host, max_factors=mf) for _ in range(n_seq)]
+    seqs = [Sequence(cfg, torch, dev, device_index, overlap=overlap, host=host, max_factors=mf) for _ in range(n_seq)]
     torch.cuda.synchronize()
     gate = threading.Barrier(n_seq + 1)
     t_done = [0.0] * n_seq
@@ -328,7 +328,8 @@ def multi_sequence(cfg, torch, dev, device_index, host, n_seq, steps, warmup):
     if errors:
         return {"sequences": n_seq, "error": errors[0]}
     elapsed = max(t_done) - t0
-    return {"sequences": n_seq, "frames_per_sequence": steps, "aggregate_fps": round(n_seq * steps / elapsed, 1),
+    return {"sequences": n_seq, "streams_per_sequence": 3 if overlap else 1, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+            "frames_per_sequence": steps, "aggregate_fps": round(n_seq * steps / elapsed, 1),
             "per_sequence_fps": round(steps / elapsed, 1), "ms_per_frame_per_sequence": round(1e3 * elapsed / steps, 4),
             "note": "independent sequences sharing one GPU (one context, three HIP streams and one host thread each); the same per-frame "
                     "step as `value`; wall time from the common start to the last sequence's last frame"}
@@ -532,6 +533,8 @@ def parse_args(argv=None):
     ap.add_argument("--end-to-end-frames", type=int, default=100, help="frames of the pipeline run (0 = skip)")
     ap.add_argument("--sequences", type=int, default=16,
                     help="extra leg (1 GPU, rank 0): this many independent sequences sharing the GPU, aggregate frames/s reported beside `value` (0 = skip)")
+    ap.add_argument("--sequence-lanes", type=int, default=1, choices=(1, 3),
+                    help="streams per sequence in the multi-sequence leg: 1 = stages back to back (the device overlaps ACROSS sequences), 3 = the lanes of `value`")
     ap.add_argument("--serial", action="store_true", help="one stream, stages back to back (the round-1 step); default: frontend / estimator streams overlapped")
     # internal modes
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
@@ -599,6 +602,10 @@ def main(argv=None):
     if args.stub_step_ms is not None:
         return run_stub(args)
     cfg = CONFIGS[args.config]
+    if args.sequences > 1:
+        # the multi-sequence leg runs one HIP stream per sequence: the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues
+        # (default 4), and streams that share a queue run one after the other -- ask for one queue per sequence before HIP starts
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(max(4, args.sequences * args.sequence_lanes), 64)))
 
     import torch
 
@@ -702,7 +709,8 @@ def main(argv=None):
         if world == 1 and args.end_to_end_frames > 0:
             out["end_to_end"] = end_to_end(cfg, ctx, args.end_to_end_frames, with_cpu_path=not args.no_cpu_baseline)
         if world == 1 and args.sequences > 1 and not args.serial:
-            out["multi_sequence"] = multi_sequence(cfg, torch, dev, local_rank, wl, args.sequences, steps=min(args.steps, 100), warmup=10)
+            out["multi_sequence"] = multi_sequence(cfg, torch, dev, local_rank, wl, args.sequences, steps=min(args.steps, 100), warmup=10,
+                                                   overlap=args.sequence_lanes == 3)
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

@@ -263,6 +263,12 @@ DM double prior_part(const WS &w, const Shared &sh, int pi, int a, int pj, int b
 
 // index of the frame pair (lo <= hi) in the host's enumeration
 DM int pair_id(int lo, int hi, int nfree) { return lo * nfree - lo * (lo - 1) / 2 + (hi - lo); }
+// p-th lower block of the nfree x nfree block grid in row-major order -> fi * nfree + fj
+DM int lower_block_of(int p, int nfree) {
+    int fi = 0;
+    while ((fi + 1) * (fi + 2) / 2 <= p) ++fi;
+    return fi * nfree + (p - fi * (fi + 1) / 2);
+}
 
 // per factor group, X^T X with X = [J_lo | J_hi | r] (2 n_g x 13) on the matrix cores, groups g0, g0 + gstride, ...
 // (one wavefront per group; lane l feeds A[i = l & 15][k] and B[k][j = l & 15] -- the same record element for i = j < 12 --,
@@ -304,12 +310,23 @@ __device__ __attribute__((noinline)) void ne_pair_products(LdsWs &w, int g0, int
 }
 
 // every entry of H, output-stationary: prior + preintegration band + reprojection groups.  One wavefront per 15 x 15 lower
-// block (block-level conditions are wave-uniform), four lane passes per block whose loads are independent and issued
-// together; wavefront p0 of pstride takes the lower blocks p0, p0 + 2 pstride, ... two at a time.
+// block, in the matrix cores' result layout -- lane l holds the entries (row a = (l >> 4) + 4 r, column b = l & 15), r = 0..3:
+//   prior part  E_i^T Lam_ij E_j  (E = blockdiag(Jr^-1, I12)) as two 15 x 15 x 15 products: T = Lam_ij E_j, then E_i^T T -- the
+//               result registers of the first are, as they stand, the B operand of the second; the identity part of E costs
+//               exact multiplications by one / zero, so entries outside the rotation rows / columns are Lam_ij itself;
+//   band, group tiles: plain loads in the same layout.
+// EVERY load of a block (4 Lam + 8 band + 2 or 2 nfree group entries per lane) is issued before the first use, for two blocks
+// at a time: one L2 round trip per pair of blocks (the per-entry conditionals this replaces were each a round trip of its
+// own: 62 waits per trip).  Block-level conditions are wave-uniform.  Wavefront p0 of pstride takes the lower blocks
+// p0, p0 + 2 pstride, ...
 __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh, int p0, int pstride) {
-    const int lane = threadIdx.x & 63;
-    const int N = w.N, nfree = w.nfree;
-    auto block_entries = [&](int blk, double (&v)[4]) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const int N = w.N, nfree = w.nfree, D = w.D;
+    constexpr int GD = 12;   // group tiles of a diagonal block loaded with the block (windows of up to 12 free frames: all)
+    struct Loads {
+        double lam[4], pp0[4], pp1[4], gp[2], gd[2][GD];
+    };
+    auto block_load = [&](int blk, Loads &L) {
         const int fi = blk / nfree, fj = blk - fi * nfree;
         const int pi = sh.pcol[fi], pj = sh.pcol[fj];
         const bool has_prior = pi >= 0 && pj >= 0;
@@ -318,53 +335,95 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
         const int src1 = (which >= 0 && which <= 2) ? sh.band_src[(fi * 3 + which) * 2 + 1] : -1;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int e = lane + 64 * u;
-            const int a = e / 15, b = e - 15 * a;
-            double acc = 0.0;
-            if (e < 225) {
-                if (has_prior && !((a < 6 && sh.pfixc[fi]) || (b < 6 && sh.pfixc[fj]))) acc += prior_part(w, sh, pi, a, pj, b);
-                if (src0 >= 0) acc += w.PP[900 * (size_t)(src0 >> 2) + 30 * (15 * ((src0 >> 1) & 1) + a) + 15 * (src0 & 1) + b];
-                if (src1 >= 0) acc += w.PP[900 * (size_t)(src1 >> 2) + 30 * (15 * ((src1 >> 1) & 1) + a) + 15 * (src1 & 1) + b];
-                if (a < 6 && b < 6) {
-                    if (fi == fj) {
-                        // the nfree group tiles that touch this frame, twelve loads in flight: one round trip covers a
-                        // window of up to 12 free frames (summed in f2 order)
-                        for (int f0 = 0; f0 < nfree; f0 += 12) {
-                            double gv[12];
+            // A operand of T = Lam_ij E_j: A[i = li][k = 4 u + lk]
+            const int k = 4 * u + lk;
+            L.lam[u] = (has_prior && li < 15 && k < 15) ? w.Lam[(size_t)(15 * pi + li) * D + 15 * pj + k] : 0.0;
+            // result layout: entry (a = lk + 4 u, b = li)
+            const int a = lk + 4 * u, b = li;
+            const bool ok = a < 15 && b < 15;
+            L.pp0[u] = (ok && src0 >= 0) ? w.PP[900 * (size_t)(src0 >> 2) + 30 * (15 * ((src0 >> 1) & 1) + a) + 15 * (src0 & 1) + b] : 0.0;
+            L.pp1[u] = (ok && src1 >= 0) ? w.PP[900 * (size_t)(src1 >> 2) + 30 * (15 * ((src1 >> 1) & 1) + a) + 15 * (src1 & 1) + b] : 0.0;
+        }
 #pragma unroll
-                            for (int u4 = 0; u4 < 12; ++u4) {
-                                const int f2 = f0 + u4;
+        for (int u = 0; u < 2; ++u) {   // pose rows a < 6 live in r = 0 (a = lk) and r = 1 (a = lk + 4 < 6)
+            const int a = lk + 4 * u, b = li;
+            const bool ok = a < 6 && b < 6;
+            // off-diagonal lower block (fi > fj): the (lo = fj, hi = fi) group's cross quadrant, transposed
+            L.gp[u] = (ok && fi != fj) ? w.GP[256 * (size_t)pair_id(fj, fi, nfree) + 16 * b + 6 + a] : 0.0;
+#pragma unroll
+            for (int q = 0; q < GD; ++q) {
+                // diagonal block: the nfree group tiles that touch this frame (summed in f2 order)
+                const int f2 = q;
+                const int lo = f2 < fi ? f2 : fi, hi = f2 < fi ? fi : f2;
+                const int off = (fi == lo) ? 0 : 6;  // quadrant (lo,lo) or (hi,hi); the single group (f,f) uses (lo,lo)
+                L.gd[u][q] = (ok && fi == fj && f2 < nfree) ? w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + off + b] : 0.0;
+            }
+        }
+    };
+    auto block_finish = [&](int blk, const Loads &L) {
+        const int fi = blk / nfree, fj = blk - fi * nfree;
+        const int pi = sh.pcol[fi], pj = sh.pcol[fj];
+        const bool has_prior = pi >= 0 && pj >= 0;
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        if (has_prior) {
+            double4_t T = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {   // B[k = 4 u + lk][j = li] = E_j[k][j]
+                const int k = 4 * u + lk;
+                const double e = (k < 3 && li < 3) ? sh.Jri[9 * pj + 3 * k + li] : ((k == li && k < 15) ? 1.0 : 0.0);
+                T = __builtin_amdgcn_mfma_f64_16x16x4f64(L.lam[u], e, T, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {   // A[i = li][k = 4 u + lk] = E_i[k][i];  B[k][j] = T[k][j] = result register u of T
+                const int k = 4 * u + lk;
+                const double e = (k < 3 && li < 3) ? sh.Jri[9 * pi + 3 * k + li] : ((k == li && k < 15) ? 1.0 : 0.0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(e, T[u], acc, 0, 0, 0);
+            }
+        }
+        const bool fxi = sh.pfixc[fi], fxj = sh.pfixc[fj];
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int a = lk + 4 * u, b = li;
+            double x = ((a < 6 && fxi) || (b < 6 && fxj)) ? 0.0 : acc[u];   // pose-constant frames: no prior Jacobian in those columns
+            x += L.pp0[u];
+            x += L.pp1[u];
+            if (u < 2) {
+                if (fi == fj) {
+#pragma unroll
+                    for (int q = 0; q < GD; ++q)
+                        if (q < nfree) x += L.gd[u][q];
+                    if (a < 6 && b < 6) {
+                        for (int f0 = GD; f0 < nfree; f0 += GD) {   // (windows of more than GD free frames)
+                            double gv[GD];
+#pragma unroll
+                            for (int q = 0; q < GD; ++q) {
+                                const int f2 = f0 + q;
                                 const int lo = f2 < fi ? f2 : fi, hi = f2 < fi ? fi : f2;
-                                const int off = (fi == lo) ? 0 : 6;  // quadrant (lo,lo) or (hi,hi); the single group (f,f) uses (lo,lo)
-                                gv[u4] = f2 < nfree ? w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + off + b] : 0.0;
+                                const int off = (fi == lo) ? 0 : 6;
+                                gv[q] = f2 < nfree ? w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + off + b] : 0.0;
                             }
 #pragma unroll
-                            for (int u4 = 0; u4 < 12; ++u4)
-                                if (f0 + u4 < nfree) acc += gv[u4];
+                            for (int q = 0; q < GD; ++q)
+                                if (f0 + q < nfree) x += gv[q];
                         }
                         if (a < 3 && b < 3)
                             for (int k = 0; k < w.nrot; ++k)
-                                if (sh.fcol[w.rot_tgt[k]] == fi) acc += w.Jro[6 * k + a] * w.Jro[6 * k + b] + w.Jro[6 * k + 3 + a] * w.Jro[6 * k + 3 + b];
-                    } else if (fi < fj) {
-                        acc += w.GP[256 * (size_t)pair_id(fi, fj, nfree) + 16 * a + 6 + b];
-                    } else {
-                        acc += w.GP[256 * (size_t)pair_id(fj, fi, nfree) + 16 * b + 6 + a];
+                                if (sh.fcol[w.rot_tgt[k]] == fi) x += w.Jro[6 * k + a] * w.Jro[6 * k + b] + w.Jro[6 * k + 3 + a] * w.Jro[6 * k + 3 + b];
                     }
+                } else {
+                    x += L.gp[u];
                 }
             }
-            v[u] = acc;
+            v[u] = x;
         }
-    };
-    // H is symmetric: only the lower blocks are formed, an off-diagonal block is stored a second time transposed
-    // (the scattered stores cost nothing on the dependent path; forming the block again would be another trip)
-    auto block_store = [&](int blk, const double (&v)[4]) {
-        const int fi = blk / nfree, fj = blk - fi * nfree;
+        // H is symmetric: only the lower blocks are formed, an off-diagonal block is stored a second time transposed
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int e = lane + 64 * u;
-            if (e < 225) {
-                w.H[(size_t)(15 * fi + e / 15) * N + 15 * fj + e % 15] = v[u];
-                if (fi != fj) w.H[(size_t)(15 * fj + e % 15) * N + 15 * fi + e / 15] = v[u];
+            const int a = lk + 4 * u, b = li;
+            if (a < 15 && b < 15) {
+                w.H[(size_t)(15 * fi + a) * N + 15 * fj + b] = v[u];
+                if (fi != fj) w.H[(size_t)(15 * fj + b) * N + 15 * fi + a] = v[u];
             }
         }
     };
@@ -373,16 +432,15 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
         while (tri(fi + 1) <= p) ++fi;
         return fi * nfree + (p - tri(fi));
     };
-    // two blocks per trip: their loads are independent, so twice as many are in flight per L2 round trip
     const int n_lower = nfree * (nfree + 1) / 2;
     for (int p = p0; p < n_lower; p += 2 * pstride) {
-        double v0[4], v1[4];
+        Loads L0, L1;
         const bool two = p + pstride < n_lower;
-        const int b0 = lower_block(p), b1 = two ? lower_block(p + pstride) : 0;
-        block_entries(b0, v0);
-        if (two) block_entries(b1, v1);
-        block_store(b0, v0);
-        if (two) block_store(b1, v1);
+        const int b0 = lower_block(p), b1 = two ? lower_block(p + pstride) : b0;
+        block_load(b0, L0);
+        block_load(b1, L1);
+        block_finish(b0, L0);
+        if (two) block_finish(b1, L1);
     }
 }
 
@@ -409,13 +467,15 @@ __device__ __attribute__((noinline)) void schur_gemm_share(LdsWs &w, lds_double 
 template <class WS>
 DM double schur_cm(const WS &w, size_t idx, bool split, size_t stride) {
     if (!split) return w.Cm[idx];
-    double v[RDVIO_MAX_SOLVER_WGS];
+    double acc = 0.0;
+    for (int g0 = 0; g0 < w.n_wg; g0 += 8) {   // eight partials in flight (the default team has eight workgroups)
+        double v[8];
 #pragma unroll
-    for (int g = 0; g < RDVIO_MAX_SOLVER_WGS; ++g) v[g] = g < w.n_wg ? w.Cmp[g * stride + idx] : 0.0;
-    double acc = v[0];
+        for (int g = 0; g < 8; ++g) v[g] = g0 + g < w.n_wg ? w.Cmp[(g0 + g) * stride + idx] : 0.0;
 #pragma unroll
-    for (int g = 1; g < RDVIO_MAX_SOLVER_WGS; ++g)
-        if (g < w.n_wg) acc += v[g];
+        for (int g = 0; g < 8; ++g)
+            if (g0 + g < w.n_wg) acc += v[g];
+    }
     return acc;
 }
 
@@ -1113,34 +1173,53 @@ PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap
     }
     __syncthreads();
     STAMP(29);
-    // one wave per 15 x 15 block, 4 passes in flight
+    // one wavefront per LOWER 15 x 15 block, two blocks per trip; the H and Schur-term loads of both blocks are issued before
+    // the first use (a conditional subtraction inside the entry loop is a second round trip per entry)
     for (int i = t; i < N; i += T) sh.xv[i] = w.sig_p[i];
     __syncthreads();
-    for (int blk = t >> 6; blk < nfree * nfree; blk += NW) {
-        const int fi = blk / nfree, fj = blk - fi * nfree;
-        if (fj > fi) continue;
-        double vv[4];
+    {
+        const int lane = t & 63, n_lower = nfree * (nfree + 1) / 2;
+        auto entry = [&](int blk, int u, int &i, int &j, bool &ok, bool &pose) {
+            const int fi = blk / nfree, fj = blk - fi * nfree;
+            const int e = lane + 64 * u, a = e / 15, b = e - 15 * a;
+            ok = e < 225 && (fi != fj || b <= a);
+            pose = ok && a < 6 && b < 6 && has_lm;
+            i = 15 * fi + a;
+            j = 15 * fj + b;
+        };
+        for (int p = t >> 6; p < n_lower; p += 2 * NW) {
+            const bool two = p + NW < n_lower;
+            const int blk[2] = {lower_block_of(p, nfree), lower_block_of(two ? p + NW : p, nfree)};
+            double hv[2][4], cv[2][4], dv[2][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = (t & 63) + 64 * u, a = e / 15, b = e - 15 * a;
-            double v = 0.0;
-            if (e < 225 && (fi != fj || b <= a)) {
-                const int i = 15 * fi + a, j = 15 * fj + b;
-                v = w.H[(size_t)i * N + j];
-                if (a < 6 && b < 6 && has_lm) v -= schur_cm(w, (size_t)(6 * fi + a) * NAs + 6 * fj + b, split, cstride);
-                v *= sh.xv[i] * sh.xv[j];
-                if (i == j) v += mu * w.diag_p[i] * w.diag_p[i];
-            }
-            vv[u] = v;
-        }
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = (t & 63) + 64 * u, a = e / 15, b = e - 15 * a;
-            if (e < 225 && (fi != fj || b <= a)) {
-                const int i = 15 * fi + a, j = 15 * fj + b;
-                if (w.lds_chol) Sl[tri(i) + j] = vv[u];
-                else w.Sm[(size_t)i * N + j] = vv[u];
-            }
+                for (int u = 0; u < 4; ++u) {
+                    int i, j;
+                    bool ok, pose;
+                    entry(blk[q], u, i, j, ok, pose);
+                    hv[q][u] = ok ? w.H[(size_t)i * N + j] : 0.0;
+                    dv[q][u] = (ok && i == j) ? w.diag_p[i] : 0.0;
+                    const size_t ci = (size_t)(6 * (i / 15) + i % 15) * NAs + 6 * (j / 15) + j % 15;
+                    if (!split) cv[q][u] = pose ? w.Cm[ci] : 0.0;   // (workgroup-uniform branch)
+                    else cv[q][u] = pose ? schur_cm(w, ci, true, cstride) : 0.0;
+                }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int i, j;
+                    bool ok, pose;
+                    entry(blk[q], u, i, j, ok, pose);
+                    if (ok && (q == 0 || two)) {
+                        double v = hv[q][u];
+                        if (pose) v -= cv[q][u];
+                        v *= sh.xv[i] * sh.xv[j];
+                        if (i == j) v += mu * dv[q][u] * dv[q][u];
+                        if (w.lds_chol) Sl[tri(i) + j] = v;
+                        else w.Sm[(size_t)i * N + j] = v;
+                    }
+                }
         }
     }
     for (int i = t; i < N; i += T) {
