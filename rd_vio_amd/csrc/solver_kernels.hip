@@ -1674,6 +1674,46 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
 
     solver_setup(wl, sh, RDVIO_LDS(lds_chol_buf), LDS_CAP, prof_last);
 
+    // ---- small vectors resident in LDS.  The phases between two linearisations are chains of short passes over N- and
+    // nl-sized vectors (scalings, gradient, Gauss-Newton step, landmark scalars, frame states): in global memory every pass
+    // is an L2 round trip per read plus the store drain in front of its barrier.  When the window leaves room behind the
+    // packed triangle (config 2: 5 000 of the buffer's 16 336 doubles; a one-frame localisation: nearly all of it), the
+    // descriptor's pointers to those vectors are redirected into that room: the phases read the descriptor, so they follow
+    // (generic pointers into LDS: FLAT accesses at LDS latency).  lds_cap shrinks accordingly for every scratch user of
+    // the buffer (operand staging, candidate states); x / xd are copied back before the summary.
+    size_t lds_cap = LDS_CAP;
+    int resident = 0;
+    if (w.n_wg == 1 && w.lds_chol && !w.no_lds_vectors) {
+        const int NAs = 6 * w.nfree + 2;
+        size_t need = (size_t)(N + 1) * (N + 2) / 2 + 225 * (size_t)(N / 15);                          // packed triangle + diagonal inverses
+        const size_t stage = (w.nl > 0 && w.n_lfree_hint > 0) ? (size_t)w.nl * NAs + w.nl : 0;          // Schur operand staging
+        const size_t cand = candidates_lds_doubles(w.nfr, w.nl, w.npre);                                // speculative candidates
+        if (stage > need) need = stage;
+        if (cand > need) need = cand;
+        need = (need + 1) & ~(size_t)1;
+        const size_t lfree_d = ((size_t)w.nl + 7) / 8;
+        const size_t want = 6 * (size_t)N + 10 * (size_t)w.nl + lfree_d + 48 * (size_t)w.nfr;
+        if (need + want <= LDS_CAP) {
+            resident = 1;
+            lds_cap = need;
+            if (t == 0) {
+                double *p = lds_chol_buf + need;
+                auto take = [&](size_t n) { double *q = p; p += n; return q; };
+                w_lds.g = take(N); w_lds.yp = take(N); w_lds.sig_p = take(N); w_lds.diag_p = take(N); w_lds.grad_p = take(N); w_lds.gn_p = take(N);
+                w_lds.lm_m = take(w.nl); w_lds.lm_g = take(w.nl); w_lds.lm_w = take(w.nl); w_lds.yl = take(w.nl);
+                w_lds.sig_l = take(w.nl); w_lds.diag_l = take(w.nl); w_lds.grad_l = take(w.nl); w_lds.gn_l = take(w.nl);
+                w_lds.xd = take(w.nl); w_lds.xdc = take(w.nl);
+                w_lds.x = take(16 * (size_t)w.nfr); w_lds.xc = take(16 * (size_t)w.nfr); w_lds.user = take(16 * (size_t)w.nfr);
+                w_lds.lfree = (uint8_t *)take(lfree_d);
+            }
+            __syncthreads();
+            // what the setup left in the global copies
+            for (int i = t; i < w.nfr * 16; i += T) { wl.x[i] = w.x[i]; wl.user[i] = w.user[i]; }
+            for (int l = t; l < w.nl; l += T) { wl.xd[l] = w.xd[l]; wl.lfree[l] = w.lfree[l]; }
+            __syncthreads();
+        }
+    }
+
     double radius = 1e4, mu = 1e-8, alpha = 0.0, dogleg_step_norm = 0.0;
     double gnorm = 0.0, gn_norm = 0.0, gdotgn = 0.0, gsq_keep = 0.0;
     double msc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // q_uu q_uv q_vv l_u l_v of the current linearisation
@@ -1708,7 +1748,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     // bookkeeping of an accepted step (x already holds the candidate): new linearisation, radius and damping updates
     auto accepted_step = [&](double rel) {  // (x_norm was set by the accept function)
         STAMP(10);
-        x_cost = evaluate<true>(wl, sh, phase, w.x, w.xd, prof_last);  // `user` still holds the previous point here
+        x_cost = evaluate<true>(wl, sh, phase, wl.x, wl.xd, prof_last);  // `user` still holds the previous point here
         phase ^= 1;  // (one reduction inside)
         STAMP(1);
         build_normal_equations(wl, sh, prof_last);
@@ -1725,12 +1765,12 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
         prev_rejected = 0;
     };
     // a run of rejections is evaluated four trial radii at a time (evaluate_candidates) when the candidates fit the LDS
-    const bool speculate = !w.no_speculation && w.n_wg == 1 && w.lds_chol && candidates_lds_doubles(w.nfr, w.nl, w.npre) <= LDS_CAP &&
+    const bool speculate = !w.no_speculation && w.n_wg == 1 && w.lds_chol && candidates_lds_doubles(w.nfr, w.nl, w.npre) <= lds_cap &&
                            4 * w.D <= RDVIO_SOLVER_XV && 4 * w.npre <= 64;
 
-    x_norm = x_norm_of(wl, sh, phase, w.x, w.xd);
+    x_norm = x_norm_of(wl, sh, phase, wl.x, wl.xd);
     phase ^= 1;  // (one reduction inside)
-    x_cost = evaluate<true>(wl, sh, phase, w.x, w.xd, prof_last);
+    x_cost = evaluate<true>(wl, sh, phase, wl.x, wl.xd, prof_last);
     phase ^= 1;  // (one reduction inside)
     STAMP(1);
     const double initial_cost = x_cost;
@@ -1810,14 +1850,14 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                 // Gauss-Newton step: (H_s + mu D^2) y = g_s with the landmarks eliminated
                 solve_ok = 0;
                 while (mu < 1.0) {
-                    schur_reduce(wl, sh, RDVIO_LDS(lds_chol_buf), LDS_CAP, mu, prof_last);
+                    schur_reduce(wl, sh, RDVIO_LDS(lds_chol_buf), lds_cap, mu, prof_last);
                     STAMP(4);
                     int ok = 1;
                     if (N > 0) ok = w.lds_chol ? cholesky_lds(sh, RDVIO_LDS(Sl), RDVIO_LDS(Dinv), N) : cholesky_blocked(sh, w.Sm, N, N + 1);
                     STAMP(5);
                     if (ok && N > 0) {
-                        if (w.lds_chol) cholesky_solve_lds(sh, RDVIO_LDS(Sl), RDVIO_LDS(Dinv), N, w.yp);
-                        else cholesky_solve(sh, w.Sm, N, w.yp, false, true, true);   // (row N holds L^-1 b)
+                        if (w.lds_chol) cholesky_solve_lds(sh, RDVIO_LDS(Sl), RDVIO_LDS(Dinv), N, wl.yp);
+                        else cholesky_solve(sh, w.Sm, N, wl.yp, false, true, true);   // (row N holds L^-1 b)
                     }
                     STAMP(6);
                     const bool fused = 3 * N <= RDVIO_SOLVER_XV || !w.lds_chol;   // (3 N <= 1440 doubles always fit the LDS buffer)
@@ -1865,7 +1905,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             // candidate = Plus(x, delta), its cost and the ambient step norm in one pass
             STAMP(28);
             double sn2 = 0.0;
-            double cand_cost = evaluate<false, true>(wl, sh, phase, w.xc, w.xdc, prof_last, &sn2, step_ca, step_cb);
+            double cand_cost = evaluate<false, true>(wl, sh, phase, wl.xc, wl.xdc, prof_last, &sn2, step_ca, step_cb);
             phase ^= 1;  // (one reduction inside)
             if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
             STAMP(9);
@@ -1885,6 +1925,10 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             }
         }
     if (w.n_wg > 1) post_command(w, sh, CMD_EXIT);
+    if (resident) {   // the result lives in LDS: back to the arena ([x | xd | summary] travels to the host with one copy)
+        for (int i = t; i < w.nfr * 16; i += T) w.x[i] = wl.x[i];
+        for (int l = t; l < w.nl; l += T) w.xd[l] = wl.xd[l];
+    }
     // Every thread carries its own copy of the loop's scalars and branches on it; they are computed from identical inputs in
     // identical order, so all copies must agree.  Checked once per launch (one LDS word per wavefront): a disagreement means
     // wavefronts took different paths through the loop -- reported as summary[6] -> RDVIO_ERR_HIP from rdvio_hip_ba_fetch.
@@ -1956,6 +2000,8 @@ void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w0) {
     w.mute_helpers = (mh && mh[0] == '1') ? 1 : 0;
     const char *pl = getenv("RDVIO_TEST_POISON_LDS");
     w.poison_lds = (pl && pl[0] == '1') ? 1 : 0;
+    const char *nv = getenv("RDVIO_NO_LDS_VECTORS");   // diagnostic: keep every vector in global memory (the A/B of the LDS-resident vectors)
+    w.no_lds_vectors = (nv && nv[0] == '1') ? 1 : 0;
     const char *sp = getenv("RDVIO_SOLVER_SPREAD");   // diagnostic: one team member per XCD (the round-robin placement of a plain grid)
     w.wg_stride = (w.n_wg > 1 && !(sp && sp[0] == '1')) ? 8 : 1;
     hipLaunchKernelGGL(ba_solve_kernel, dim3((w.n_wg > 1 ? w.n_wg : 1) * w.wg_stride), dim3(T), 0, stream, w);

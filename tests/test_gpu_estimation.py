@@ -289,6 +289,35 @@ def test_speculative_trial_steps_replay_the_sequential_loop(ctx, oracle, monkeyp
         assert sm_seq.iterations - sm_seq.successful_steps >= 5   # there was a run of rejections to batch
 
 
+def test_lds_resident_vectors_do_not_change_results(ctx, oracle, monkeypatch):
+    """Windows that leave room behind the packed triangle keep their small vectors (scalings, gradient, steps, landmark scalars,
+    frame states) in LDS (solver_kernels.hip, "small vectors resident in LDS"); where they live must not change a bit of the
+    result.  RDVIO_NO_LDS_VECTORS=1 keeps them in global memory for the comparison.  Shapes: the config-2 window, a small
+    window, the one-free-frame localisation shape and a problem with rotation priors."""
+    cases = []
+    for nfr, nl, seed in ((9, 150, 648), (5, 40, 651)):
+        cases.append(synth.make_window_problem(nfr, nl, seed, preintegrate=_oracle_pre(oracle)))
+    loc = synth.make_window_problem(9, 150, 652, preintegrate=_oracle_pre(oracle))
+    loc["frame_fixed"] = np.ones(9, dtype=np.uint8)
+    loc["frame_fixed"][8] = 0
+    loc["lm_fixed"] = np.ones(len(loc["inv_depth"]), dtype=np.uint8)
+    for k in ("prior_frames", "lin", "S", "f"):
+        loc.pop(k, None)
+    cases.append(loc)
+    rot = synth.make_window_problem(9, 150, 660, preintegrate=_oracle_pre(oracle))
+    synth.add_rotation_priors(rot, 40)
+    cases.append(rot)
+    for pb in cases:
+        monkeypatch.setenv("RDVIO_NO_LDS_VECTORS", "1")
+        s_g, d_g, sm_g = ctx.ba_solve(pb, 30)
+        monkeypatch.setenv("RDVIO_NO_LDS_VECTORS", "0")
+        s_l, d_l, sm_l = ctx.ba_solve(pb, 30)
+        assert (sm_g.iterations, sm_g.successful_steps, sm_g.termination) == (sm_l.iterations, sm_l.successful_steps, sm_l.termination)
+        assert sm_g.final_cost == sm_l.final_cost and sm_g.initial_cost == sm_l.initial_cost
+        assert np.array_equal(s_g, s_l) and np.array_equal(d_g, d_l)
+        assert sm_l.iterations >= 1
+
+
 # ---------------------------------------------------------------------------------------------- row A10
 def test_rotation_prior_eval_parity(ctx, oracle):
     """CeresRotationPriorFactor::Evaluate (ceres/rotation_factor.h:22-58) on the device against the oracle, 1e-11 relative
