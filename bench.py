@@ -223,6 +223,19 @@ class Sequence:
         self.n_out = ctypes.c_int(0)
         self.nseg = len(self.wl["imu_segs"])
 
+    def frame_step_desc(self):
+        """this sequence as a rdvio_frame_step (include/rdvio_hip.h): the same per-frame step as step(), for the native driver"""
+        from rd_vio_amd.binding import FrameStep
+
+        wl, cfg, ct = self.wl, self.cfg, self.ctypes
+        self._images = (ct.c_void_p * len(wl["frames"]))(*[f.data_ptr() for f in wl["frames"]])
+        return FrameStep(ctx=self.ctx._h, width=cfg["width"], height=cfg["height"], stride=cfg["width"], n_images=len(wl["frames"]),
+                         images_dev=ct.cast(self._images, ct.POINTER(ct.c_void_p)), n_features=cfg["features"], keypoints_capacity=len(self.kp_buf),
+                         curr_xy_dev=wl["curr"].data_ptr(), next_xy_dev=wl["next"].data_ptr(), status_dev=wl["status"].data_ptr(),
+                         keypoints_host=self.kp_buf.ctypes.data, min_distance=10.0, nseg=self.nseg, ba_iterations=cfg["iters"],
+                         seg_off_dev=wl["imu_off"].data_ptr(), imu_dev=wl["imu"].data_ptr(), par_dev=wl["imu_par_dev"].data_ptr(),
+                         noise_dev=wl["noise"].data_ptr(), preint_out_dev=wl["pre_out"].data_ptr(), overlap=1 if self.overlap else 0, reserved=0)
+
     def estimator(self, ev):
         """frame k's estimation on the solver / marginalisation lanes: localize_newframe, refine_window (reads the prior the
         previous marginalisation wrote: device-side wait on the marginalisation lane), then slide_window ->
@@ -283,56 +296,34 @@ class Sequence:
 
 
 def multi_sequence(cfg, torch, dev, device_index, host, n_seq, steps, warmup, overlap=False):
-    """n_seq independent sequences on ONE GPU, each with its own context and lanes, each driven by its own host thread (the
-    C ABI releases the GIL; a sequence is sequential in itself, so its thread mostly waits).  One sequence occupies one
-    compute unit for most of a frame (the persistent single-workgroup solver), so a GPU has room for many: this is what the
-    device sustains when it is kept busy.  NOT `value` (BASELINE's configs are one stream per GPU): reported beside it."""
-    import threading
+    """n_seq independent sequences on ONE GPU, each with its own context and stream(s), each driven by its own host thread
+    through the native driver (rdvio_hip_run_sequences: the same per-frame step as `value`, as one C call per frame).  One
+    sequence occupies one compute unit for most of a frame (the persistent single-workgroup solver), so a GPU has room for
+    many: this is what the device sustains when it is kept busy.  NOT `value` (BASELINE's configs are one stream per GPU):
+    reported beside it."""
+    import ctypes
+
+    from rd_vio_amd.binding import FrameStep
 
     mf = max(2048, 2 * len(host["window_pb"]["tgt"]))
     seqs = [Sequence(cfg, torch, dev, device_index, overlap=overlap, host=host, max_factors=mf) for _ in range(n_seq)]
     torch.cuda.synchronize()
-    gate = threading.Barrier(n_seq + 1)
-    t_done = [0.0] * n_seq
-    errors = []
-
-    def run(i):
-        try:
-            sq = seqs[i]
-            for k in range(warmup):
-                sq.step(k)
-            gate.wait()
-            for k in range(warmup, warmup + steps):
-                sq.step(k)
-            sq.ctx.sync()
-            t_done[i] = time.perf_counter()
-        except Exception as e:  # noqa: BLE001 -- reported by the caller
-            errors.append(repr(e))
-            try:
-                gate.abort()
-            except Exception:  # noqa: BLE001
-                pass
-
-    threads = [threading.Thread(target=run, args=(i,)) for i in range(n_seq)]
-    for t in threads:
-        t.start()
-    try:
-        gate.wait()
-    except threading.BrokenBarrierError:
-        pass
-    t0 = time.perf_counter()
-    for t in threads:
-        t.join()
+    descs = (FrameStep * n_seq)(*[sq.frame_step_desc() for sq in seqs])
+    elapsed = ctypes.c_double(0.0)
+    per = np.zeros(n_seq)
+    rc = seqs[0].ctx._lib.rdvio_hip_run_sequences(descs, n_seq, warmup, steps, ctypes.byref(elapsed), per.ctypes.data)
+    sm = [sq.ctx.ba_fetch(0)[2] for sq in seqs] if rc == 0 else []
     for sq in seqs:
         sq.ctx.close()
-    if errors:
-        return {"sequences": n_seq, "error": errors[0]}
-    elapsed = max(t_done) - t0
+    if rc != 0:
+        return {"sequences": n_seq, "error": f"rdvio_hip_run_sequences returned {rc}"}
     return {"sequences": n_seq, "streams_per_sequence": 3 if overlap else 1, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-            "frames_per_sequence": steps, "aggregate_fps": round(n_seq * steps / elapsed, 1),
-            "per_sequence_fps": round(steps / elapsed, 1), "ms_per_frame_per_sequence": round(1e3 * elapsed / steps, 4),
-            "note": "independent sequences sharing one GPU (one context, three HIP streams and one host thread each); the same per-frame "
-                    "step as `value`; wall time from the common start to the last sequence's last frame"}
+            "frames_per_sequence": steps, "aggregate_fps": round(n_seq * steps / elapsed.value, 1),
+            "per_sequence_fps": round(steps / elapsed.value, 1), "ms_per_frame_per_sequence": round(1e3 * elapsed.value / steps, 4),
+            "slowest_over_fastest_sequence": round(float(per.max() / per.min()), 3),
+            "window_solve_iterations": sorted({int(m.iterations) for m in sm}),
+            "note": "independent sequences sharing one GPU (one context and one host thread each, rdvio_hip_run_sequences); the same "
+                    "per-frame step as `value`; wall time from the common start to the last sequence's last frame"}
 
 
 CPU_STAGES = ["preprocess", "lk_track", "detect", "preintegrate", "ba_localize", "ba_window", "marginalize"]

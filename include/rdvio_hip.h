@@ -273,6 +273,37 @@ int rdvio_hip_parsac_score(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *batch, 
 /* inlier mask (n_points) and per-occupied-bin inlier counts (n_valid) of model `model` of the last scored batch */
 int rdvio_hip_parsac_fetch(rdvio_hip_ctx *ctx, int model, uint8_t *mask, int32_t *bin_inliers);
 
+/* ------------------------------------------------------------------ multi-sequence driver */
+/* One camera frame of the hot path over inputs that are resident in HBM, as one call: preprocess -> LK -> detect ->
+ * preintegration (frame segment without covariance, then nseg - 1 keyframe segments with) on the frontend lane;
+ * localize_newframe (BA slot 1) -> refine_window (slot 0) on the solver lane -> marginalisation on its lane -- the per-frame call
+ * order of FeatureTracker::run (feature_tracker.cpp:26-111) and SlidingWindowTracker::track (sliding_window_tracker.cpp:80-99).
+ * k = frame index (image slot parity, image k % n_images).  overlap != 0: the estimation of frame k is enqueued first and the
+ * frontend of the next image runs beside it (handler.cpp:35-50), the host waits on the frontend and solver lanes; 0: back to
+ * back, one wait.  The BA / marginalisation problems are the ones last uploaded (rdvio_hip_ba_upload, _marginalize_upload). */
+typedef struct rdvio_frame_step {
+    rdvio_hip_ctx *ctx;
+    int32_t width, height, stride, n_images;
+    const uint8_t *const *images_dev;       /* n_images device images (u8, width x height) */
+    int32_t n_features, keypoints_capacity;
+    const double *curr_xy_dev;              /* n_features x 2 */
+    double *next_xy_dev;
+    uint8_t *status_dev;
+    double *keypoints_host;                 /* detect output, keypoints_capacity x 2 */
+    double min_distance;
+    int32_t nseg, ba_iterations;
+    const int32_t *seg_off_dev;             /* nseg + 1 */
+    const double *imu_dev, *par_dev, *noise_dev;
+    double *preint_out_dev;                 /* nseg x RDVIO_PREINT_SIZE */
+    int32_t overlap, reserved;
+} rdvio_frame_step;
+int rdvio_hip_frame_step(const rdvio_frame_step *step, int k);
+/* n_seq independent sequences (one context each; the reference is one process per sequence), one host thread per
+ * sequence: `warmup` untimed frames each, a common start, then `steps` frames each.  elapsed_s = common start -> last frame of the
+ * slowest sequence; per_sequence_s (n_seq, may be NULL) = each sequence's own time.  Returns the first error met (0 = none). */
+int rdvio_hip_run_sequences(const rdvio_frame_step *seqs, int n_seq, int warmup, int steps, double *elapsed_s,
+                            double *per_sequence_s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,7 @@ EXPORTS = [
     "rdvio_hip_reprojection_eval", "rdvio_hip_rotation_prior_eval", "rdvio_hip_ba_solve", "rdvio_hip_ba_upload", "rdvio_hip_ba_solve_resident",
     "rdvio_hip_ba_fetch", "rdvio_hip_marginalize", "rdvio_hip_marginalize_upload", "rdvio_hip_marginalize_resident",
     "rdvio_hip_marginalize_fetch", "rdvio_hip_parsac_score", "rdvio_hip_parsac_fetch",
+    "rdvio_hip_frame_step", "rdvio_hip_run_sequences",
 ]
 
 
@@ -41,6 +42,22 @@ class PyrLayout(ctypes.Structure):
         ("stride", ctypes.c_int32 * MAX_LEVELS),
         ("img_off", ctypes.c_int64 * MAX_LEVELS), ("deriv_off", ctypes.c_int64 * MAX_LEVELS),
         ("img_bytes", ctypes.c_int64), ("deriv_elems", ctypes.c_int64),
+    ]
+
+
+class FrameStep(ctypes.Structure):
+    """rdvio_frame_step (include/rdvio_hip.h): one camera frame of the resident hot path / one sequence of the multi-sequence driver"""
+    _fields_ = [
+        ("ctx", ctypes.c_void_p),
+        ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("stride", ctypes.c_int32), ("n_images", ctypes.c_int32),
+        ("images_dev", ctypes.POINTER(ctypes.c_void_p)),
+        ("n_features", ctypes.c_int32), ("keypoints_capacity", ctypes.c_int32),
+        ("curr_xy_dev", ctypes.c_void_p), ("next_xy_dev", ctypes.c_void_p), ("status_dev", ctypes.c_void_p),
+        ("keypoints_host", ctypes.c_void_p), ("min_distance", ctypes.c_double),
+        ("nseg", ctypes.c_int32), ("ba_iterations", ctypes.c_int32),
+        ("seg_off_dev", ctypes.c_void_p), ("imu_dev", ctypes.c_void_p), ("par_dev", ctypes.c_void_p), ("noise_dev", ctypes.c_void_p),
+        ("preint_out_dev", ctypes.c_void_p),
+        ("overlap", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
 
@@ -108,6 +125,9 @@ def load_library():
     lib.rdvio_hip_lane_wait.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.rdvio_hip_lane_sync.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.rdvio_hip_pyr_layout_init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(PyrLayout)]
+    lib.rdvio_hip_frame_step.argtypes = [ctypes.POINTER(FrameStep), ctypes.c_int]
+    lib.rdvio_hip_run_sequences.argtypes = [ctypes.POINTER(FrameStep), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                            ctypes.c_void_p]
     img_args = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                 ctypes.c_double, ctypes.c_int, ctypes.c_int]
     lib.rdvio_hip_image_preprocess.argtypes = img_args

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librdvio_hip.so")
 SOURCES = ["capi.hip", "image_kernels.hip", "lk_kernels.hip", "ba_kernels.hip", "select_kernels.hip", "parsac_kernels.hip", "solver_kernels.hip", "solver_host.hip", "marg_host.hip",
-           "host_select.cpp"]
+           "host_select.cpp", "sequences.cpp"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # No FMA contraction anywhere: the image / LK arithmetic must round exactly like the oracle (bit-exact feature
 # indices), and the FP64 estimation code relies on exact cancellations the reference (built without FMA) also has --
@@ -85,7 +85,7 @@ def _build_hip(force=False, verbose=False):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1,6 +1,7 @@
-"""bench.py's multi-sequence leg: independent sequences sharing one GPU (one context, three lanes and one host thread each)
-must not see each other -- every sequence's solver / marginalisation results are bit-identical to those of a sequence that
+"""bench.py's multi-sequence leg: independent sequences sharing one GPU (one context and one host thread each, with three lanes
+or one, stepped from Python or through the native rdvio_hip_frame_step) must not see each other -- every sequence's solver / marginalisation results are bit-identical to those of a sequence that
 ran alone.  (The library keeps its state per context: SURVEY F9's process-global state is not reproduced.)"""
+import ctypes
 import os
 import sys
 import threading
@@ -35,18 +36,23 @@ def test_concurrent_sequences_do_not_interact():
     alone.ctx.sync()
     ref = _results(alone)
     host = alone.wl
-    seqs = [bench.Sequence(cfg, torch, dev, 0, overlap=True, host=host, max_factors=4096) for _ in range(4)]
+    seqs = [bench.Sequence(cfg, torch, dev, 0, overlap=(i % 2 == 0), host=host, max_factors=4096) for i in range(4)]
     errs = []
 
-    def run(sq):
+    def run(sq, native):
         try:
-            for k in range(6):
-                sq.step(k)
+            if native:   # rdvio_hip_frame_step: the whole frame as one C call (what rdvio_hip_run_sequences drives)
+                d = sq.frame_step_desc()
+                for k in range(6):
+                    sq.ctx._check(sq.ctx._lib.rdvio_hip_frame_step(ctypes.byref(d), k))
+            else:
+                for k in range(6):
+                    sq.step(k)
             sq.ctx.sync()
         except Exception as e:  # noqa: BLE001
             errs.append(repr(e))
 
-    th = [threading.Thread(target=run, args=(sq,)) for sq in seqs]
+    th = [threading.Thread(target=run, args=(sq, i >= 2)) for i, sq in enumerate(seqs)]
     for t in th:
         t.start()
     for t in th:
@@ -74,3 +80,4 @@ def test_multi_sequence_leg_reports_an_aggregate():
     first.ctx.close()
     assert "error" not in rep, rep
     assert rep["sequences"] == 3 and rep["aggregate_fps"] > 0 and abs(rep["aggregate_fps"] - 3 * rep["per_sequence_fps"]) <= 1.0
+    assert rep["window_solve_iterations"] == [30]   # every sequence's last window solve ran the bench problem to the limit
