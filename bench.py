@@ -295,7 +295,7 @@ class Sequence:
             self.ctx.sync()
 
 
-def multi_sequence(cfg, torch, dev, device_index, host, n_seq, steps, warmup, overlap=False):
+def multi_sequence(cfg, torch, dev, device_index, host, n_seq, steps, warmup, overlap=False, wait_mode=-1):
     """n_seq independent sequences on ONE GPU, each with its own context and stream(s), each driven by its own host thread
     through the native driver (rdvio_hip_run_sequences: the same per-frame step as `value`, as one C call per frame).  One
     sequence occupies one compute unit for most of a frame (the persistent single-workgroup solver), so a GPU has room for
@@ -311,13 +311,13 @@ def multi_sequence(cfg, torch, dev, device_index, host, n_seq, steps, warmup, ov
     descs = (FrameStep * n_seq)(*[sq.frame_step_desc() for sq in seqs])
     elapsed = ctypes.c_double(0.0)
     per = np.zeros(n_seq)
-    rc = seqs[0].ctx._lib.rdvio_hip_run_sequences(descs, n_seq, warmup, steps, ctypes.byref(elapsed), per.ctypes.data)
+    rc = seqs[0].ctx._lib.rdvio_hip_run_sequences(descs, n_seq, warmup, steps, wait_mode, ctypes.byref(elapsed), per.ctypes.data)
     sm = [sq.ctx.ba_fetch(0)[2] for sq in seqs] if rc == 0 else []
     for sq in seqs:
         sq.ctx.close()
     if rc != 0:
         return {"sequences": n_seq, "error": f"rdvio_hip_run_sequences returned {rc}"}
-    return {"sequences": n_seq, "streams_per_sequence": 3 if overlap else 1, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+    return {"sequences": n_seq, "streams_per_sequence": 3 if overlap else 1, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "host_wait": {-1: "auto", 0: "spin", 1: "block"}[wait_mode], "host_cores": os.cpu_count(),
             "frames_per_sequence": steps, "aggregate_fps": round(n_seq * steps / elapsed.value, 1),
             "per_sequence_fps": round(steps / elapsed.value, 1), "ms_per_frame_per_sequence": round(1e3 * elapsed.value / steps, 4),
             "slowest_over_fastest_sequence": round(float(per.max() / per.min()), 3),
@@ -524,6 +524,7 @@ def parse_args(argv=None):
     ap.add_argument("--end-to-end-frames", type=int, default=100, help="frames of the pipeline run (0 = skip)")
     ap.add_argument("--sequences", type=int, default=16,
                     help="extra leg (1 GPU, rank 0): this many independent sequences sharing the GPU, aggregate frames/s reported beside `value` (0 = skip)")
+    ap.add_argument("--sequence-wait", type=int, default=-1, choices=(-1, 0, 1), help="host waits of the multi-sequence leg: 0 spin, 1 block, -1 auto")
     ap.add_argument("--sequence-lanes", type=int, default=1, choices=(1, 3),
                     help="streams per sequence in the multi-sequence leg: 1 = stages back to back (the device overlaps ACROSS sequences), 3 = the lanes of `value`")
     ap.add_argument("--serial", action="store_true", help="one stream, stages back to back (the round-1 step); default: frontend / estimator streams overlapped")
@@ -596,7 +597,7 @@ def main(argv=None):
     if args.sequences > 1:
         # the multi-sequence leg runs one HIP stream per sequence: the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues
         # (default 4), and streams that share a queue run one after the other -- ask for one queue per sequence before HIP starts
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(max(4, args.sequences * args.sequence_lanes), 64)))
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(max(4, 2 * args.sequences * args.sequence_lanes), 32)))
 
     import torch
 
@@ -701,7 +702,7 @@ def main(argv=None):
             out["end_to_end"] = end_to_end(cfg, ctx, args.end_to_end_frames, with_cpu_path=not args.no_cpu_baseline)
         if world == 1 and args.sequences > 1 and not args.serial:
             out["multi_sequence"] = multi_sequence(cfg, torch, dev, local_rank, wl, args.sequences, steps=min(args.steps, 100), warmup=10,
-                                                   overlap=args.sequence_lanes == 3)
+                                                   overlap=args.sequence_lanes == 3, wait_mode=args.sequence_wait)
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

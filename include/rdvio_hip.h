@@ -81,6 +81,11 @@ int rdvio_hip_sync(rdvio_hip_ctx *ctx);
 #define RDVIO_LANE_SOLVER 1
 #define RDVIO_LANE_MARG 2
 int rdvio_hip_ctx_set_lane_stream(rdvio_hip_ctx *ctx, int lane, void *stream);
+/* How the library's host-side waits wait: 0 (default) = spinning (hipStreamSynchronize: lowest latency, one core per waiting
+ * thread); 1 = blocking on an event created with hipEventBlockingSync (the waiting thread sleeps) -- for processes that drive
+ * more sequences than they have cores (rdvio_hip_run_sequences switches its contexts to 1 for the run when n_seq exceeds
+ * the hardware concurrency). */
+int rdvio_hip_ctx_set_wait_mode(rdvio_hip_ctx *ctx, int blocking);
 int rdvio_hip_lane_wait(rdvio_hip_ctx *ctx, int lane, int on_lane);
 int rdvio_hip_lane_sync(rdvio_hip_ctx *ctx, int lane);
 int rdvio_hip_pyr_layout_init(int width, int height, int max_level, rdvio_pyr_layout *out);
@@ -300,8 +305,10 @@ typedef struct rdvio_frame_step {
 int rdvio_hip_frame_step(const rdvio_frame_step *step, int k);
 /* n_seq independent sequences (one context each; the reference is one process per sequence), one host thread per
  * sequence: `warmup` untimed frames each, a common start, then `steps` frames each.  elapsed_s = common start -> last frame of the
- * slowest sequence; per_sequence_s (n_seq, may be NULL) = each sequence's own time.  Returns the first error met (0 = none). */
-int rdvio_hip_run_sequences(const rdvio_frame_step *seqs, int n_seq, int warmup, int steps, double *elapsed_s,
+ * slowest sequence; per_sequence_s (n_seq, may be NULL) = each sequence's own time.  wait_mode: how the threads wait for the
+ * device during the run (rdvio_hip_ctx_set_wait_mode): 0 spin, 1 block, -1 = block when 2 n_seq exceeds the host's cores; the
+ * contexts are back in spin mode afterwards.  Returns the first error met (0 = none). */
+int rdvio_hip_run_sequences(const rdvio_frame_step *seqs, int n_seq, int warmup, int steps, int wait_mode, double *elapsed_s,
                             double *per_sequence_s);
 
 #ifdef __cplusplus

@@ -177,7 +177,9 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
 void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (int l = 0; l < 3; ++l) (void)hipStreamSynchronize(ctx->lane[l]);
+    for (int l = 0; l < 3; ++l) (void)rdvio_wait(ctx, ctx->lane[l]);
+    if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
+    ctx->wait_ev = nullptr;
     for (int s = 0; s < RDVIO_NUM_SLOTS; ++s) {
         (void)hipFree(ctx->slots[s].pyr_img);
         (void)hipFree(ctx->slots[s].pyr_deriv);
@@ -209,16 +211,24 @@ const char *rdvio_hip_last_error(const rdvio_hip_ctx *ctx) { return ctx ? ctx->e
 int rdvio_hip_sync(rdvio_hip_ctx *ctx) {
     if (!ctx) return RDVIO_ERR_INVALID;
     for (int l = 0; l < 3; ++l)
-        if (l == 0 || ctx->lane[l] != ctx->lane[0]) RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane[l]));
+        if (l == 0 || ctx->lane[l] != ctx->lane[0]) RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->lane[l]));
     return RDVIO_OK;
 }
 
 static bool bad_lane(int lane) { return lane < 0 || lane > 2; }
 
+int rdvio_hip_ctx_set_wait_mode(rdvio_hip_ctx *ctx, int blocking) {
+    if (!ctx) return RDVIO_ERR_INVALID;
+    RDVIO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (blocking && !ctx->wait_ev) RDVIO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->wait_ev, hipEventBlockingSync | hipEventDisableTiming));
+    ctx->blocking_wait = blocking != 0;
+    return RDVIO_OK;
+}
+
 int rdvio_hip_ctx_set_lane_stream(rdvio_hip_ctx *ctx, int lane, void *stream) {
     if (!ctx || bad_lane(lane)) return RDVIO_ERR_INVALID;
     if (lane == RDVIO_LANE_FRONTEND) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "the frontend lane is the context's stream (rdvio_hip_ctx_create)");
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane[lane]));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->lane[lane]));
     if (ctx->own_lane[lane]) {
         RDVIO_HIP_CHECK(ctx, hipStreamDestroy(ctx->lane[lane]));
         ctx->own_lane[lane] = false;
@@ -245,7 +255,7 @@ int rdvio_hip_lane_wait(rdvio_hip_ctx *ctx, int lane, int on_lane) {
 
 int rdvio_hip_lane_sync(rdvio_hip_ctx *ctx, int lane) {
     if (!ctx || bad_lane(lane)) return RDVIO_ERR_INVALID;
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane[lane]));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->lane[lane]));
     return RDVIO_OK;
 }
 
@@ -279,7 +289,7 @@ int rdvio_hip_image_download(rdvio_hip_ctx *ctx, int slot, uint8_t *pyr_img, int
     if (pyr_img) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(pyr_img, S.pyr_img, (size_t)S.L.img_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (pyr_deriv)
         RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(pyr_deriv, S.pyr_deriv, (size_t)S.L.deriv_elems * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream));
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->stream));
     return RDVIO_OK;
 }
 
@@ -312,7 +322,7 @@ int rdvio_hip_track_keypoints(rdvio_hip_ctx *ctx, int slot_curr, int slot_next, 
     if (int rc = rdvio_launch_track(ctx, slot_curr, slot_next, n, d_curr, d_next, has_guess, d_status)) return rc;
     uint8_t *down = (uint8_t *)(up + 2 * nd);
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, d_next, nd * sizeof(double) + (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->stream));
     memcpy(next_xy, down, nd * sizeof(double));
     memcpy(status, down + nd * sizeof(double), (size_t)n);
     return RDVIO_OK;
@@ -329,7 +339,7 @@ int rdvio_hip_lk_flow(rdvio_hip_ctx *ctx, int slot_prev, int slot_next, int n, c
     if (int rc = rdvio_launch_lk_flow(ctx, slot_prev, slot_next, n, ctx->lk_prevf, ctx->lk_nextf, ctx->lk_status, max_iter, eps)) return rc;
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(next_xy, ctx->lk_nextf, bytes, hipMemcpyDeviceToHost, ctx->stream));
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(status, ctx->lk_status, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->stream));
     return RDVIO_OK;
 }
 
@@ -339,7 +349,7 @@ int rdvio_hip_harris_response(rdvio_hip_ctx *ctx, int slot, float *resp) {
     if (!S.valid) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "slot %d not preprocessed", slot);
     if (int rc = rdvio_launch_harris(ctx, slot)) return rc;
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(resp, ctx->harris, (size_t)S.w * S.h * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->stream));
     return RDVIO_OK;
 }
 
@@ -363,7 +373,7 @@ int rdvio_hip_detect_keypoints(rdvio_hip_ctx *ctx, int slot, double *keypoints, 
         if (int rc = rdvio_launch_select(ctx, slot, max_points, gftt_min_dist, min_distance, n_existing)) return rc;
         int32_t *hdr = (int32_t *)ctx->pinned;
         RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(hdr, ctx->sel_hdr, 64 + (size_t)max_points * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->stream));
         if (hdr[1] == 0) {
             const int n_new = hdr[3];
             if (n_existing + n_new > capacity) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "keypoint capacity %d too small", capacity);
@@ -378,12 +388,12 @@ int rdvio_hip_detect_keypoints(rdvio_hip_ctx *ctx, int slot, double *keypoints, 
     const int prefix = std::min(ctx->harris_cand_cap, 4096);
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(scalars, ctx->harris_scalars, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(cand, ctx->harris_cand, (size_t)prefix * sizeof(HarrisCand), hipMemcpyDeviceToHost, ctx->stream));
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->stream));
     const int nc = (int)std::min<uint32_t>(scalars[1], (uint32_t)ctx->harris_cand_cap);
     if (nc > prefix) {
         RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(cand + prefix, ctx->harris_cand + prefix, (size_t)(nc - prefix) * sizeof(HarrisCand), hipMemcpyDeviceToHost,
                                             ctx->stream));
-        RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->stream));
     }
     int total = rdvio_host_select_keypoints(cand, nc, S.w, S.h, max_points, 20.0, min_distance, keypoints, n_existing, capacity);
     if (total < 0) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "keypoint capacity %d too small", capacity);
@@ -427,7 +437,7 @@ int rdvio_hip_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off,
         return rc;
     double *down = blob + in_doubles;
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, ctx->pre_out, out_doubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->stream));
     memcpy(out, down, out_doubles * sizeof(double));
     return RDVIO_OK;
 }
@@ -485,7 +495,7 @@ int rdvio_hip_reprojection_eval(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, 
         RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(Jr, ctx->ba_Jr, (size_t)nf * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
         RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(Jd, ctx->ba_Jd, (size_t)nf * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     }
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));
     return RDVIO_OK;
 }
 
@@ -512,7 +522,7 @@ int rdvio_hip_rotation_prior_eval(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb
     if (int rc = rdvio_launch_rotation_prior(ctx, n, J != nullptr)) return rc;
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(r, ctx->ba_r, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (J) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(J, ctx->ba_Jt, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));
     return RDVIO_OK;
 }
 

@@ -37,6 +37,10 @@ struct rdvio_hip_ctx {
     hipStream_t lane[3] = {nullptr, nullptr, nullptr};
     bool own_lane[3] = {false, false, false};
     hipEvent_t lane_ev[3] = {nullptr, nullptr, nullptr};
+    // host waits: spinning (hipStreamSynchronize: lowest latency, one core per waiting thread) or blocking on an event created
+    // with hipEventBlockingSync (the waiting thread sleeps: many sequences per process, more waiting threads than cores)
+    bool blocking_wait = false;
+    hipEvent_t wait_ev = nullptr;
     int max_w = 0, max_h = 0, max_feat = 0, max_window = 0, max_factors = 0;
     bool force_host_select = false;  // env RDVIO_HOST_SELECT=1 (read at context creation)
     int solver_wgs = 8;  // workgroups per solver launch for problems with >= RDVIO_HELPER_MIN_FACTORS factors (env RDVIO_SOLVER_WGS)
@@ -105,6 +109,13 @@ inline int rdvio_fail(rdvio_hip_ctx *ctx, int code, const char *fmt, ...) {
         va_end(ap);
     }
     return code;
+}
+
+// every host-side wait of the library goes through here (rdvio_hip_ctx_set_wait_mode)
+static inline hipError_t rdvio_wait(rdvio_hip_ctx *ctx, hipStream_t st) {
+    if (!ctx->blocking_wait || !ctx->wait_ev) return hipStreamSynchronize(st);
+    const hipError_t e = hipEventRecord(ctx->wait_ev, st);
+    return e != hipSuccess ? e : hipEventSynchronize(ctx->wait_ev);
 }
 
 #define RDVIO_HIP_CHECK(ctx, expr)                                                                     \

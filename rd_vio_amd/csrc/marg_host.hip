@@ -50,7 +50,7 @@ extern "C" {
 int rdvio_hip_marginalize_upload(rdvio_hip_ctx *ctx, const rdvio_marg_problem *pb) {
     if (!ctx) return RDVIO_ERR_INVALID;
     ctx->marg.ready = false;
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane[RDVIO_LANE_MARG]));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->lane[RDVIO_LANE_MARG]));
     if (int rc = marg_prepare(ctx, pb)) return rc;
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->marg.arena, ctx->marg.host, ctx->marg.in_bytes, hipMemcpyHostToDevice, ctx->lane[RDVIO_LANE_MARG]));
     return RDVIO_OK;
@@ -83,7 +83,7 @@ int rdvio_hip_marginalize_fetch(rdvio_hip_ctx *ctx, double *S_out, double *f_out
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, w.S_out, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
     if (Lambda_out) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(Lambda_out, w.Lambda_out, R * R * sizeof(double), hipMemcpyDeviceToHost, st));
     if (eta_out) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(eta_out, w.eta_out, R * sizeof(double), hipMemcpyDeviceToHost, st));
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));
     if (S_out) memcpy(S_out, down, R * R * sizeof(double));
     if (f_out) memcpy(f_out, down + (w.f_out - w.S_out), R * sizeof(double));
     if (lin_out) memcpy(lin_out, down + (w.lin_out - w.S_out), (size_t)(w.nfr - 1) * 16 * sizeof(double));

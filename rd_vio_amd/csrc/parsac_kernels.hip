@@ -135,7 +135,7 @@ int rdvio_hip_parsac_score(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, rdvi
         if (b->data_to_valid[i] < 0 || b->data_to_valid[i] >= nv) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "PARSAC point %d maps outside the occupied bins", i);
     if (nm == 0) return RDVIO_OK;
     hipStream_t st = ctx->lane[RDVIO_LANE_SOLVER];
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(st));  // the pinned blob may still be in flight
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));  // the pinned blob may still be in flight
     uint8_t *hb = (uint8_t *)ctx->ps_host, *db = (uint8_t *)ctx->ps_dev;
     const int pdim = b->kind == 1 ? 3 : 2, mdim = b->kind == 1 ? 12 : 9;
     // (a batch that reuses the uploaded points keeps their layout, whatever optional pointers it passes)
@@ -176,7 +176,7 @@ int rdvio_hip_parsac_score(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, rdvi
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
     rdvio_parsac_result *down = (rdvio_parsac_result *)((uint8_t *)ctx->ps_host + ctx->ps_in_bytes);
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, ctx->ps_results, (size_t)nm * sizeof(rdvio_parsac_result), hipMemcpyDeviceToHost, st));
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));
     memcpy(results, down, (size_t)nm * sizeof(rdvio_parsac_result));
     ctx->ps_nm = nm;
     return RDVIO_OK;
@@ -192,7 +192,7 @@ int rdvio_hip_parsac_fetch(rdvio_hip_ctx *ctx, int model, uint8_t *mask, int32_t
     if (bin_inliers)
         RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down + mb, ctx->ps_bins + (size_t)model * RDVIO_PARSAC_MAX_BINS, (size_t)ctx->ps_nv * sizeof(int32_t),
                                             hipMemcpyDeviceToHost, st));
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));
     if (mask) memcpy(mask, down, (size_t)ctx->ps_n);
     if (bin_inliers) memcpy(bin_inliers, down + mb, (size_t)ctx->ps_nv * sizeof(int32_t));
     return RDVIO_OK;

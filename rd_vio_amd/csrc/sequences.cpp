@@ -52,9 +52,15 @@ extern "C" int rdvio_hip_frame_step(const rdvio_frame_step *d, int k) {
     return rdvio_hip_sync(c);
 }
 
-extern "C" int rdvio_hip_run_sequences(const rdvio_frame_step *seqs, int n_seq, int warmup, int steps, double *elapsed_s,
-                                       double *per_sequence_s) {
+extern "C" int rdvio_hip_run_sequences(const rdvio_frame_step *seqs, int n_seq, int warmup, int steps, int wait_mode,
+                                       double *elapsed_s, double *per_sequence_s) {
     if (!seqs || n_seq <= 0 || n_seq > 1024 || warmup < 0 || steps <= 0) return RDVIO_ERR_INVALID;
+    // wait mode for the run: 0 spin, 1 block, -1 (default) block when there are more sequences than half the cores (a spinning
+    // waiter holds a core, and the runtime's own threads need some too)
+    const unsigned cores = std::thread::hardware_concurrency();
+    const bool blocking = wait_mode < 0 ? (cores == 0 || 2u * (unsigned)n_seq > cores) : wait_mode != 0;
+    for (int i = 0; i < n_seq; ++i)
+        if (int rc = rdvio_hip_ctx_set_wait_mode(seqs[i].ctx, blocking ? 1 : 0)) return rc;
     using clock = std::chrono::steady_clock;
     std::atomic<int> arrived{0}, failed{0};
     std::atomic<bool> go{false};
@@ -86,5 +92,6 @@ extern "C" int rdvio_hip_run_sequences(const rdvio_frame_step *seqs, int n_seq, 
         if (s > worst) worst = s;
     }
     if (elapsed_s) *elapsed_s = worst;   // common start -> the last sequence's last frame
+    for (int i = 0; i < n_seq; ++i) (void)rdvio_hip_ctx_set_wait_mode(seqs[i].ctx, 0);
     return failed.load();
 }

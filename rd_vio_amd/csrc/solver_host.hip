@@ -293,7 +293,7 @@ int rdvio_hip_ba_upload(rdvio_hip_ctx *ctx, int slot, const rdvio_ba_problem *pb
     rdvio_hip_ctx::BaSlot &S = ctx->ba[slot];
     S.ready = false;
     // the pinned blob may still be in flight from a previous upload on this stream
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane[RDVIO_LANE_SOLVER]));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->lane[RDVIO_LANE_SOLVER]));
     if (int rc = rdvio_ba_prepare(ctx, S, pb, ctx->ba_arena_bytes, false)) return rc;
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(S.arena, S.host, S.in_bytes, hipMemcpyHostToDevice, ctx->lane[RDVIO_LANE_SOLVER]));
     return RDVIO_OK;
@@ -324,7 +324,7 @@ int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double 
     if (host_off + n_out * sizeof(double) > S.host_bytes) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "result does not fit the pinned blob");
     double *down = (double *)((uint8_t *)S.host + host_off);
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, w.x, n_out * sizeof(double), hipMemcpyDeviceToHost, ctx->lane[RDVIO_LANE_SOLVER]));
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane[RDVIO_LANE_SOLVER]));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->lane[RDVIO_LANE_SOLVER]));
     if (states_out) memcpy(states_out, down, (size_t)w.nfr * 16 * sizeof(double));
     if (inv_depth_out && w.nl > 0) memcpy(inv_depth_out, down + (w.xd - w.x), (size_t)w.nl * sizeof(double));
     const double *sum = down + (w.summary - w.x);
@@ -346,7 +346,7 @@ int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double 
 int rdvio_hip_debug_ba_prof(rdvio_hip_ctx *ctx, int slot, double *out64) {
     if (!ctx || bad_slot(slot) || !ctx->ba[slot].ready) return RDVIO_ERR_INVALID;
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(out64, ctx->ba[slot].ws.summary + 8, 64 * sizeof(double), hipMemcpyDeviceToHost, ctx->lane[RDVIO_LANE_SOLVER]));
-    RDVIO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane[RDVIO_LANE_SOLVER]));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->lane[RDVIO_LANE_SOLVER]));
     return RDVIO_OK;
 }
 
