@@ -73,3 +73,13 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
                 assert "#include \"rdvio_oracle.h\"" not in src and "ro_math.h" not in src, f
+
+
+def test_sequence_driver_rejects_bad_arguments(lib):
+    # the multi-sequence driver validates its arguments before it touches a device
+    assert lib.rdvio_hip_frame_step(None, 0) != 0
+    assert lib.rdvio_hip_run_sequences(None, 0, 0, 1, -1, None, None) != 0
+    d = binding.FrameStep()
+    assert lib.rdvio_hip_frame_step(ctypes.byref(d), 0) != 0          # no context
+    assert lib.rdvio_hip_run_sequences(ctypes.byref(d), 1, 0, 0, -1, None, None) != 0   # zero steps
+    assert lib.rdvio_hip_ctx_set_wait_mode(None, 1) != 0
