@@ -255,10 +255,10 @@ def test_marginalize_chain_feeds_solver(ctx, oracle):
     assert np.abs(s_gpu - s_ref).max() < 1e-5
 
 
-def test_ba_solve_large_problem_uses_helper_workgroups(ctx, oracle):
-    # config-5 shape (1000 landmarks, window 16, > 4096 factors): the launch has 8 workgroups, the helpers evaluate
-    # their share of the factors on request (solver_kernels.hip "Helper workgroups"); same accept / reject path and
-    # states as the single-threaded oracle
+def test_ba_solve_large_problem_uses_helper_workgroups(ctx, oracle, monkeypatch):
+    # config-5 shape (1000 landmarks, window 16, > 4096 factors): the launch has a team of 8 workgroups, the helpers take
+    # their shares of the factor evaluation, the group products, the H blocks and the Schur product on request
+    # (solver_kernels.hip "Helper workgroups"); same accept / reject path and states as the single-threaded oracle
     pb = synth.make_window_problem(17, 1000, 655, preintegrate=_oracle_pre(oracle))
     assert len(pb["tgt"]) >= 4096
     ref_s, ref_d, ref_sm = oracle.ba_solve(pb, 6)
@@ -269,6 +269,11 @@ def test_ba_solve_large_problem_uses_helper_workgroups(ctx, oracle):
     assert np.abs(got_s - ref_s).max() < 1e-6 and np.abs(got_d - ref_d).max() < 1e-6
     again_s, again_d, _ = ctx.ba_solve(pb, 6)
     assert (again_s == got_s).all() and (again_d == got_d).all()     # fixed reduction order across workgroups: reproducible
+    # where the team runs (one XCD by default, one member per XCD with the switch) is a speed matter only
+    monkeypatch.setenv("RDVIO_SOLVER_SPREAD", "1")
+    spread_s, spread_d, spread_sm = ctx.ba_solve(pb, 6)
+    monkeypatch.setenv("RDVIO_SOLVER_SPREAD", "0")
+    assert (spread_s == got_s).all() and (spread_d == got_d).all() and spread_sm.final_cost == got_sm.final_cost
 
 
 def test_speculative_trial_steps_replay_the_sequential_loop(ctx, oracle, monkeypatch):
