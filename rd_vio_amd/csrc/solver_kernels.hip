@@ -1370,6 +1370,112 @@ PHASE_FN double gauss_newton_step_and_model(LdsWs &w, Shared &sh, lds_double *bi
     return r[8];
 }
 
+// One free frame and no free landmark (localize_newframe, sliding_window_tracker.cpp:101-125: N = 15): the damped system, its
+// factorisation, both substitutions and the post-solve scalars on ONE wavefront, rows in lanes -- no workgroup barrier, no
+// round trip through memory between the steps (the general road is five phases of a few microseconds each, whatever the
+// size).  out as gauss_newton_step_and_model; returns 1 when the factorisation succeeded and every component is finite.
+PHASE_FN int small_system_solve(LdsWs &w, Shared &sh, lds_double *Sl, double mu, double (&out)[8]) {
+    const int t = threadIdx.x;
+    if (t < 64) {
+        const int r = t < 15 ? t : 14;
+        const bool on = t < 15;
+        double h[15];
+#pragma unroll
+        for (int c = 0; c < 15; ++c) h[c] = w.H[15 * r + c];
+        const double sg = w.sig_p[r], dg = w.diag_p[r], gr = w.grad_p[r], g = w.g[r];
+        // S = Sigma H Sigma + mu D^2 (lower triangle, packed), right-hand side Sigma g
+#pragma unroll
+        for (int c = 0; c < 15; ++c) {
+            double v = h[c] * (sg * readlane_d(sg, c));
+            if (c == r) v += mu * dg * dg;
+            if (on && c <= r) Sl[tri(r) + c] = v;
+        }
+        if (t == 0) sh.flag = 1;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        cholesky_diag_block<T>(sh, Sl, 0, 0.0);   // L in place, sh.vec[j] = 1 / L_jj, sh.flag = 0 on a bad pivot
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double l[15];
+#pragma unroll
+        for (int c = 0; c < 15; ++c) l[c] = (on && c <= r) ? Sl[tri(r) + c] : 0.0;
+        // forward substitution, column by column: z_j is final once the columns before it have been applied
+        double z = on ? sg * g : 0.0;
+#pragma unroll
+        for (int j = 0; j < 15; ++j) {
+            const double zj = readlane_d(z, j) * sh.vec[j];
+            if (t == j) z = zj;
+            else if (on && t > j) z = __builtin_fma(-l[j], zj, z);
+        }
+        // backward substitution with L^T: lane i < j needs L[j][i] (row j lives in lane j): read from LDS
+        double y = z;
+#pragma unroll
+        for (int j = 14; j >= 0; --j) {
+            const double yj = readlane_d(y, j) * sh.vec[j];
+            if (t == j) y = yj;
+            else if (t < j) y = __builtin_fma(-Sl[tri(j) + r], yj, y);
+        }
+        const bool fin = !on || isfinite(y);
+        const int ok = (__ballot(!fin) == 0ull && sh.flag) ? 1 : 0;
+        // Gauss-Newton step in dogleg coordinates, the two model directions and the scalars
+        const double gn = on ? -y * dg : 0.0;
+        const double sd = sg / dg;
+        const double u = on ? sd * gr : 0.0, v = on ? sd * gn : 0.0;
+        double hu = 0.0, hv = 0.0;
+#pragma unroll
+        for (int c = 0; c < 15; ++c) {
+            hu = __builtin_fma(h[c], readlane_d(u, c), hu);
+            hv = __builtin_fma(h[c], readlane_d(v, c), hv);
+        }
+        const double grz = on ? gr : 0.0;
+        double s8[8] = {grz * grz, gn * gn, grz * gn, u * hu, u * hv, v * hv, on ? g * u : 0.0, on ? g * v : 0.0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s8[i] = wave_sum(s8[i]);
+        if (on) {
+            w.yp[r] = y;
+            w.gn_p[r] = gn;
+        }
+        if (t == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sh.blk[32 + i] = s8[i];
+            sh.blk[40] = (double)ok;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = sh.blk[32 + i];
+    const int ok = sh.blk[40] != 0.0;
+    __syncthreads();   // (sh.blk is free again)
+    return ok;
+}
+
+// the Gauss-Newton solve for one damping mu and everything the step selection needs from it:
+//   out = {|g|^2, |gn|^2, g.gn, q_uu, q_uv, q_vv, l_u, l_v};
+// returns bit 0 = solved (0: the damping must grow), bit 1 = an odd number of block reductions ran (the caller's bank flips)
+PHASE_FN int solve_step(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap, int phase, double mu, double (&out)[8], unsigned long long &prof_last) {
+    const int N = w.N;
+    if (w.small_system) {
+        const int ok = small_system_solve(w, sh, lds, mu, out);
+        STAMP(7);
+        return ok;
+    }
+    lds_double *Sl = lds, *Dinv = lds + (size_t)(N + 1) * (N + 2) / 2;
+    schur_reduce(w, sh, lds, lds_cap, mu, prof_last);
+    STAMP(4);
+    int ok = 1;
+    if (N > 0) ok = w.lds_chol ? cholesky_lds(sh, Sl, Dinv, N) : cholesky_blocked(sh, w.Sm, N, N + 1);
+    STAMP(5);
+    if (!ok) return 0;
+    if (N > 0) {
+        if (w.lds_chol) cholesky_solve_lds(sh, Sl, Dinv, N, w.yp);
+        else cholesky_solve(sh, w.Sm, N, w.yp, false, true, true);   // (row N holds L^-1 b)
+    }
+    STAMP(6);
+    // (3 N doubles fit sh.xv for every LDS-factored window, the idle LDS buffer otherwise)
+    const double bad = gauss_newton_step_and_model(w, sh, lds, phase, mu, out);
+    return (bad > 0.0 ? 0 : 1) | 2;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Speculative evaluation of up to four trial steps in ONE pass.  After a rejected step the next trial is known in
 // advance: the radius halves, the dogleg step is re-interpolated from the same model scalars, nothing else changes --
@@ -1641,7 +1747,6 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     constexpr int NMAX = 15 * RDVIO_LDS_CHOL_MAX_FRAMES;
     constexpr size_t LDS_CAP = (NMAX + 1) * (NMAX + 2) / 2 + 225 * RDVIO_LDS_CHOL_MAX_FRAMES;  // (+ the right-hand-side row)
     __shared__ __attribute__((aligned(16))) double lds_chol_buf[LDS_CAP];
-    double *Sl = lds_chol_buf, *Dinv = lds_chol_buf + (w.N + 1) * (w.N + 2) / 2;
     const int t = threadIdx.x;
     // Workgroups of a multi-workgroup launch: the grid is wg_stride x n_wg blocks and only every wg_stride-th block takes part
     // (the others end here).  Blocks are dealt round-robin over the 8 XCDs, so with wg_stride = 8 the team shares one XCD's L2:
@@ -1850,40 +1955,18 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                 // Gauss-Newton step: (H_s + mu D^2) y = g_s with the landmarks eliminated
                 solve_ok = 0;
                 while (mu < 1.0) {
-                    schur_reduce(wl, sh, RDVIO_LDS(lds_chol_buf), lds_cap, mu, prof_last);
-                    STAMP(4);
-                    int ok = 1;
-                    if (N > 0) ok = w.lds_chol ? cholesky_lds(sh, RDVIO_LDS(Sl), RDVIO_LDS(Dinv), N) : cholesky_blocked(sh, w.Sm, N, N + 1);
-                    STAMP(5);
-                    if (ok && N > 0) {
-                        if (w.lds_chol) cholesky_solve_lds(sh, RDVIO_LDS(Sl), RDVIO_LDS(Dinv), N, wl.yp);
-                        else cholesky_solve(sh, w.Sm, N, wl.yp, false, true, true);   // (row N holds L^-1 b)
-                    }
-                    STAMP(6);
-                    const bool fused = 3 * N <= RDVIO_SOLVER_XV || !w.lds_chol;   // (3 N <= 1440 doubles always fit the LDS buffer)
                     double pm[8];
-                    const double bad = !ok ? 0.0 : fused ? gauss_newton_step_and_model(wl, sh, RDVIO_LDS(lds_chol_buf), phase, mu, pm) : back_substitute(wl, sh, phase, mu);
-                    if (ok) phase ^= 1;  // (the phase function above ran one reduction)
-                    if (!ok || bad > 0.0) {
+                    const int st = solve_step(wl, sh, RDVIO_LDS(lds_chol_buf), lds_cap, phase, mu, pm, prof_last);
+                    phase ^= (st >> 1) & 1;
+                    if (!(st & 1)) {
                         mu *= 10.0;
                         continue;
                     }
-                    if (fused) {
-                        gnorm = sqrt(pm[0]);
-                        gn_norm = sqrt(pm[1]);
-                        gdotgn = pm[2];
+                    gnorm = sqrt(pm[0]);
+                    gn_norm = sqrt(pm[1]);
+                    gdotgn = pm[2];
 #pragma unroll
-                        for (int i = 0; i < 5; ++i) msc[i] = pm[3 + i];
-                    } else {
-                        double a3[3];
-                        gauss_newton_norms(wl, sh, phase, a3);
-                        phase ^= 1;  // (one reduction inside)
-                        gnorm = sqrt(a3[0]);
-                        gn_norm = sqrt(a3[1]);
-                        gdotgn = a3[2];
-                        model_scalars(wl, sh, RDVIO_LDS(lds_chol_buf), phase, msc);
-                        phase ^= 1;  // (one reduction inside)
-                    }
+                    for (int i = 0; i < 5; ++i) msc[i] = pm[3 + i];
                     solve_ok = 1;
                     break;
                 }
@@ -2000,6 +2083,8 @@ void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w0) {
     w.mute_helpers = (mh && mh[0] == '1') ? 1 : 0;
     const char *pl = getenv("RDVIO_TEST_POISON_LDS");
     w.poison_lds = (pl && pl[0] == '1') ? 1 : 0;
+    const char *ss = getenv("RDVIO_NO_SMALL_SOLVE");   // diagnostic: one-frame problems take the general road
+    w.small_system = (w.nfree == 1 && w.N == 15 && w.n_lfree_hint == 0 && w.lds_chol && w.n_wg == 1 && !(ss && ss[0] == '1')) ? 1 : 0;
     const char *nv = getenv("RDVIO_NO_LDS_VECTORS");   // diagnostic: keep every vector in global memory (the A/B of the LDS-resident vectors)
     w.no_lds_vectors = (nv && nv[0] == '1') ? 1 : 0;
     const char *sp = getenv("RDVIO_SOLVER_SPREAD");   // diagnostic: one team member per XCD (the round-robin placement of a plain grid)

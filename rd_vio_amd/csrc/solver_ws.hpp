@@ -67,7 +67,7 @@ struct SolverWs {
     int mute_helpers;                    // test switch (RDVIO_TEST_MUTE_HELPERS): helper workgroups exit at once
     int poison_lds;                      // test switch (RDVIO_TEST_POISON_LDS): every workgroup fills its LDS with 0xFF bytes first
     int no_lds_vectors;                  // diagnostic switch (RDVIO_NO_LDS_VECTORS): no LDS-resident small vectors
-    int pad3_;
+    int small_system;                    // one free frame, no free landmark (N = 15): the one-wavefront solve (set at launch)
     int wg_stride;                       // multi-workgroup launches: every wg_stride-th block of the grid is a team member (8: one XCD)
     double *m_Tm, *m_Lr, *m_er, *m_Wk, *m_V, *m_cs, *m_yv;
     int32_t *m_nz;

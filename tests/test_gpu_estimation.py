@@ -323,6 +323,38 @@ def test_lds_resident_vectors_do_not_change_results(ctx, oracle, monkeypatch):
         assert sm_l.iterations >= 1
 
 
+def test_one_wavefront_solve_of_one_frame_problems(ctx, oracle, monkeypatch):
+    """One free frame and no free landmark (localize_newframe): the damped system, its factorisation, both substitutions and
+    the post-solve scalars run on one wavefront (solver_kernels.hip, small_system_solve).  Same accept / reject path as the
+    oracle, and the same as the general road (RDVIO_NO_SMALL_SOLVE=1) up to the rounding of a different summation order."""
+    for seed in (652, 653, 654):
+        loc = synth.make_window_problem(9, 150, seed, preintegrate=_oracle_pre(oracle))
+        loc["frame_fixed"] = np.ones(9, dtype=np.uint8)
+        loc["frame_fixed"][8] = 0
+        loc["lm_fixed"] = np.ones(len(loc["inv_depth"]), dtype=np.uint8)
+        keep = loc["tgt"] == 8
+        for k in ("tgt", "ref", "lm", "tangent"):
+            loc[k] = loc[k][keep]
+        loc["pre_i"], loc["pre_j"], loc["preint"] = loc["pre_i"][-1:], loc["pre_j"][-1:], loc["preint"][-1:]
+        for k in ("prior_frames", "lin", "S", "f"):
+            loc.pop(k, None)
+        # perturb the free frame so that the solve has work to do
+        rng = np.random.default_rng(seed)
+        loc["states"] = loc["states"].copy()
+        loc["states"][8, 4:7] += rng.normal(0, 0.02, 3)
+        ref_s, ref_d, ref_sm = oracle.ba_solve(loc, 30)
+        got_s, got_d, got_sm = ctx.ba_solve(loc, 30)
+        monkeypatch.setenv("RDVIO_NO_SMALL_SOLVE", "1")
+        gen_s, gen_d, gen_sm = ctx.ba_solve(loc, 30)
+        monkeypatch.setenv("RDVIO_NO_SMALL_SOLVE", "0")
+        for sm in (got_sm, gen_sm):
+            assert (sm.iterations, sm.successful_steps, sm.termination) == (ref_sm.iterations, ref_sm.successful_steps, ref_sm.termination)
+            assert abs(sm.final_cost - ref_sm.final_cost) <= 1e-6 * abs(ref_sm.final_cost)
+        assert np.abs(got_s - ref_s).max() < 1e-6 and np.abs(gen_s - ref_s).max() < 1e-6
+        assert np.abs(got_s - gen_s).max() < 1e-9
+        assert got_sm.iterations >= 2 and np.array_equal(got_d, ref_d)   # (no free landmark: depths untouched)
+
+
 # ---------------------------------------------------------------------------------------------- row A10
 def test_rotation_prior_eval_parity(ctx, oracle):
     """CeresRotationPriorFactor::Evaluate (ceres/rotation_factor.h:22-58) on the device against the oracle, 1e-11 relative
