@@ -104,6 +104,7 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
     CTX_ALLOC(ctx->lk_nextf, (size_t)max_feat * 2 * sizeof(float));
     CTX_ALLOC(ctx->lk_status, (size_t)max_feat);
     if (const char *e = getenv("RDVIO_HOST_SELECT")) ctx->force_host_select = e[0] == '1';  // diagnostic: keypoint selection on the host road
+    if (const char *e = getenv("RDVIO_HELPER_MIN_FACTORS")) ctx->helper_min_factors = std::max(atoi(e), 1);
     if (const char *e = getenv("RDVIO_SOLVER_WGS")) ctx->solver_wgs = std::min(std::max(atoi(e), 1), RDVIO_MAX_SOLVER_WGS);
     const int nfr = max_window + 2;
     const int max_lm = max_factors;  // every factor could belong to its own landmark

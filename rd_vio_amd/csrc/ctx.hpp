@@ -43,6 +43,7 @@ struct rdvio_hip_ctx {
     hipEvent_t wait_ev = nullptr;
     int max_w = 0, max_h = 0, max_feat = 0, max_window = 0, max_factors = 0;
     bool force_host_select = false;  // env RDVIO_HOST_SELECT=1 (read at context creation)
+    int helper_min_factors = 4096;  // problems with at least this many factors launch the team (env RDVIO_HELPER_MIN_FACTORS)
     int solver_wgs = 8;  // workgroups per solver launch for problems with >= RDVIO_HELPER_MIN_FACTORS factors (env RDVIO_SOLVER_WGS)
     rdvio_pyr_layout maxL{};
 
