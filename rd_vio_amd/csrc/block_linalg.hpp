@@ -16,7 +16,7 @@ typedef __attribute__((address_space(3))) double lds_double;
 
 template <int T>
 struct BlockShared {
-    double red[2][10][T / 64];  // double-buffered partials for up to 10 simultaneous reductions
+    double red[2][16][T / 64];  // double-buffered partials for up to 16 simultaneous reductions
     double blk[15 * 16];
     double vec[16];
     int flag;
@@ -172,6 +172,48 @@ DM void quad_col_dot4(const double *__restrict__ M, long ld, const double *__res
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+        acc[k] += __shfl_xor(acc[k], 1);
+        acc[k] += __shfl_xor(acc[k], 2);
+        out[k] = acc[k];
+    }
+}
+
+// the same for up to KN right-hand sides (the speculative trial steps)
+template <int KN>
+DM void quad_col_dotk(const double *__restrict__ M, long ld, const double *__restrict__ x, int xs, int K, int C, int r, int part,
+                      double (&out)[KN]) {
+    double acc[KN];
+#pragma unroll
+    for (int k = 0; k < KN; ++k) acc[k] = 0.0;
+    int c = part;
+    for (; c + 60 < C; c += 64) {
+        double mv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) mv[u] = M[(long)(c + 4 * u) * ld + r];
+#pragma unroll
+        for (int k = 0; k < KN; ++k)
+            if (k < K)
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc[k] += mv[u] * x[k * xs + c + 4 * u];
+    }
+    for (; c + 28 < C; c += 32) {
+        double mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mv[u] = M[(long)(c + 4 * u) * ld + r];
+#pragma unroll
+        for (int k = 0; k < KN; ++k)
+            if (k < K)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[k] += mv[u] * x[k * xs + c + 4 * u];
+    }
+    for (; c < C; c += 4) {
+        const double m = M[(long)c * ld + r];
+#pragma unroll
+        for (int k = 0; k < KN; ++k)
+            if (k < K) acc[k] += m * x[k * xs + c];
+    }
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
         acc[k] += __shfl_xor(acc[k], 1);
         acc[k] += __shfl_xor(acc[k], 2);
         out[k] = acc[k];

@@ -1486,7 +1486,8 @@ PHASE_FN int solve_step(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap, i
 // in the order the one-candidate evaluation does).  Candidates live in the idle LDS Cholesky buffer:
 //   states [4][nfr*16] | camera poses [4][nfr*12] | inverse depths [4][nl] | preintegration errors [4][npre*15].
 // ---------------------------------------------------------------------------------------------
-DM size_t candidates_lds_doubles(int nfr, int nl, int npre) { return 4 * ((size_t)28 * nfr + nl + 15 * npre); }
+constexpr int KC = 8;   // trial steps evaluated per speculative pass (radii r, r/2, ..., r/128)
+DM size_t candidates_lds_doubles(int nfr, int nl, int npre, int D) { return KC * ((size_t)28 * nfr + nl + 15 * npre + D); }
 
 // one candidate state: Plus(x_i, delta_i) for the trial step (ca, cb) of frame i, its camera pose, and the squared ambient
 // step; written to the candidate's LDS slots.  Out of line: its ~100 live doubles (state, step, four scaling vectors,
@@ -1521,25 +1522,26 @@ PHASE_FN double form_candidate_state(LdsWs &w, Shared &sh, lds_double *st_out, l
     return e2;
 }
 
-// Trial-step coefficients arrive by value and the eight results leave through sh.blk[0..7] (cost, then squared step
-// norm, per candidate): arrays handed over by reference would live in scratch memory on both sides of the call.
-PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int phase, int K, double ca0, double ca1, double ca2,
-                                  double ca3, double cb0, double cb1, double cb2, double cb3, unsigned long long &prof_last) {
+// Trial-step coefficients arrive through sh.blk[16 .. 16 + 2 KC) (ca, then cb; written by the caller in front of a barrier)
+// and the 2 KC results leave through sh.blk[0 .. 2 KC) (cost, then squared step norm, per candidate): arrays handed over by
+// reference would live in scratch memory on both sides of the call.
+PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int phase, int K, unsigned long long &prof_last) {
     const int t = threadIdx.x, nfr = w.nfr, nl = w.nl, npre = w.npre, D = w.D;
-    lds_double *stK = lds, *camK = stK + 4 * nfr * 16, *xdK = camK + 4 * nfr * 12, *epK = xdK + 4 * nl;
-    const double ca[4] = {ca0, ca1, ca2, ca3}, cb[4] = {cb0, cb1, cb2, cb3};
-    double cost[4] = {0.0, 0.0, 0.0, 0.0}, sn2[4] = {0.0, 0.0, 0.0, 0.0};
+    lds_double *stK = lds, *camK = stK + KC * nfr * 16, *xdK = camK + KC * nfr * 12, *epK = xdK + KC * nl, *eK = epK + KC * npre * 15;
+    double ca[KC], cb[KC], cost[KC], sn2[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) { ca[k] = sh.blk[16 + k]; cb[k] = sh.blk[16 + KC + k]; cost[k] = 0.0; sn2[k] = 0.0; }
     // the candidate loops below are real loops (the bodies are large: four unrolled copies overflow the instruction
     // cache); the per-candidate accumulators are selected with compares so that they stay in registers
-    auto add_to = [](double (&acc)[4], int k, double v) {
+    auto add_to = [](double (&acc)[KC], int k, double v) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < KC; ++q)
             if (q == k) acc[q] += v;
     };
-    auto pick = [](const double (&arr)[4], int k) {
+    auto pick = [](const double (&arr)[KC], int k) {
         double v = arr[0];
 #pragma unroll
-        for (int q = 1; q < 4; ++q)
+        for (int q = 1; q < KC; ++q)
             if (q == k) v = arr[q];
         return v;
     };
@@ -1551,19 +1553,19 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int pha
     };
     if (nfr <= 16) {
         if (t >= T - 64) {
-            const int L = T - 1 - t, k = L >> 4, i = L & 15;  // (L = 0 is the workgroup's last thread)
-            double e2 = 0.0;
-            if (k < K && i < nfr) {
-                double cak = ca[0], cbk = cb[0];  // (select the candidate's coefficients without indexing the register arrays)
+            const int L = T - 1 - t, i = L & 15;  // (L = 0 is the workgroup's last thread)
 #pragma unroll
-                for (int q = 1; q < 4; ++q)
-                    if (k == q) { cak = ca[q]; cbk = cb[q]; }
-                candidate_state(k, i, cak, cbk, e2);
-            }
+            for (int p = 0; p < KC / 4; ++p) {   // four candidates per pass of the wavefront
+                const int k = 4 * p + (L >> 4);
+                double e2 = 0.0;
+                if (4 * p < K) {   // (wave-uniform)
+                    if (k < K && i < nfr) candidate_state(k, i, pick(ca, k), pick(cb, k), e2);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double v = __shfl(e2, 63 - ((L & 15) + 16 * q));  // from the lane that formed candidate q of this frame
-                if (L < 16 && L < nfr && q < K && sh.fcol[L] >= 0) sn2[q] += v;
+                    for (int q = 0; q < 4; ++q) {
+                        const double v = __shfl(e2, 63 - ((L & 15) + 16 * q));  // from the lane that formed candidate 4 p + q of this frame
+                        if (L < 16 && L < nfr && 4 * p + q < K && sh.fcol[L] >= 0) sn2[4 * p + q] += v;
+                    }
+                }
             }
         }
     } else {
@@ -1582,7 +1584,7 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int pha
         double sl = 0.0, gl = 0.0, gnl = 0.0, dl = 1.0;
         if (lf) { sl = w.sig_l[l]; gl = w.grad_l[l]; gnl = w.gn_l[l]; dl = w.diag_l[l]; }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < KC; ++k) {
             if (k >= K) break;
             const double v = xd + (lf ? sl * ((ca[k] * gl + cb[k] * gnl) / dl) : 0.0);
             xdK[k * nl + l] = v;
@@ -1621,13 +1623,13 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int pha
 #pragma unroll 1
         for (int k = 0; k < K; ++k) add_to(cost, k, rotation_factors<false>(w, sh, RDVIO_GEN(stK) + (size_t)k * nfr * 16, extr, W, t, TF));
         // the prior's per-frame errors on the tail of the last factor wave, one operand vector per candidate
-        if (w.np <= 16) {  // one (candidate, prior frame) pair per lane
-            const int j = t - (TF - 64), k = j >> 4, i = j & 15;
-            if (j >= 0 && k < K && i < w.np) {
+        if (w.np <= 16) {  // one (candidate, prior frame) pair per lane, four candidates per pass
+            const int j = t - (TF - 64), i = j & 15;
+            for (int k = j >> 4; j >= 0 && k < K && i < w.np; k += 4) {
                 double e15[15];
                 marginalization_frame_error(RDVIO_GEN(stK) + ((size_t)k * nfr + w.prior_frames[i]) * 16, w.lin + 16 * i, e15, nullptr);
 #pragma unroll
-                for (int a = 0; a < 15; ++a) sh.xv[k * D + 15 * i + a] = e15[a];
+                for (int a = 0; a < 15; ++a) eK[k * D + 15 * i + a] = e15[a];
             }
         } else {
             for (int i = t - (TF - 64); i >= 0 && i < w.np; i += 64) {
@@ -1636,7 +1638,7 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int pha
                     double e15[15];
                     marginalization_frame_error(RDVIO_GEN(stK) + ((size_t)k * nfr + w.prior_frames[i]) * 16, w.lin + 16 * i, e15, nullptr);
 #pragma unroll
-                    for (int a = 0; a < 15; ++a) sh.xv[k * D + 15 * i + a] = e15[a];
+                    for (int a = 0; a < 15; ++a) eK[k * D + 15 * i + a] = e15[a];
                 }
             }
         }
@@ -1662,7 +1664,7 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int pha
 #pragma unroll
         for (int q = 0; q < 15; ++q) sr[q] = Sic[row * 15 + q];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < KC; ++k) {
             if (k >= K) break;
             double acc = 0.0;
 #pragma unroll
@@ -1675,29 +1677,31 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int pha
         for (int base = 0; base < D; base += T / 4) {
             const int row = base + (t >> 2), part = t & 3;
             if (row < D) {
-                double r4[4];
-                quad_col_dot4(w.ST, D, RDVIO_GEN(sh.xv), D, K, D, row, part, r4);
+                double rk[KC];
+                quad_col_dotk<KC>(w.ST, D, RDVIO_GEN(eK), D, K, D, row, part, rk);
                 if (part == 0) {
                     const double fr = w.f[row];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (k < K) { const double r = r4[k] + fr; cost[k] += 0.5 * r * r; }
+                    for (int k = 0; k < KC; ++k)
+                        if (k < K) { const double r = rk[k] + fr; cost[k] += 0.5 * r * r; }
                 }
             }
         }
     }
-    double v8[8] = {cost[0], cost[1], cost[2], cost[3], sn2[0], sn2[1], sn2[2], sn2[3]};
-    block_sum_n<T, 8>(sh, v8, phase);
+    double v2k[2 * KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) { v2k[k] = cost[k]; v2k[KC + k] = sn2[k]; }
+    block_sum_n<T, 2 * KC>(sh, v2k, phase);
     if (t == 0)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) sh.blk[k] = v8[k];
+        for (int k = 0; k < 2 * KC; ++k) sh.blk[k] = v2k[k];
     __syncthreads();
 }
 
 // x <- speculative candidate k (still in the LDS buffer evaluate_candidates filled)
 PHASE_FN double accept_speculative(LdsWs &w, Shared &sh, int phase, lds_double *lds, int k) {
     const int t = threadIdx.x, nfr = w.nfr, nl = w.nl;
-    const lds_double *stK = lds + (size_t)k * nfr * 16, *xdK = lds + 4 * nfr * 28 + (size_t)k * nl;
+    const lds_double *stK = lds + (size_t)k * nfr * 16, *xdK = lds + KC * nfr * 28 + (size_t)k * nl;
     double s = 0.0;  // |x|^2 of the accepted point, accumulated exactly as x_norm_of accumulates it
     for (int o = t; o < nfr * 16; o += T) {
         const double v = stK[o];
@@ -1792,7 +1796,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
         const int NAs = 6 * w.nfree + 2;
         size_t need = (size_t)(N + 1) * (N + 2) / 2 + 225 * (size_t)(N / 15);                          // packed triangle + diagonal inverses
         const size_t stage = (w.nl > 0 && w.n_lfree_hint > 0) ? (size_t)w.nl * NAs + w.nl : 0;          // Schur operand staging
-        const size_t cand = candidates_lds_doubles(w.nfr, w.nl, w.npre);                                // speculative candidates
+        const size_t cand = candidates_lds_doubles(w.nfr, w.nl, w.npre, w.D);                           // speculative candidates
         if (stage > need) need = stage;
         if (cand > need) need = cand;
         need = (need + 1) & ~(size_t)1;
@@ -1870,8 +1874,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
         prev_rejected = 0;
     };
     // a run of rejections is evaluated four trial radii at a time (evaluate_candidates) when the candidates fit the LDS
-    const bool speculate = !w.no_speculation && w.n_wg == 1 && w.lds_chol && candidates_lds_doubles(w.nfr, w.nl, w.npre) <= lds_cap &&
-                           4 * w.D <= RDVIO_SOLVER_XV && 4 * w.npre <= 64;
+    const bool speculate = !w.no_speculation && w.n_wg == 1 && w.lds_chol && candidates_lds_doubles(w.nfr, w.nl, w.npre, w.D) <= lds_cap;
 
     x_norm = x_norm_of(wl, sh, phase, wl.x, wl.xd);
     phase ^= 1;  // (one reduction inside)
@@ -1895,40 +1898,44 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             if (radius <= 1e-32) { term = 0; break; }
             if (speculate && prev_rejected && reuse) {
                 // the trial steps the next iterations would take one by one, as long as each is a valid step within the limits
-                // (static indices throughout: these small arrays must stay in registers)
-                double ca4[4] = {0.0, 0.0, 0.0, 0.0}, cb4[4] = {0.0, 0.0, 0.0, 0.0}, dsn4[4] = {0.0, 0.0, 0.0, 0.0}, mcc4[4] = {1.0, 1.0, 1.0, 1.0};
+                // (coefficients, step norms and model changes go straight to sh.blk[16 ..): 4 KC doubles held in registers across the
+                // call would be spilled around it; the barrier keeps thread 0's stores behind the last replay's reads)
+                __syncthreads();
                 int Kc = 0;
                 {
                     double rk = radius;
                     bool open = true;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (open && iteration + k < w.max_iter && rk > 1e-32 && dogleg_step(rk, ca4[k], cb4[k], dsn4[k], mcc4[k])) {
+#pragma unroll 1
+                    for (int k = 0; k < KC; ++k) {
+                        double ca_k = 0.0, cb_k = 0.0, dsn_k = 0.0, mcc_k = 1.0;
+                        if (open && iteration + k < w.max_iter && rk > 1e-32 && dogleg_step(rk, ca_k, cb_k, dsn_k, mcc_k)) {
                             Kc = k + 1;
                             rk *= 0.5;
                         } else {
                             open = false;
                         }
+                        if (t == 0) { sh.blk[16 + k] = ca_k; sh.blk[16 + KC + k] = cb_k; sh.blk[16 + 2 * KC + k] = dsn_k; sh.blk[16 + 3 * KC + k] = mcc_k; }
                     }
                 }
                 if (Kc >= 2) {
-                    evaluate_candidates(wl, sh, RDVIO_LDS(lds_chol_buf), phase, Kc, ca4[0], ca4[1], ca4[2], ca4[3], cb4[0], cb4[1], cb4[2], cb4[3], prof_last);
+                    __syncthreads();
+                    evaluate_candidates(wl, sh, RDVIO_LDS(lds_chol_buf), phase, Kc, prof_last);
                     phase ^= 1;  // (one reduction inside)
                     STAMP(9);
                     int accepted = -1, finished = 0, live = 1;
                     double rel_acc = 0.0, dsn_acc = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {  // replay: exactly the decisions of Kc sequential iterations
-                        if (live && k < Kc) {
+#pragma unroll 1
+                    for (int k = 0; k < Kc; ++k) {  // replay: exactly the decisions of Kc sequential iterations
+                        if (live) {
                             iteration++;
                             last_successful = 0;
                             invalid_steps = 0;
-                            const double ck = sh.blk[k], sk = sh.blk[4 + k];
+                            const double ck = sh.blk[k], sk = sh.blk[KC + k];
                             const double cand_cost = isfinite(ck) ? ck : 1.7976931348623157e308;
-                            const double rel = (cand_cost >= 1.7976931348623157e308) ? -1.7976931348623157e308 : (x_cost - cand_cost) / mcc4[k];
+                            const double rel = (cand_cost >= 1.7976931348623157e308) ? -1.7976931348623157e308 : (x_cost - cand_cost) / sh.blk[16 + 3 * KC + k];
                             if (sqrt(sk) <= 1e-8 * (x_norm + 1e-8)) { term = 0; finished = 1; live = 0; }
                             else if (fabs(x_cost - cand_cost) <= 1e-6 * x_cost) { term = 0; finished = 1; live = 0; }
-                            else if (rel > 1e-3) { accepted = k; rel_acc = rel; dsn_acc = dsn4[k]; live = 0; }
+                            else if (rel > 1e-3) { accepted = k; rel_acc = rel; dsn_acc = sh.blk[16 + 2 * KC + k]; live = 0; }
                             else radius *= 0.5;
                         }
                     }
