@@ -19,6 +19,7 @@ struct BlockShared {
     double red[2][16][T / 64];  // double-buffered partials for up to 16 simultaneous reductions
     double blk[15 * 16];
     double vec[16];
+    double spec[16];  // solver: the current linearisation's step-selection scalars (|gn|, |g|, alpha, g.gn, q_uu q_uv q_vv l_u l_v)
     int flag;
     int lost;  // set when a helper workgroup did not answer in time (solver)
     int seq;  // command sequence number of the helper-workgroup protocol (solver)

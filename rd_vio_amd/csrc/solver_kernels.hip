@@ -1698,6 +1698,78 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int pha
     __syncthreads();
 }
 
+// dogleg step for a trust-region radius from the scalars of the current linearisation (no memory traffic): coefficients of
+// delta = ca u + cb v, its norm and the model cost change; returns whether the step is valid (model change > 0)
+DM int dogleg_step_of(double rad, double gn_norm, double gnorm, double alpha, double gdotgn, double m0, double m1, double m2, double m3, double m4,
+                      double &ca, double &cb, double &step_norm, double &model_change) {
+    bool need_norm = false;
+    if (gn_norm <= rad) { ca = 0.0; cb = 1.0; step_norm = gn_norm; }
+    else if (gnorm * alpha >= rad) { ca = -(rad / gnorm); cb = 0.0; step_norm = rad; }
+    else {
+        const double b_dot_a = -alpha * gdotgn;
+        const double a_sq = (alpha * gnorm) * (alpha * gnorm);
+        const double bma_sq = a_sq - 2 * b_dot_a + gn_norm * gn_norm;
+        const double c = b_dot_a - a_sq;
+        const double d = sqrt(c * c + bma_sq * (rad * rad - a_sq));
+        const double beta = (c <= 0) ? (d - c) / bma_sq : (rad * rad - a_sq) / (d + c);
+        ca = -alpha * (1.0 - beta);
+        cb = beta;
+        need_norm = true;
+    }
+    // delta = (ca grad + cb gn) / D * Jacobi scaling is formed inside the candidate evaluation
+    if (need_norm) step_norm = sqrt(ca * ca * gnorm * gnorm + 2.0 * ca * cb * gdotgn + cb * cb * gn_norm * gn_norm);
+    const double jsq = ca * ca * m0 + 2.0 * ca * cb * m1 + cb * cb * m2;
+    const double jdr = ca * m3 + cb * m4;
+    model_change = -(jdr + 0.5 * jsq);
+    return model_change > 0.0;
+}
+
+// A run of rejections, up to KC trial steps in one pass: the coefficients of the radii r, r/2, ... (as long as each is a valid
+// step within the iteration limit), their evaluation (evaluate_candidates) and the replay of exactly the decisions the
+// sequential loop would take.  Out of line and fed through LDS (sh.spec, sh.blk), so that none of it lives in the registers of
+// the kernel body.  Returns -1 when fewer than two trials qualify (nothing evaluated, no reduction run); otherwise
+//   bits 0..3 trials consumed, bit 4 a termination test fired (convergence), bits 5..8 accepted trial + 1 (0: none);
+// step norm / model change of trial k stay in sh.blk[16 + 2 KC + k] / [16 + 3 KC + k], its cost in sh.blk[k].
+PHASE_FN int speculative_trials(LdsWs &w, Shared &sh, lds_double *lds, int phase, double radius, int iteration, double x_cost, double x_norm,
+                                unsigned long long &prof_last) {
+    const int t = threadIdx.x;
+    __syncthreads();   // (thread 0's stores below stay behind the last replay's reads)
+    const double gn_norm = sh.spec[0], gnorm = sh.spec[1], alpha = sh.spec[2], gdotgn = sh.spec[3];
+    const double m0 = sh.spec[4], m1 = sh.spec[5], m2 = sh.spec[6], m3 = sh.spec[7], m4 = sh.spec[8];
+    int Kc = 0;
+    {
+        double rk = radius;
+        bool open = true;
+#pragma unroll 1
+        for (int k = 0; k < KC; ++k) {
+            double ca_k = 0.0, cb_k = 0.0, dsn_k = 0.0, mcc_k = 1.0;
+            if (open && iteration + k < w.max_iter && rk > 1e-32 && dogleg_step_of(rk, gn_norm, gnorm, alpha, gdotgn, m0, m1, m2, m3, m4, ca_k, cb_k, dsn_k, mcc_k)) {
+                Kc = k + 1;
+                rk *= 0.5;
+            } else {
+                open = false;
+            }
+            if (t == 0) { sh.blk[16 + k] = ca_k; sh.blk[16 + KC + k] = cb_k; sh.blk[16 + 2 * KC + k] = dsn_k; sh.blk[16 + 3 * KC + k] = mcc_k; }
+        }
+    }
+    if (Kc < 2) return -1;
+    __syncthreads();
+    evaluate_candidates(w, sh, lds, phase, Kc, prof_last);
+    STAMP(9);
+    int n = 0, finished = 0, accepted = -1;
+#pragma unroll 1
+    for (int k = 0; k < Kc; ++k) {  // replay: exactly the decisions of Kc sequential iterations
+        ++n;
+        const double ck = sh.blk[k], sk = sh.blk[KC + k];
+        const double cand_cost = isfinite(ck) ? ck : 1.7976931348623157e308;
+        const double rel = (cand_cost >= 1.7976931348623157e308) ? -1.7976931348623157e308 : (x_cost - cand_cost) / sh.blk[16 + 3 * KC + k];
+        if (sqrt(sk) <= 1e-8 * (x_norm + 1e-8)) { finished = 1; break; }
+        if (fabs(x_cost - cand_cost) <= 1e-6 * x_cost) { finished = 1; break; }
+        if (rel > 1e-3) { accepted = k; break; }
+    }
+    return n | (finished << 4) | ((accepted + 1) << 5);
+}
+
 // x <- speculative candidate k (still in the LDS buffer evaluate_candidates filled)
 PHASE_FN double accept_speculative(LdsWs &w, Shared &sh, int phase, lds_double *lds, int k) {
     const int t = threadIdx.x, nfr = w.nfr, nl = w.nl;
@@ -1829,28 +1901,8 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     int reuse = 0, iteration = 0, invalid_steps = 0, last_successful = 0, n_success = 0;
     int term = 1;  // NO_CONVERGENCE
     STAMP(0);
-    // dogleg step for a trust-region radius from the scalars of the current linearisation (no memory traffic)
     auto dogleg_step = [&](double rad, double &ca, double &cb, double &step_norm, double &model_change) -> int {
-        bool need_norm = false;
-        if (gn_norm <= rad) { ca = 0.0; cb = 1.0; step_norm = gn_norm; }
-        else if (gnorm * alpha >= rad) { ca = -(rad / gnorm); cb = 0.0; step_norm = rad; }
-        else {
-            const double b_dot_a = -alpha * gdotgn;
-            const double a_sq = (alpha * gnorm) * (alpha * gnorm);
-            const double bma_sq = a_sq - 2 * b_dot_a + gn_norm * gn_norm;
-            const double c = b_dot_a - a_sq;
-            const double d = sqrt(c * c + bma_sq * (rad * rad - a_sq));
-            const double beta = (c <= 0) ? (d - c) / bma_sq : (rad * rad - a_sq) / (d + c);
-            ca = -alpha * (1.0 - beta);
-            cb = beta;
-            need_norm = true;
-        }
-        // delta = (ca grad + cb gn) / D * Jacobi scaling is formed inside the candidate evaluation
-        if (need_norm) step_norm = sqrt(ca * ca * gnorm * gnorm + 2.0 * ca * cb * gdotgn + cb * cb * gn_norm * gn_norm);
-        const double jsq = ca * ca * msc[0] + 2.0 * ca * cb * msc[1] + cb * cb * msc[2];
-        const double jdr = ca * msc[3] + cb * msc[4];
-        model_change = -(jdr + 0.5 * jsq);
-        return model_change > 0.0;
+        return dogleg_step_of(rad, gn_norm, gnorm, alpha, gdotgn, msc[0], msc[1], msc[2], msc[3], msc[4], ca, cb, step_norm, model_change);
     };
     int prev_rejected = 0;
     double x_norm = 0.0, x_cost = 0.0, grad_max = 0.0;
@@ -1897,50 +1949,20 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
             if (grad_max <= 1e-10) { term = 0; break; }
             if (radius <= 1e-32) { term = 0; break; }
             if (speculate && prev_rejected && reuse) {
-                // the trial steps the next iterations would take one by one, as long as each is a valid step within the limits
-                // (coefficients, step norms and model changes go straight to sh.blk[16 ..): 4 KC doubles held in registers across the
-                // call would be spilled around it; the barrier keeps thread 0's stores behind the last replay's reads)
-                __syncthreads();
-                int Kc = 0;
-                {
-                    double rk = radius;
-                    bool open = true;
-#pragma unroll 1
-                    for (int k = 0; k < KC; ++k) {
-                        double ca_k = 0.0, cb_k = 0.0, dsn_k = 0.0, mcc_k = 1.0;
-                        if (open && iteration + k < w.max_iter && rk > 1e-32 && dogleg_step(rk, ca_k, cb_k, dsn_k, mcc_k)) {
-                            Kc = k + 1;
-                            rk *= 0.5;
-                        } else {
-                            open = false;
-                        }
-                        if (t == 0) { sh.blk[16 + k] = ca_k; sh.blk[16 + KC + k] = cb_k; sh.blk[16 + 2 * KC + k] = dsn_k; sh.blk[16 + 3 * KC + k] = mcc_k; }
-                    }
-                }
-                if (Kc >= 2) {
-                    __syncthreads();
-                    evaluate_candidates(wl, sh, RDVIO_LDS(lds_chol_buf), phase, Kc, prof_last);
+                // the trial steps the next iterations would take one by one, evaluated together and replayed (speculative_trials)
+                const int oc = speculative_trials(wl, sh, RDVIO_LDS(lds_chol_buf), phase, radius, iteration, x_cost, x_norm, prof_last);
+                if (oc >= 0) {
                     phase ^= 1;  // (one reduction inside)
-                    STAMP(9);
-                    int accepted = -1, finished = 0, live = 1;
-                    double rel_acc = 0.0, dsn_acc = 0.0;
-#pragma unroll 1
-                    for (int k = 0; k < Kc; ++k) {  // replay: exactly the decisions of Kc sequential iterations
-                        if (live) {
-                            iteration++;
-                            last_successful = 0;
-                            invalid_steps = 0;
-                            const double ck = sh.blk[k], sk = sh.blk[KC + k];
-                            const double cand_cost = isfinite(ck) ? ck : 1.7976931348623157e308;
-                            const double rel = (cand_cost >= 1.7976931348623157e308) ? -1.7976931348623157e308 : (x_cost - cand_cost) / sh.blk[16 + 3 * KC + k];
-                            if (sqrt(sk) <= 1e-8 * (x_norm + 1e-8)) { term = 0; finished = 1; live = 0; }
-                            else if (fabs(x_cost - cand_cost) <= 1e-6 * x_cost) { term = 0; finished = 1; live = 0; }
-                            else if (rel > 1e-3) { accepted = k; rel_acc = rel; dsn_acc = sh.blk[16 + 2 * KC + k]; live = 0; }
-                            else radius *= 0.5;
-                        }
-                    }
-                    if (finished) break;
+                    const int n = oc & 15, finished = (oc >> 4) & 1, accepted = ((oc >> 5) & 15) - 1;
+                    iteration += n;
+                    last_successful = 0;
+                    invalid_steps = 0;
+                    for (int q = (finished || accepted >= 0) ? 1 : 0; q < n; ++q) radius *= 0.5;   // (one halving per rejected trial)
+                    if (finished) { term = 0; break; }
                     if (accepted >= 0) {
+                        const double ck = sh.blk[accepted];
+                        const double rel_acc = (x_cost - (isfinite(ck) ? ck : 1.7976931348623157e308)) / sh.blk[16 + 3 * KC + accepted];
+                        const double dsn_acc = sh.blk[16 + 2 * KC + accepted];
                         x_norm = accept_speculative(wl, sh, phase, RDVIO_LDS(lds_chol_buf), accepted);
                         phase ^= 1;  // (one reduction inside)
                         dogleg_step_norm = dsn_acc;
@@ -1977,7 +1999,14 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
                     solve_ok = 1;
                     break;
                 }
-                if (solve_ok) alpha = gsq_keep / msc[0];
+                if (solve_ok) {
+                    alpha = gsq_keep / msc[0];
+                    if (t == 0) {   // for speculative_trials (read behind its entry barrier)
+                        sh.spec[0] = gn_norm; sh.spec[1] = gnorm; sh.spec[2] = alpha; sh.spec[3] = gdotgn;
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) sh.spec[4 + i] = msc[i];
+                    }
+                }
                 STAMP(7);
             }
             int step_valid = 0;
