@@ -1486,7 +1486,8 @@ PHASE_FN int solve_step(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap, i
 // in the order the one-candidate evaluation does).  Candidates live in the idle LDS Cholesky buffer:
 //   states [4][nfr*16] | camera poses [4][nfr*12] | inverse depths [4][nl] | preintegration errors [4][npre*15].
 // ---------------------------------------------------------------------------------------------
-constexpr int KC = 8;   // trial steps evaluated per speculative pass (radii r, r/2, ..., r/128)
+constexpr int KC = 4;   // trial steps evaluated per speculative pass (radii r, r/2, r/4, r/8).  Eight per pass measured slower: sixteen
+                        // accumulators per thread spill in the factor loop, and what the callee clobbers costs the kernel body registers too
 DM size_t candidates_lds_doubles(int nfr, int nl, int npre, int D) { return KC * ((size_t)28 * nfr + nl + 15 * npre + D); }
 
 // one candidate state: Plus(x_i, delta_i) for the trial step (ca, cb) of frame i, its camera pose, and the squared ambient
