@@ -217,7 +217,12 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     const size_t s_em = dd(D), s_rm = dd(D), s_cm = dd(D), s_Jri = dd((size_t)np * 9), s_Lam = dd((size_t)D * D), s_eta0 = dd(D), s_le = dd(D), s_Ex = dd(D);
     const size_t s_H = dd((size_t)N * N), s_Sm = dd((size_t)(N + 1) * N), s_g = dd(N), s_yp = dd(N);  // Sm: + the right-hand-side row
     const size_t s_Cm = dd((size_t)(6 * nfree + 2) * (6 * nfree + 2));
-    const int n_wg = (!with_marg_tail && nf >= ctx->helper_min_factors && ctx->solver_wgs > 1) ? ctx->solver_wgs : 1;
+    // the helper team: from helper_min_factors (4096) factors on; windows whose reduced system is factored in global memory
+    // (more than RDVIO_LDS_CHOL_MAX_FRAMES free frames: no speculative trial steps to lose) already from 1500 factors
+    // (3183 factors, 13 free frames: 3.85 -> 3.16 ms)
+    const bool global_chol = nfree > RDVIO_LDS_CHOL_MAX_FRAMES;
+    const int team_from = global_chol ? std::min(ctx->helper_min_factors, 1500) : ctx->helper_min_factors;
+    const int n_wg = (!with_marg_tail && nf >= team_from && ctx->solver_wgs > 1) ? ctx->solver_wgs : 1;
     const size_t s_Cmp = dd(n_wg > 1 ? (size_t)n_wg * (6 * nfree + 2) * (6 * nfree + 2) : 1);
     const size_t s_lmm = dd(nl), s_lmg = dd(nl), s_lmw = dd(nl), s_A = dd((size_t)nl * (6 * nfree + 2)), s_yl = dd(nl);
     const size_t s_sigp = dd(N), s_sigl = dd(nl), s_dgp = dd(N), s_dgl = dd(nl), s_grp = dd(N), s_grl = dd(nl), s_gnp = dd(N), s_gnl = dd(nl), s_tp = dd(N), s_tl = dd(nl);
