@@ -286,22 +286,22 @@ __device__ __attribute__((noinline)) void ne_pair_products(LdsWs &w, int g0, int
         const double *rec = w.prec + RDVIO_REC_STRIDE * (size_t)w.grp_off[g] + eo;
         double4_t acc = {0.0, 0.0, 0.0, 0.0};
         int it = 0;
-        for (; it + 16 <= n; it += 16) {  // 8 MFMAs (16 items) per trip, loads issued together
-            double v[8];
+        for (; it + 32 <= n; it += 32) {  // 16 MFMAs (32 items) per trip, loads issued together
+            double v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = has ? rec[RDVIO_REC_STRIDE * (size_t)(it + 2 * u + item_off)] : 0.0;
+            for (int u = 0; u < 16; ++u) v[u] = has ? rec[RDVIO_REC_STRIDE * (size_t)(it + 2 * u + item_off)] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v[u] : 0.0, v[u], acc, 0, 0, 0);
+            for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v[u] : 0.0, v[u], acc, 0, 0, 0);
         }
-        if (it < n) {  // the remainder as ONE masked trip of eight loads (a two-item loop here is one L2 round trip per MFMA)
-            double v[8];
+        if (it < n) {  // the remainder (up to 31 items: the usual group of a window, ~18) as ONE masked trip of sixteen loads
+            double v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int item = it + 2 * u + item_off;
                 v[u] = (has && item < n) ? rec[RDVIO_REC_STRIDE * (size_t)item] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 16; ++u)
                 if (it + 2 * u < n) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v[u] : 0.0, v[u], acc, 0, 0, 0);
         }
 #pragma unroll
@@ -759,30 +759,35 @@ __device__ __attribute__((noinline)) void build_normal_equations(LdsWs &w, Share
     // ---- phase 1b: landmarks (factors of one landmark are contiguous): scalars m, g and the anchor slot of the
     // coupling row (target slots were stored at linearisation time; untouched slots stay zero from the setup).
     // Column NA of the row holds g_l so that A^T W [A | g] yields the Schur gradient term with the same GEMM.
+    // (loads batched: the landmark's flags / range in one round trip, then four factors per trip -- a window of eight keyframes
+    // is two trips -- with the anchor frame's index riding on the first; summation order k ascending, as ever)
     for (int l = t; l < w.nl; l += T) {
-        if (!w.lfree[l]) continue;
+        const bool lf = w.lfree[l] != 0;
+        const int k0 = w.lm_first[l], cnt = w.lm_count[l];
+        if (!lf) continue;
+        const int k1 = k0 + cnt;
         double m = 0.0, gl = 0.0, ha[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        const int k0 = w.lm_first[l], k1 = k0 + w.lm_count[l];
-        for (int k = k0; k < k1; k += 2) {
-            double h0[8], h1[8];
-            const double *o0 = w.fac + RDVIO_FAC_STRIDE * (size_t)k + 34;
-            const bool two = k + 1 < k1;
-            const double *o1 = two ? o0 + RDVIO_FAC_STRIDE : o0;
+        int refk0 = 0;
+        for (int k = k0; k < k1; k += 4) {
+            double h[4][8];
 #pragma unroll
-            for (int a = 0; a < 8; ++a) { h0[a] = o0[a]; h1[a] = o1[a]; }
+            for (int q = 0; q < 4; ++q) {
+                const double *o = w.fac + RDVIO_FAC_STRIDE * (size_t)(k + q < k1 ? k + q : k) + 34;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) ha[a] += h0[a];
-            m += h0[6];
-            gl += h0[7];
-            if (two) {
-#pragma unroll
-                for (int a = 0; a < 6; ++a) ha[a] += h1[a];
-                m += h1[6];
-                gl += h1[7];
+                for (int a = 0; a < 8; ++a) h[q][a] = o[a];
             }
+            if (k == k0) refk0 = w.ref[k0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (k + q < k1) {
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) ha[a] += h[q][a];
+                    m += h[q][6];
+                    gl += h[q][7];
+                }
         }
         double *Arow = w.A + (size_t)l * NAs;
-        const int ca = sh.fcol[w.ref[k0]];
+        const int ca = sh.fcol[refk0];
         if (ca >= 0)
 #pragma unroll
             for (int a = 0; a < 6; ++a) Arow[6 * ca + a] = ha[a];
@@ -843,38 +848,57 @@ __device__ __attribute__((noinline)) void build_normal_equations(LdsWs &w, Share
     if (multi) post_command(w, sh, CMD_HBLK);
     ne_h_blocks(w, sh, wave, GW);
     STAMP(27);
+    // gradient: every load of an entry (up to 12 group tiles, two preintegration terms, three prior terms) is issued before the
+    // first use -- the conditionals used to be a round trip each; same summation order
     for (int o = t; o < N; o += T) {
         const int c = o / 15, a = o - 15 * c;
+        const bool pose = a < 6;
+        double gv[12];
+#pragma unroll
+        for (int u4 = 0; u4 < 12; ++u4) {
+            const int f2 = u4;
+            const int lo = f2 < c ? f2 : c, hi = f2 < c ? c : f2;
+            const int off = (c == lo) ? 0 : 6;
+            gv[u4] = (pose && f2 < nfree) ? w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + 12] : 0.0;
+        }
+        const int src0 = sh.g_src[2 * c], src1 = sh.g_src[2 * c + 1];
+        const double pg0 = src0 >= 0 ? w.Pg[30 * (size_t)(src0 >> 1) + 15 * (src0 & 1) + a] : 0.0;
+        const double pg1 = src1 >= 0 ? w.Pg[30 * (size_t)(src1 >> 1) + 15 * (src1 & 1) + a] : 0.0;
+        const int pi = sh.pcol[c];
+        const bool prior = pi >= 0 && !(pose && sh.pfixc[c]);
+        double le3[3];
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa) le3[aa] = prior ? w.le[15 * pi + (a < 3 ? aa : a)] : 0.0;
         double acc = 0.0;
-        if (a < 6) {
-            for (int f0 = 0; f0 < nfree; f0 += 12) {
-                double gv[12];
+        if (pose) {
+#pragma unroll
+            for (int u4 = 0; u4 < 12; ++u4)
+                if (u4 < nfree) acc += gv[u4];
+            for (int f0 = 12; f0 < nfree; f0 += 12) {
+                double gw[12];
 #pragma unroll
                 for (int u4 = 0; u4 < 12; ++u4) {
                     const int f2 = f0 + u4;
                     const int lo = f2 < c ? f2 : c, hi = f2 < c ? c : f2;
                     const int off = (c == lo) ? 0 : 6;
-                    gv[u4] = f2 < nfree ? w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + 12] : 0.0;
+                    gw[u4] = f2 < nfree ? w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + 12] : 0.0;
                 }
 #pragma unroll
                 for (int u4 = 0; u4 < 12; ++u4)
-                    if (f0 + u4 < nfree) acc += gv[u4];
+                    if (f0 + u4 < nfree) acc += gw[u4];
             }
             if (a < 3)
                 for (int k = 0; k < w.nrot; ++k)
                     if (sh.fcol[w.rot_tgt[k]] == c) acc += w.Jro[6 * k + a] * w.r_r[2 * k] + w.Jro[6 * k + 3 + a] * w.r_r[2 * k + 1];
         }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int src = sh.g_src[2 * c + s2];
-            if (src >= 0) acc += w.Pg[30 * (size_t)(src >> 1) + 15 * (src & 1) + a];
-        }
-        const int pi = sh.pcol[c];
-        if (pi >= 0 && !(a < 6 && sh.pfixc[c])) {
+        if (src0 >= 0) acc += pg0;
+        if (src1 >= 0) acc += pg1;
+        if (prior) {
             if (a < 3) {
-                for (int aa = 0; aa < 3; ++aa) acc += prior_E(sh, pi, aa, a) * w.le[15 * pi + aa];
+#pragma unroll
+                for (int aa = 0; aa < 3; ++aa) acc += prior_E(sh, pi, aa, a) * le3[aa];
             } else {
-                acc += w.le[15 * pi + a];
+                acc += le3[0];
             }
         }
         w.g[o] = acc;
@@ -1141,24 +1165,30 @@ PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap
     const bool split = w.n_wg > 1 && !(w.lds_chol && (size_t)nl * NAs + nl <= lds_cap);   // Schur product shared with the helpers
     const size_t cstride = (size_t)NAs * NAs;
     lds_double *Sl = lds;
+    // the landmark weights go straight into the staged operand's weight vector when the operand fits LDS (no pass and barrier
+    // of their own); the other roads read them from memory
+    const bool staged = NA > 0 && has_lm && w.lds_chol && (size_t)nl * NAs + nl <= lds_cap;
     if (has_lm) {
+        lds_double *ws = lds + nl * NAs;
         for (int l = t; l < nl; l += T) {
+            const bool lf = w.lfree[l] != 0;
+            const double sl = w.sig_l[l], lm = w.lm_m[l], dl = w.diag_l[l];
             double lw = 0.0;
-            if (w.lfree[l]) {
-                const double s2 = w.sig_l[l] * w.sig_l[l];
-                lw = s2 / (s2 * w.lm_m[l] + mu * w.diag_l[l] * w.diag_l[l]);
+            if (lf) {
+                const double s2 = sl * sl;
+                lw = s2 / (s2 * lm + mu * dl * dl);
             }
             w.lm_w[l] = lw;
+            if (staged) ws[l] = lw;
         }
-        __syncthreads();
+        if (!staged) __syncthreads();
     }
     // The operand is first staged into the (currently idle) LDS Cholesky buffer with one batch of coalesced loads: a
     // K-loop over global memory is a chain of ~nl/16 dependent L2 round trips per tile.
     if (NA > 0 && has_lm) {
-        if (w.lds_chol && (size_t)nl * NAs + nl <= lds_cap) {
+        if (staged) {
             lds_double *As = lds, *ws = lds + nl * NAs;
             stage_to_lds<T, 16>(As, w.A, nl * NAs);
-            for (int l = t; l < nl; l += T) ws[l] = w.lm_w[l];
             __syncthreads();
             block_gemm_tn_lds<T>(w.Cm, NAs, As, NAs, As, NAs, ws, true, NA, NA + 1, nl, true);
         } else {
