@@ -73,7 +73,17 @@ DM double dot_strided(const double *__restrict__ a, long sa, const double *__res
 #pragma unroll
         for (int u = 0; u < U; ++u) acc += av[u] * xv[u];
     }
-    for (; i < n; ++i) acc += a[(long)i * sa] * x[(long)i * sx];
+    if (i < n) {  // (remainder as one masked batch: a one-element loop is a round trip per element)
+        double av[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            av[u] = (i + u < n) ? a[(long)(i + u) * sa] : 0.0;
+            xv[u] = (i + u < n) ? x[(long)(i + u) * sx] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i + u < n) acc += av[u] * xv[u];
+    }
     return acc;
 }
 
@@ -102,7 +112,18 @@ DM double quad_col_dot(const double *__restrict__ M, long ld, const double *__re
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += mv[u] * xv[u];
     }
-    for (; c < C; c += 4) acc += M[(long)c * ld + r] * x[c];
+    if (c < C) {  // the remainder (at most seven columns of this part) as ONE masked batch: a one-column loop is a round trip per column
+        double mv[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = c + 4 * u < C;
+            mv[u] = ok ? M[(long)(c + 4 * u) * ld + r] : 0.0;
+            xv[u] = ok ? x[c + 4 * u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c + 4 * u < C) acc += mv[u] * xv[u];
+    }
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
     return acc;
@@ -127,10 +148,13 @@ DM void quad_col_dot2(const double *__restrict__ M, long ld, const double *__res
 #pragma unroll
         for (int u = 0; u < 8; ++u) { ax += mv[u] * x[c + 4 * u]; ay += mv[u] * y[c + 4 * u]; }
     }
-    for (; c < C; c += 4) {
-        const double m = M[(long)c * ld + r];
-        ax += m * x[c];
-        ay += m * y[c];
+    if (c < C) {  // (remainder as one masked batch, as in quad_col_dot)
+        double mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mv[u] = (c + 4 * u < C) ? M[(long)(c + 4 * u) * ld + r] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c + 4 * u < C) { ax += mv[u] * x[c + 4 * u]; ay += mv[u] * y[c + 4 * u]; }
     }
     ax += __shfl_xor(ax, 1);
     ax += __shfl_xor(ax, 2);
@@ -165,11 +189,16 @@ DM void quad_col_dot4(const double *__restrict__ M, long ld, const double *__res
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc[k] += mv[u] * x[k * xs + c + 4 * u];
     }
-    for (; c < C; c += 4) {
-        const double m = M[(long)c * ld + r];
+    if (c < C) {  // (remainder as one masked batch, as in quad_col_dot)
+        double mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mv[u] = (c + 4 * u < C) ? M[(long)(c + 4 * u) * ld + r] : 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (k < K) acc[k] += m * x[k * xs + c];
+            if (k < K)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (c + 4 * u < C) acc[k] += mv[u] * x[k * xs + c + 4 * u];
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -207,11 +236,16 @@ DM void quad_col_dotk(const double *__restrict__ M, long ld, const double *__res
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc[k] += mv[u] * x[k * xs + c + 4 * u];
     }
-    for (; c < C; c += 4) {
-        const double m = M[(long)c * ld + r];
+    if (c < C) {  // (remainder as one masked batch, as in quad_col_dot)
+        double mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mv[u] = (c + 4 * u < C) ? M[(long)(c + 4 * u) * ld + r] : 0.0;
 #pragma unroll
         for (int k = 0; k < KN; ++k)
-            if (k < K) acc[k] += m * x[k * xs + c];
+            if (k < K)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (c + 4 * u < C) acc[k] += mv[u] * x[k * xs + c + 4 * u];
     }
 #pragma unroll
     for (int k = 0; k < KN; ++k) {
