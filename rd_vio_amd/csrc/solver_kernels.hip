@@ -335,9 +335,11 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
         const int src1 = (which >= 0 && which <= 2) ? sh.band_src[(fi * 3 + which) * 2 + 1] : -1;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            // A operand of T = Lam_ij E_j: A[i = li][k = 4 u + lk]
+            // A operand of T = Lam_ij E_j: A[i = li][k = 4 u + lk] = Lam[15 pi + li][15 pj + k], read through the mirror entry
+            // Lam[15 pj + k][15 pi + li] (Lam = S^T S is stored as a full, exactly symmetric matrix): the sixteen lanes of a
+            // quarter-wavefront then read one row segment -- one cache line instead of sixteen
             const int k = 4 * u + lk;
-            L.lam[u] = (has_prior && li < 15 && k < 15) ? w.Lam[(size_t)(15 * pi + li) * D + 15 * pj + k] : 0.0;
+            L.lam[u] = (has_prior && li < 15 && k < 15) ? w.Lam[(size_t)(15 * pj + k) * D + 15 * pi + li] : 0.0;
             // result layout: entry (a = lk + 4 u, b = li)
             const int a = lk + 4 * u, b = li;
             const bool ok = a < 15 && b < 15;
@@ -349,7 +351,7 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
             const int a = lk + 4 * u, b = li;
             const bool ok = a < 6 && b < 6;
             // off-diagonal lower block (fi > fj): the (lo = fj, hi = fi) group's cross quadrant, transposed
-            L.gp[u] = (ok && fi != fj) ? w.GP[256 * (size_t)pair_id(fj, fi, nfree) + 16 * b + 6 + a] : 0.0;
+            L.gp[u] = (ok && fi != fj) ? w.GP[256 * (size_t)pair_id(fj, fi, nfree) + 16 * b + 6 + a] : 0.0;   // (transposed read of a 6 x 6 quadrant)
 #pragma unroll
             for (int q = 0; q < GD; ++q) {
                 // diagonal block: the nfree group tiles that touch this frame (summed in f2 order)
