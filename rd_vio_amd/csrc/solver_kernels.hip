@@ -322,9 +322,6 @@ __device__ __attribute__((noinline)) void ne_pair_products(LdsWs &w, int g0, int
 __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh, int p0, int pstride) {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const int N = w.N, nfree = w.nfree, D = w.D;
-    // wave-uniform, global-typed operands (32-bit per-lane offsets off a scalar base: see RDVIO_UG)
-    cgdouble *Lam = RDVIO_UG(w.Lam), *PP = RDVIO_UG(w.PP), *GP = RDVIO_UG(w.GP);
-    gdouble *H = RDVIO_UGW(w.H);
     constexpr int GD = 12;   // group tiles of a diagonal block loaded with the block (windows of up to 12 free frames: all)
     struct Loads {
         double lam[4], pp0[4], pp1[4], gp[2], gd[2][GD];
@@ -336,37 +333,32 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
         const int which = fj - fi + 1;
         const int src0 = (which >= 0 && which <= 2) ? sh.band_src[(fi * 3 + which) * 2] : -1;
         const int src1 = (which >= 0 && which <= 2) ? sh.band_src[(fi * 3 + which) * 2 + 1] : -1;
-        const unsigned pp0 = 900u * (unsigned)(src0 >> 2) + 450u * ((src0 >> 1) & 1) + 15u * (src0 & 1);
-        const unsigned pp1 = 900u * (unsigned)(src1 >> 2) + 450u * ((src1 >> 1) & 1) + 15u * (src1 & 1);
-        const unsigned lam0 = (unsigned)(15 * pj) * (unsigned)D + (unsigned)(15 * pi);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             // A operand of T = Lam_ij E_j: A[i = li][k = 4 u + lk] = Lam[15 pi + li][15 pj + k], read through the mirror entry
             // Lam[15 pj + k][15 pi + li] (Lam = S^T S is stored as a full, exactly symmetric matrix): the sixteen lanes of a
             // quarter-wavefront then read one row segment -- one cache line instead of sixteen
             const int k = 4 * u + lk;
-            L.lam[u] = rdvio_gload(Lam, lam0 + (unsigned)k * (unsigned)D + (unsigned)li, has_prior && li < 15 && k < 15);
+            L.lam[u] = (has_prior && li < 15 && k < 15) ? w.Lam[(size_t)(15 * pj + k) * D + 15 * pi + li] : 0.0;
             // result layout: entry (a = lk + 4 u, b = li)
             const int a = lk + 4 * u, b = li;
             const bool ok = a < 15 && b < 15;
-            L.pp0[u] = rdvio_gload(PP, pp0 + 30u * (unsigned)a + (unsigned)b, ok && src0 >= 0);
-            L.pp1[u] = rdvio_gload(PP, pp1 + 30u * (unsigned)a + (unsigned)b, ok && src1 >= 0);
+            L.pp0[u] = (ok && src0 >= 0) ? w.PP[900 * (size_t)(src0 >> 2) + 30 * (15 * ((src0 >> 1) & 1) + a) + 15 * (src0 & 1) + b] : 0.0;
+            L.pp1[u] = (ok && src1 >= 0) ? w.PP[900 * (size_t)(src1 >> 2) + 30 * (15 * ((src1 >> 1) & 1) + a) + 15 * (src1 & 1) + b] : 0.0;
         }
-        const unsigned gpo = 256u * (unsigned)pair_id(fj, fi, nfree);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {   // pose rows a < 6 live in r = 0 (a = lk) and r = 1 (a = lk + 4 < 6)
             const int a = lk + 4 * u, b = li;
             const bool ok = a < 6 && b < 6;
             // off-diagonal lower block (fi > fj): the (lo = fj, hi = fi) group's cross quadrant, transposed
-            L.gp[u] = rdvio_gload(GP, gpo + 16u * (unsigned)b + 6u + (unsigned)a, ok && fi != fj);
+            L.gp[u] = (ok && fi != fj) ? w.GP[256 * (size_t)pair_id(fj, fi, nfree) + 16 * b + 6 + a] : 0.0;   // (transposed read of a 6 x 6 quadrant)
 #pragma unroll
             for (int q = 0; q < GD; ++q) {
                 // diagonal block: the nfree group tiles that touch this frame (summed in f2 order)
                 const int f2 = q;
                 const int lo = f2 < fi ? f2 : fi, hi = f2 < fi ? fi : f2;
                 const int off = (fi == lo) ? 0 : 6;  // quadrant (lo,lo) or (hi,hi); the single group (f,f) uses (lo,lo)
-                const bool okd = ok && fi == fj && f2 < nfree;
-                L.gd[u][q] = rdvio_gload(GP, 256u * (unsigned)(okd ? pair_id(lo, hi, nfree) : 0) + 16u * (unsigned)(off + a) + (unsigned)(off + b), okd);
+                L.gd[u][q] = (ok && fi == fj && f2 < nfree) ? w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + off + b] : 0.0;
             }
         }
     };
@@ -411,7 +403,7 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
                                 const int f2 = f0 + q;
                                 const int lo = f2 < fi ? f2 : fi, hi = f2 < fi ? fi : f2;
                                 const int off = (fi == lo) ? 0 : 6;
-                                gv[q] = f2 < nfree ? GP[256 * pair_id(lo, hi, nfree) + 16 * (off + a) + off + b] : 0.0;
+                                gv[q] = f2 < nfree ? w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + off + b] : 0.0;
                             }
 #pragma unroll
                             for (int q = 0; q < GD; ++q)
@@ -432,8 +424,8 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
         for (int u = 0; u < 4; ++u) {
             const int a = lk + 4 * u, b = li;
             if (a < 15 && b < 15) {
-                H[(15 * fi + a) * N + 15 * fj + b] = v[u];
-                if (fi != fj) H[(15 * fj + b) * N + 15 * fi + a] = v[u];
+                w.H[(size_t)(15 * fi + a) * N + 15 * fj + b] = v[u];
+                if (fi != fj) w.H[(size_t)(15 * fj + b) * N + 15 * fi + a] = v[u];
             }
         }
     };
