@@ -12,6 +12,17 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // Pointers that keep the LDS address space across (noinline) function boundaries: a generic `double *` to LDS makes the
 // compiler emit FLAT loads / stores, which resolve the aperture first and cost about twice the latency of ds_read / ds_write.
 typedef __attribute__((address_space(3))) double lds_double;
+// Global-memory operands of the hot phases.  The descriptor's pointers are generic and come out of LDS as per-lane values: an
+// access through them is a FLAT instruction whose 64-bit address every lane computes with VALU arithmetic.  RDVIO_UG(p) makes
+// the pointer wave-uniform (two v_readfirstlane) and global-typed: `global_load` off a scalar base with a 32-bit index.
+typedef __attribute__((address_space(1))) double gdouble;
+typedef const __attribute__((address_space(1))) double cgdouble;
+DM unsigned long long rdvio_uniform64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+#define RDVIO_UG(p) ((cgdouble *)rdvio_uniform64((unsigned long long)(p)))
+#define RDVIO_UGW(p) ((gdouble *)rdvio_uniform64((unsigned long long)(p)))
 #define RDVIO_LDS(p) ((lds_double *)(p))
 
 template <int T>

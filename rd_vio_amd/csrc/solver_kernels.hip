@@ -322,6 +322,9 @@ __device__ __attribute__((noinline)) void ne_pair_products(LdsWs &w, int g0, int
 __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh, int p0, int pstride) {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const int N = w.N, nfree = w.nfree, D = w.D;
+    // wave-uniform, global-typed operands (see RDVIO_UG)
+    cgdouble *Lam = RDVIO_UG(w.Lam), *PP = RDVIO_UG(w.PP), *GP = RDVIO_UG(w.GP);
+    gdouble *H = RDVIO_UGW(w.H);
     constexpr int GD = 12;   // group tiles of a diagonal block loaded with the block (windows of up to 12 free frames: all)
     struct Loads {
         double lam[4], pp0[4], pp1[4], gp[2], gd[2][GD];
@@ -339,26 +342,26 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
             // Lam[15 pj + k][15 pi + li] (Lam = S^T S is stored as a full, exactly symmetric matrix): the sixteen lanes of a
             // quarter-wavefront then read one row segment -- one cache line instead of sixteen
             const int k = 4 * u + lk;
-            L.lam[u] = (has_prior && li < 15 && k < 15) ? w.Lam[(size_t)(15 * pj + k) * D + 15 * pi + li] : 0.0;
+            L.lam[u] = (has_prior && li < 15 && k < 15) ? Lam[(15 * pj + k) * D + 15 * pi + li] : 0.0;
             // result layout: entry (a = lk + 4 u, b = li)
             const int a = lk + 4 * u, b = li;
             const bool ok = a < 15 && b < 15;
-            L.pp0[u] = (ok && src0 >= 0) ? w.PP[900 * (size_t)(src0 >> 2) + 30 * (15 * ((src0 >> 1) & 1) + a) + 15 * (src0 & 1) + b] : 0.0;
-            L.pp1[u] = (ok && src1 >= 0) ? w.PP[900 * (size_t)(src1 >> 2) + 30 * (15 * ((src1 >> 1) & 1) + a) + 15 * (src1 & 1) + b] : 0.0;
+            L.pp0[u] = (ok && src0 >= 0) ? PP[900 * (src0 >> 2) + 30 * (15 * ((src0 >> 1) & 1) + a) + 15 * (src0 & 1) + b] : 0.0;
+            L.pp1[u] = (ok && src1 >= 0) ? PP[900 * (src1 >> 2) + 30 * (15 * ((src1 >> 1) & 1) + a) + 15 * (src1 & 1) + b] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {   // pose rows a < 6 live in r = 0 (a = lk) and r = 1 (a = lk + 4 < 6)
             const int a = lk + 4 * u, b = li;
             const bool ok = a < 6 && b < 6;
             // off-diagonal lower block (fi > fj): the (lo = fj, hi = fi) group's cross quadrant, transposed
-            L.gp[u] = (ok && fi != fj) ? w.GP[256 * (size_t)pair_id(fj, fi, nfree) + 16 * b + 6 + a] : 0.0;   // (transposed read of a 6 x 6 quadrant)
+            L.gp[u] = (ok && fi != fj) ? GP[256 * pair_id(fj, fi, nfree) + 16 * b + 6 + a] : 0.0;   // (transposed read of a 6 x 6 quadrant)
 #pragma unroll
             for (int q = 0; q < GD; ++q) {
                 // diagonal block: the nfree group tiles that touch this frame (summed in f2 order)
                 const int f2 = q;
                 const int lo = f2 < fi ? f2 : fi, hi = f2 < fi ? fi : f2;
                 const int off = (fi == lo) ? 0 : 6;  // quadrant (lo,lo) or (hi,hi); the single group (f,f) uses (lo,lo)
-                L.gd[u][q] = (ok && fi == fj && f2 < nfree) ? w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + off + b] : 0.0;
+                L.gd[u][q] = (ok && fi == fj && f2 < nfree) ? GP[256 * pair_id(lo, hi, nfree) + 16 * (off + a) + off + b] : 0.0;
             }
         }
     };
@@ -403,7 +406,7 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
                                 const int f2 = f0 + q;
                                 const int lo = f2 < fi ? f2 : fi, hi = f2 < fi ? fi : f2;
                                 const int off = (fi == lo) ? 0 : 6;
-                                gv[q] = f2 < nfree ? w.GP[256 * (size_t)pair_id(lo, hi, nfree) + 16 * (off + a) + off + b] : 0.0;
+                                gv[q] = f2 < nfree ? GP[256 * pair_id(lo, hi, nfree) + 16 * (off + a) + off + b] : 0.0;
                             }
 #pragma unroll
                             for (int q = 0; q < GD; ++q)
@@ -424,8 +427,8 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
         for (int u = 0; u < 4; ++u) {
             const int a = lk + 4 * u, b = li;
             if (a < 15 && b < 15) {
-                w.H[(size_t)(15 * fi + a) * N + 15 * fj + b] = v[u];
-                if (fi != fj) w.H[(size_t)(15 * fj + b) * N + 15 * fi + a] = v[u];
+                H[(15 * fi + a) * N + 15 * fj + b] = v[u];
+                if (fi != fj) H[(15 * fj + b) * N + 15 * fi + a] = v[u];
             }
         }
     };
