@@ -350,7 +350,7 @@ int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double 
 // diagnostic (RDVIO_PROF builds): per-phase ticks / counts of the last solve in a slot; not part of the public header
 int rdvio_hip_debug_ba_prof(rdvio_hip_ctx *ctx, int slot, double *out64) {
     if (!ctx || bad_slot(slot) || !ctx->ba[slot].ready) return RDVIO_ERR_INVALID;
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(out64, ctx->ba[slot].ws.summary + 8, 64 * sizeof(double), hipMemcpyDeviceToHost, ctx->lane[RDVIO_LANE_SOLVER]));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(out64, ctx->ba[slot].ws.summary + 8, 72 * sizeof(double), hipMemcpyDeviceToHost, ctx->lane[RDVIO_LANE_SOLVER]));
     RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->lane[RDVIO_LANE_SOLVER]));
     return RDVIO_OK;
 }

@@ -438,15 +438,36 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
         return fi * nfree + (p - tri(fi));
     };
     const int n_lower = nfree * (nfree + 1) / 2;
+#ifdef RDVIO_PROF_HBLK
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, tt;
+#define HB_T(x) do { tt = wall_clock64(); x; } while (0)
+#endif
     for (int p = p0; p < n_lower; p += 2 * pstride) {
         Loads L0, L1;
         const bool two = p + pstride < n_lower;
         const int b0 = lower_block(p), b1 = two ? lower_block(p + pstride) : b0;
+#ifdef RDVIO_PROF_HBLK
+        const unsigned long long t0 = wall_clock64();
+#endif
         block_load(b0, L0);
         block_load(b1, L1);
+#ifdef RDVIO_PROF_HBLK
+        const unsigned long long t1 = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long t2 = wall_clock64();
+#endif
         block_finish(b0, L0);
         if (two) block_finish(b1, L1);
+#ifdef RDVIO_PROF_HBLK
+        const unsigned long long t3 = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long t4 = wall_clock64();
+        c0 += t1 - t0; c1 += t2 - t1; c2 += t3 - t2; c3 += t4 - t3;
+#endif
     }
+#ifdef RDVIO_PROF_HBLK
+    if (threadIdx.x == 0) { w.summary[72] += (double)c0; w.summary[73] += (double)c1; w.summary[74] += (double)c2; w.summary[75] += (double)c3; }
+#endif
 }
 
 // workgroup g's share of the Schur product [C | Cg] = A^T W [A | g] of a multi-workgroup launch: the landmarks are split
@@ -1886,7 +1907,7 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
     unsigned long long prof_last = 0;
 #ifdef RDVIO_PROF
     prof_last = wall_clock64();
-    if (t == 0) for (int i = 8; i < 72; ++i) w.summary[i] = 0.0;
+    if (t == 0) for (int i = 8; i < 80; ++i) w.summary[i] = 0.0;
 #endif
 
     solver_setup(wl, sh, RDVIO_LDS(lds_chol_buf), LDS_CAP, prof_last);
@@ -2125,7 +2146,7 @@ __global__ __launch_bounds__(T) void marginalize_kernel(SolverWs w) {
     unsigned long long prof_last = 0;
 #ifdef RDVIO_PROF
     prof_last = wall_clock64();
-    if (threadIdx.x == 0) for (int i = 8; i < 72; ++i) w.summary[i] = 0.0;
+    if (threadIdx.x == 0) for (int i = 8; i < 80; ++i) w.summary[i] = 0.0;
 #endif
     solver_setup(wl, sh, RDVIO_LDS(lds_buf), sizeof(lds_buf) / sizeof(double), prof_last);
     STAMP(0);

@@ -29,7 +29,7 @@ for iters in (0, 1, 5, 30):
     _, _, sm = ctx.ba_fetch(0)
     print(f"localize F={len(loc['tgt'])} max_iter={iters:2d}: {dt*1e6:8.1f} us iterations={sm.iterations} successful={sm.successful_steps} term={sm.termination}")
 if os.environ.get("RDVIO_PROF"):
-    prof = np.zeros(64)
+    prof = np.zeros(72)
     ctx._lib.rdvio_hip_debug_ba_prof(ctx._h, 0, ctypes.c_void_p(prof.ctypes.data))
     names = ["setup", "eval_lin", "build_ne", "dogleg_prep", "schur", "cholesky", "tri_solve", "lm_y+norms",
              "step+model", "cand_eval", "misc", "gradmax", "ne:pairs", "ne:landm", "ne:preint", "ne:wait", "ne:phase2",

@@ -33,12 +33,14 @@ for name, kw in (("full", {}), ("no_prior", dict(with_prior=False)), ("no_preint
         print(f"{name:12s} F={len(pb['tgt'])} max_iter={iters:2d}: {us:9.1f} us  iterations={it} successful={ok}")
         if os.environ.get("RDVIO_PROF") and iters == 30:
             import ctypes
-            prof = np.zeros(64)
+            prof = np.zeros(72)
             ctx._lib.rdvio_hip_debug_ba_prof(ctx._h, 0, ctypes.c_void_p(prof.ctypes.data))
             names = ["setup", "eval_lin", "build_ne", "dogleg_prep", "schur", "cholesky", "tri_solve", "lm_y+norms",
                      "step+model", "cand_eval", "misc", "gradmax", "ne:pairs", "ne:landm", "ne:preint", "ne:wait", "ne:phase2",
                      "evL:factors(w0)", "evL:wait", "evL:whiten", "evC:factors(w0)", "evC:wait", "evC:whiten",
                      "setup:copy/zero", "setup:stage S+ST", "setup:Lam gemm", "setup:eta0+mirror", "ne:H blocks", "candidate", "schur:lm_w+gemm", "evL:stage", "evC:stage"]
+            if prof[64:68].any():
+                print("      H blocks, wave 0: load issue %.1f us, load wait %.1f us, products + store issue %.1f us, store drain %.1f us" % tuple(prof[64:68] / 100))
             for i, nm in enumerate(names):
                 if prof[32 + i] > 0:
                     print(f"      {nm:12s} total {prof[i] / 100:9.1f} us  calls {int(prof[32 + i]):3d}  avg {prof[i] / 100 / prof[32 + i]:8.2f} us")
