@@ -319,55 +319,94 @@ __device__ __attribute__((noinline)) void ne_pair_products(LdsWs &w, int g0, int
 // at a time: one L2 round trip per pair of blocks (the per-entry conditionals this replaces were each a round trip of its
 // own: 62 waits per trip).  Block-level conditions are wave-uniform.  Wavefront p0 of pstride takes the lower blocks
 // p0, p0 + 2 pstride, ...
-__device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh, int p0, int pstride) {
+__device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh, int p0_, int pstride_) {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-    const int N = w.N, nfree = w.nfree, D = w.D;
-    // wave-uniform, global-typed operands (see RDVIO_UG)
+    // Addresses = wave-uniform part (which block: scalar registers, scalar arithmetic) + per-lane part (where in the block:
+    // computed ONCE per call).  Measured with stamps inside this routine (RDVIO_PROF_HBLK): the wait for the loads of a trip
+    // was 0.1 us, ISSUING them 2.7 us -- ~25 VALU instructions of 64-bit per-lane address arithmetic per load, on a
+    // workgroup with two wavefronts per SIMD; the routine is instruction-issue bound.
+    const int p0 = __builtin_amdgcn_readfirstlane(p0_), pstride = __builtin_amdgcn_readfirstlane(pstride_);
+    const int N = __builtin_amdgcn_readfirstlane(w.N), nfree = __builtin_amdgcn_readfirstlane(w.nfree), D = __builtin_amdgcn_readfirstlane(w.D);
     cgdouble *Lam = RDVIO_UG(w.Lam), *PP = RDVIO_UG(w.PP), *GP = RDVIO_UG(w.GP);
     gdouble *H = RDVIO_UGW(w.H);
+    // per-lane parts: entry (a = lk + 4 u, b = li) of a block in the matrix cores' result layout
+    int lam_off[4], pp_off[4], h_off[4], ht_off[4];
+    bool lam_ok[4], ok15[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = 4 * u + lk, a = lk + 4 * u;
+        lam_off[u] = k * D + li;          // mirror entry Lam[15 pj + k][15 pi + li] of A[i = li][k] (Lam is exactly symmetric)
+        lam_ok[u] = li < 15 && k < 15;
+        pp_off[u] = 30 * a + li;
+        ok15[u] = a < 15 && li < 15;
+        h_off[u] = a * N + li;
+        ht_off[u] = li * N + a;
+    }
+    int gpt_off[2], gd_off[2];
+    bool ok6[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {         // pose rows a < 6 live in r = 0 (a = lk) and r = 1 (a = lk + 4 < 6)
+        const int a = lk + 4 * u;
+        gpt_off[u] = 16 * li + 6 + a;     // transposed read of the cross quadrant
+        gd_off[u] = 16 * a + li;
+        ok6[u] = a < 6 && li < 6;
+    }
     constexpr int GD = 12;   // group tiles of a diagonal block loaded with the block (windows of up to 12 free frames: all)
     struct Loads {
         double lam[4], pp0[4], pp1[4], gp[2], gd[2][GD];
     };
-    auto block_load = [&](int blk, Loads &L) {
-        const int fi = blk / nfree, fj = blk - fi * nfree;
-        const int pi = sh.pcol[fi], pj = sh.pcol[fj];
-        const bool has_prior = pi >= 0 && pj >= 0;
-        const int which = fj - fi + 1;
-        const int src0 = (which >= 0 && which <= 2) ? sh.band_src[(fi * 3 + which) * 2] : -1;
-        const int src1 = (which >= 0 && which <= 2) ? sh.band_src[(fi * 3 + which) * 2 + 1] : -1;
+    // block-level (scalar) quantities
+    struct Blk {
+        int fi, fj, pi, pj, src0, src1;
+    };
+    auto block_of = [&](int p) {  // p-th lower block in row-major order
+        int fi = 0;
+        while (tri(fi + 1) <= p) ++fi;
+        Blk B;
+        B.fi = fi;
+        B.fj = p - tri(fi);
+        B.pi = __builtin_amdgcn_readfirstlane(sh.pcol[B.fi]);
+        B.pj = __builtin_amdgcn_readfirstlane(sh.pcol[B.fj]);
+        const int which = B.fj - B.fi + 1;   // (lower blocks: 0 or 1)
+        B.src0 = (which >= 0 && which <= 2) ? __builtin_amdgcn_readfirstlane(sh.band_src[(B.fi * 3 + which) * 2]) : -1;
+        B.src1 = (which >= 0 && which <= 2) ? __builtin_amdgcn_readfirstlane(sh.band_src[(B.fi * 3 + which) * 2 + 1]) : -1;
+        return B;
+    };
+    auto block_load = [&](const Blk &B, Loads &L) {
+        const bool has_prior = B.pi >= 0 && B.pj >= 0;
+        const int lam_base = (15 * B.pj) * D + 15 * B.pi;
+        const int pp0_base = 900 * (B.src0 >> 2) + 450 * ((B.src0 >> 1) & 1) + 15 * (B.src0 & 1);
+        const int pp1_base = 900 * (B.src1 >> 2) + 450 * ((B.src1 >> 1) & 1) + 15 * (B.src1 & 1);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            // A operand of T = Lam_ij E_j: A[i = li][k = 4 u + lk] = Lam[15 pi + li][15 pj + k], read through the mirror entry
-            // Lam[15 pj + k][15 pi + li] (Lam = S^T S is stored as a full, exactly symmetric matrix): the sixteen lanes of a
-            // quarter-wavefront then read one row segment -- one cache line instead of sixteen
-            const int k = 4 * u + lk;
-            L.lam[u] = (has_prior && li < 15 && k < 15) ? Lam[(15 * pj + k) * D + 15 * pi + li] : 0.0;
-            // result layout: entry (a = lk + 4 u, b = li)
-            const int a = lk + 4 * u, b = li;
-            const bool ok = a < 15 && b < 15;
-            L.pp0[u] = (ok && src0 >= 0) ? PP[900 * (src0 >> 2) + 30 * (15 * ((src0 >> 1) & 1) + a) + 15 * (src0 & 1) + b] : 0.0;
-            L.pp1[u] = (ok && src1 >= 0) ? PP[900 * (src1 >> 2) + 30 * (15 * ((src1 >> 1) & 1) + a) + 15 * (src1 & 1) + b] : 0.0;
+            L.lam[u] = (has_prior && lam_ok[u]) ? Lam[lam_base + lam_off[u]] : 0.0;
+            L.pp0[u] = (B.src0 >= 0 && ok15[u]) ? PP[pp0_base + pp_off[u]] : 0.0;
+            L.pp1[u] = (B.src1 >= 0 && ok15[u]) ? PP[pp1_base + pp_off[u]] : 0.0;
         }
+        if (B.fi != B.fj) {   // off-diagonal lower block (fi > fj): the (lo = fj, hi = fi) group's cross quadrant, transposed
+            const int gp_base = 256 * pair_id(B.fj, B.fi, nfree);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {   // pose rows a < 6 live in r = 0 (a = lk) and r = 1 (a = lk + 4 < 6)
-            const int a = lk + 4 * u, b = li;
-            const bool ok = a < 6 && b < 6;
-            // off-diagonal lower block (fi > fj): the (lo = fj, hi = fi) group's cross quadrant, transposed
-            L.gp[u] = (ok && fi != fj) ? GP[256 * pair_id(fj, fi, nfree) + 16 * b + 6 + a] : 0.0;   // (transposed read of a 6 x 6 quadrant)
+            for (int u = 0; u < 2; ++u) {
+                L.gp[u] = ok6[u] ? GP[gp_base + gpt_off[u]] : 0.0;
+#pragma unroll
+                for (int q = 0; q < GD; ++q) L.gd[u][q] = 0.0;
+            }
+        } else {              // diagonal block: the nfree group tiles that touch this frame (summed in f2 order)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) L.gp[u] = 0.0;
 #pragma unroll
             for (int q = 0; q < GD; ++q) {
-                // diagonal block: the nfree group tiles that touch this frame (summed in f2 order)
-                const int f2 = q;
+                const int f2 = q, fi = B.fi;
                 const int lo = f2 < fi ? f2 : fi, hi = f2 < fi ? fi : f2;
                 const int off = (fi == lo) ? 0 : 6;  // quadrant (lo,lo) or (hi,hi); the single group (f,f) uses (lo,lo)
-                L.gd[u][q] = (ok && fi == fj && f2 < nfree) ? GP[256 * pair_id(lo, hi, nfree) + 16 * (off + a) + off + b] : 0.0;
+                const int gd_base = 256 * pair_id(lo, hi, nfree) + 17 * off;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) L.gd[u][q] = (f2 < nfree && ok6[u]) ? GP[gd_base + gd_off[u]] : 0.0;
             }
         }
     };
-    auto block_finish = [&](int blk, const Loads &L) {
-        const int fi = blk / nfree, fj = blk - fi * nfree;
-        const int pi = sh.pcol[fi], pj = sh.pcol[fj];
+    auto block_finish = [&](const Blk &B, const Loads &L) {
+        const int fi = B.fi, fj = B.fj, pi = B.pi, pj = B.pj;
         const bool has_prior = pi >= 0 && pj >= 0;
         double4_t acc = {0.0, 0.0, 0.0, 0.0};
         if (has_prior) {
@@ -385,7 +424,7 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(e, T[u], acc, 0, 0, 0);
             }
         }
-        const bool fxi = sh.pfixc[fi], fxj = sh.pfixc[fj];
+        const bool fxi = __builtin_amdgcn_readfirstlane(sh.pfixc[fi]) != 0, fxj = __builtin_amdgcn_readfirstlane(sh.pfixc[fj]) != 0;
         double v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -406,7 +445,7 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
                                 const int f2 = f0 + q;
                                 const int lo = f2 < fi ? f2 : fi, hi = f2 < fi ? fi : f2;
                                 const int off = (fi == lo) ? 0 : 6;
-                                gv[q] = f2 < nfree ? GP[256 * pair_id(lo, hi, nfree) + 16 * (off + a) + off + b] : 0.0;
+                                gv[q] = f2 < nfree ? GP[256 * pair_id(lo, hi, nfree) + 17 * off + gd_off[u]] : 0.0;
                             }
 #pragma unroll
                             for (int q = 0; q < GD; ++q)
@@ -423,41 +462,34 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
             v[u] = x;
         }
         // H is symmetric: only the lower blocks are formed, an off-diagonal block is stored a second time transposed
+        const int h_base = (15 * fi) * N + 15 * fj, ht_base = (15 * fj) * N + 15 * fi;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int a = lk + 4 * u, b = li;
-            if (a < 15 && b < 15) {
-                H[(15 * fi + a) * N + 15 * fj + b] = v[u];
-                if (fi != fj) H[(15 * fj + b) * N + 15 * fi + a] = v[u];
+        for (int u = 0; u < 4; ++u)
+            if (ok15[u]) {
+                H[h_base + h_off[u]] = v[u];
+                if (fi != fj) H[ht_base + ht_off[u]] = v[u];
             }
-        }
-    };
-    auto lower_block = [&](int p) {  // p-th lower block in row-major order -> fi * nfree + fj
-        int fi = 0;
-        while (tri(fi + 1) <= p) ++fi;
-        return fi * nfree + (p - tri(fi));
     };
     const int n_lower = nfree * (nfree + 1) / 2;
 #ifdef RDVIO_PROF_HBLK
-    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, tt;
-#define HB_T(x) do { tt = wall_clock64(); x; } while (0)
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #endif
     for (int p = p0; p < n_lower; p += 2 * pstride) {
         Loads L0, L1;
         const bool two = p + pstride < n_lower;
-        const int b0 = lower_block(p), b1 = two ? lower_block(p + pstride) : b0;
+        const Blk B0 = block_of(p), B1 = block_of(two ? p + pstride : p);
 #ifdef RDVIO_PROF_HBLK
         const unsigned long long t0 = wall_clock64();
 #endif
-        block_load(b0, L0);
-        block_load(b1, L1);
+        block_load(B0, L0);
+        block_load(B1, L1);
 #ifdef RDVIO_PROF_HBLK
         const unsigned long long t1 = wall_clock64();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const unsigned long long t2 = wall_clock64();
 #endif
-        block_finish(b0, L0);
-        if (two) block_finish(b1, L1);
+        block_finish(B0, L0);
+        if (two) block_finish(B1, L1);
 #ifdef RDVIO_PROF_HBLK
         const unsigned long long t3 = wall_clock64();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
