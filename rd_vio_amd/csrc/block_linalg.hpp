@@ -175,6 +175,44 @@ DM void quad_col_dot2(const double *__restrict__ M, long ld, const double *__res
     oy = ay;
 }
 
+// quad_col_dot2 with the matrix behind a wave-uniform global-typed pointer and the vectors behind LDS-typed pointers: every load is
+// `scalar base + per-lane offset (row r, part) + compile-time column step`, the vector reads are ds_read with immediate
+// offsets -- the generic-pointer form spends two to four VALU instructions on each 64-bit address.  Same summation order.
+DM void quad_col_dot2_u(cgdouble *M, int ld, const lds_double *x, const lds_double *y, int C, int r, int part, double &ox, double &oy) {
+    double ax = 0.0, ay = 0.0;
+    const int lane_off = part * ld + r;
+    const lds_double *xp = x + part, *yp = y + part;
+    int c = 0;   // (column = part + c)
+    for (; part + c + 60 < C; c += 64) {
+        double mv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) mv[u] = M[(c + 4 * u) * ld + lane_off];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { ax += mv[u] * xp[c + 4 * u]; ay += mv[u] * yp[c + 4 * u]; }
+    }
+    for (; part + c + 28 < C; c += 32) {
+        double mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mv[u] = M[(c + 4 * u) * ld + lane_off];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { ax += mv[u] * xp[c + 4 * u]; ay += mv[u] * yp[c + 4 * u]; }
+    }
+    if (part + c < C) {
+        double mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mv[u] = (part + c + 4 * u < C) ? M[(c + 4 * u) * ld + lane_off] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (part + c + 4 * u < C) { ax += mv[u] * xp[c + 4 * u]; ay += mv[u] * yp[c + 4 * u]; }
+    }
+    ax += __shfl_xor(ax, 1);
+    ax += __shfl_xor(ax, 2);
+    ay += __shfl_xor(ay, 1);
+    ay += __shfl_xor(ay, 2);
+    ox = ax;
+    oy = ay;
+}
+
 // up to four right-hand sides x_k = x + k * xs at once, each summed exactly like quad_col_dot sums it
 DM void quad_col_dot4(const double *__restrict__ M, long ld, const double *__restrict__ x, int xs, int K, int C, int r, int part,
                       double (&out)[4]) {

@@ -273,39 +273,43 @@ DM int lower_block_of(int p, int nfree) {
 // per factor group, X^T X with X = [J_lo | J_hi | r] (2 n_g x 13) on the matrix cores, groups g0, g0 + gstride, ...
 // (one wavefront per group; lane l feeds A[i = l & 15][k] and B[k][j = l & 15] -- the same record element for i = j < 12 --,
 // k = (item, row))
-__device__ __attribute__((noinline)) void ne_pair_products(LdsWs &w, int g0, int gstride) {
+__device__ __attribute__((noinline)) void ne_pair_products(LdsWs &w, int g0_, int gstride_) {
     const int lane = threadIdx.x & 63;
-    for (int g = g0; g < w.npairs; g += gstride) {
-        const int n = w.grp_off[g + 1] - w.grp_off[g];
-        double *out = w.GP + 256 * (size_t)g;
-        const int i = lane & 15, kk = lane >> 4;
-        const int item_off = kk >> 1, row = kk & 1;
-        // element of the record this lane supplies: i < 6: first[row][i]; 6 <= i < 12: second[row][i - 6]; i == 12: r[row]
-        const int eo = (i < 6) ? row * 6 + i : (i < 12 ? 12 + row * 6 + (i - 6) : 24 + row);
-        const bool has = i < 13;
-        const double *rec = w.prec + RDVIO_REC_STRIDE * (size_t)w.grp_off[g] + eo;
+    // (group quantities in scalar registers, the lane's record element and item offset computed once: see ne_h_blocks)
+    const int g0 = __builtin_amdgcn_readfirstlane(g0_), gstride = __builtin_amdgcn_readfirstlane(gstride_);
+    const int npairs = __builtin_amdgcn_readfirstlane(w.npairs);
+    cgdouble *prec = RDVIO_UG(w.prec);
+    gdouble *GPw = RDVIO_UGW(w.GP);
+    const int *grp_off = w.grp_off;
+    const int i = lane & 15, kk = lane >> 4;
+    const int item_off = kk >> 1, row = kk & 1;
+    // element of the record this lane supplies: i < 6: first[row][i]; 6 <= i < 12: second[row][i - 6]; i == 12: r[row]
+    const int eo = (i < 6) ? row * 6 + i : (i < 12 ? 12 + row * 6 + (i - 6) : 24 + row);
+    const bool has = i < 13;
+    const int lane_off = RDVIO_REC_STRIDE * item_off + eo;
+    const int out_off = 16 * (lane >> 4) + (lane & 15);
+    for (int g = g0; g < npairs; g += gstride) {
+        const int go = __builtin_amdgcn_readfirstlane(grp_off[g]), n = __builtin_amdgcn_readfirstlane(grp_off[g + 1]) - go;
+        const int base = RDVIO_REC_STRIDE * go;
         double4_t acc = {0.0, 0.0, 0.0, 0.0};
         int it = 0;
         for (; it + 32 <= n; it += 32) {  // 16 MFMAs (32 items) per trip, loads issued together
             double v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = has ? rec[RDVIO_REC_STRIDE * (size_t)(it + 2 * u + item_off)] : 0.0;
+            for (int u = 0; u < 16; ++u) v[u] = has ? prec[base + RDVIO_REC_STRIDE * (it + 2 * u) + lane_off] : 0.0;
 #pragma unroll
             for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v[u] : 0.0, v[u], acc, 0, 0, 0);
         }
         if (it < n) {  // the remainder (up to 31 items: the usual group of a window, ~18) as ONE masked trip of sixteen loads
             double v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int item = it + 2 * u + item_off;
-                v[u] = (has && item < n) ? rec[RDVIO_REC_STRIDE * (size_t)item] : 0.0;
-            }
+            for (int u = 0; u < 16; ++u) v[u] = (has && it + 2 * u + item_off < n) ? prec[base + RDVIO_REC_STRIDE * (it + 2 * u) + lane_off] : 0.0;
 #pragma unroll
             for (int u = 0; u < 16; ++u)
                 if (it + 2 * u < n) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v[u] : 0.0, v[u], acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[16 * ((lane >> 4) + 4 * r) + (lane & 15)] = acc[r];
+        for (int r = 0; r < 4; ++r) GPw[256 * g + 64 * r + out_off] = acc[r];
     }
 }
 
@@ -1261,53 +1265,71 @@ PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap
     }
     __syncthreads();
     STAMP(29);
-    // one wavefront per LOWER 15 x 15 block, two blocks per trip; the H and Schur-term loads of both blocks are issued before
-    // the first use (a conditional subtraction inside the entry loop is a second round trip per entry)
+    // one wavefront per LOWER 15 x 15 block, two blocks per trip; the loads of both blocks are issued before the first use.
+    // Block quantities are scalars (readfirstlane), the lane's four entries (a, b) and their offsets are computed once: this
+    // pass, like the H blocks, is bound by the issue of address arithmetic, not by memory.
     for (int i = t; i < N; i += T) sh.xv[i] = w.sig_p[i];
     __syncthreads();
     {
         const int lane = t & 63, n_lower = nfree * (nfree + 1) / 2;
-        auto entry = [&](int blk, int u, int &i, int &j, bool &ok, bool &pose) {
-            const int fi = blk / nfree, fj = blk - fi * nfree;
-            const int e = lane + 64 * u, a = e / 15, b = e - 15 * a;
-            ok = e < 225 && (fi != fj || b <= a);
-            pose = ok && a < 6 && b < 6 && has_lm;
-            i = 15 * fi + a;
-            j = 15 * fj + b;
-        };
-        for (int p = t >> 6; p < n_lower; p += 2 * NW) {
+        const int Ns = __builtin_amdgcn_readfirstlane(N), NAss = __builtin_amdgcn_readfirstlane(NAs);
+        const bool lds_chol = __builtin_amdgcn_readfirstlane(w.lds_chol) != 0;
+        cgdouble *Hg = RDVIO_UG(w.H), *Cg = RDVIO_UG(w.Cm), *Dg = RDVIO_UG(w.diag_p);
+        int ea[4], eb[4], h_off[4], c_off[4];
+        bool in_blk[4], in_pose[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = lane + 64 * u;
+            ea[u] = e / 15;
+            eb[u] = e - 15 * ea[u];
+            in_blk[u] = e < 225;
+            in_pose[u] = in_blk[u] && ea[u] < 6 && eb[u] < 6 && has_lm;
+            h_off[u] = ea[u] * Ns + eb[u];
+            c_off[u] = ea[u] * NAss + eb[u];
+        }
+        for (int p = __builtin_amdgcn_readfirstlane(t >> 6); p < n_lower; p += 2 * NW) {
             const bool two = p + NW < n_lower;
-            const int blk[2] = {lower_block_of(p, nfree), lower_block_of(two ? p + NW : p, nfree)};
+            int fi[2], fj[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int blk = lower_block_of((q == 0 || two) ? p + q * NW : p, nfree);
+                fi[q] = blk / nfree;
+                fj[q] = blk - fi[q] * nfree;
+            }
             double hv[2][4], cv[2][4], dv[2][4];
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < 2; ++q) {
+                const int h_base = 15 * fi[q] * Ns + 15 * fj[q], c_base = 6 * fi[q] * NAss + 6 * fj[q];
+                const bool diag = fi[q] == fj[q];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    int i, j;
-                    bool ok, pose;
-                    entry(blk[q], u, i, j, ok, pose);
-                    hv[q][u] = ok ? w.H[(size_t)i * N + j] : 0.0;
-                    dv[q][u] = (ok && i == j) ? w.diag_p[i] : 0.0;
-                    const size_t ci = (size_t)(6 * (i / 15) + i % 15) * NAs + 6 * (j / 15) + j % 15;
-                    if (!split) cv[q][u] = pose ? w.Cm[ci] : 0.0;   // (workgroup-uniform branch)
-                    else cv[q][u] = pose ? schur_cm(w, ci, true, cstride) : 0.0;
+                    const bool ok = in_blk[u] && (!diag || eb[u] <= ea[u]);
+                    hv[q][u] = ok ? Hg[h_base + h_off[u]] : 0.0;
+                    dv[q][u] = (ok && diag && ea[u] == eb[u]) ? Dg[15 * fi[q] + ea[u]] : 0.0;
+                    const bool pose = ok && in_pose[u];
+                    if (!split) cv[q][u] = pose ? Cg[c_base + c_off[u]] : 0.0;   // (workgroup-uniform branch)
+                    else cv[q][u] = pose ? schur_cm(w, (size_t)(c_base + c_off[u]), true, cstride) : 0.0;
                 }
+            }
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < 2; ++q) {
+                const bool diag = fi[q] == fj[q];
+                if (q == 0 || two) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    int i, j;
-                    bool ok, pose;
-                    entry(blk[q], u, i, j, ok, pose);
-                    if (ok && (q == 0 || two)) {
-                        double v = hv[q][u];
-                        if (pose) v -= cv[q][u];
-                        v *= sh.xv[i] * sh.xv[j];
-                        if (i == j) v += mu * dv[q][u] * dv[q][u];
-                        if (w.lds_chol) Sl[tri(i) + j] = v;
-                        else w.Sm[(size_t)i * N + j] = v;
+                    for (int u = 0; u < 4; ++u) {
+                        const bool ok = in_blk[u] && (!diag || eb[u] <= ea[u]);
+                        if (ok) {
+                            const int i = 15 * fi[q] + ea[u], j = 15 * fj[q] + eb[u];
+                            double v = hv[q][u];
+                            if (in_pose[u]) v -= cv[q][u];
+                            v *= sh.xv[i] * sh.xv[j];
+                            if (i == j) v += mu * dv[q][u] * dv[q][u];
+                            if (lds_chol) Sl[tri(i) + j] = v;
+                            else w.Sm[(size_t)i * N + j] = v;
+                        }
                     }
                 }
+            }
         }
     }
     for (int i = t; i < N; i += T) {
@@ -1383,7 +1405,10 @@ PHASE_FN double gauss_newton_step_and_model(LdsWs &w, Shared &sh, lds_double *bi
     const int N = w.N, nl = w.nl, nfree = w.nfree, NA = 6 * nfree, NAs = NA + 2;
     // the three staged pose vectors: sh.xv for windows whose 3 N doubles fit it, the idle LDS Cholesky buffer otherwise
     // (those windows factor in global memory)
-    double *y = (3 * N <= RDVIO_SOLVER_XV) ? RDVIO_GEN(sh.xv) : RDVIO_GEN(big), *u = y + N, *v = y + 2 * N;
+    // (LDS-typed: ds_read / ds_write with immediate offsets instead of FLAT accesses through 64-bit addresses)
+    lds_double *y = (3 * N <= RDVIO_SOLVER_XV) ? (lds_double *)sh.xv : big, *u = y + N, *v = y + 2 * N;
+    cgdouble *Hg = RDVIO_UG(w.H);
+    const int Ns = __builtin_amdgcn_readfirstlane(N);
     double r[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // r[8]: count of non-finite components
     for (int i = t; i < N; i += T) {
         const double yp = w.yp[i], sg = w.sig_p[i], dg = w.diag_p[i], gr = w.grad_p[i];
@@ -1403,7 +1428,7 @@ PHASE_FN double gauss_newton_step_and_model(LdsWs &w, Shared &sh, lds_double *bi
         const int row = base + (t >> 2), part = t & 3;
         if (row < N) {
             double hu, hv;
-            quad_col_dot2(w.H, N, u, v, N, row, part, hu, hv);
+            quad_col_dot2_u(Hg, Ns, u, v, Ns, row, part, hu, hv);
             if (part == 0) {
                 r[3] += u[row] * hu;
                 r[4] += u[row] * hv;
