@@ -21,6 +21,8 @@ DM unsigned long long rdvio_uniform64(unsigned long long v) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
 }
+// ONLY for operands that always live in global memory: the solver redirects its small vectors (g, yp, sig / diag / grad / gn, the
+// landmark scalars, x / xd and their candidates, user, lfree) into LDS when there is room -- those stay generic pointers.
 #define RDVIO_UG(p) ((cgdouble *)rdvio_uniform64((unsigned long long)(p)))
 #define RDVIO_UGW(p) ((gdouble *)rdvio_uniform64((unsigned long long)(p)))
 #define RDVIO_LDS(p) ((lds_double *)(p))

@@ -1274,7 +1274,7 @@ PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap
         const int lane = t & 63, n_lower = nfree * (nfree + 1) / 2;
         const int Ns = __builtin_amdgcn_readfirstlane(N), NAss = __builtin_amdgcn_readfirstlane(NAs);
         const bool lds_chol = __builtin_amdgcn_readfirstlane(w.lds_chol) != 0;
-        cgdouble *Hg = RDVIO_UG(w.H), *Cg = RDVIO_UG(w.Cm), *Dg = RDVIO_UG(w.diag_p);
+        cgdouble *Hg = RDVIO_UG(w.H), *Cg = RDVIO_UG(w.Cm);   // (never w.diag_p & co.: the small vectors may live in LDS -- generic pointers only)
         int ea[4], eb[4], h_off[4], c_off[4];
         bool in_blk[4], in_pose[4];
 #pragma unroll
@@ -1305,7 +1305,7 @@ PHASE_FN void schur_reduce(LdsWs &w, Shared &sh, lds_double *lds, size_t lds_cap
                 for (int u = 0; u < 4; ++u) {
                     const bool ok = in_blk[u] && (!diag || eb[u] <= ea[u]);
                     hv[q][u] = ok ? Hg[h_base + h_off[u]] : 0.0;
-                    dv[q][u] = (ok && diag && ea[u] == eb[u]) ? Dg[15 * fi[q] + ea[u]] : 0.0;
+                    dv[q][u] = (ok && diag && ea[u] == eb[u]) ? w.diag_p[15 * fi[q] + ea[u]] : 0.0;
                     const bool pose = ok && in_pose[u];
                     if (!split) cv[q][u] = pose ? Cg[c_base + c_off[u]] : 0.0;   // (workgroup-uniform branch)
                     else cv[q][u] = pose ? schur_cm(w, (size_t)(c_base + c_off[u]), true, cstride) : 0.0;
