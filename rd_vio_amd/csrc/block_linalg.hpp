@@ -215,6 +215,60 @@ DM void quad_col_dot2_u(cgdouble *M, int ld, const lds_double *x, const lds_doub
     oy = ay;
 }
 
+// typed-pointer forms of quad_col_dot / quad_col_dotk (see quad_col_dot2_u): M behind a wave-uniform global-typed pointer, the
+// vector(s) in LDS.  Same summation order as the generic forms.
+template <int KN>
+DM void quad_col_dotk_u(cgdouble *M, int ld, const lds_double *x, int xs, int K, int C, int r, int part, double (&out)[KN]) {
+    double acc[KN];
+#pragma unroll
+    for (int k = 0; k < KN; ++k) acc[k] = 0.0;
+    const int lane_off = part * ld + r;
+    const lds_double *xp = x + part;
+    int c = 0;   // (column = part + c)
+    for (; part + c + 60 < C; c += 64) {
+        double mv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) mv[u] = M[(c + 4 * u) * ld + lane_off];
+#pragma unroll
+        for (int k = 0; k < KN; ++k)
+            if (k < K)
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc[k] += mv[u] * xp[k * xs + c + 4 * u];
+    }
+    for (; part + c + 28 < C; c += 32) {
+        double mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mv[u] = M[(c + 4 * u) * ld + lane_off];
+#pragma unroll
+        for (int k = 0; k < KN; ++k)
+            if (k < K)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[k] += mv[u] * xp[k * xs + c + 4 * u];
+    }
+    if (part + c < C) {
+        double mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mv[u] = (part + c + 4 * u < C) ? M[(c + 4 * u) * ld + lane_off] : 0.0;
+#pragma unroll
+        for (int k = 0; k < KN; ++k)
+            if (k < K)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (part + c + 4 * u < C) acc[k] += mv[u] * xp[k * xs + c + 4 * u];
+    }
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+        acc[k] += __shfl_xor(acc[k], 1);
+        acc[k] += __shfl_xor(acc[k], 2);
+        out[k] = acc[k];
+    }
+}
+DM double quad_col_dot_u(cgdouble *M, int ld, const lds_double *x, int C, int r, int part) {
+    double o[1];
+    quad_col_dotk_u<1>(M, ld, x, 0, 1, C, r, part, o);
+    return o[0];
+}
+
 // up to four right-hand sides x_k = x + k * xs at once, each summed exactly like quad_col_dot sums it
 DM void quad_col_dot4(const double *__restrict__ M, long ld, const double *__restrict__ x, int xs, int K, int C, int r, int part,
                       double (&out)[4]) {

@@ -288,28 +288,61 @@ __device__ __attribute__((noinline)) void ne_pair_products(LdsWs &w, int g0_, in
     const bool has = i < 13;
     const int lane_off = RDVIO_REC_STRIDE * item_off + eo;
     const int out_off = 16 * (lane >> 4) + (lane & 15);
-    for (int g = g0; g < npairs; g += gstride) {
-        const int go = __builtin_amdgcn_readfirstlane(grp_off[g]), n = __builtin_amdgcn_readfirstlane(grp_off[g + 1]) - go;
-        const int base = RDVIO_REC_STRIDE * go;
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
-        int it = 0;
-        for (; it + 32 <= n; it += 32) {  // 16 MFMAs (32 items) per trip, loads issued together
-            double v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = has ? prec[base + RDVIO_REC_STRIDE * (it + 2 * u) + lane_off] : 0.0;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v[u] : 0.0, v[u], acc, 0, 0, 0);
+    // the group offsets (npairs + 1 ints) first, one per lane: reading them group by group put a dependent round trip in front
+    // of every group's record loads
+    const bool tab = npairs + 1 <= 64;
+    const int off_tab = (tab && lane <= npairs) ? grp_off[lane] : 0;
+    auto group_range = [&](int g, int &base, int &n) {
+        int go, g1;
+        if (tab) {
+            go = __builtin_amdgcn_readlane(off_tab, g);
+            g1 = __builtin_amdgcn_readlane(off_tab, g + 1);
+        } else {
+            go = __builtin_amdgcn_readfirstlane(grp_off[g]);
+            g1 = __builtin_amdgcn_readfirstlane(grp_off[g + 1]);
         }
-        if (it < n) {  // the remainder (up to 31 items: the usual group of a window, ~18) as ONE masked trip of sixteen loads
-            double v[16];
+        base = RDVIO_REC_STRIDE * go;
+        n = g1 - go;
+    };
+    // one group: X^T X accumulated over its items (k ascending); groups of up to 32 items -- the usual size -- are one trip
+    auto group_loads = [&](int base, int n, int it, double (&v)[16]) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = (has && it + 2 * u + item_off < n) ? prec[base + RDVIO_REC_STRIDE * (it + 2 * u) + lane_off] : 0.0;
+        for (int u = 0; u < 16; ++u) v[u] = (has && it + 2 * u + item_off < n) ? prec[base + RDVIO_REC_STRIDE * (it + 2 * u) + lane_off] : 0.0;
+    };
+    auto group_mfma = [&](int n, int it, const double (&v)[16], double4_t &acc) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (it + 2 * u < n) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v[u] : 0.0, v[u], acc, 0, 0, 0);
-        }
+        for (int u = 0; u < 16; ++u)
+            if (it + 2 * u < n) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v[u] : 0.0, v[u], acc, 0, 0, 0);
+    };
+    auto group_store = [&](int g, const double4_t &acc) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) GPw[256 * g + 64 * r + out_off] = acc[r];
+    };
+    // two groups per trip: the first 32 items of both are loaded before either is used
+    for (int g = g0; g < npairs; g += 2 * gstride) {
+        const bool two = g + gstride < npairs;
+        const int gB = two ? g + gstride : g;
+        int baseA, nA, baseB, nB;
+        group_range(g, baseA, nA);
+        group_range(gB, baseB, nB);
+        double vA[16], vB[16];
+        group_loads(baseA, nA, 0, vA);
+        group_loads(baseB, two ? nB : 0, 0, vB);
+        double4_t accA = {0.0, 0.0, 0.0, 0.0}, accB = {0.0, 0.0, 0.0, 0.0};
+        group_mfma(nA, 0, vA, accA);
+        for (int it = 32; it < nA; it += 32) {
+            group_loads(baseA, nA, it, vA);
+            group_mfma(nA, it, vA, accA);
+        }
+        group_store(g, accA);
+        if (two) {
+            group_mfma(nB, 0, vB, accB);
+            for (int it = 32; it < nB; it += 32) {
+                group_loads(baseB, nB, it, vB);
+                group_mfma(nB, it, vB, accB);
+            }
+            group_store(gB, accB);
+        }
     }
 }
 
@@ -778,16 +811,18 @@ __device__ __attribute__((noinline)) double evaluate(LdsWs &w, Shared &sh, int p
         double *r_m = LIN ? w.r_m : w.c_m;
         const int D = w.D;
         // (sh.xv = e was filled by the factor wave's tail before the barrier above)
+        cgdouble *STg = RDVIO_UG(w.ST), *Lamg = RDVIO_UG(w.Lam);   // (typed: scalar base + 32-bit lane offset; the operand vector is LDS)
+        const int Ds = __builtin_amdgcn_readfirstlane(D);
         for (int base = 0; base < D; base += T / 4) {
             const int row = base + (t >> 2), part = t & 3;
             if (row < D) {
-                const double r = quad_col_dot(w.ST, D, RDVIO_GEN(sh.xv), D, row, part) + w.f[row];
+                const double r = quad_col_dot_u(STg, Ds, sh.xv, Ds, row, part) + w.f[row];
                 if (part == 0) {
                     r_m[row] = r;
                     cost += 0.5 * r * r;
                 }
                 if (LIN) {
-                    const double le = quad_col_dot(w.Lam, D, RDVIO_GEN(sh.xv), D, row, part) + w.eta0[row];
+                    const double le = quad_col_dot_u(Lamg, Ds, sh.xv, Ds, row, part) + w.eta0[row];
                     if (part == 0) w.le[row] = le;
                 }
             }
@@ -1788,11 +1823,13 @@ PHASE_FN void evaluate_candidates(LdsWs &w, Shared &sh, lds_double *lds, int pha
     }
     STAMP(22);
     if (w.np > 0) {
+        cgdouble *STg = RDVIO_UG(w.ST);
+        const int Ds = __builtin_amdgcn_readfirstlane(D);
         for (int base = 0; base < D; base += T / 4) {
             const int row = base + (t >> 2), part = t & 3;
             if (row < D) {
                 double rk[KC];
-                quad_col_dotk<KC>(w.ST, D, RDVIO_GEN(eK), D, K, D, row, part, rk);
+                quad_col_dotk_u<KC>(STg, Ds, eK, Ds, K, Ds, row, part, rk);
                 if (part == 0) {
                     const double fr = w.f[row];
 #pragma unroll
