@@ -319,15 +319,28 @@ __device__ __attribute__((noinline)) void ne_pair_products(LdsWs &w, int g0_, in
         for (int r = 0; r < 4; ++r) GPw[256 * g + 64 * r + out_off] = acc[r];
     };
     // two groups per trip: the first 32 items of both are loaded before either is used
+#ifdef RDVIO_PROF_HBLK
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    const unsigned long long tq_in = wall_clock64();
+#endif
     for (int g = g0; g < npairs; g += 2 * gstride) {
         const bool two = g + gstride < npairs;
         const int gB = two ? g + gstride : g;
         int baseA, nA, baseB, nB;
+#ifdef RDVIO_PROF_HBLK
+        const unsigned long long t0 = wall_clock64();
+#endif
         group_range(g, baseA, nA);
         group_range(gB, baseB, nB);
         double vA[16], vB[16];
         group_loads(baseA, nA, 0, vA);
         group_loads(baseB, two ? nB : 0, 0, vB);
+#ifdef RDVIO_PROF_HBLK
+        const unsigned long long t1 = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long t2 = wall_clock64();
+        q0 += t1 - t0; q1 += t2 - t1;
+#endif
         double4_t accA = {0.0, 0.0, 0.0, 0.0}, accB = {0.0, 0.0, 0.0, 0.0};
         group_mfma(nA, 0, vA, accA);
         for (int it = 32; it < nA; it += 32) {
@@ -343,7 +356,16 @@ __device__ __attribute__((noinline)) void ne_pair_products(LdsWs &w, int g0_, in
             }
             group_store(gB, accB);
         }
+#ifdef RDVIO_PROF_HBLK
+        const unsigned long long t3 = wall_clock64();
+        q2 += t3 - t2;
+#endif
     }
+#ifdef RDVIO_PROF_HBLK
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    q3 = wall_clock64() - tq_in;
+    if (threadIdx.x == 0) { w.summary[76] += (double)q0; w.summary[77] += (double)q1; w.summary[78] += (double)q2; w.summary[79] += (double)q3; }
+#endif
 }
 
 // every entry of H, output-stationary: prior + preintegration band + reprojection groups.  One wavefront per 15 x 15 lower

@@ -41,6 +41,8 @@ for name, kw in (("full", {}), ("no_prior", dict(with_prior=False)), ("no_preint
                      "setup:copy/zero", "setup:stage S+ST", "setup:Lam gemm", "setup:eta0+mirror", "ne:H blocks", "candidate", "schur:lm_w+gemm", "evL:stage", "evC:stage"]
             if prof[64:68].any():
                 print("      H blocks, wave 0: load issue %.1f us, load wait %.1f us, products + store issue %.1f us, store drain %.1f us" % tuple(prof[64:68] / 100))
+            if prof[68:72].any():
+                print("      group products, wave 0: ranges + load issue %.1f us, load wait %.1f us, products + stores %.1f us, whole routine %.1f us" % tuple(prof[68:72] / 100))
             for i, nm in enumerate(names):
                 if prof[32 + i] > 0:
                     print(f"      {nm:12s} total {prof[i] / 100:9.1f} us  calls {int(prof[32 + i]):3d}  avg {prof[i] / 100 / prof[32 + i]:8.2f} us")
