@@ -322,6 +322,7 @@ __device__ __attribute__((noinline)) void ne_pair_products(LdsWs &w, int g0_, in
 #ifdef RDVIO_PROF_HBLK
     unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     const unsigned long long tq_in = wall_clock64();
+    const unsigned long long cq_in = clock64();
 #endif
     for (int g = g0; g < npairs; g += 2 * gstride) {
         const bool two = g + gstride < npairs;
@@ -364,7 +365,8 @@ __device__ __attribute__((noinline)) void ne_pair_products(LdsWs &w, int g0_, in
 #ifdef RDVIO_PROF_HBLK
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     q3 = wall_clock64() - tq_in;
-    if (threadIdx.x == 0) { w.summary[76] += (double)q0; w.summary[77] += (double)q1; w.summary[78] += (double)q2; w.summary[79] += (double)q3; }
+    const unsigned long long cq = clock64() - cq_in;   // shader clocks over the same interval: the clock the CU actually runs at
+    if (threadIdx.x == 0) { w.summary[76] += (double)q0; w.summary[77] += (double)q1; w.summary[78] += (double)q2; w.summary[79] += (double)q3; w.summary[71] += (double)cq; }
 #endif
 }
 

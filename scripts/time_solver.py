@@ -42,6 +42,7 @@ for name, kw in (("full", {}), ("no_prior", dict(with_prior=False)), ("no_preint
             if prof[64:68].any():
                 print("      H blocks, wave 0: load issue %.1f us, load wait %.1f us, products + store issue %.1f us, store drain %.1f us" % tuple(prof[64:68] / 100))
             if prof[68:72].any():
+                print("      shader clock during the group products: %.0f MHz (s_memtime ticks / s_memrealtime time)" % (prof[63] / (prof[71] / 100)))
                 print("      group products, wave 0: ranges + load issue %.1f us, load wait %.1f us, products + stores %.1f us, whole routine %.1f us" % tuple(prof[68:72] / 100))
             for i, nm in enumerate(names):
                 if prof[32 + i] > 0:
