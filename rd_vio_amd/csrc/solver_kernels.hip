@@ -366,7 +366,7 @@ __device__ __attribute__((noinline)) void ne_pair_products(LdsWs &w, int g0_, in
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     q3 = wall_clock64() - tq_in;
     const unsigned long long cq = clock64() - cq_in;   // shader clocks over the same interval: the clock the CU actually runs at
-    if (threadIdx.x == 0) { w.summary[76] += (double)q0; w.summary[77] += (double)q1; w.summary[78] += (double)q2; w.summary[79] += (double)q3; w.summary[71] += (double)cq; }
+    if (threadIdx.x == 0) { w.summary[76] += (double)q0; w.summary[77] += (double)q1; w.summary[78] += (double)q2; w.summary[79] += (double)q3; w.summary[75] += (double)cq; }
 #endif
 }
 
@@ -559,7 +559,7 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
 #endif
     }
 #ifdef RDVIO_PROF_HBLK
-    if (threadIdx.x == 0) { w.summary[72] += (double)c0; w.summary[73] += (double)c1; w.summary[74] += (double)c2; w.summary[75] += (double)c3; }
+    if (threadIdx.x == 0) { w.summary[72] += (double)c0; w.summary[73] += (double)c1; w.summary[74] += (double)(c2 + c3); }   // ([75]: shader clocks of the group products)
 #endif
 }
 

@@ -40,9 +40,9 @@ for name, kw in (("full", {}), ("no_prior", dict(with_prior=False)), ("no_preint
                      "evL:factors(w0)", "evL:wait", "evL:whiten", "evC:factors(w0)", "evC:wait", "evC:whiten",
                      "setup:copy/zero", "setup:stage S+ST", "setup:Lam gemm", "setup:eta0+mirror", "ne:H blocks", "candidate", "schur:lm_w+gemm", "evL:stage", "evC:stage"]
             if prof[64:68].any():
-                print("      H blocks, wave 0: load issue %.1f us, load wait %.1f us, products + store issue %.1f us, store drain %.1f us" % tuple(prof[64:68] / 100))
+                print("      H blocks, wave 0: load issue %.1f us, load wait %.1f us, products + stores %.1f us" % tuple(prof[64:67] / 100))
             if prof[68:72].any():
-                print("      shader clock during the group products: %.0f MHz (s_memtime ticks / s_memrealtime time)" % (prof[63] / (prof[71] / 100)))
+                print("      shader clock during the group products: %.0f MHz (s_memtime ticks / s_memrealtime time)" % (prof[67] / (prof[71] / 100)))
                 print("      group products, wave 0: ranges + load issue %.1f us, load wait %.1f us, products + stores %.1f us, whole routine %.1f us" % tuple(prof[68:72] / 100))
             for i, nm in enumerate(names):
                 if prof[32 + i] > 0:
