@@ -25,6 +25,14 @@ DM unsigned long long rdvio_uniform64(unsigned long long v) {
 // landmark scalars, x / xd and their candidates, user, lfree) into LDS when there is room -- those stay generic pointers.
 #define RDVIO_UG(p) ((cgdouble *)rdvio_uniform64((unsigned long long)(p)))
 #define RDVIO_UGW(p) ((gdouble *)rdvio_uniform64((unsigned long long)(p)))
+// Lane-masked load WITHOUT an exec-masked block: `ok ? p[i] : 0.0` compiles to v_cmp / s_and_saveexec / s_cbranch_execz / load /
+// s_or exec -- two scalar mask operations and a branch per load, ~60-90 cycles of a lone wavefront's issue (measured: the
+// group products spent 3.8 of 8.4 us issuing 96 such loads).  Here every lane loads (a masked lane reads entry `safe`, which
+// the caller guarantees to be valid) and the value is selected afterwards: two v_cndmask.
+DM double rdvio_ldm(cgdouble *p, int off, bool ok, int safe = 0) {
+    const double v = p[ok ? off : safe];
+    return ok ? v : 0.0;
+}
 #define RDVIO_LDS(p) ((lds_double *)(p))
 
 template <int T>

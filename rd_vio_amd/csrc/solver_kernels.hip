@@ -307,12 +307,13 @@ __device__ __attribute__((noinline)) void ne_pair_products(LdsWs &w, int g0_, in
     // one group: X^T X accumulated over its items (k ascending); groups of up to 32 items -- the usual size -- are one trip
     auto group_loads = [&](int base, int n, int it, double (&v)[16]) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = (has && it + 2 * u + item_off < n) ? prec[base + RDVIO_REC_STRIDE * (it + 2 * u) + lane_off] : 0.0;
+        for (int u = 0; u < 16; ++u)   // (branch-free: masked lanes read the group's first record)
+            v[u] = rdvio_ldm(prec, base + RDVIO_REC_STRIDE * (it + 2 * u) + lane_off, has && it + 2 * u + item_off < n, base);
     };
     auto group_mfma = [&](int n, int it, const double (&v)[16], double4_t &acc) {
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if (it + 2 * u < n) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < 12 ? v[u] : 0.0, v[u], acc, 0, 0, 0);
+            if (it + 2 * u < n) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], v[u], acc, 0, 0, 0);   // (A = B: rows 12.. of the tile are never read)
     };
     auto group_store = [&](int g, const double4_t &acc) {
 #pragma unroll
@@ -440,15 +441,16 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
         const int pp1_base = 900 * (B.src1 >> 2) + 450 * ((B.src1 >> 1) & 1) + 15 * (B.src1 & 1);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            L.lam[u] = (has_prior && lam_ok[u]) ? Lam[lam_base + lam_off[u]] : 0.0;
-            L.pp0[u] = (B.src0 >= 0 && ok15[u]) ? PP[pp0_base + pp_off[u]] : 0.0;
-            L.pp1[u] = (B.src1 >= 0 && ok15[u]) ? PP[pp1_base + pp_off[u]] : 0.0;
+            // (block-level conditions are scalar branches; lane masks are clamped loads + selects: rdvio_ldm)
+            L.lam[u] = has_prior ? rdvio_ldm(Lam, lam_base + lam_off[u], lam_ok[u], lam_base) : 0.0;
+            L.pp0[u] = B.src0 >= 0 ? rdvio_ldm(PP, pp0_base + pp_off[u], ok15[u], pp0_base) : 0.0;
+            L.pp1[u] = B.src1 >= 0 ? rdvio_ldm(PP, pp1_base + pp_off[u], ok15[u], pp1_base) : 0.0;
         }
         if (B.fi != B.fj) {   // off-diagonal lower block (fi > fj): the (lo = fj, hi = fi) group's cross quadrant, transposed
             const int gp_base = 256 * pair_id(B.fj, B.fi, nfree);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                L.gp[u] = ok6[u] ? GP[gp_base + gpt_off[u]] : 0.0;
+                L.gp[u] = rdvio_ldm(GP, gp_base + gpt_off[u], ok6[u], gp_base);
 #pragma unroll
                 for (int q = 0; q < GD; ++q) L.gd[u][q] = 0.0;
             }
@@ -462,7 +464,7 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
                 const int off = (fi == lo) ? 0 : 6;  // quadrant (lo,lo) or (hi,hi); the single group (f,f) uses (lo,lo)
                 const int gd_base = 256 * pair_id(lo, hi, nfree) + 17 * off;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) L.gd[u][q] = (f2 < nfree && ok6[u]) ? GP[gd_base + gd_off[u]] : 0.0;
+                for (int u = 0; u < 2; ++u) L.gd[u][q] = f2 < nfree ? rdvio_ldm(GP, gd_base + gd_off[u], ok6[u], gd_base) : 0.0;
             }
         }
     };
