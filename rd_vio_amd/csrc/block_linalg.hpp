@@ -28,7 +28,9 @@ DM unsigned long long rdvio_uniform64(unsigned long long v) {
 // Lane-masked load WITHOUT an exec-masked block: `ok ? p[i] : 0.0` compiles to v_cmp / s_and_saveexec / s_cbranch_execz / load /
 // s_or exec -- two scalar mask operations and a branch per load, ~60-90 cycles of a lone wavefront's issue (measured: the
 // group products spent 3.8 of 8.4 us issuing 96 such loads).  Here every lane loads (a masked lane reads entry `safe`, which
-// the caller guarantees to be valid) and the value is selected afterwards: two v_cndmask.
+// the caller guarantees to be valid) and the value is selected afterwards: two v_cndmask.  Only where (nearly) all lanes are
+// active anyway: a vector load occupies the CU's memory pipeline in proportion to its active lanes, so turning sparsely
+// masked loads into full ones costs more than the branches (measured in ne_h_blocks).
 DM double rdvio_ldm(cgdouble *p, int off, bool ok, int safe = 0) {
     const double v = p[ok ? off : safe];
     return ok ? v : 0.0;

@@ -441,16 +441,18 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
         const int pp1_base = 900 * (B.src1 >> 2) + 450 * ((B.src1 >> 1) & 1) + 15 * (B.src1 & 1);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            // (block-level conditions are scalar branches; lane masks are clamped loads + selects: rdvio_ldm)
-            L.lam[u] = has_prior ? rdvio_ldm(Lam, lam_base + lam_off[u], lam_ok[u], lam_base) : 0.0;
-            L.pp0[u] = B.src0 >= 0 ? rdvio_ldm(PP, pp0_base + pp_off[u], ok15[u], pp0_base) : 0.0;
-            L.pp1[u] = B.src1 >= 0 ? rdvio_ldm(PP, pp1_base + pp_off[u], ok15[u], pp1_base) : 0.0;
+            // (lane masks stay exec masks here: a vector load costs the memory pipeline in proportion to its ACTIVE lanes -- with all
+            // eight wavefronts issuing their ~60 loads of a trip together the pass is bound by that rate; the clamped-load form
+            // (rdvio_ldm) doubled the issue time of this routine, 14 -> 30 us over a solve)
+            L.lam[u] = (has_prior && lam_ok[u]) ? Lam[lam_base + lam_off[u]] : 0.0;
+            L.pp0[u] = (B.src0 >= 0 && ok15[u]) ? PP[pp0_base + pp_off[u]] : 0.0;
+            L.pp1[u] = (B.src1 >= 0 && ok15[u]) ? PP[pp1_base + pp_off[u]] : 0.0;
         }
         if (B.fi != B.fj) {   // off-diagonal lower block (fi > fj): the (lo = fj, hi = fi) group's cross quadrant, transposed
             const int gp_base = 256 * pair_id(B.fj, B.fi, nfree);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                L.gp[u] = rdvio_ldm(GP, gp_base + gpt_off[u], ok6[u], gp_base);
+                L.gp[u] = ok6[u] ? GP[gp_base + gpt_off[u]] : 0.0;
 #pragma unroll
                 for (int q = 0; q < GD; ++q) L.gd[u][q] = 0.0;
             }
@@ -464,7 +466,7 @@ __device__ __attribute__((noinline)) void ne_h_blocks(LdsWs &w, const Shared &sh
                 const int off = (fi == lo) ? 0 : 6;  // quadrant (lo,lo) or (hi,hi); the single group (f,f) uses (lo,lo)
                 const int gd_base = 256 * pair_id(lo, hi, nfree) + 17 * off;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) L.gd[u][q] = f2 < nfree ? rdvio_ldm(GP, gd_base + gd_off[u], ok6[u], gd_base) : 0.0;
+                for (int u = 0; u < 2; ++u) L.gd[u][q] = (f2 < nfree && ok6[u]) ? GP[gd_base + gd_off[u]] : 0.0;
             }
         }
     };
