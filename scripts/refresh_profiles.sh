@@ -17,8 +17,12 @@ echo "write done"
 python $R/scripts/summarize_pmc.py $O/pmc_fetch $O/pmc_write $O/pmc_all.csv > /dev/null
 grep -v "^__amd\|^at::" $O/pmc_all.csv > $O/pmc_fetch_write.csv
 cp $O/pmc_fetch_write.csv $R/profiles/${TAG}_pmc_fetch_write.csv
+# bench.py reads profiles/<round>_pmc_fetch_write.csv (+ .meta.json): refresh it in place so that the bench lines below carry `traffic`
+ROUND=${TAG%%_*}
+cp $O/pmc_fetch_write.csv $R/profiles/${ROUND}_pmc_fetch_write.csv
 python -c "import sys, json; sys.path.insert(0, '$R'); import bench; json.dump({'kernel_source_sha256': bench.kernel_source_hash(), 'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --no-cpu-baseline --end-to-end-frames 0 --sequences 0 --steps 30 --warmup 5'}, open('$O/pmc_fetch_write.meta.json', 'w'))"
 cp $O/pmc_fetch_write.meta.json $R/profiles/${TAG}_pmc_fetch_write.meta.json
+cp $O/pmc_fetch_write.meta.json $R/profiles/${ROUND}_pmc_fetch_write.meta.json
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_all.csv
 python $R/bench.py > $O/bench.json 2> $O/bench.err
