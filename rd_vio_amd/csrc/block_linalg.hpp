@@ -8,6 +8,11 @@
 #include "dmath.hpp"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+#ifdef RDVIO_PROF_CHOL
+// diagnostic build: ticks (100 MHz) of thread 0 inside cholesky_lds -- [0] panel, [1] tile (0,0), [2] diagonal block, [3] waiting
+// at the barriers (= the other wavefronts' trailing tiles), [4] diagonal inverses; copied to summary[72..76] at the end of a solve
+__device__ unsigned long long rdvio_chol_prof[8];
+#endif
 
 // Pointers that keep the LDS address space across (noinline) function boundaries: a generic `double *` to LDS makes the
 // compiler emit FLAT loads / stores, which resolve the aperture first and cost about twice the latency of ds_read / ds_write.
@@ -935,10 +940,19 @@ template <int T>
 __device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_double *Lp, lds_double *Dinv, int N, double tol = 0.0, bool want_dinv = true) {
     const int t = threadIdx.x, wave = t >> 6, nw = T / 64;
     const int nb = N / 15, NR = N + 1;
+#ifdef RDVIO_PROF_CHOL
+    unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, pt;
+#define CH_T(acc) do { const unsigned long long n__ = wall_clock64(); acc += n__ - pt; pt = n__; } while (0)
+    pt = wall_clock64();
+#else
+#define CH_T(acc) do {} while (0)
+#endif
     if (t == 0) sh.flag = 1;
     __syncthreads();
     if (wave == 0 && nb > 0) cholesky_diag_block<T>(sh, Lp, 0, tol);
+    CH_T(pc2);
     __syncthreads();
+    CH_T(pc3);
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = 15 * kb;
         // ---- panel: row i solves x L_kk^T = row  (forward substitution with reciprocal pivots)
@@ -959,13 +973,17 @@ __device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_doub
 #pragma unroll
             for (int c = 0; c < 15; ++c) row[c] = x[c];
         }
+        CH_T(pc0);
         if (kb + 1 == nb) break;
         __syncthreads();
+        CH_T(pc3);
         // ---- trailing update C -= P P^T, lower 16 x 16 tiles; tile (0, 0) and the next diagonal block on wavefront 0
         const int rem = NR - (k0 + 15), tn = (rem + 15) / 16;
         if (wave == 0) {
             cholesky_trailing_tile(Lp, k0, NR, 0, 0);
+            CH_T(pc1);
             cholesky_diag_block<T>(sh, Lp, k0 + 15, tol);
+            CH_T(pc2);
         } else {
             for (int tile = wave; tile < tn * tn; tile += nw - 1) {  // tiles 1.. (tile 0 is (0, 0))
                 const int bi = tile / tn, bj = tile - bi * tn;
@@ -974,8 +992,10 @@ __device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_doub
             }
         }
         __syncthreads();
+        CH_T(pc3);
     }
     __syncthreads();
+    CH_T(pc3);
     // inverses of the diagonal blocks: column c of L_kk^-1 by forward substitution, one thread per (block, column)
     for (int o = t; want_dinv && o < nb * 15; o += T) {
         const int kb = o / 15, c = o - 15 * kb;
@@ -993,6 +1013,10 @@ __device__ __attribute__((noinline)) int cholesky_lds(LdsShared<T> &sh, lds_doub
         for (int r = 0; r < 15; ++r) Dinv[225 * kb + 15 * r + c] = x[r];
     }
     __syncthreads();
+    CH_T(pc4);
+#ifdef RDVIO_PROF_CHOL
+    if (t == 0) { rdvio_chol_prof[0] += pc0; rdvio_chol_prof[1] += pc1; rdvio_chol_prof[2] += pc2; rdvio_chol_prof[3] += pc3; rdvio_chol_prof[4] += pc4; }
+#endif
     return sh.flag;
 }
 

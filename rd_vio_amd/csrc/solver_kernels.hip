@@ -2243,6 +2243,9 @@ __global__ __launch_bounds__(T) void ba_solve_kernel(SolverWs w) {
         w.summary[3] = x_cost;
         w.summary[4] = (double)term;
         w.summary[5] = (w.n_wg > 1 && sh.lost) ? 1.0 : 0.0;
+#ifdef RDVIO_PROF_CHOL
+        for (int i = 0; i < 5; ++i) { w.summary[72 + i] = (double)rdvio_chol_prof[i]; rdvio_chol_prof[i] = 0; }
+#endif
     }
 }
 

@@ -39,7 +39,9 @@ for name, kw in (("full", {}), ("no_prior", dict(with_prior=False)), ("no_preint
                      "step+model", "cand_eval", "misc", "gradmax", "ne:pairs", "ne:landm", "ne:preint", "ne:wait", "ne:phase2",
                      "evL:factors(w0)", "evL:wait", "evL:whiten", "evC:factors(w0)", "evC:wait", "evC:whiten",
                      "setup:copy/zero", "setup:stage S+ST", "setup:Lam gemm", "setup:eta0+mirror", "ne:H blocks", "candidate", "schur:lm_w+gemm", "evL:stage", "evC:stage"]
-            if prof[64:68].any():
+            if os.environ.get("RDVIO_PROF_CHOL") and prof[64:69].any():
+                print("      cholesky_lds, thread 0 (whole solve): panel %.1f us, tile (0,0) %.1f us, diagonal block %.1f us, at barriers %.1f us, diagonal inverses %.1f us" % tuple(prof[64:69] / 100))
+            elif prof[64:68].any():
                 print("      H blocks, wave 0: load issue %.1f us, load wait %.1f us, products + stores %.1f us" % tuple(prof[64:67] / 100))
             if prof[68:72].any():
                 print("      shader clock during the group products: %.0f MHz (s_memtime ticks / s_memrealtime time)" % (prof[67] / (prof[71] / 100)))
