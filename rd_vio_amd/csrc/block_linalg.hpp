@@ -672,9 +672,7 @@ DM double rsqrt_nr(double x) {
     double y = __builtin_amdgcn_rsq(x);
     const double h = 0.5 * x;
     y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);
-#ifndef RDVIO_RSQRT_ONE_STEP
     y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);
-#endif
     return y;
 }
 
