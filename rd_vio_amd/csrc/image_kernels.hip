@@ -108,6 +108,18 @@ __device__ __forceinline__ uint8_t clahe_apply(const uint8_t *__restrict__ src, 
 // ---------------------------------------------------------------------------------------------
 #define PT_W 32
 #define PT_H 8
+// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (observed, MI355X_MICROARCH.md), each with its own L2:
+// with the plain blockIdx -> tile map, horizontally adjacent 32-px tiles -- which share every 128-B line of an image row -- run
+// on different XCDs and each XCD fetches the line for itself (round-2 PMC: the level-0 pyramid kernel fetched 1.21 MB for a
+// 0.36 MB image, the Harris kernel 1.11 MB for 0.43 MB).  Here the workgroups of one XCD take a contiguous run of tiles
+// (row-major: a band of tile rows), so a line is fetched by one L2.  A pure relabelling: results are unchanged.
+__device__ __forceinline__ void xcd_tile(int &bx, int &by) {
+    const int gx = gridDim.x, nb = gx * gridDim.y, b = blockIdx.y * gx + blockIdx.x;
+    const int per = nb / 8;
+    const int t = (b < per * 8) ? (b % 8) * per + b / 8 : b;   // (the last nb % 8 blocks keep their tiles)
+    by = t / gx;
+    bx = t - by * gx;
+}
 template <bool LEVEL0>
 __global__ __launch_bounds__(256) void pyr_level_kernel(rdvio_pyr_layout L, int lv, uint8_t *__restrict__ pyr_img,
                                                        int16_t *__restrict__ pyr_deriv,
@@ -116,7 +128,9 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(rdvio_pyr_layout L, int 
                                                        float inv_tw, float inv_th) {
     __shared__ int tile[(PT_H + 2)][(PT_W + 2) + 1];
     const int B = L.border, w = L.w[lv], h = L.h[lv], s = L.stride[lv];
-    const int bx0 = blockIdx.x * PT_W - B, by0 = blockIdx.y * PT_H - B;  // image coords of the tile origin
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int bx0 = tbx * PT_W - B, by0 = tby * PT_H - B;  // image coords of the tile origin
     const uint8_t *prev = nullptr;
     int ps = 0;
     if (!LEVEL0) {
@@ -186,7 +200,9 @@ __global__ __launch_bounds__(256) void harris_kernel(rdvio_pyr_layout L, const u
     __shared__ uint32_t smax[4];
     const int B = L.border, w = L.w[0], h = L.h[0], s = L.stride[0];
     const uint8_t *img = pyr_img + L.img_off[0] + (size_t)B * s + B;
-    const int bx0 = blockIdx.x * PT_W, by0 = blockIdx.y * PT_H;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int bx0 = tbx * PT_W, by0 = tby * PT_H;
     for (int i = threadIdx.x; i < (PT_H + 2) * (PT_W + 2); i += 256) {
         int ly = i / (PT_W + 2), lx = i - ly * (PT_W + 2);
         int x = bx0 + lx - 1, y = by0 + ly - 1;
@@ -238,7 +254,9 @@ __global__ __launch_bounds__(256) void harris_kernel(rdvio_pyr_layout L, const u
 __global__ __launch_bounds__(256) void harris_candidates_kernel(const float *__restrict__ resp, int w, int h,
                                                                double quality, uint32_t *__restrict__ scalars,
                                                                HarrisCand *__restrict__ cand, int cap) {
-    const int x = blockIdx.x * PT_W + threadIdx.x % PT_W, y = blockIdx.y * PT_H + threadIdx.x / PT_W;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int x = tbx * PT_W + threadIdx.x % PT_W, y = tby * PT_H + threadIdx.x / PT_W;
     if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) return;
     const float maxv = ordered_to_float(scalars[0]);
     const float thr = (float)((double)maxv * quality);
