@@ -94,7 +94,7 @@ DM double wave_max_d(double v) {
 DM Q4 shfl_q(const Q4 &q, int src) { return Q4{shfl_d(q.x, src), shfl_d(q.y, src), shfl_d(q.z, src), shfl_d(q.w, src)}; }
 DM V3 shfl_v(const V3 &v, int src) { return V3{shfl_d(v.x, src), shfl_d(v.y, src), shfl_d(v.z, src)}; }
 
-__global__ __launch_bounds__(64) void preintegrate_kernel(int nseg, const int32_t *__restrict__ seg_off,
+__global__ __launch_bounds__(128) void preintegrate_kernel(int nseg, const int32_t *__restrict__ seg_off,
                                                           const double *__restrict__ imu,
                                                           const double *__restrict__ par /* nseg x 7: t_end,bg,ba */,
                                                           const double *__restrict__ noise, int cj, int cc,
@@ -109,7 +109,13 @@ __global__ __launch_bounds__(64) void preintegrate_kernel(int nseg, const int32_
     __shared__ double s_Mk[64][37];
     const int seg = blockIdx.x;
     if (seg >= nseg) return;
-    const int lane = threadIdx.x;
+    // Two wavefronts per segment.  Wavefront 0 (tid 0..63) does everything a one-wavefront block did -- per-sample increments,
+    // the scans, the sample matrices, the inverse / LLT at the end.  In the covariance recurrence, which walks the samples one by
+    // one and is bound by the instruction issue of a lone wavefront, the 81 matrix entries are spread over 81 THREADS (one
+    // dot-product chain each instead of two on the first 17 lanes) and the Jacobian / bias-block updates move to wavefront 1.
+    // Every entry is still the same 9-term dot product in the same order: results are bit-identical to the one-wavefront kernel.
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool w0 = tid < 64;
     const int s0 = seg_off[seg], n = seg_off[seg + 1] - s0;
     double *o = out + (size_t)seg * RDVIO_PREINT_SIZE;
     if (n <= 0) {  // PreIntegrator::integrate returns false on empty data (:80-81): leave a reset() state
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(64) void preintegrate_kernel(int nseg, const int32_
         // (parallel over samples), then the recurrence walks the samples with two barriers per step and nothing but
         // 9-term dot products in the dependent chain.
         if (cj || cc) {
-            if (lane < cnt) {
+            if (w0 && lane < cnt) {   // (wavefront 1 computed the same increments and scans redundantly; only wavefront 0 publishes)
                 const M3 R = to_mat(dq_pre);
                 const M3 RHa = R * hat(a);
                 const M3 Et = to_mat(conj(e));
@@ -223,26 +229,22 @@ __global__ __launch_bounds__(64) void preintegrate_kernel(int nseg, const int32_
                 }
             }
             __syncthreads();
+            // one matrix entry per thread (81 of the 128), Jacobian entries on threads 96..104, bias blocks on 105..122
+            const int e_a = tid, r_a = e_a / 9, c_a = e_a - r_a * 9;
+            const bool has = e_a < 81;
+            const int jl = tid - 96, bq = tid - 105;
             for (int j = 0; j < cnt; ++j) {
                 const double *Aj = s_Ak[j], *Nj = s_Nk[j], *mk = s_Mk[j];
                 const double dt_j = mk[36];
-                double T0 = 0.0, T1 = 0.0;
-                // 81 outputs on 64 lanes: lanes 0..16 carry a second output in the same loop (two independent chains
-                // instead of a second pass); fused multiply-adds -- the recurrence is a serial chain of such dot products
-                const int r_a = lane / 9, c_a = lane - r_a * 9;
-                const bool two = lane < 17;
-                const int i_b = two ? lane + 64 : lane, r_b = i_b / 9, c_b = i_b - r_b * 9;
-                if (cc) {  // T = A * cov9
+                double T0 = 0.0;
+                if (cc && has) {  // T = A * cov9 (fused multiply-adds: the recurrence is a serial chain of such dot products)
 #pragma unroll
-                    for (int x = 0; x < 9; ++x) {
-                        T0 = __builtin_fma(Aj[r_a * 9 + x], s_cov[x * 15 + c_a], T0);
-                        T1 = __builtin_fma(Aj[r_b * 9 + x], s_cov[x * 15 + c_b], T1);
-                    }
+                    for (int x = 0; x < 9; ++x) T0 = __builtin_fma(Aj[r_a * 9 + x], s_cov[x * 15 + c_a], T0);
                 }
-                // one entry of each 3x3 Jacobian per lane (preintegrator.cpp:59-70; old values feed p and v)
+                // one entry of each 3x3 Jacobian per thread (preintegrator.cpp:59-70; old values feed p and v)
                 double n_dq_dbg = 0, n_dp_dbg = 0, n_dp_dba = 0, n_dv_dbg = 0, n_dv_dba = 0;
-                if (cj && lane < 9) {
-                    const int r = lane / 3, c = lane % 3;
+                if (cj && jl >= 0 && jl < 9) {
+                    const int r = jl / 3, c = jl % 3;
                     const double *dq_dbg = s_jac, *dv_dbg = s_jac + 27, *dv_dba = s_jac + 36;
                     double t_rha = 0.0, t_et = 0.0;
 #pragma unroll
@@ -250,37 +252,30 @@ __global__ __launch_bounds__(64) void preintegrate_kernel(int nseg, const int32_
                         t_rha += mk[9 + r * 3 + x] * dq_dbg[x * 3 + c];
                         t_et += mk[18 + r * 3 + x] * dq_dbg[x * 3 + c];
                     }
-                    const double Rrc = mk[lane];
-                    n_dp_dbg = s_jac[9 + lane] + dt_j * dv_dbg[lane] - 0.5 * dt_j * dt_j * t_rha;
-                    n_dp_dba = s_jac[18 + lane] + dt_j * dv_dba[lane] - 0.5 * dt_j * dt_j * Rrc;
-                    n_dv_dbg = dv_dbg[lane] - dt_j * t_rha;
-                    n_dv_dba = dv_dba[lane] - dt_j * Rrc;
-                    n_dq_dbg = t_et - dt_j * mk[27 + lane];
+                    const double Rrc = mk[jl];
+                    n_dp_dbg = s_jac[9 + jl] + dt_j * dv_dbg[jl] - 0.5 * dt_j * dt_j * t_rha;
+                    n_dp_dba = s_jac[18 + jl] + dt_j * dv_dba[jl] - 0.5 * dt_j * dt_j * Rrc;
+                    n_dv_dbg = dv_dbg[jl] - dt_j * t_rha;
+                    n_dv_dba = dv_dba[jl] - dt_j * Rrc;
+                    n_dq_dbg = t_et - dt_j * mk[27 + jl];
                 }
-                if (cc) {
-                    s_T[lane] = T0;
-                    if (lane < 17) s_T[lane + 64] = T1;
-                }
+                if (cc && has) s_T[e_a] = T0;
                 __syncthreads();
-                if (cj && lane < 9) {
-                    s_jac[lane] = n_dq_dbg;
-                    s_jac[9 + lane] = n_dp_dbg;
-                    s_jac[18 + lane] = n_dp_dba;
-                    s_jac[27 + lane] = n_dv_dbg;
-                    s_jac[36 + lane] = n_dv_dba;
+                if (cj && jl >= 0 && jl < 9) {
+                    s_jac[jl] = n_dq_dbg;
+                    s_jac[9 + jl] = n_dp_dbg;
+                    s_jac[18 + jl] = n_dp_dba;
+                    s_jac[27 + jl] = n_dv_dbg;
+                    s_jac[36 + jl] = n_dv_dba;
                 }
                 if (cc) {  // cov9 = T A^T + N; bias random walks
-                    double acc_a = 0.0, acc_b = 0.0;
+                    if (has) {
+                        double acc_a = 0.0;
 #pragma unroll
-                    for (int x = 0; x < 9; ++x) {
-                        acc_a = __builtin_fma(s_T[r_a * 9 + x], Aj[c_a * 9 + x], acc_a);
-                        acc_b = __builtin_fma(s_T[r_b * 9 + x], Aj[c_b * 9 + x], acc_b);
-                    }
-                    s_cov[r_a * 15 + c_a] = acc_a + Nj[lane];
-                    if (two) {
-                        s_cov[r_b * 15 + c_b] = acc_b + Nj[i_b];
-                    } else if (lane < 35) {
-                        const int q = lane - 17, which = q / 9, i9 = q % 9, r = i9 / 3, c = i9 % 3;
+                        for (int x = 0; x < 9; ++x) acc_a = __builtin_fma(s_T[r_a * 9 + x], Aj[c_a * 9 + x], acc_a);
+                        s_cov[r_a * 15 + c_a] = acc_a + Nj[e_a];
+                    } else if (bq >= 0 && bq < 18) {
+                        const int which = bq / 9, i9 = bq % 9, r = i9 / 3, c = i9 % 3;
                         const int o0 = which ? ES_BA : ES_BG;
                         s_cov[(o0 + r) * 15 + o0 + c] += noise[18 + 9 * which + i9] * dt_j;
                     }
@@ -301,18 +296,22 @@ __global__ __launch_bounds__(64) void preintegrate_kernel(int nseg, const int32_
     }
     __syncthreads();
     // ---- outputs
-    if (lane == 0) {
+    if (tid == 0) {
         o[PRE_T] = run_t;
         q_store(o + PRE_Q, run_q);
         v3_store(o + PRE_P, run_p);
         v3_store(o + PRE_V, run_v);
     }
-    for (int i = lane; i < 225; i += 64) o[PRE_COV + i] = s_cov[i];
-    if (lane < 45) o[PRE_JAC + lane] = s_jac[lane];
+    if (w0) {
+        for (int i = lane; i < 225; i += 64) o[PRE_COV + i] = s_cov[i];
+        if (lane < 45) o[PRE_JAC + lane] = s_jac[lane];
+    }
     if (!cc) {
-        for (int i = lane; i < 225; i += 64) o[PRE_SIC + i] = 0.0;
+        if (w0)
+            for (int i = lane; i < 225; i += 64) o[PRE_SIC + i] = 0.0;
         return;
     }
+    if (!w0) return;   // (the inverse and its LLT below run in the registers of wavefront 0; a terminated wavefront does not take part in barriers)
     // ---- compute_sqrt_inv_cov (:97-100): inverse by Gauss-Jordan with partial pivoting on [cov | I], then LLT of the
     //      inverse, transposed.  Both run in registers: lane r holds row r, pivot rows / multipliers travel through
     //      v_readlane, so the 15-step dependent chains never touch LDS.  Rows are not swapped physically; the lane that
@@ -391,7 +390,7 @@ int rdvio_launch_rotation_prior(rdvio_hip_ctx *ctx, int n, int with_jac) {
 int rdvio_launch_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *off, const double *imu, const double *par,
                               const double *noise, int cj, int cc, double *out) {
     if (nseg <= 0) return RDVIO_OK;
-    hipLaunchKernelGGL(preintegrate_kernel, dim3(nseg), dim3(64), 0, ctx->stream, nseg, off, imu, par, noise, cj, cc, out);
+    hipLaunchKernelGGL(preintegrate_kernel, dim3(nseg), dim3(128), 0, ctx->stream, nseg, off, imu, par, noise, cj, cc, out);
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
     return RDVIO_OK;
 }
