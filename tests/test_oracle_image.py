@@ -136,3 +136,21 @@ def test_detect_keypoints_poisson_and_border(oracle):
     assert np.allclose(kp2[:10], kp[:10])
     d2 = np.linalg.norm(kp2[10:, None] - kp[None, :10], axis=-1)
     assert d2.min() >= 20.0 - 1e-9
+
+
+def test_xcd_tile_order_is_a_permutation():
+    """rd_vio_amd/csrc/image_kernels.hip, xcd_tile(): blocks are dealt round-robin over 8 XCDs; block b takes tile
+    (b % 8) * (nb // 8) + b // 8 (the last nb % 8 blocks keep theirs).  Every tile must be taken exactly once, and the
+    blocks of one XCD (equal b % 8) must take a contiguous run of tiles -- for the grids of every image size the tests use."""
+    for (w, h) in ((752, 480), (1280, 720), (750, 477), (100, 90), (64, 48)):
+        for border in (0, 32):
+            for lv in range(4):
+                lw, lh = max(1, (w + (1 << lv) - 1) >> lv), max(1, (h + (1 << lv) - 1) >> lv)
+                gx, gy = (lw + 2 * border + 31) // 32, (lh + 2 * border + 7) // 8
+                nb, per = gx * gy, (gx * gy) // 8
+                b = np.arange(nb)
+                t = np.where(b < per * 8, (b % 8) * per + b // 8, b)
+                assert np.array_equal(np.sort(t), b)
+                for x in range(8):
+                    run = np.sort(t[(b % 8 == x) & (b < per * 8)])
+                    assert len(run) == per and (per == 0 or np.array_equal(run, np.arange(run[0], run[0] + per)))
