@@ -96,6 +96,7 @@ void BaBuilder::add_preintegration(Frame *frame_i, Frame *frame_j, const PreInte
 }
 
 bool BaBuilder::solve(rdvio_ba_summary *summary_out) {
+    HostTimer host_timer__(sh.prof, 10);
     const int nfr = (int)frames.size(), nl = (int)lms.size();
     std::vector<double> states((size_t)nfr * 16), invd((size_t)std::max(nl, 1)), zref((size_t)std::max(nl, 1) * 3);
     for (int i = 0; i < nfr; ++i) frames[i]->get_state(&states[16 * (size_t)i]);
@@ -198,6 +199,7 @@ void FeatureTracker::track_frame(std::unique_ptr<Frame> frame) {
 }
 
 void FeatureTracker::detect_keypoints(Frame *frame) {
+    HostTimer host_timer__(sh.prof, 2);
     const int max_points = sh.cfg.feature_tracker_max_keypoint_detection;
     const size_t n0 = frame->bearings.size();
     std::vector<double> kps((n0 + (size_t)max_points + 8) * 2);
@@ -216,6 +218,7 @@ void FeatureTracker::detect_keypoints(Frame *frame) {
 }
 
 void FeatureTracker::track_keypoints(Frame *frame, Frame *next_frame) {
+    HostTimer host_timer__(sh.prof, 1);
     const size_t n = frame->bearings.size();
     std::vector<V2> curr(n);
     std::vector<double> curr_xy(2 * std::max<size_t>(n, 1)), next_xy(2 * std::max<size_t>(n, 1));
@@ -300,6 +303,7 @@ void FeatureTracker::track_keypoints(Frame *frame, Frame *next_frame) {
 
 void FeatureTracker::run() {
     if (frames.empty()) return;
+    HostTimer host_timer__(sh.prof, 0);
     std::unique_ptr<Frame> frame = std::move(frames.front());
     frames.pop_front();
     Backend &be = sh.backend;
@@ -370,6 +374,7 @@ void Frontend::issue_frame(Frame *frame) {
 
 void Frontend::run() {
     if (pending_frame_ids.empty()) return;
+    HostTimer host_timer__(sh.prof, 3);
     if (initializer) {
         const size_t pending_frame_id = pending_frame_ids.front();
         pending_frame_ids.clear();
@@ -406,6 +411,7 @@ SlidingWindowTracker::SlidingWindowTracker(std::unique_ptr<Map> keyframe_map, Sh
 }
 
 void SlidingWindowTracker::mirror_frame(Map *ftmap, size_t frame_id) {
+    HostTimer host_timer__(sh.prof, 4);
     Frame *keyframe = map->get_frame(map->frame_num() - 1);
     Frame *new_frame_i = keyframe;
     if (!keyframe->subframes.empty()) new_frame_i = keyframe->subframes.back().get();
@@ -448,6 +454,7 @@ bool SlidingWindowTracker::track() {
 }
 
 void SlidingWindowTracker::localize_newframe() {
+    HostTimer host_timer__(sh.prof, 5);
     BaBuilder solver(sh);
     Frame *frame_i = map->get_frame(map->frame_num() - 2);
     if (!frame_i->subframes.empty()) frame_i = frame_i->subframes.back().get();
@@ -462,6 +469,7 @@ void SlidingWindowTracker::localize_newframe() {
 }
 
 bool SlidingWindowTracker::manage_keyframe() {
+    HostTimer host_timer__(sh.prof, 9);
     Frame *keyframe_i = map->get_frame(map->frame_num() - 2);
     Frame *newframe_j = map->get_frame(map->frame_num() - 1);
     if (!keyframe_i->subframes.empty()) {
@@ -521,6 +529,7 @@ void SlidingWindowTracker::track_landmark() {
 }
 
 void SlidingWindowTracker::refine_window() {
+    HostTimer host_timer__(sh.prof, 6);
     BaBuilder solver(sh);
     if (!map->marginalization_factor) {
         // MarginalizationFactor::MarginalizationFactor (marginalization_factor.h:16-32): every frame but the newest, the
@@ -621,6 +630,7 @@ void SlidingWindowTracker::slide_window() {
 // Map::marginalize_frame(0) (map.cpp:50-62) with the graph of CeresMarginalizationFactor::marginalize
 // (ceres/marginalization_factor.h:95-380) exported as SoA
 void SlidingWindowTracker::marginalize_frame0() {
+    HostTimer host_timer__(sh.prof, 8);
     MarginalizationPrior &prior = *map->marginalization_factor;
     const int nfm = (int)map->frame_num();
     std::unordered_map<const Frame *, int> index;
@@ -714,6 +724,7 @@ void SlidingWindowTracker::integrate_subframes(Frame *frame) {
 }
 
 void SlidingWindowTracker::refine_subwindow() {
+    HostTimer host_timer__(sh.prof, 7);
     Frame *frame = map->get_frame(map->frame_num() - 1);
     if (frame->subframes.empty()) return;
     if (frame->subframes[0]->tag(FT_NO_TRANSLATION)) {
@@ -832,6 +843,7 @@ bool SlidingWindowTracker::filter_parsac_2d2d(Frame *frame_i, Frame *frame_j, st
 }
 
 bool SlidingWindowTracker::judge_track_status() {
+    HostTimer host_timer__(sh.prof, 11);
     Frame *curr_frame = map->get_frame(map->frame_num() - 1);
     Frame *keyframe = map->get_frame(map->frame_num() - 2);
     Frame *last_frame = keyframe;
@@ -1114,6 +1126,7 @@ int rdvio_pipeline_create(rdvio_pipeline **out, const rdvio_pipeline_config *cfg
     auto *p = new rdvio_pipeline();
     p->shared.cfg = *cfg;
     p->shared.backend.fn = *backend;
+    if (const char *e = std::getenv("RDVIO_PIPELINE_PROF")) p->shared.prof.on = e[0] == '1';
     p->handler = std::make_unique<Handler>(p->shared);
     *out = p;
     return RDVIO_OK;
@@ -1122,6 +1135,17 @@ int rdvio_pipeline_create(rdvio_pipeline **out, const rdvio_pipeline_config *cfg
 void rdvio_pipeline_destroy(rdvio_pipeline *p) {
     if (!p) return;
     const rdvio_backend fn = p->shared.backend.fn;
+    if (p->shared.prof.on) {   // diagnostic: inclusive stage times (backend calls inside) and the backend's own share
+        const Counters &c = p->shared.counters;
+        std::fprintf(stderr, "[rdvio pipeline] %ld frames; inclusive stage times, ms per frame:\n", (long)c.frames_tracked);
+        for (int k = 0; k < HostProf::N; ++k)
+            if (p->shared.prof.calls[k])
+                std::fprintf(stderr, "  %-32s %8.4f  (%ld calls, %.1f us each)\n", HostProf::names[k], 1e3 * p->shared.prof.seconds[k] / std::max<long>(c.frames_tracked, 1),
+                             p->shared.prof.calls[k], 1e6 * p->shared.prof.seconds[k] / p->shared.prof.calls[k]);
+        static const char *bn[7] = {"preprocess", "detect", "track", "preintegrate", "ba_solve", "marginalize", "image_create"};
+        for (int k = 0; k < 7; ++k)
+            std::fprintf(stderr, "  backend %-24s %8.4f  (%ld calls)\n", bn[k], 1e3 * c.backend_seconds[k] / std::max<long>(c.frames_tracked, 1), (long)c.backend_calls[k]);
+    }
     p->handler.reset();  // frames release their images through the backend first
     delete p;
     if (fn.destroy) fn.destroy(fn.user);

@@ -34,7 +34,34 @@ struct BackendTimer {
     }
 };
 
+// host-side stage profile (diagnostic: RDVIO_PIPELINE_PROF=1 prints it to stderr when the pipeline is destroyed): inclusive
+// wall time of the orchestration's stages, backend calls included -- subtract the backend counters for the host share
+struct HostProf {
+    static constexpr int N = 12;
+    static constexpr const char *names[N] = {"tracker.run", "tracker.track_keypoints", "tracker.detect_keypoints", "frontend.run", "swt.mirror_frame",
+                                             "swt.localize_newframe", "swt.refine_window", "swt.refine_subwindow", "swt.marginalize_frame0",
+                                             "swt.track_landmark+manage", "ba.solve (assembly + backend)", "rd path"};
+    double seconds[N] = {};
+    long calls[N] = {};
+    bool on = false;
+};
+struct HostTimer {
+    HostProf &p;
+    int k;
+    std::chrono::steady_clock::time_point t0;
+    HostTimer(HostProf &p, int k) : p(p), k(k) {
+        if (p.on) t0 = std::chrono::steady_clock::now();
+    }
+    ~HostTimer() {
+        if (p.on) {
+            p.seconds[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            p.calls[k]++;
+        }
+    }
+};
+
 struct Shared {  // what every stage needs
+    HostProf prof;
     rdvio_pipeline_config cfg;
     Backend backend;
     IdGenerator ids;
