@@ -695,14 +695,22 @@ def main(argv=None):
             "roofline": roof,
             "image_kernels_roofline": image_roof,
         }
+        # the legs beside `value`: a failure in one of them is recorded in its own field and never costs the line
+        def leg(name, fn):
+            try:
+                out[name] = fn()
+            except Exception as exc:  # noqa: BLE001
+                out[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, wl)
-            out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 2)
+            leg("cpu_baseline", lambda: cpu_baseline(cfg, wl))
+            if out["cpu_baseline"].get("value"):
+                out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 2)
         if world == 1 and args.end_to_end_frames > 0:
-            out["end_to_end"] = end_to_end(cfg, ctx, args.end_to_end_frames, with_cpu_path=not args.no_cpu_baseline)
+            leg("end_to_end", lambda: end_to_end(cfg, ctx, args.end_to_end_frames, with_cpu_path=not args.no_cpu_baseline))
         if world == 1 and args.sequences > 1 and not args.serial:
-            out["multi_sequence"] = multi_sequence(cfg, torch, dev, local_rank, wl, args.sequences, steps=min(args.steps, 100), warmup=10,
-                                                   overlap=args.sequence_lanes == 3, wait_mode=args.sequence_wait)
+            leg("multi_sequence", lambda: multi_sequence(cfg, torch, dev, local_rank, wl, args.sequences, steps=min(args.steps, 100), warmup=10,
+                                                         overlap=args.sequence_lanes == 3, wait_mode=args.sequence_wait))
         print(json.dumps(out))
     ctx.close()
     if dist is not None:
