@@ -87,6 +87,9 @@ int rdvio_hip_ctx_set_lane_stream(rdvio_hip_ctx *ctx, int lane, void *stream);
  * the hardware concurrency). */
 int rdvio_hip_ctx_set_wait_mode(rdvio_hip_ctx *ctx, int blocking);
 int rdvio_hip_lane_wait(rdvio_hip_ctx *ctx, int lane, int on_lane);
+/* Binds the calling thread to the context's device (hipSetDevice): call once on every host thread other than the creating one
+ * before it uses the context (a new thread starts on device 0). */
+int rdvio_hip_ctx_attach_thread(rdvio_hip_ctx *ctx);
 int rdvio_hip_lane_sync(rdvio_hip_ctx *ctx, int lane);
 int rdvio_hip_pyr_layout_init(int width, int height, int max_level, rdvio_pyr_layout *out);
 const char *rdvio_hip_version(void);
@@ -132,6 +135,12 @@ int rdvio_hip_image_release(rdvio_hip_ctx *ctx, int slot);
 int rdvio_hip_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off, const double *imu,
                            const double *t_end, const double *bg, const double *ba, const double *noise,
                            int compute_jacobian, int compute_covariance, double *preint_out);
+/* The same call for a second host thread: the estimator of a threaded pipeline (rdvio_pipeline_config::threading == 2)
+ * integrates while the tracker does -- this entry enqueues on RDVIO_LANE_SOLVER and has staging buffers of its own, so the
+ * two never meet. */
+int rdvio_hip_preintegrate_estimator(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off, const double *imu,
+                                     const double *t_end, const double *bg, const double *ba, const double *noise,
+                                     int compute_jacobian, int compute_covariance, double *preint_out);
 /* Same with every array resident in HBM: imu_dev (n x 7), par_dev (nseg x 7: t_end, bg, ba), noise_dev (36),
  * seg_off_dev (nseg+1), out_dev (nseg x RDVIO_PREINT_SIZE).  Only enqueues the kernel. */
 int rdvio_hip_preintegrate_dev(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off_dev, const double *imu_dev,

@@ -62,6 +62,15 @@ typedef struct rdvio_backend {
      * batch of models and the mask / bin counts of one of them (rdvio_hip_parsac_score / _fetch) */
     int (*parsac_score)(void *user, const rdvio_parsac_batch *batch, rdvio_parsac_result *results);
     int (*parsac_fetch)(void *user, int model, uint8_t *mask, int32_t *bin_inliers);
+    /* optional, for threaded pipelines (rdvio_pipeline_config::threading == 2).  The feature tracker calls the image
+     * functions and `preintegrate` on the caller's thread; the estimator (Frontend: sliding-window tracker) calls
+     * ba_solve / marginalize / parsac_* and -- when set -- `preintegrate_estimator` on the worker thread, concurrently.
+     * preintegrate_estimator: the same contract as preintegrate on staging buffers of its own (NULL = preintegrate is
+     * safe to call from both threads at once); thread_attach: called once on the worker thread before its first backend
+     * call (a HIP backend binds the thread to its device). */
+    int (*preintegrate_estimator)(void *user, int nseg, const int32_t *seg_off, const double *imu, const double *t_end, const double *bg,
+                                  const double *ba, const double *noise, int compute_jacobian, int compute_covariance, double *preint_out);
+    int (*thread_attach)(void *user);
 } rdvio_backend;
 
 /* rdvio::Config (types.h:85-151) with the defaults of src/rdvio/src/config.cpp; rdvio_pipeline_config_default fills
@@ -88,6 +97,16 @@ typedef struct rdvio_pipeline_config {
     int32_t random;
     int32_t parsac_flag; /* RD dynamic-outlier handling (judge_track_status / update_track_status) */
     int32_t parsac_keyframe_check_size;
+    /* The reference's tracker / frontend split (handler.cpp:35-50, CMake option THREADING):
+     *   0  inline, the reference's THREADING=OFF: the frontend's step for frame k runs inside the tracker's step for
+     *      frame k, which therefore sees the states optimised with frame k - 1;
+     *   1  the pipelined schedule, executed on one thread: the frontend's step for frame k is issued when the tracker has
+     *      finished frame k and its results (latest optimised state, track tags) become visible to the tracker when it has
+     *      finished frame k + 1 -- one admissible interleaving of the reference's THREADING=ON, made deterministic;
+     *   2  the same schedule with the frontend's step on a worker thread, concurrent with the tracker's next frame.
+     * 1 and 2 produce identical results by construction (the two steps share no mutable state between hand-overs); the
+     * CPU path of the comparison runs 1, the product 2. */
+    int32_t threading;
 } rdvio_pipeline_config;
 
 void rdvio_pipeline_config_default(rdvio_pipeline_config *cfg);

@@ -36,7 +36,7 @@ def build_pipeline(force=False, verbose=False):
         return PIPE_LIB
     cxx = os.environ.get("CXX", "g++")
     # same no-FMA-contraction rule as the device code: the CPU-path comparison runs this very code over the oracle
-    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-ffp-contract=off", "-o", PIPE_LIB] + \
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-ffp-contract=off", "-pthread", "-o", PIPE_LIB] + \
           [os.path.join(PIPE_DIR, s) for s in PIPE_SOURCES] + ["-L" + HERE, "-lrdvio_hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
@@ -54,7 +54,7 @@ def build_test_euroc(force=False, verbose=False):
     if not force and os.path.exists(EUROC_EXE) and all(os.path.getmtime(d) <= os.path.getmtime(EUROC_EXE) for d in deps):
         return EUROC_EXE
     cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-Wextra", "-ffp-contract=off", "-o", EUROC_EXE, os.path.join(hdir, "test_euroc.cpp"),
-           "-L" + HERE, "-lrdvio_pipeline", "-lrdvio_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+           "-L" + HERE, "-lrdvio_pipeline", "-lrdvio_hip", "-lz", "-pthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -387,10 +387,10 @@ int rdvio_launch_rotation_prior(rdvio_hip_ctx *ctx, int n, int with_jac) {
     return RDVIO_OK;
 }
 
-int rdvio_launch_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *off, const double *imu, const double *par,
+int rdvio_launch_preintegrate(rdvio_hip_ctx *ctx, hipStream_t st, int nseg, const int32_t *off, const double *imu, const double *par,
                               const double *noise, int cj, int cc, double *out) {
     if (nseg <= 0) return RDVIO_OK;
-    hipLaunchKernelGGL(preintegrate_kernel, dim3(nseg), dim3(128), 0, ctx->stream, nseg, off, imu, par, noise, cj, cc, out);
+    hipLaunchKernelGGL(preintegrate_kernel, dim3(nseg), dim3(128), 0, st, nseg, off, imu, par, noise, cj, cc, out);
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
     return RDVIO_OK;
 }

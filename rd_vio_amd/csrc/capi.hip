@@ -122,6 +122,8 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
     ctx->pre_max_samples = ctx->pre_max_seg * 256;
     CTX_ALLOC(ctx->pre_out, (size_t)ctx->pre_max_seg * RDVIO_PREINT_SIZE * sizeof(double));
     CTX_ALLOC(ctx->pre_blob, ((size_t)ctx->pre_max_seg * 7 + 36 + (size_t)ctx->pre_max_samples * 7 + (size_t)ctx->pre_max_seg + 8) * sizeof(double));
+    CTX_ALLOC(ctx->pre2_out, (size_t)ctx->pre_max_seg * RDVIO_PREINT_SIZE * sizeof(double));
+    CTX_ALLOC(ctx->pre2_blob, ((size_t)ctx->pre_max_seg * 7 + 36 + (size_t)ctx->pre_max_samples * 7 + (size_t)ctx->pre_max_seg + 8) * sizeof(double));
     {
         const size_t F = (size_t)max_factors, Lm = (size_t)max_factors, Nmax = 15 * (size_t)nfr, npre = (size_t)nfr + 8;
         size_t bytes = (1 << 16) + F * (520 + 3 * 26 * 8 + 12) + Lm * (192 + 48 * (size_t)nfr) + Nmax * Nmax * 8 * 7 + npre * 930 * 8 +
@@ -171,6 +173,12 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
         *out = ctx;
         return RDVIO_ERR_HIP;
     }
+    ctx->pre2_pinned_bytes = ((size_t)ctx->pre_max_seg * (7 + RDVIO_PREINT_SIZE + 1) + 64 + (size_t)ctx->pre_max_samples * 7) * sizeof(double);
+    if (hipHostMalloc(&ctx->pre2_pinned, ctx->pre2_pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+        rdvio_fail(ctx, RDVIO_ERR_HIP, "hipHostMalloc failed");
+        *out = ctx;
+        return RDVIO_ERR_HIP;
+    }
     *out = ctx;
     return RDVIO_OK;
 }
@@ -179,8 +187,10 @@ void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (int l = 0; l < 3; ++l) (void)rdvio_wait(ctx, ctx->lane[l]);
-    if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
-    ctx->wait_ev = nullptr;
+    for (int l = 0; l < 3; ++l) {
+        if (ctx->wait_ev[l]) (void)hipEventDestroy(ctx->wait_ev[l]);
+        ctx->wait_ev[l] = nullptr;
+    }
     for (int s = 0; s < RDVIO_NUM_SLOTS; ++s) {
         (void)hipFree(ctx->slots[s].pyr_img);
         (void)hipFree(ctx->slots[s].pyr_deriv);
@@ -189,9 +199,10 @@ void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
                     ctx->lk_curr,
                     ctx->lk_next, ctx->lk_prevf, ctx->lk_nextf, ctx->lk_status, ctx->ba_states, ctx->ba_extr,
                     ctx->ba_zref, ctx->ba_invd, ctx->ba_tangent, ctx->ba_idx, ctx->ba_r, ctx->ba_Jt, ctx->ba_Jr,
-                    ctx->ba_Jd, ctx->pre_out, ctx->pre_blob};
+                    ctx->ba_Jd, ctx->pre_out, ctx->pre_blob, ctx->pre2_out, ctx->pre2_blob};
     for (void *b : bufs) (void)hipFree(b);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pre2_pinned) (void)hipHostFree(ctx->pre2_pinned);
     if (ctx->ps_host) (void)hipHostFree(ctx->ps_host);
     if (ctx->marg.host) (void)hipHostFree(ctx->marg.host);
     (void)hipFree(ctx->marg.arena);
@@ -221,7 +232,8 @@ static bool bad_lane(int lane) { return lane < 0 || lane > 2; }
 int rdvio_hip_ctx_set_wait_mode(rdvio_hip_ctx *ctx, int blocking) {
     if (!ctx) return RDVIO_ERR_INVALID;
     RDVIO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    if (blocking && !ctx->wait_ev) RDVIO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->wait_ev, hipEventBlockingSync | hipEventDisableTiming));
+    for (int l = 2; l >= 0; --l)   // [0] last: rdvio_wait tests it
+        if (blocking && !ctx->wait_ev[l]) RDVIO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->wait_ev[l], hipEventBlockingSync | hipEventDisableTiming));
     ctx->blocking_wait = blocking != 0;
     return RDVIO_OK;
 }
@@ -229,7 +241,10 @@ int rdvio_hip_ctx_set_wait_mode(rdvio_hip_ctx *ctx, int blocking) {
 int rdvio_hip_ctx_set_lane_stream(rdvio_hip_ctx *ctx, int lane, void *stream) {
     if (!ctx || bad_lane(lane)) return RDVIO_ERR_INVALID;
     if (lane == RDVIO_LANE_FRONTEND) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "the frontend lane is the context's stream (rdvio_hip_ctx_create)");
+    RDVIO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->lane[lane]));
+    for (int l = 0; l < 3; ++l)   // the lanes' dependency events belong to the context's device, whichever thread waits later
+        if (!ctx->lane_ev[l]) RDVIO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->lane_ev[l], hipEventDisableTiming));
     if (ctx->own_lane[lane]) {
         RDVIO_HIP_CHECK(ctx, hipStreamDestroy(ctx->lane[lane]));
         ctx->own_lane[lane] = false;
@@ -403,8 +418,17 @@ int rdvio_hip_detect_keypoints(rdvio_hip_ctx *ctx, int slot, double *keypoints, 
 }
 
 // ------------------------------------------------------------------------------------------ seam 2
-int rdvio_hip_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off, const double *imu, const double *t_end,
-                           const double *bg, const double *ba, const double *noise, int cj, int cc, double *out) {
+// staging of one caller of the host entry point: the frontend lane's (Image / tracker side) or the solver lane's (the
+// estimator's integrations, concurrent with the tracker's in a threaded pipeline)
+struct PreStage {
+    hipStream_t st;
+    double *pinned;
+    size_t pinned_bytes;
+    double *blob, *out;
+};
+
+static int preintegrate_host(rdvio_hip_ctx *ctx, const PreStage &S, int nseg, const int32_t *seg_off, const double *imu, const double *t_end,
+                             const double *bg, const double *ba, const double *noise, int cj, int cc, double *out) {
     if (!ctx || nseg < 0 || (nseg > 0 && (!seg_off || !imu || !t_end || !bg || !ba || !noise || !out))) return RDVIO_ERR_INVALID;
     if (nseg == 0) return RDVIO_OK;
     if (nseg > ctx->pre_max_seg) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d segments exceed capacity %d", nseg, ctx->pre_max_seg);
@@ -417,8 +441,8 @@ int rdvio_hip_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off,
     // these calls, so the per-call fixed cost matters more than the 4 KB of payload
     const size_t o_par = 0, o_noise = (size_t)ctx->pre_max_seg * 7, o_imu = o_noise + 36, o_off = o_imu + (size_t)ctx->pre_max_samples * 7;
     const size_t in_doubles = o_off + ((size_t)ctx->pre_max_seg + 2) / 2 + 1, out_doubles = (size_t)nseg * RDVIO_PREINT_SIZE;
-    if ((in_doubles + out_doubles) * sizeof(double) > ctx->pinned_bytes) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "preintegration staging buffer too small");
-    double *blob = (double *)ctx->pinned;
+    if ((in_doubles + out_doubles) * sizeof(double) > S.pinned_bytes) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "preintegration staging buffer too small");
+    double *blob = S.pinned;
     for (int i = 0; i < nseg; ++i) {
         blob[o_par + 7 * i] = t_end[i];
         for (int k = 0; k < 3; ++k) {
@@ -431,22 +455,41 @@ int rdvio_hip_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off,
     memcpy(blob + o_off, seg_off, (size_t)(nseg + 1) * sizeof(int32_t));
     // only the used prefix of each region travels: par, noise and the samples are contiguous up to the last sample
     const size_t head = (o_imu + (size_t)ns * 7) * sizeof(double);
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pre_blob, blob, head, hipMemcpyHostToDevice, ctx->stream));
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pre_blob + o_off, blob + o_off, (size_t)(nseg + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    if (int rc = rdvio_launch_preintegrate(ctx, nseg, (const int32_t *)(ctx->pre_blob + o_off), ctx->pre_blob + o_imu, ctx->pre_blob + o_par,
-                                           ctx->pre_blob + o_noise, cj, cc, ctx->pre_out))
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(S.blob, blob, head, hipMemcpyHostToDevice, S.st));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(S.blob + o_off, blob + o_off, (size_t)(nseg + 1) * sizeof(int32_t), hipMemcpyHostToDevice, S.st));
+    if (int rc = rdvio_launch_preintegrate(ctx, S.st, nseg, (const int32_t *)(S.blob + o_off), S.blob + o_imu, S.blob + o_par, S.blob + o_noise, cj, cc, S.out))
         return rc;
     double *down = blob + in_doubles;
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, ctx->pre_out, out_doubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, S.out, out_doubles * sizeof(double), hipMemcpyDeviceToHost, S.st));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, S.st));
     memcpy(out, down, out_doubles * sizeof(double));
+    return RDVIO_OK;
+}
+
+int rdvio_hip_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off, const double *imu, const double *t_end,
+                           const double *bg, const double *ba, const double *noise, int cj, int cc, double *out) {
+    if (!ctx) return RDVIO_ERR_INVALID;
+    return preintegrate_host(ctx, PreStage{ctx->stream, (double *)ctx->pinned, ctx->pinned_bytes, ctx->pre_blob, ctx->pre_out}, nseg, seg_off, imu,
+                             t_end, bg, ba, noise, cj, cc, out);
+}
+
+int rdvio_hip_preintegrate_estimator(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off, const double *imu, const double *t_end,
+                                     const double *bg, const double *ba, const double *noise, int cj, int cc, double *out) {
+    if (!ctx) return RDVIO_ERR_INVALID;
+    return preintegrate_host(ctx, PreStage{ctx->lane[RDVIO_LANE_SOLVER], (double *)ctx->pre2_pinned, ctx->pre2_pinned_bytes, ctx->pre2_blob, ctx->pre2_out},
+                             nseg, seg_off, imu, t_end, bg, ba, noise, cj, cc, out);
+}
+
+int rdvio_hip_ctx_attach_thread(rdvio_hip_ctx *ctx) {
+    if (!ctx) return RDVIO_ERR_INVALID;
+    RDVIO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     return RDVIO_OK;
 }
 
 int rdvio_hip_preintegrate_dev(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off_dev, const double *imu_dev,
                                const double *par_dev, const double *noise_dev, int cj, int cc, double *out_dev) {
     if (!ctx || nseg < 0 || (nseg > 0 && (!seg_off_dev || !imu_dev || !par_dev || !noise_dev || !out_dev))) return RDVIO_ERR_INVALID;
-    return rdvio_launch_preintegrate(ctx, nseg, seg_off_dev, imu_dev, par_dev, noise_dev, cj, cc, out_dev);
+    return rdvio_launch_preintegrate(ctx, ctx->stream, nseg, seg_off_dev, imu_dev, par_dev, noise_dev, cj, cc, out_dev);
 }
 
 static int upload_ba_problem(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb) {

@@ -40,7 +40,7 @@ struct rdvio_hip_ctx {
     // host waits: spinning (hipStreamSynchronize: lowest latency, one core per waiting thread) or blocking on an event created
     // with hipEventBlockingSync (the waiting thread sleeps: many sequences per process, more waiting threads than cores)
     bool blocking_wait = false;
-    hipEvent_t wait_ev = nullptr;
+    hipEvent_t wait_ev[3] = {nullptr, nullptr, nullptr};
     int max_w = 0, max_h = 0, max_feat = 0, max_window = 0, max_factors = 0;
     bool force_host_select = false;  // env RDVIO_HOST_SELECT=1 (read at context creation)
     int helper_min_factors = 4096;  // problems with at least this many factors launch the team (env RDVIO_HELPER_MIN_FACTORS)
@@ -72,6 +72,10 @@ struct rdvio_hip_ctx {
     double *ba_r = nullptr, *ba_Jt = nullptr, *ba_Jr = nullptr, *ba_Jd = nullptr;
     double *pre_out = nullptr, *pre_blob = nullptr;  // results; one staging blob (par | noise | samples | offsets)
     int pre_max_samples = 0, pre_max_seg = 0;
+    // the estimator's preintegrations (rdvio_hip_preintegrate_estimator, solver lane): staging of their own
+    double *pre2_out = nullptr, *pre2_blob = nullptr;
+    void *pre2_pinned = nullptr;
+    size_t pre2_pinned_bytes = 0;
 
     // BA solver: pinned input blob, device arena (inputs + scratch), workspace descriptor
     struct BaSlot {
@@ -112,11 +116,15 @@ inline int rdvio_fail(rdvio_hip_ctx *ctx, int code, const char *fmt, ...) {
     return code;
 }
 
-// every host-side wait of the library goes through here (rdvio_hip_ctx_set_wait_mode)
+// every host-side wait of the library goes through here (rdvio_hip_ctx_set_wait_mode).  Blocking waits use one event per
+// lane (two host threads may wait on two lanes at once: tracker and estimator of a threaded pipeline).
 static inline hipError_t rdvio_wait(rdvio_hip_ctx *ctx, hipStream_t st) {
-    if (!ctx->blocking_wait || !ctx->wait_ev) return hipStreamSynchronize(st);
-    const hipError_t e = hipEventRecord(ctx->wait_ev, st);
-    return e != hipSuccess ? e : hipEventSynchronize(ctx->wait_ev);
+    if (!ctx->blocking_wait || !ctx->wait_ev[0]) return hipStreamSynchronize(st);
+    int l = 0;
+    for (int k = 1; k < 3; ++k)
+        if (st == ctx->lane[k] && st != ctx->lane[0]) l = k;
+    const hipError_t e = hipEventRecord(ctx->wait_ev[l], st);
+    return e != hipSuccess ? e : hipEventSynchronize(ctx->wait_ev[l]);
 }
 
 #define RDVIO_HIP_CHECK(ctx, expr)                                                                     \
@@ -143,5 +151,5 @@ int rdvio_launch_harris_candidates(rdvio_hip_ctx *ctx, int slot, double quality)
 int rdvio_launch_select(rdvio_hip_ctx *ctx, int slot, int max_corners, double gftt_min_dist, double poisson_radius, int n_existing);
 int rdvio_launch_reprojection(rdvio_hip_ctx *ctx, int nf, int with_jac);
 int rdvio_launch_rotation_prior(rdvio_hip_ctx *ctx, int n, int with_jac);
-int rdvio_launch_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *off, const double *imu, const double *par,
+int rdvio_launch_preintegrate(rdvio_hip_ctx *ctx, hipStream_t st, int nseg, const int32_t *off, const double *imu, const double *par,
                               const double *noise, int cj, int cc, double *out);

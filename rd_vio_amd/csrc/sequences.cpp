@@ -67,7 +67,8 @@ extern "C" int rdvio_hip_run_sequences(const rdvio_frame_step *seqs, int n_seq, 
     std::vector<clock::time_point> done(n_seq);
     clock::time_point t0;
     auto worker = [&](int i) {
-        int rc = 0;
+        // a new thread starts on device 0: bind it to the context's device before anything creates an event or launches
+        int rc = rdvio_hip_ctx_attach_thread(seqs[i].ctx);
         for (int k = 0; k < warmup && !rc; ++k) rc = rdvio_hip_frame_step(&seqs[i], k);
         if (!rc) rc = rdvio_hip_sync(seqs[i].ctx);
         if (rc) failed.store(rc);

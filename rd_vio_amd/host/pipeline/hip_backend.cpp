@@ -69,6 +69,13 @@ int preintegrate(void *user, int nseg, const int32_t *seg_off, const double *imu
     return rdvio_hip_preintegrate(static_cast<HipBackend *>(user)->ctx, nseg, seg_off, imu, t_end, bg, ba, noise, cj, cc, out);
 }
 
+int preintegrate_estimator(void *user, int nseg, const int32_t *seg_off, const double *imu, const double *t_end, const double *bg, const double *ba,
+                           const double *noise, int cj, int cc, double *out) {
+    return rdvio_hip_preintegrate_estimator(static_cast<HipBackend *>(user)->ctx, nseg, seg_off, imu, t_end, bg, ba, noise, cj, cc, out);
+}
+
+int thread_attach(void *user) { return rdvio_hip_ctx_attach_thread(static_cast<HipBackend *>(user)->ctx); }
+
 int ba_solve(void *user, const rdvio_ba_problem *pb, int max_iter, double *states, double *invd, rdvio_ba_summary *sm) {
     return rdvio_hip_ba_solve(static_cast<HipBackend *>(user)->ctx, pb, max_iter, states, invd, sm);
 }
@@ -109,6 +116,8 @@ extern "C" int rdvio_pipeline_create_hip(rdvio_pipeline **out, const rdvio_pipel
     fn.destroy = destroy;
     fn.parsac_score = parsac_score;
     fn.parsac_fetch = parsac_fetch;
+    fn.preintegrate_estimator = preintegrate_estimator;
+    fn.thread_attach = thread_attach;
     const int rc = rdvio_pipeline_create(out, cfg, &fn);
     if (rc != RDVIO_OK) delete b;
     return rc;

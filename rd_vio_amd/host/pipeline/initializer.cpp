@@ -89,7 +89,7 @@ std::unique_ptr<SlidingWindowTracker> Initializer::initialize() {
     }
     for (size_t j = 1; j < map->frame_num(); ++j) {
         Frame *frame_i = map->get_frame(j - 1), *frame_j = map->get_frame(j);
-        if (frame_j->preintegration.integrate(sh.backend, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba, true, true))
+        if (frame_j->preintegration.integrate(sh.backend, LANE_ESTIMATOR, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba, true, true))
             solver.add_preintegration(frame_i, frame_j, frame_j->preintegration, false);
     }
     solver.solve();
@@ -258,7 +258,7 @@ void Initializer::reset_states() {
 void Initializer::preintegrate() {
     std::vector<PreIntegrator::Job> jobs;
     for (size_t j = 1; j < map->frame_num(); ++j) jobs.push_back({&map->get_frame(j)->preintegration, map->get_frame(j)->image->t, bg, ba});
-    (void)PreIntegrator::integrate_batch(sh.backend, jobs, true, false);
+    (void)PreIntegrator::integrate_batch(sh.backend, LANE_ESTIMATOR, jobs, true, false);
 }
 
 void Initializer::solve_gyro_bias() {

@@ -28,11 +28,11 @@ std::array<double, 9> tangent_frame(const V3 &x) {
 }
 
 // ---------------------------------------------------------------------------------------------- PreIntegrator
-bool PreIntegrator::integrate(Backend &be, double t, const V3 &bg, const V3 &ba, bool compute_jacobian, bool compute_covariance) {
-    return integrate_batch(be, {Job{this, t, bg, ba}}, compute_jacobian, compute_covariance)[0] != 0;
+bool PreIntegrator::integrate(Backend &be, CallerLane lane, double t, const V3 &bg, const V3 &ba, bool compute_jacobian, bool compute_covariance) {
+    return integrate_batch(be, lane, {Job{this, t, bg, ba}}, compute_jacobian, compute_covariance)[0] != 0;
 }
 
-std::vector<char> PreIntegrator::integrate_batch(Backend &be, const std::vector<Job> &jobs, bool compute_jacobian, bool compute_covariance) {
+std::vector<char> PreIntegrator::integrate_batch(Backend &be, CallerLane lane, const std::vector<Job> &jobs, bool compute_jacobian, bool compute_covariance) {
     std::vector<char> ok(jobs.size(), 0);
     std::vector<int32_t> off(1, 0);
     std::vector<double> imu, t_end, bg, ba;
@@ -54,14 +54,17 @@ std::vector<char> PreIntegrator::integrate_batch(Backend &be, const std::vector<
         const auto t0 = std::chrono::steady_clock::now();
         struct Acc {
             Backend &be;
+            int lane;
             std::chrono::steady_clock::time_point t0;
             ~Acc() {
-                be.preintegrate_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                be.preintegrate_calls++;
+                be.preintegrate_seconds[lane] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                be.preintegrate_calls[lane]++;
             }
-        } acc{be, t0};
-        be.check(be.fn.preintegrate(be.fn.user, (int)which.size(), off.data(), imu.data(), t_end.data(), bg.data(), ba.data(),
-                                    jobs[which[0]].pre->noise, compute_jacobian ? 1 : 0, compute_covariance ? 1 : 0, out.data()),
+        } acc{be, (int)lane, t0};
+        // the estimator's integrations have an entry of their own when the backend separates the two callers' staging
+        auto fn = (lane == LANE_ESTIMATOR && be.fn.preintegrate_estimator) ? be.fn.preintegrate_estimator : be.fn.preintegrate;
+        be.check(fn(be.fn.user, (int)which.size(), off.data(), imu.data(), t_end.data(), bg.data(), ba.data(), jobs[which[0]].pre->noise,
+                    compute_jacobian ? 1 : 0, compute_covariance ? 1 : 0, out.data()),
                  "preintegrate");
     }
     for (size_t k = 0; k < which.size(); ++k)

@@ -50,11 +50,15 @@ struct IdGenerator {
     size_t next_frame = 0, next_track = 0;
 };
 
+// Who calls: the feature tracker (the caller's thread) or the estimator (Frontend: SlidingWindowTracker / Initializer --
+// the worker thread when the pipeline runs threaded).  The two never share a staging buffer or a counter.
+enum CallerLane { LANE_TRACKER = 0, LANE_ESTIMATOR = 1 };
+
 struct Backend {
     rdvio_backend fn;
     std::string error;
-    double preintegrate_seconds = 0.0;  // PreIntegrator::integrate is called from map-level code
-    int64_t preintegrate_calls = 0;
+    double preintegrate_seconds[2] = {0.0, 0.0};  // PreIntegrator::integrate is called from map-level code; per CallerLane
+    int64_t preintegrate_calls[2] = {0, 0};
     void check(int rc, const char *what);  // throws std::runtime_error on failure
 };
 
@@ -77,12 +81,12 @@ struct PreIntegrator {
     double noise[36] = {0};                   // cov_w cov_a cov_bg cov_ba
     std::vector<double> delta = std::vector<double>(RDVIO_PREINT_SIZE, 0.0);
     PreIntegrator() { delta[PRE_Q + 3] = 1.0; }
-    bool integrate(Backend &be, double t, const V3 &bg, const V3 &ba, bool compute_jacobian, bool compute_covariance);
+    bool integrate(Backend &be, CallerLane lane, double t, const V3 &bg, const V3 &ba, bool compute_jacobian, bool compute_covariance);
     void predict(const Frame *old_frame, Frame *new_frame) const;  // preintegrator.cpp:102-112
     // the same integrate() for several independent integrators in one backend call (all with the same noise model and
     // flags); ok[i] = false where data is empty
     struct Job { PreIntegrator *pre; double t; V3 bg, ba; };
-    static std::vector<char> integrate_batch(Backend &be, const std::vector<Job> &jobs, bool compute_jacobian, bool compute_covariance);
+    static std::vector<char> integrate_batch(Backend &be, CallerLane lane, const std::vector<Job> &jobs, bool compute_jacobian, bool compute_covariance);
     double dt() const { return delta[PRE_T]; }
     Q4 dq() const { return {delta[PRE_Q], delta[PRE_Q + 1], delta[PRE_Q + 2], delta[PRE_Q + 3]}; }
     V3 dp() const { return {delta[PRE_P], delta[PRE_P + 1], delta[PRE_P + 2]}; }

@@ -327,7 +327,7 @@ void FeatureTracker::run() {
                 latest->motion = latest_optimized_motion;
                 for (size_t j = idx + 1; j < map->frame_num(); ++j) {
                     Frame *frame_i = map->get_frame(j - 1), *frame_j = map->get_frame(j);
-                    frame_j->preintegration.integrate(be, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba, false, false);
+                    frame_j->preintegration.integrate(be, LANE_TRACKER, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba, false, false);
                     frame_j->preintegration.predict(frame_i, frame_j);
                 }
             } else {
@@ -342,7 +342,7 @@ void FeatureTracker::run() {
                 frame->preintegration.data.insert(frame->preintegration.data.begin(), imu);
             }
         }
-        frame->preintegration.integrate(be, frame->image->t, last_frame->motion.bg, last_frame->motion.ba, false, false);
+        frame->preintegration.integrate(be, LANE_TRACKER, frame->image->t, last_frame->motion.bg, last_frame->motion.ba, false, false);
         track_keypoints(last_frame, frame.get());
         if (is_initialized) {
             frame->preintegration.predict(last_frame, frame.get());
@@ -365,6 +365,19 @@ void FeatureTracker::run() {
 Frontend::Frontend(FeatureTracker *ft, Shared &sh) : feature_tracker(ft), sh(sh) {
     initializer = std::make_unique<Initializer>(sh);
     latest_state = std::make_tuple(0.0, nil, PoseState{}, MotionState{});
+    if (sh.cfg.threading == 2) worker = std::thread([this] { worker_main(); });
+}
+
+Frontend::~Frontend() {
+    if (worker.joinable()) {
+        try { drain(); } catch (...) {}
+        {
+            std::lock_guard<std::mutex> lk(mtx);
+            phase.store(3, std::memory_order_release);
+        }
+        cv.notify_all();
+        worker.join();
+    }
 }
 
 void Frontend::issue_frame(Frame *frame) {
@@ -372,30 +385,110 @@ void Frontend::issue_frame(Frame *frame) {
     run();
 }
 
+namespace {
+// a wait that spins first: a hand-over is a few hundred microseconds away when frames are replayed at full speed, a whole
+// frame period away when they arrive in real time
+template <class Pred>
+void spin_then_sleep(std::mutex &mtx, std::condition_variable &cv, Pred ready) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spins = 0;; ++spins) {
+        if (ready()) return;
+        if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+    std::unique_lock<std::mutex> lk(mtx);
+    cv.wait(lk, ready);
+}
+}  // namespace
+
+void Frontend::worker_main() {
+    if (sh.backend.fn.thread_attach) (void)sh.backend.fn.thread_attach(sh.backend.fn.user);
+    for (;;) {
+        spin_then_sleep(mtx, cv, [this] { const int p = phase.load(std::memory_order_acquire); return p == 1 || p == 3; });
+        if (phase.load(std::memory_order_acquire) == 3) return;
+        execute(*job);
+        {
+            std::lock_guard<std::mutex> lk(mtx);
+            phase.store(2, std::memory_order_release);
+        }
+        cv.notify_all();
+    }
+}
+
+void Frontend::drain() {
+    if (!worker.joinable()) return;
+    spin_then_sleep(mtx, cv, [this] { return phase.load(std::memory_order_acquire) != 1; });
+}
+
+// the frontend's step proper: everything of Frontend::run's tracking branch that does not touch the feature-tracking map
+void Frontend::execute(FrontendJob &j) {
+    try {
+        if (j.mirrored) sliding_window_tracker->mirror_frame_finish(j);
+        j.ok = sliding_window_tracker->track(j);
+        j.latest_state = sliding_window_tracker->get_latest_state();
+    } catch (...) {
+        j.error = std::current_exception();
+    }
+}
+
+void Frontend::publish() {
+    if (!job) return;
+    std::unique_ptr<FrontendJob> done = std::move(job);
+    phase.store(0, std::memory_order_relaxed);
+    if (done->error) std::rethrow_exception(done->error);
+    if (done->ok) {
+        auto [t, pose, motion] = done->latest_state;
+        latest_state = std::make_tuple(t, done->frame_id, pose, motion);
+    } else {
+        latest_state = std::make_tuple(0.0, nil, PoseState{}, MotionState{});
+        initializer = std::make_unique<Initializer>(sh);
+        sliding_window_tracker.reset();
+    }
+    // update_track_status's writes to the feature-tracking map's tracks (sliding_window_tracker.cpp:751-756)
+    if (!done->old_tracks_nonstatic.empty()) {
+        Map *ftmap = feature_tracker->map.get();
+        if (const size_t idx = ftmap->frame_index_by_id(done->frame_id); idx != nil) {
+            Frame *old_frame = ftmap->get_frame(idx);
+            for (size_t kp : done->old_tracks_nonstatic)
+                if (kp < old_frame->keypoint_num())
+                    if (Track *old_track = old_frame->get_track(kp)) old_track->set_tag(TT_STATIC, false);
+        }
+    }
+}
+
 void Frontend::run() {
     if (pending_frame_ids.empty()) return;
     HostTimer host_timer__(sh.prof, 3);
+    const int mode = sh.cfg.threading;
+    // the hand-over: the previous step has finished and (pipelined schedule) its results become visible to the tracker
+    drain();
+    if (mode != 0) publish();
     if (initializer) {
+        // initialisation reads the whole feature-tracking map and runs once: always inline
         const size_t pending_frame_id = pending_frame_ids.front();
         pending_frame_ids.clear();
         initializer->mirror_keyframe_map(feature_tracker->map.get(), pending_frame_id);
         if ((sliding_window_tracker = initializer->initialize())) {
-            sliding_window_tracker->feature_tracking_map = feature_tracker->map.get();
             auto [t, pose, motion] = sliding_window_tracker->get_latest_state();
             latest_state = std::make_tuple(t, pending_frame_id, pose, motion);
             initializer.reset();
         }
     } else if (sliding_window_tracker) {
-        const size_t pending_frame_id = pending_frame_ids.front();
+        job = std::make_unique<FrontendJob>();
+        job->frame_id = pending_frame_ids.front();
         pending_frame_ids.pop_front();
-        sliding_window_tracker->mirror_frame(feature_tracker->map.get(), pending_frame_id);
-        if (sliding_window_tracker->track()) {
-            auto [t, pose, motion] = sliding_window_tracker->get_latest_state();
-            latest_state = std::make_tuple(t, pending_frame_id, pose, motion);
+        sliding_window_tracker->mirror_frame_maps(feature_tracker->map.get(), *job);
+        if (mode == 2) {
+            {
+                std::lock_guard<std::mutex> lk(mtx);
+                phase.store(1, std::memory_order_release);
+            }
+            cv.notify_all();
         } else {
-            latest_state = std::make_tuple(0.0, nil, PoseState{}, MotionState{});
-            initializer = std::make_unique<Initializer>(sh);
-            sliding_window_tracker.reset();
+            execute(*job);
+            if (mode == 0) publish();
         }
     }
 }
@@ -406,16 +499,16 @@ void Frontend::run() {
 SlidingWindowTracker::SlidingWindowTracker(std::unique_ptr<Map> keyframe_map, Shared &sh) : map(std::move(keyframe_map)), sh(sh) {
     for (size_t j = 1; j < map->frame_num(); ++j) {
         Frame *frame_i = map->get_frame(j - 1), *frame_j = map->get_frame(j);
-        frame_j->preintegration.integrate(sh.backend, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba, true, true);
+        frame_j->preintegration.integrate(sh.backend, LANE_ESTIMATOR, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba, true, true);
     }
 }
 
-void SlidingWindowTracker::mirror_frame(Map *ftmap, size_t frame_id) {
+void SlidingWindowTracker::mirror_frame_maps(Map *ftmap, FrontendJob &job) {
     HostTimer host_timer__(sh.prof, 4);
     Frame *keyframe = map->get_frame(map->frame_num() - 1);
     Frame *new_frame_i = keyframe;
     if (!keyframe->subframes.empty()) new_frame_i = keyframe->subframes.back().get();
-    const size_t index_i = ftmap->frame_index_by_id(new_frame_i->id()), index_j = ftmap->frame_index_by_id(frame_id);
+    const size_t index_i = ftmap->frame_index_by_id(new_frame_i->id()), index_j = ftmap->frame_index_by_id(job.frame_id);
     if (index_i == nil || index_j == nil) return;
     Frame *old_frame_i = ftmap->get_frame(index_i), *old_frame_j = ftmap->get_frame(index_j);
     std::unique_ptr<Frame> curr_frame = old_frame_j->clone();
@@ -434,13 +527,28 @@ void SlidingWindowTracker::mirror_frame(Map *ftmap, size_t frame_id) {
                 track->set_tag(TT_TRASH, new_track->tag(TT_TRASH) && !new_track->tag(TT_STATIC));
             }
     map->prune_tracks([](const Track *track) { return track->tag(TT_TRASH) && !track->tag(TT_STATIC); });
-    new_frame_j->preintegration.integrate(sh.backend, new_frame_j->image->t, new_frame_i->motion.bg, new_frame_i->motion.ba, true, true);
+    job.mirrored = true;
+    job.new_frame_i = new_frame_i;
+    job.new_frame_j = new_frame_j;
+    if (sh.cfg.parsac_flag) {
+        // what update_track_status will read of the feature-tracking map (nobody writes these bits before the step's own
+        // deferred writes are published: Track::Track is the only other writer of TT_STATIC on that map)
+        job.old_track_flags.assign(old_frame_j->keypoint_num(), 0);
+        for (size_t j = 0; j < old_frame_j->keypoint_num(); ++j)
+            if (const Track *old_track = old_frame_j->get_track(j)) job.old_track_flags[j] = (uint8_t)(1u | (old_track->tag(TT_STATIC) ? 2u : 0u));
+    }
+}
+
+void SlidingWindowTracker::mirror_frame_finish(FrontendJob &job) {
+    HostTimer host_timer__(sh.prof, 4);
+    Frame *new_frame_i = job.new_frame_i, *new_frame_j = job.new_frame_j;
+    new_frame_j->preintegration.integrate(sh.backend, LANE_ESTIMATOR, new_frame_j->image->t, new_frame_i->motion.bg, new_frame_i->motion.ba, true, true);
     new_frame_j->preintegration.predict(new_frame_i, new_frame_j);
 }
 
-bool SlidingWindowTracker::track() {
+bool SlidingWindowTracker::track(FrontendJob &job) {
     if (sh.cfg.parsac_flag) {
-        if (judge_track_status()) update_track_status();
+        if (judge_track_status()) update_track_status(job);
     }
     localize_newframe();
     if (manage_keyframe()) {
@@ -581,7 +689,7 @@ void SlidingWindowTracker::refine_window() {
         }
         jobs.push_back({&frame_j->keyframe_preintegration, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba});
     }
-    const std::vector<char> integrated = PreIntegrator::integrate_batch(sh.backend, jobs, true, true);
+    const std::vector<char> integrated = PreIntegrator::integrate_batch(sh.backend, LANE_ESTIMATOR, jobs, true, true);
     for (size_t j = 1; j < map->frame_num(); ++j)
         if (integrated[j - 1]) solver.add_preintegration(map->get_frame(j - 1), map->get_frame(j), map->get_frame(j)->keyframe_preintegration, false);
     solver.solve();
@@ -720,7 +828,7 @@ void SlidingWindowTracker::integrate_subframes(Frame *frame) {
         const Frame *prev_frame = (i == 0 ? frame : frame->subframes[i - 1].get());
         jobs.push_back({&subframe->preintegration, subframe->image->t, prev_frame->motion.bg, prev_frame->motion.ba});
     }
-    (void)PreIntegrator::integrate_batch(sh.backend, jobs, true, true);
+    (void)PreIntegrator::integrate_batch(sh.backend, LANE_ESTIMATOR, jobs, true, true);
 }
 
 void SlidingWindowTracker::refine_subwindow() {
@@ -848,7 +956,7 @@ bool SlidingWindowTracker::judge_track_status() {
     Frame *keyframe = map->get_frame(map->frame_num() - 2);
     Frame *last_frame = keyframe;
     if (!keyframe->subframes.empty()) last_frame = keyframe->subframes.back().get();
-    curr_frame->preintegration.integrate(sh.backend, curr_frame->image->t, last_frame->motion.bg, last_frame->motion.ba, true, true);
+    curr_frame->preintegration.integrate(sh.backend, LANE_ESTIMATOR, curr_frame->image->t, last_frame->motion.bg, last_frame->motion.ba, true, true);
     curr_frame->preintegration.predict(last_frame, curr_frame);
 
     std::vector<V2> P2D;
@@ -907,12 +1015,11 @@ bool SlidingWindowTracker::judge_track_status() {
     return true;
 }
 
-void SlidingWindowTracker::update_track_status() {
+void SlidingWindowTracker::update_track_status(FrontendJob &job) {
     Frame *curr_frame = map->get_frame(map->frame_num() - 1);
-    if (!feature_tracking_map) return;
-    const size_t frame_id = feature_tracking_map->frame_index_by_id(curr_frame->id());
-    if (frame_id == nil) return;
-    Frame *old_frame = feature_tracking_map->get_frame(frame_id);
+    // the reference looks the new frame up in the feature-tracking map here (:700-704); its tracks' TT_STATIC bits were
+    // taken at the hand-over (mirror_frame_maps) and the writes below are published at the next one
+    if (!job.mirrored || job.old_track_flags.size() != curr_frame->keypoint_num()) return;
     std::vector<size_t> outlier_cnts(curr_frame->keypoint_num(), 0), matches_cnts(curr_frame->keypoint_num(), 0);
     const size_t last = map->frame_num() - 1;
     // std::min(last, std::max(last - check_size, size_t(0))) with unsigned wrap-around, as written (:706-709)
@@ -930,16 +1037,19 @@ void SlidingWindowTracker::update_track_status() {
     }
     for (size_t i = 0; i < curr_frame->keypoint_num(); i++)
         if (Track *curr_track = curr_frame->get_track(i)) {
-            // the lookup goes through the frame id (compare<Frame *>), so the feature-tracker's frame finds the window's clone
-            const size_t j = curr_track->get_keypoint_index(old_frame);
-            if (j == 0 || j == nil) continue;  // (`if (size_t j = ...)` index-0 quirk, :727)
-            Track *old_track = old_frame->get_track(j);
+            // the lookup goes through the frame id (compare<Frame *>), so the feature-tracker's frame finds the window's
+            // clone: the keypoint index in old_frame is the one in curr_frame
+            const size_t j = i;
+            if (j == 0) continue;  // (`if (size_t j = ...)` index-0 quirk, :727)
+            const bool old_exists = (job.old_track_flags[j] & 1u) != 0;
+            bool old_static = (job.old_track_flags[j] & 2u) != 0;
             const size_t outlier_th = map->frame_num() / 2;
             if (outlier_cnts[i] > outlier_th / 2 && outlier_cnts[i] > 0.8 * matches_cnts[i]) curr_track->set_tag(TT_STATIC, false);
-            if (old_track && (!old_track->tag(TT_STATIC) || !curr_track->tag(TT_STATIC))) {
-                if (curr_track->tag(TT_STATIC) || old_track->tag(TT_STATIC)) sh.counters.tracks_marked_dynamic++;
+            if (old_exists && (!old_static || !curr_track->tag(TT_STATIC))) {
+                if (curr_track->tag(TT_STATIC) || old_static) sh.counters.tracks_marked_dynamic++;
                 curr_track->set_tag(TT_STATIC, false);
-                old_track->set_tag(TT_STATIC, false);
+                job.old_tracks_nonstatic.push_back(j);
+                old_static = false;
             }
         }
 }
@@ -1112,6 +1222,7 @@ void rdvio_pipeline_config_default(rdvio_pipeline_config *c) {
     c->random = 648;
     c->parsac_flag = 0;
     c->parsac_keyframe_check_size = 3;
+    c->threading = 0;
 }
 
 int rdvio_pipeline_create(rdvio_pipeline **out, const rdvio_pipeline_config *cfg, const rdvio_backend *backend) {
@@ -1121,7 +1232,8 @@ int rdvio_pipeline_create(rdvio_pipeline **out, const rdvio_pipeline_config *cfg
         !backend->image_destroy || !backend->preintegrate || !backend->ba_solve || !backend->marginalize)
         return RDVIO_ERR_INVALID;
     if (cfg->width <= 0 || cfg->height <= 0 || cfg->sliding_window_size < 2 || cfg->sliding_window_tracker_frequent < 1 ||
-        cfg->initializer_keyframe_num < 2 || cfg->initializer_keyframe_gap < 1 || cfg->feature_tracker_max_keypoint_detection < 1)
+        cfg->initializer_keyframe_num < 2 || cfg->initializer_keyframe_gap < 1 || cfg->feature_tracker_max_keypoint_detection < 1 ||
+        cfg->threading < 0 || cfg->threading > 2)
         return RDVIO_ERR_INVALID;
     auto *p = new rdvio_pipeline();
     p->shared.cfg = *cfg;
@@ -1135,6 +1247,7 @@ int rdvio_pipeline_create(rdvio_pipeline **out, const rdvio_pipeline_config *cfg
 void rdvio_pipeline_destroy(rdvio_pipeline *p) {
     if (!p) return;
     const rdvio_backend fn = p->shared.backend.fn;
+    try { p->handler->frontend.drain(); } catch (...) {}
     if (p->shared.prof.on) {   // diagnostic: inclusive stage times (backend calls inside) and the backend's own share
         const Counters &c = p->shared.counters;
         std::fprintf(stderr, "[rdvio pipeline] %ld frames; inclusive stage times, ms per frame:\n", (long)c.frames_tracked);
@@ -1223,8 +1336,11 @@ int rdvio_pipeline_latest_state(const rdvio_pipeline *p, double *t, double *pose
 }
 
 int rdvio_pipeline_window_state(const rdvio_pipeline *p, double *t, double *state16) {
-    if (!p || !p->handler->frontend.sliding_window_tracker) return 0;
-    auto [ts, pose, motion] = p->handler->frontend.sliding_window_tracker->get_latest_state();
+    if (!p) return 0;
+    // Frontend::get_latest_state (frontend.cpp:79-83): the newest state the frontend has handed to the tracker -- in inline
+    // mode SlidingWindowTracker::get_latest_state() of the step that just ran, in the pipelined modes the published one
+    auto [ts, frame_id, pose, motion] = p->handler->frontend.get_latest_state();
+    if (frame_id == nil) return 0;
     if (t) *t = ts;
     if (state16) {
         store_pose(pose, state16);
@@ -1263,7 +1379,9 @@ int rdvio_pipeline_transform_world_cam(const rdvio_pipeline *p, double *T) {
 }
 
 int rdvio_pipeline_local_map(const rdvio_pipeline *p, double *xyz, int capacity) {
-    if (!p || !p->handler->frontend.sliding_window_tracker) return 0;
+    if (!p) return 0;
+    p->handler->frontend.drain();  // the frontend's step in flight owns the sliding-window map
+    if (!p->handler->frontend.sliding_window_tracker) return 0;
     const Map *map = p->handler->frontend.sliding_window_tracker->map.get();
     int n = 0;
     for (size_t i = 0; i < map->track_num(); ++i) {
@@ -1297,6 +1415,7 @@ int rdvio_pipeline_last_frame_keypoints(const rdvio_pipeline *p, int64_t *track_
 
 int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out) {
     if (!p || !out) return RDVIO_ERR_INVALID;
+    p->handler->frontend.drain();
     const Counters &c = p->shared.counters;
     const Map *ft = p->handler->feature_tracker.map.get();
     out[0] = c.frames_tracked; out[1] = c.window_solves; out[2] = c.keyframes; out[3] = c.marginalizations;
@@ -1312,8 +1431,9 @@ int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out) {
     out[28] = c.tracks_marked_dynamic;
     for (int k = 0; k < 7; ++k) {
         const bool pre = k == 3;  // microseconds and calls per backend call class
-        out[11 + 2 * k] = (int64_t)(1e6 * (pre ? p->shared.backend.preintegrate_seconds : c.backend_seconds[k]));
-        out[12 + 2 * k] = pre ? p->shared.backend.preintegrate_calls : c.backend_calls[k];
+        const Backend &be = p->shared.backend;
+        out[11 + 2 * k] = (int64_t)(1e6 * (pre ? be.preintegrate_seconds[0] + be.preintegrate_seconds[1] : c.backend_seconds[k]));
+        out[12 + 2 * k] = pre ? be.preintegrate_calls[0] + be.preintegrate_calls[1] : c.backend_calls[k];
     }
     return RDVIO_OK;
 }

@@ -1,18 +1,36 @@
 // The per-frame orchestration: Handler -> FeatureTracker -> Frontend -> (bootstrap | SlidingWindowTracker).
-// Single-threaded (the reference's THREADING=OFF path: FeatureTracker::track_frame and Frontend::issue_frame run
-// synchronously, feature_tracker.cpp:113-118, frontend.cpp:72-77).
+//
+// Threading (rdvio_pipeline_config::threading).  The reference runs FeatureTracker and Frontend either synchronously
+// (THREADING=OFF: FeatureTracker::track_frame and Frontend::issue_frame call run() directly, feature_tracker.cpp:113-118,
+// frontend.cpp:72-77) or on two polling worker threads that meet under the map mutex (handler.cpp:35-50) -- in which case
+// what the tracker sees of the frontend's results depends on timing.  Here:
+//   0  inline (THREADING=OFF);
+//   1  the pipelined schedule on one thread;
+//   2  the pipelined schedule with the frontend's step on a worker thread.
+// The pipelined schedule fixes the interleaving: when the tracker has finished frame k it (a) waits for the frontend's step
+// for frame k-1 and PUBLISHES its results to the tracker's side (latest optimised state, deferred track tags), (b) does the
+// part of mirror_frame that touches both maps, (c) starts the frontend's step for frame k.  Between two hand-overs the two
+// steps share no mutable state: the frontend's step works on the sliding-window map and a snapshot, the tracker on the
+// feature-tracking map and what was published.  1 and 2 therefore compute the same thing; 2 overlaps them.
 #pragma once
 
 #include <array>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <deque>
+#include <exception>
+#include <mutex>
 #include <optional>
+#include <thread>
 #include <tuple>
 
 #include "map.hpp"
 
 namespace rdvio_pipe {
 
+// Written by the tracker's side: frames_tracked, no_translation_frames, backend classes 0-2 and 6; by the frontend's
+// step: everything else -- no field has two writers.
 struct Counters {
     int64_t frames_tracked = 0, window_solves = 0, keyframes = 0, marginalizations = 0, localizations = 0, subwindow_solves = 0;
     int64_t max_problem_frames = 0, max_problem_factors = 0, solver_iterations = 0;
@@ -105,11 +123,30 @@ class BaBuilder {
     const MarginalizationPrior *prior = nullptr;
 };
 
+// One step of the frontend (Frontend::run's tracking branch, frontend.cpp:47-66) as a unit of work: prepared at the
+// hand-over (both maps quiescent), executed inline or on the worker, its results published at the next hand-over.
+struct FrontendJob {
+    size_t frame_id = nil;
+    bool mirrored = false;                   // mirror_frame found both frames (sliding_window_tracker.cpp:33-36)
+    Frame *new_frame_i = nullptr, *new_frame_j = nullptr;
+    // update_track_status reads, per keypoint of the new frame, whether the FEATURE-TRACKING map's track exists (bit 0) and
+    // is TT_STATIC (bit 1) (sliding_window_tracker.cpp:731-757); taken at the hand-over
+    std::vector<uint8_t> old_track_flags;
+    // ---- results
+    bool ok = true;
+    std::tuple<double, PoseState, MotionState> latest_state;
+    std::vector<size_t> old_tracks_nonstatic;  // keypoints of the new frame whose feature-tracking-map track loses TT_STATIC
+    std::exception_ptr error;
+};
+
 class SlidingWindowTracker {
   public:
     SlidingWindowTracker(std::unique_ptr<Map> keyframe_map, Shared &sh);
-    void mirror_frame(Map *feature_tracking_map, size_t frame_id);
-    bool track();
+    // mirror_frame (sliding_window_tracker.cpp:29-78) in two halves: the part that reads and tags the feature-tracking map
+    // (hand-over, caller's thread) and the preintegration + prediction of the new frame (the frontend's step)
+    void mirror_frame_maps(Map *feature_tracking_map, FrontendJob &job);
+    void mirror_frame_finish(FrontendJob &job);
+    bool track(FrontendJob &job);
     std::tuple<double, PoseState, MotionState> get_latest_state() const;
     std::unique_ptr<Map> map;
 
@@ -124,13 +161,10 @@ class SlidingWindowTracker {
     void marginalize_frame0();
     // RD dynamic-outlier path (parsac_flag; sliding_window_tracker.cpp:487-769)
     bool judge_track_status();
-    void update_track_status();
+    void update_track_status(FrontendJob &job);
     bool filter_parsac_2d2d(Frame *frame_i, Frame *frame_j, std::vector<char> &mask, std::vector<size_t> &pts_to_index);
     Shared &sh;
     double m_th = 0.0;
-
-  public:
-    Map *feature_tracking_map = nullptr;  // frontend.cpp:37-38
 };
 
 // Bootstrap of the window from externally supplied keyframe states (the reference's Initializer without its SfM /
@@ -163,18 +197,32 @@ class FeatureTracker;
 class Frontend {
   public:
     Frontend(FeatureTracker *ft, Shared &sh);
+    ~Frontend();
     void issue_frame(Frame *frame);
+    // what the feature tracker sees: the state PUBLISHED at the last hand-over (in inline mode: the newest)
     std::tuple<double, size_t, PoseState, MotionState> get_latest_state() const { return latest_state; }
     int get_system_state() const { return initializer ? 0 : (sliding_window_tracker ? 1 : 3); }
+    // waits for the step in flight (threading == 2); publishes nothing -- for readers of the sliding-window map
+    void drain();
     std::unique_ptr<SlidingWindowTracker> sliding_window_tracker;
 
   private:
     void run();
+    void execute(FrontendJob &job);   // the frontend's step proper (either thread)
+    void publish();                   // the finished step's results -> the tracker's side
+    void worker_main();
     FeatureTracker *feature_tracker;
     Shared &sh;
     std::unique_ptr<Initializer> initializer;
     std::deque<size_t> pending_frame_ids;
     std::tuple<double, size_t, PoseState, MotionState> latest_state;
+    // the step in flight / finished but not yet published
+    std::unique_ptr<FrontendJob> job;
+    // worker (threading == 2): one slot, phase 0 idle, 1 posted, 2 done, 3 quit; waits spin briefly, then sleep
+    std::thread worker;
+    std::atomic<int> phase{0};
+    std::mutex mtx;
+    std::condition_variable cv;
 };
 
 class FeatureTracker {

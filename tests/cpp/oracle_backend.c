@@ -137,4 +137,6 @@ void rdvio_oracle_backend_fill(rdvio_backend *b) {
     b->destroy = NULL;
     b->parsac_score = NULL; /* the CPU path scores hypotheses with the orchestration's own host code (parsac.hpp) */
     b->parsac_fetch = NULL;
+    b->preintegrate_estimator = NULL; /* ro_preintegrate keeps no state: safe from both threads */
+    b->thread_attach = NULL;
 }

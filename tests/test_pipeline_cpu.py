@@ -92,6 +92,42 @@ def test_oracle_backed_pipeline_tracks_the_stream(libs, stream):
         assert np.array_equal(ia, ib) and np.array_equal(xa, xb)
 
 
+@pytest.mark.parametrize("parsac", [0, 1])
+def test_pipelined_schedule_is_the_same_on_one_thread_and_on_two(libs, parsac):
+    """rdvio_pipeline_config::threading: 1 (the pipelined tracker / frontend schedule executed on one thread -- the CPU path of the
+    comparison) and 2 (the frontend's step on a worker thread, concurrent with the tracker's next frame -- the product) must
+    agree bit for bit: between two hand-overs the steps share no mutable state.  With the RD path on, the deferred TT_STATIC
+    writes and the track-flag snapshot are exercised as well."""
+    lib, shim = libs
+    # the RD case at full resolution: only there does the moving billboard carry enough tracks for judge_track_status to fire
+    Wt, Ht, Kt = (752, 480, synth.EUROC_K) if parsac else (W, H, K)
+    frames, ts, imu, gt = synth.make_stream(80 if parsac else 60, Wt, Ht, Kt, mover=bool(parsac))
+    over = dict(OVER, parsac_flag=parsac, parsac_keyframe_check_size=1)
+    runs = {}
+    for mode in (0, 1, 2):
+        cfg = pu.default_config(lib, Kt, Wt, Ht, synth.EUROC_EXTR, synth.EUROC_NOISE, **dict(over, threading=mode))
+        runs[mode] = pu.run_stream(lib, pu.oracle_pipeline_factory(lib, shim, cfg), frames, ts, imu, gt)
+    a, b = runs[1], runs[2]
+    assert np.array_equal(a["states"], b["states"], equal_nan=True) and np.array_equal(a["traj"], b["traj"], equal_nan=True)
+    assert (a["counters"][:11] == b["counters"][:11]).all() and (a["counters"][25:] == b["counters"][25:]).all()
+    for (ia, xa), (ib, xb) in zip(a["keypoints"], b["keypoints"]):
+        assert np.array_equal(ia, ib) and np.array_equal(xa, xb)
+    # the pipelined schedule still tracks: same frames through, on the ground truth like the inline schedule
+    st = a["states"]
+    ok = ~np.isnan(st[:, 0])
+    assert a["counters"][0] == len(ts) and a["sys_state"][-1] == 1 and ok.sum() >= 30
+    p_gt = np.array([synth.traj_pose(t)[1] for t in st[ok, 0]])
+    assert np.linalg.norm(st[ok, 5:8] - p_gt, axis=1).max() < (0.25 if parsac else 0.15)
+    e0 = runs[0]["states"]
+    ok0 = ~np.isnan(e0[:, 0])
+    err0 = np.linalg.norm(e0[ok0, 5:8] - np.array([synth.traj_pose(t)[1] for t in e0[ok0, 0]]), axis=1).mean()
+    assert np.linalg.norm(st[ok, 5:8] - p_gt, axis=1).mean() < 1.2 * err0    # no accuracy lost to the one-frame lag
+    # the inline schedule (the reference's THREADING=OFF) sees every result one frame earlier: same work, not the same bits
+    assert runs[0]["counters"][0] == len(ts) and abs(int(runs[0]["counters"][4]) - int(a["counters"][4])) <= 1
+    if parsac:
+        assert a["counters"][27] >= 30 and a["counters"][28] >= 20   # judgements ran; tracks were switched to non-static
+
+
 def test_pipeline_stays_initialising_while_the_initializer_fails(libs, stream):
     # no bootstrap states and an unreachable match count (initializer.cpp:172: common_track_num < min_matches)
     lib, shim = libs
