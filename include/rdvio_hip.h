@@ -81,6 +81,9 @@ int rdvio_hip_sync(rdvio_hip_ctx *ctx);
 #define RDVIO_LANE_SOLVER 1
 #define RDVIO_LANE_MARG 2
 int rdvio_hip_ctx_set_lane_stream(rdvio_hip_ctx *ctx, int lane, void *stream);
+/* gives the solver and the marginalisation lane a context-owned stream each unless they already have one (a threaded
+ * pipeline calls this: two host threads on one stream would wait for each other's kernels) */
+int rdvio_hip_ctx_ensure_lane_streams(rdvio_hip_ctx *ctx);
 /* How the library's host-side waits wait: 0 (default) = spinning (hipStreamSynchronize: lowest latency, one core per waiting
  * thread); 1 = blocking on an event created with hipEventBlockingSync (the waiting thread sleeps) -- for processes that drive
  * more sequences than they have cores (rdvio_hip_run_sequences switches its contexts to 1 for the run when n_seq exceeds

@@ -156,6 +156,32 @@ int rdvio_pipeline_last_frame_keypoints(const rdvio_pipeline *p, int64_t *track_
  * switched to non-static by update_track_status */
 int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out29);
 
+/* The reference's test_euroc loop (examples/test_euroc.cpp:46-95: IMU samples and camera frames pushed in timestamp order)
+ * over a stream that is resident in host memory, as one call -- what a benchmark or an offline run drives instead of paying an
+ * FFI crossing per sample.  Every IMU sample with t <= frame_t[k] is pushed (add_motion) before frame k (add_frame), the
+ * remaining samples after the last frame.  Outputs (each may be NULL) get one row per camera frame the feature tracker has
+ * consumed, in processing order: the keypoint table of the newest tracked frame (rdvio_pipeline_last_frame_keypoints), the
+ * output pose (rdvio_pipeline_latest_state), the window state (rdvio_pipeline_window_state; NaN rows before the first),
+ * rdvio_pipeline_state, and the time since the start of the call at which the frame was done. */
+typedef struct rdvio_replay {
+    int32_t n_frames, width, height, stride;
+    const uint8_t *const *frames; /* n_frames gray images */
+    const double *frame_t;        /* n_frames */
+    int32_t n_imu;
+    const double *imu;            /* n_imu x 7: t, gyro (3), acc (3) */
+    int32_t kp_capacity;          /* rows of kp_ids / kp_xy per frame */
+    int64_t *kp_ids;              /* n_frames x kp_capacity */
+    double *kp_xy;                /* n_frames x kp_capacity x 2 */
+    int32_t *kp_n;                /* n_frames */
+    double *latest;               /* n_frames x 8: t, q(4), p(3) */
+    double *window;               /* n_frames x 17: t, state16 */
+    int32_t *sys_state;           /* n_frames */
+    double *done_s;               /* n_frames */
+    int32_t frames_processed;     /* out */
+    double elapsed_s;             /* out: whole call */
+} rdvio_replay;
+int rdvio_pipeline_replay(rdvio_pipeline *p, rdvio_replay *r);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,31 @@ def build_variant(name):
         subprocess.check_call(["gcc", "-std=c99", "-fPIC", "-shared", "-Wall", "-Wno-unused-parameter"] + flags + ["-o", out] + srcs + ["-lm"])
     return out
 
+
+
+def build_backend(variant=None):
+    """gcc oracle/backend/oracle_backend.c (the rdvio_backend function table over the oracle: the CPU path of the pipeline
+    comparison) against liboracle.so -- or against the timing build `variant` (VARIANTS) -- into oracle/_build/; returns the
+    loaded library (exports rdvio_oracle_backend_fill)."""
+    root = os.path.dirname(_HERE)
+    out_dir = os.path.join(_HERE, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    if variant is None:
+        build()
+        core = os.path.join(_HERE, "liboracle.so")
+        out = os.path.join(out_dir, "liboracle_backend.so")
+        flags = ["-O2"]
+    else:
+        core = build_variant(variant)
+        out = os.path.join(out_dir, f"liboracle_backend_{variant}_{_host_tag()}.so")
+        flags = VARIANTS[variant]
+    src = os.path.join(_HERE, "backend", "oracle_backend.c")
+    deps = [src, core, os.path.join(root, "include", "rdvio_pipeline.h"), os.path.join(root, "include", "rdvio_hip.h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["gcc", "-std=c99", "-fPIC", "-shared", "-Wall"] + flags + ["-o", out, src, core, "-Wl,-rpath," + os.path.dirname(core), "-lm"])
+    return ctypes.CDLL(out)
+
+
 STATE_SIZE = 16
 PREINT_SIZE = 506
 PREINT_T, PREINT_Q, PREINT_P, PREINT_V, PREINT_COV, PREINT_SIC, PREINT_JAC = 0, 1, 5, 8, 11, 236, 461

@@ -1,11 +1,12 @@
-/* TEST INFRASTRUCTURE: an rdvio_backend (include/rdvio_pipeline.h) over the CPU oracle, so that the test-suite can run
- * the product's host orchestration over the CPU path and compare trajectories / feature indices with the HIP path
- * (SURVEY.md 8d metrics 2 and 3).  Built by tests/pipeline_util.py into tests/_build/; never part of the product. */
+/* ORACLE / TEST INFRASTRUCTURE: an rdvio_backend (include/rdvio_pipeline.h) over the CPU oracle, so that the test-suite and
+ * bench.py's cpu_baseline leg can run the product's host orchestration over the CPU path and compare trajectories / feature
+ * indices with the HIP path (SURVEY.md 8d metrics 2 and 3).  Built by oracle.build_backend() into oracle/_build/; never part
+ * of the product (nothing under rd_vio_amd/ refers to it). */
 #include <stdlib.h>
 #include <string.h>
 
 #include "../../include/rdvio_pipeline.h"
-#include "../../oracle/rdvio_oracle.h"
+#include "../rdvio_oracle.h"
 
 typedef struct {
     uint8_t *gray;

@@ -260,6 +260,14 @@ int rdvio_hip_ctx_set_lane_stream(rdvio_hip_ctx *ctx, int lane, void *stream) {
     return RDVIO_OK;
 }
 
+int rdvio_hip_ctx_ensure_lane_streams(rdvio_hip_ctx *ctx) {
+    if (!ctx) return RDVIO_ERR_INVALID;
+    for (int lane = RDVIO_LANE_SOLVER; lane <= RDVIO_LANE_MARG; ++lane)
+        if (ctx->lane[lane] == ctx->lane[RDVIO_LANE_FRONTEND])
+            if (int rc = rdvio_hip_ctx_set_lane_stream(ctx, lane, nullptr)) return rc;
+    return RDVIO_OK;
+}
+
 int rdvio_hip_lane_wait(rdvio_hip_ctx *ctx, int lane, int on_lane) {
     if (!ctx || bad_lane(lane) || bad_lane(on_lane)) return RDVIO_ERR_INVALID;
     if (ctx->lane[lane] == ctx->lane[on_lane]) return RDVIO_OK;  // same stream: already ordered

@@ -100,6 +100,10 @@ void destroy(void *user) { delete static_cast<HipBackend *>(user); }
 
 extern "C" int rdvio_pipeline_create_hip(rdvio_pipeline **out, const rdvio_pipeline_config *cfg, rdvio_hip_ctx *ctx) {
     if (!out || !cfg || !ctx) return RDVIO_ERR_INVALID;
+    // tracker and estimator on two host threads: each needs a stream of its own (a shared stream would make every wait of
+    // one thread wait for the other's kernels)
+    if (cfg->threading == 2)
+        if (int rc = rdvio_hip_ctx_ensure_lane_streams(ctx)) return rc;
     auto *b = new HipBackend{ctx};
     rdvio_backend fn;
     fn.user = b;

@@ -4,6 +4,7 @@
 #include "parsac.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1411,6 +1412,52 @@ int rdvio_pipeline_last_frame_keypoints(const rdvio_pipeline *p, int64_t *track_
         }
     }
     return n;
+}
+
+int rdvio_pipeline_replay(rdvio_pipeline *p, rdvio_replay *r) {
+    if (!p || !r || r->n_frames < 0 || r->n_imu < 0 || (r->n_frames > 0 && (!r->frames || !r->frame_t)) || (r->n_imu > 0 && !r->imu)) return RDVIO_ERR_INVALID;
+    if ((r->kp_ids || r->kp_xy) && r->kp_capacity <= 0) return RDVIO_ERR_INVALID;
+    const auto t0 = std::chrono::steady_clock::now();
+    const double nan = std::nan("");
+    int64_t seen = p->shared.counters.frames_tracked;
+    int rows = 0;
+    auto record = [&]() {   // the feature tracker consumed another frame
+        if (rows >= r->n_frames) return;
+        const size_t k = (size_t)rows++;
+        if (r->kp_n || r->kp_ids || r->kp_xy) {
+            const int n = rdvio_pipeline_last_frame_keypoints(p, r->kp_ids ? r->kp_ids + k * (size_t)r->kp_capacity : nullptr,
+                                                              r->kp_xy ? r->kp_xy + 2 * k * (size_t)r->kp_capacity : nullptr, r->kp_capacity);
+            if (r->kp_n) r->kp_n[k] = n;
+        }
+        if (r->latest) {
+            double *o = r->latest + 8 * k;
+            if (!rdvio_pipeline_latest_state(p, o, o + 1)) std::fill(o, o + 8, nan);
+        }
+        if (r->window) {
+            double *o = r->window + 17 * k;
+            if (!rdvio_pipeline_window_state(p, o, o + 1)) std::fill(o, o + 17, nan);
+        }
+        if (r->sys_state) r->sys_state[k] = rdvio_pipeline_state(p);
+        if (r->done_s) r->done_s[k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    };
+    int ii = 0;
+    auto push_imu = [&](const double *row) {
+        const int rc = rdvio_pipeline_add_motion(p, row[0], row + 4, row + 1);
+        if (rc == RDVIO_OK && p->shared.counters.frames_tracked != seen) {
+            seen = p->shared.counters.frames_tracked;
+            record();
+        }
+        return rc;
+    };
+    int rc = RDVIO_OK;
+    for (int k = 0; k < r->n_frames && rc == RDVIO_OK; ++k) {
+        while (ii < r->n_imu && r->imu[7 * (size_t)ii] <= r->frame_t[k] && rc == RDVIO_OK) rc = push_imu(r->imu + 7 * (size_t)ii++);
+        if (rc == RDVIO_OK) rc = rdvio_pipeline_add_frame(p, r->frame_t[k], r->frames[k], r->width, r->height, r->stride, nullptr);
+    }
+    while (ii < r->n_imu && rc == RDVIO_OK) rc = push_imu(r->imu + 7 * (size_t)ii++);
+    r->frames_processed = rows;
+    r->elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
 }
 
 int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out) {

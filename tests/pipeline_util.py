@@ -1,5 +1,5 @@
-"""Test harness for the per-frame orchestration (librdvio_pipeline.so): builds the oracle-backed rdvio_backend shim
-(tests/cpp/oracle_backend.c -> tests/_build/), feeds a synthetic stream through rdvio_pipeline_* exactly like the
+"""Test harness for the per-frame orchestration (librdvio_pipeline.so): loads the oracle-backed rdvio_backend shim
+(oracle/backend/oracle_backend.c -> oracle/_build/), feeds a synthetic stream through rdvio_pipeline_* exactly like the
 reference's test_euroc loop (examples/test_euroc.cpp:46-95: IMU and camera interleaved by timestamp) and collects the
 trajectory, the per-frame keypoint/track tables and the counters."""
 import ctypes
@@ -25,23 +25,14 @@ PIPELINE_EXPORTS = [
     "rdvio_pipeline_last_error", "rdvio_pipeline_set_init_states", "rdvio_pipeline_add_frame", "rdvio_pipeline_add_motion",
     "rdvio_pipeline_add_gyro", "rdvio_pipeline_add_acc", "rdvio_pipeline_state", "rdvio_pipeline_latest_state",
     "rdvio_pipeline_window_state", "rdvio_pipeline_transform_world_cam", "rdvio_pipeline_local_map",
-    "rdvio_pipeline_last_frame_keypoints", "rdvio_pipeline_counters",
+    "rdvio_pipeline_last_frame_keypoints", "rdvio_pipeline_counters", "rdvio_pipeline_replay",
 ]
 
 
 def build_oracle_backend():
-    """gcc the shim against liboracle.so; returns the loaded library (exports rdvio_oracle_backend_fill)."""
+    """the rdvio_backend shim over the oracle (oracle/backend/oracle_backend.c), built by the oracle package"""
     import oracle
-    oracle.build()
-    os.makedirs(BUILD, exist_ok=True)
-    out = os.path.join(BUILD, "liboracle_backend.so")
-    src = os.path.join(ROOT, "tests", "cpp", "oracle_backend.c")
-    odir = os.path.join(ROOT, "oracle")
-    deps = [src, os.path.join(odir, "liboracle.so"), os.path.join(ROOT, "include", "rdvio_pipeline.h")]
-    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.check_call(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-Wall", "-o", out, src, "-L" + odir, "-loracle",
-                               "-Wl,-rpath," + odir, "-lm"])
-    return ctypes.CDLL(out)
+    return oracle.build_backend()
 
 
 def run_stream(lib, make_pipeline, frames, ts, imu, gt, max_kp=600):

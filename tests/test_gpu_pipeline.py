@@ -14,9 +14,13 @@ OVER = dict(sliding_window_size=8, feature_tracker_max_keypoint_detection=150, f
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("schedule", ["inline", "threaded"])
 @pytest.mark.parametrize("case", ["translation_full_res", "rotation_phase_half_res", "full_initializer_half_res", "dynamic_object_parsac",
                                   "dynamic_object_parsac_300_w10", "synthetic_720p_1000_w16"])
-def test_hip_pipeline_reproduces_the_cpu_path(case):
+def test_hip_pipeline_reproduces_the_cpu_path(case, schedule):
+    """schedule "inline": the reference's THREADING=OFF on both paths.  "threaded": the product's tracker / frontend split --
+    the HIP path with the frontend's step on a worker thread (threading = 2: two host threads, frontend lane and solver lane
+    concurrently) against the CPU path running the same pipelined schedule on one thread (threading = 1)."""
     if case == "translation_full_res":
         W, H, K = 752, 480, synth.EUROC_K
         frames, ts, imu, gt = synth.make_stream(36, W, H, K)
@@ -64,11 +68,13 @@ def test_hip_pipeline_reproduces_the_cpu_path(case):
     if case == "synthetic_720p_1000_w16":
         over = dict(OVER, sliding_window_size=16, feature_tracker_max_keypoint_detection=1000)
     max_kp = 4096
-    cfg = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **over)
+    threaded = schedule == "threaded"
+    cfg = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **dict(over, threading=1 if threaded else 0))
     cpu = pu.run_stream(lib, pu.oracle_pipeline_factory(lib, shim, cfg), frames, ts, imu, gt, max_kp=max_kp)
+    cfg_gpu = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **dict(over, threading=2 if threaded else 0))
     ctx = rd_vio_amd.Context(max_width=W, max_height=H, max_features=4096, max_window=over["sliding_window_size"] + 8, max_factors=20000)
     try:
-        gpu = pu.run_stream(lib, pu.hip_pipeline_factory(lib, ctx, cfg), frames, ts, imu, gt, max_kp=max_kp)
+        gpu = pu.run_stream(lib, pu.hip_pipeline_factory(lib, ctx, cfg_gpu), frames, ts, imu, gt, max_kp=max_kp)
     finally:
         ctx.close()
     assert (gpu["counters"][:11] == cpu["counters"][:11]).all(), (gpu["counters"], cpu["counters"])   # [11:] are timers
@@ -108,7 +114,7 @@ def test_hip_pipeline_reproduces_the_cpu_path(case):
         assert cpu["counters"][8] >= 17 and cpu["counters"][9] >= 4096   # a solve large enough for the helper workgroups
     if case.startswith("dynamic_object_parsac"):
         assert cpu["counters"][27] >= 30 and cpu["counters"][28] >= 20   # judgements ran, tracks were switched to non-static
-        off = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **dict(over, parsac_flag=0))
+        off = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **dict(over, parsac_flag=0, threading=1 if threaded else 0))
         ref = pu.run_stream(lib, pu.oracle_pipeline_factory(lib, shim, off), frames, ts, imu, gt, max_kp=max_kp)
         so = ref["states"]
         oo = ~np.isnan(so[:, 0])
