@@ -287,6 +287,16 @@ typedef struct {
     int32_t pad_;
 } rdvio_parsac_result;
 int rdvio_hip_parsac_score(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *batch, rdvio_parsac_result *results);
+/* The same with the hypotheses GENERATED on the device (row N2): sampling stays with the caller (the reference's samplers draw
+ * in a fixed rand() / default_random_engine order), `samples` holds the point indices of n_iterations minimal samples -- six per
+ * iteration for kind 1 (solve_pnp_6pt, src/rdvio_geometry/include/rdvio/geometry/pnp.h:11-48: EPnP on float32 copies, float32
+ * Rodrigues round trip; one pose per iteration), five for kind 0 (solve_essential_5pt, src/rdvio_geometry/src/essential.cpp:286-298;
+ * up to ten essential matrices per iteration).  One launch solves all samples (one wavefront each, csrc/hypo_solvers.hpp: the
+ * source the host road runs, so models are bit-identical) and the scoring kernel reads the models where they were written.
+ * batch->models / n_models are ignored.  Out: models_per_iteration (n_iterations), then packed in iteration order models
+ * (x 12 or x 9 doubles; capacity n_iterations x (1 | 10)) and results; rdvio_hip_parsac_fetch takes packed indices. */
+int rdvio_hip_parsac_generate_score(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *batch, int n_iterations, const int32_t *samples,
+                                    int32_t *models_per_iteration, double *models, rdvio_parsac_result *results);
 /* inlier mask (n_points) and per-occupied-bin inlier counts (n_valid) of model `model` of the last scored batch */
 int rdvio_hip_parsac_fetch(rdvio_hip_ctx *ctx, int model, uint8_t *mask, int32_t *bin_inliers);
 

@@ -140,4 +140,5 @@ void rdvio_oracle_backend_fill(rdvio_backend *b) {
     b->parsac_fetch = NULL;
     b->preintegrate_estimator = NULL; /* ro_preintegrate keeps no state: safe from both threads */
     b->thread_attach = NULL;
+    b->parsac_generate_score = NULL;
 }

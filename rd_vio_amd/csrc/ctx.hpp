@@ -97,6 +97,7 @@ struct rdvio_hip_ctx {
     int32_t *ps_bins = nullptr;            // RDVIO_PARSAC_MAX_MODELS x RDVIO_PARSAC_MAX_BINS
     rdvio_parsac_result *ps_results = nullptr;
     int ps_n = 0, ps_kind = -1, ps_nv = 0, ps_nm = 0;
+    int ps_slot_of[RDVIO_PARSAC_MAX_MODELS] = {0};   // model index of the last batch (as the caller counts) -> device slot
     bool ps_has_prior = false, ps_has_lens = false;
 
     // pinned host staging

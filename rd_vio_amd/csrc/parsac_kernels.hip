@@ -11,11 +11,15 @@
 // reference's operation order, so scores, masks and counts are bit-identical to the host restatement
 // (host/pipeline/parsac.hpp), which is what the orchestration runs over a backend without this hook.
 #include "ctx.hpp"
+#include "hypo_solvers.hpp"
 
 namespace {
 
 struct PsArgs {
     int kind, n, n_valid, n_models, has_prior, has_lens;
+    // generated batches: slot m belongs to iteration m / per_iter and is a hypothesis only if m % per_iter < counts[m / per_iter]
+    int per_iter;
+    const int32_t *counts;
     double threshold;
     const double *pa, *pb, *bin_xy, *models;
     const int32_t *d2v, *valid_sizes;
@@ -39,6 +43,14 @@ __device__ __forceinline__ double ess_err(const double *E, bool transposed, doub
 __global__ __launch_bounds__(64) void parsac_score_kernel(PsArgs a) {
     __shared__ int bins[RDVIO_PARSAC_MAX_BINS];
     const int m = blockIdx.x, lane = threadIdx.x;
+    if (a.counts && m % a.per_iter >= a.counts[m / a.per_iter]) {   // an empty slot of a generated batch (workgroup-uniform)
+        if (lane == 0) {
+            rdvio_parsac_result r;
+            r.count = -1; r.effective = -1; r.score = 0.f; r.pad_ = 0;
+            a.results[m] = r;
+        }
+        return;
+    }
     for (int i = lane; i < a.n_valid; i += 64) bins[i] = 0;
     __syncthreads();
     const double *M = a.models + (a.kind == 1 ? 12 : 9) * (size_t)m;
@@ -107,6 +119,46 @@ __global__ __launch_bounds__(64) void parsac_score_kernel(PsArgs a) {
     a.results[m] = r;
 }
 
+// Hypothesis generation (row N2): one 64-lane workgroup per PARSAC iteration solves the minimal problem of that iteration's
+// sample -- EPnP from six 3-D / 2-D correspondences (solve_pnp_6pt, pnp.h:11-48) or the five-point essential solver
+// (essential.cpp:286-298) -- with the shared solvers of hypo_solvers.hpp, i.e. the very source the host road runs, step by
+// step over the lanes; the models land in the slots parsac_score_kernel reads next (no host hop).
+struct GenArgs {
+    int kind, n_iter;
+    const double *pa, *pb;
+    const int32_t *samples;   // n_iter x (6 | 5) point indices (range-checked on the host)
+    double *models;           // n_iter x 12, or n_iter x 10 x 9
+    int32_t *counts;          // n_iter: hypotheses found (1 for EPnP, 0..10 for the five-point solver)
+};
+
+__global__ __launch_bounds__(64) void parsac_generate_kernel(GenArgs a) {
+    __shared__ union {
+        hypo::EpnpWork pnp;
+        hypo::Ess5Work ess;
+    } work;
+    __shared__ double pts_a[18], pts_b[12];
+    __shared__ int n_found;
+    const int b = blockIdx.x;
+    const hypo::WaveExec x{(int)threadIdx.x};
+    if (a.kind == 1) {
+        const int32_t *smp = a.samples + 6 * (size_t)b;
+        x.each(30, [=](int e) {
+            if (e < 18) pts_a[e] = a.pa[3 * (size_t)smp[e / 3] + e % 3];
+            else pts_b[e - 18] = a.pb[2 * (size_t)smp[(e - 18) / 2] + (e - 18) % 2];
+        });
+        hypo::epnp6(x, &work.pnp, pts_a, pts_b, a.models + 12 * (size_t)b);
+        if (threadIdx.x == 0) a.counts[b] = 1;
+    } else {
+        const int32_t *smp = a.samples + 5 * (size_t)b;
+        x.each(20, [=](int e) {
+            if (e < 10) pts_a[e] = a.pa[2 * (size_t)smp[e / 2] + e % 2];
+            else pts_b[e - 10] = a.pb[2 * (size_t)smp[(e - 10) / 2] + (e - 10) % 2];
+        });
+        hypo::essential5(x, &work.ess, pts_a, pts_b, a.models + 90 * (size_t)b, &n_found);
+        if (threadIdx.x == 0) a.counts[b] = n_found;
+    }
+}
+
 template <class Tp>
 size_t put(uint8_t *base, size_t &off, const Tp *src, size_t n) {
     off = (off + 15) & ~(size_t)15;
@@ -120,11 +172,16 @@ size_t put(uint8_t *base, size_t &off, const Tp *src, size_t n) {
 
 extern "C" {
 
-int rdvio_hip_parsac_score(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, rdvio_parsac_result *results) {
+// one scoring launch; n_iter > 0: the hypotheses are generated on the device first (samples: n_iter x dof point indices)
+static int parsac_run(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, rdvio_parsac_result *results, int n_iter, const int32_t *samples,
+                      int32_t *models_per_iteration, double *models_out) {
     if (!ctx || !b || !results) return RDVIO_ERR_INVALID;
-    const int n = b->n_points, nv = b->n_valid, nm = b->n_models;
+    const bool gen = n_iter > 0;
+    const int n = b->n_points, nv = b->n_valid;
+    const int per_iter = b->kind == 1 ? 1 : 10, dof = b->kind == 1 ? 6 : 5;
+    const int nm = gen ? n_iter * per_iter : b->n_models;
     if ((b->kind != 0 && b->kind != 1) || n <= 0 || nv <= 0 || nm < 0 || !b->pa || !b->pb || !b->data_to_valid || !b->valid_sizes || !b->bin_xy ||
-        (nm > 0 && !b->models))
+        (!gen && nm > 0 && !b->models) || (gen && (!samples || !models_per_iteration || !models_out)))
         return rdvio_fail(ctx, RDVIO_ERR_INVALID, "bad PARSAC batch");
     if (n > ctx->ps_max_points || nv > RDVIO_PARSAC_MAX_BINS || nm > RDVIO_PARSAC_MAX_MODELS)
         return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "PARSAC batch of %d points / %d bins / %d models exceeds capacity (%d / %d / %d)", n, nv, nm,
@@ -133,6 +190,9 @@ int rdvio_hip_parsac_score(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, rdvi
         return rdvio_fail(ctx, RDVIO_ERR_INVALID, "PARSAC batch reuses points that were never uploaded");
     for (int i = 0; b->points_changed && i < n; ++i)
         if (b->data_to_valid[i] < 0 || b->data_to_valid[i] >= nv) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "PARSAC point %d maps outside the occupied bins", i);
+    // shapes are checked on the host so that the generation kernel can never gather out of bounds
+    for (int i = 0; gen && i < n_iter * dof; ++i)
+        if (samples[i] < 0 || samples[i] >= n) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "PARSAC sample index %d outside the %d points", samples[i], n);
     if (nm == 0) return RDVIO_OK;
     hipStream_t st = ctx->lane[RDVIO_LANE_SOLVER];
     RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));  // the pinned blob may still be in flight
@@ -141,7 +201,7 @@ int rdvio_hip_parsac_score(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, rdvi
     // (a batch that reuses the uploaded points keeps their layout, whatever optional pointers it passes)
     const bool has_lens = b->points_changed ? b->lens_weight != nullptr : ctx->ps_has_lens;
     const bool has_prior = b->points_changed ? b->prior_mask != nullptr : ctx->ps_has_prior;
-    // static part (points, grid) at fixed offsets, models behind it; one copy each
+    // static part (points, grid) at fixed offsets, models (or samples + model slots + counts) behind it; one copy each
     size_t off = 0;
     const size_t o_pa = put(hb, off, b->points_changed ? b->pa : (const double *)nullptr, (size_t)n * pdim);
     const size_t o_pb = put(hb, off, b->points_changed ? b->pb : (const double *)nullptr, (size_t)n * 2);
@@ -150,22 +210,43 @@ int rdvio_hip_parsac_score(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, rdvi
     const size_t o_vs = put(hb, off, b->points_changed ? b->valid_sizes : (const int32_t *)nullptr, (size_t)nv);
     const size_t o_lw = put(hb, off, b->points_changed ? b->lens_weight : (const float *)nullptr, has_lens ? (size_t)nv : 0);
     const size_t o_pm = put(hb, off, b->points_changed ? b->prior_mask : (const uint8_t *)nullptr, has_prior ? (size_t)n : 0);
-    const size_t static_bytes = (off + 15) & ~(size_t)15;
-    const size_t o_models = put(hb, off, b->models, (size_t)nm * mdim);
+    const size_t o_dyn = (off + 15) & ~(size_t)15;
+    off = o_dyn;
+    size_t o_models, o_samples = 0, o_counts = 0, up_end;
+    if (gen) {
+        o_samples = put(hb, off, samples, (size_t)n_iter * dof);
+        up_end = off;                                                         // only the samples travel up
+        o_counts = put(hb, off, (const int32_t *)nullptr, (size_t)n_iter);   // device-written: counts, then the model slots
+        o_models = put(hb, off, (const double *)nullptr, (size_t)nm * mdim);
+    } else {
+        o_models = put(hb, off, b->models, (size_t)nm * mdim);
+        up_end = off;
+    }
     if (off > ctx->ps_in_bytes) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "PARSAC staging buffer too small");
     if (b->points_changed) {
-        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(db, hb, off, hipMemcpyHostToDevice, st));
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(db, hb, up_end, hipMemcpyHostToDevice, st));
         ctx->ps_n = n;
         ctx->ps_kind = b->kind;
         ctx->ps_nv = nv;
         ctx->ps_has_prior = has_prior;
         ctx->ps_has_lens = has_lens;
     } else {
-        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(db + o_models, hb + o_models, off - o_models, hipMemcpyHostToDevice, st));
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(db + o_dyn, hb + o_dyn, up_end - o_dyn, hipMemcpyHostToDevice, st));
     }
-    (void)static_bytes;
+    if (gen) {
+        GenArgs g;
+        g.kind = b->kind; g.n_iter = n_iter;
+        g.pa = (const double *)(db + o_pa); g.pb = (const double *)(db + o_pb);
+        g.samples = (const int32_t *)(db + o_samples);
+        g.models = (double *)(db + o_models);
+        g.counts = (int32_t *)(db + o_counts);
+        hipLaunchKernelGGL(parsac_generate_kernel, dim3(n_iter), dim3(64), 0, st, g);
+        RDVIO_HIP_CHECK(ctx, hipGetLastError());
+    }
     PsArgs a;
     a.kind = b->kind; a.n = n; a.n_valid = nv; a.n_models = nm; a.has_prior = ctx->ps_has_prior; a.has_lens = ctx->ps_has_lens;
+    a.per_iter = per_iter;
+    a.counts = gen ? (const int32_t *)(db + o_counts) : nullptr;
     a.threshold = b->threshold;
     a.pa = (const double *)(db + o_pa); a.pb = (const double *)(db + o_pb); a.bin_xy = (const double *)(db + o_xy);
     a.models = (const double *)(db + o_models);
@@ -174,12 +255,45 @@ int rdvio_hip_parsac_score(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, rdvi
     a.masks = ctx->ps_masks; a.bin_inliers = ctx->ps_bins; a.results = ctx->ps_results;
     hipLaunchKernelGGL(parsac_score_kernel, dim3(nm), dim3(64), 0, st, a);
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
-    rdvio_parsac_result *down = (rdvio_parsac_result *)((uint8_t *)ctx->ps_host + ctx->ps_in_bytes);
+    uint8_t *down0 = (uint8_t *)ctx->ps_host + ctx->ps_in_bytes;
+    rdvio_parsac_result *down = (rdvio_parsac_result *)down0;
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, ctx->ps_results, (size_t)nm * sizeof(rdvio_parsac_result), hipMemcpyDeviceToHost, st));
+    const size_t gen_bytes = gen ? (o_models + (size_t)nm * mdim * sizeof(double)) - o_counts : 0;
+    uint8_t *down_gen = down0 + (((size_t)nm * sizeof(rdvio_parsac_result) + 15) & ~(size_t)15);
+    if (gen) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down_gen, db + o_counts, gen_bytes, hipMemcpyDeviceToHost, st));   // counts | models, one copy
     RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));
-    memcpy(results, down, (size_t)nm * sizeof(rdvio_parsac_result));
-    ctx->ps_nm = nm;
+    if (!gen) {
+        memcpy(results, down, (size_t)nm * sizeof(rdvio_parsac_result));
+        for (int k = 0; k < nm; ++k) ctx->ps_slot_of[k] = k;
+        ctx->ps_nm = nm;
+        return RDVIO_OK;
+    }
+    // pack the occupied slots in iteration order (the order Parsac<>::solve meets the models in)
+    const int32_t *cnt = (const int32_t *)down_gen;
+    const double *mod = (const double *)(down_gen + (o_models - o_counts));
+    int packed = 0;
+    for (int it = 0; it < n_iter; ++it) {
+        const int c = cnt[it] < 0 ? 0 : (cnt[it] > per_iter ? per_iter : cnt[it]);
+        models_per_iteration[it] = c;
+        for (int k = 0; k < c; ++k, ++packed) {
+            const int slot = it * per_iter + k;
+            memcpy(models_out + (size_t)packed * mdim, mod + (size_t)slot * mdim, (size_t)mdim * sizeof(double));
+            results[packed] = down[slot];
+            ctx->ps_slot_of[packed] = slot;
+        }
+    }
+    ctx->ps_nm = packed;
     return RDVIO_OK;
+}
+
+int rdvio_hip_parsac_score(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, rdvio_parsac_result *results) {
+    return parsac_run(ctx, b, results, 0, nullptr, nullptr, nullptr);
+}
+
+int rdvio_hip_parsac_generate_score(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, int n_iterations, const int32_t *samples,
+                                    int32_t *models_per_iteration, double *models, rdvio_parsac_result *results) {
+    if (n_iterations <= 0) return ctx ? rdvio_fail(ctx, RDVIO_ERR_INVALID, "no PARSAC iterations to generate") : RDVIO_ERR_INVALID;
+    return parsac_run(ctx, b, results, n_iterations, samples, models_per_iteration, models);
 }
 
 int rdvio_hip_parsac_fetch(rdvio_hip_ctx *ctx, int model, uint8_t *mask, int32_t *bin_inliers) {
@@ -188,6 +302,7 @@ int rdvio_hip_parsac_fetch(rdvio_hip_ctx *ctx, int model, uint8_t *mask, int32_t
     hipStream_t st = ctx->lane[RDVIO_LANE_SOLVER];
     uint8_t *down = (uint8_t *)ctx->ps_host + ctx->ps_in_bytes;
     const size_t mb = ((size_t)ctx->ps_n + 15) & ~(size_t)15;
+    model = ctx->ps_slot_of[model];   // a generated batch leaves unoccupied slots between its models
     if (mask) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, ctx->ps_masks + (size_t)model * ctx->ps_n, (size_t)ctx->ps_n, hipMemcpyDeviceToHost, st));
     if (bin_inliers)
         RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down + mb, ctx->ps_bins + (size_t)model * RDVIO_PARSAC_MAX_BINS, (size_t)ctx->ps_nv * sizeof(int32_t),

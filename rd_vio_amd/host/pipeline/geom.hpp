@@ -24,6 +24,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include "../../csrc/hypo_solvers.hpp"
+
 namespace rdvio_pipe {
 
 struct V2 { double x = 0, y = 0; };
@@ -397,140 +399,19 @@ inline std::vector<double> eigenvector_for(int n, const std::vector<double> &a, 
 // five-point essential matrix (essential.cpp:8-299): null-space basis, ten cubic constraints in GRevLex order,
 // Gauss-Jordan to the action matrix of multiplication by x, real eigenvectors -> (x, y, z).
 // ------------------------------------------------------------------------------------------------------------------
-namespace five_point {
-enum Mono { XXX = 0, XXY, XYY, YYY, XXZ, XYZ, YYZ, XZZ, YZZ, ZZZ, XX, XY, YY, XZ, YZ, ZZ, X, Y, Z, I };
-struct Poly {
-    double v[20];
-    Poly() { for (double &c : v) c = 0.0; }
-    static Poly linear(double x, double y, double z, double w) {
-        Poly p;
-        p.v[X] = x; p.v[Y] = y; p.v[Z] = z; p.v[I] = w;
-        return p;
-    }
-    Poly operator+(const Poly &b) const { Poly r; for (int i = 0; i < 20; ++i) r.v[i] = v[i] + b.v[i]; return r; }
-    Poly operator-(const Poly &b) const { Poly r; for (int i = 0; i < 20; ++i) r.v[i] = v[i] - b.v[i]; return r; }
-    Poly scaled(double s) const { Poly r; for (int i = 0; i < 20; ++i) r.v[i] = s * v[i]; return r; }
-    // product truncated at degree 3, term by term as essential.cpp:50-104
-    Poly operator*(const Poly &b) const {
-        Poly r;
-        const double *a = v, *c = b.v;
-        r.v[I] = a[I] * c[I];
-        r.v[Z] = a[I] * c[Z] + a[Z] * c[I];
-        r.v[Y] = a[I] * c[Y] + a[Y] * c[I];
-        r.v[X] = a[I] * c[X] + a[X] * c[I];
-        r.v[ZZ] = a[I] * c[ZZ] + a[Z] * c[Z] + a[ZZ] * c[I];
-        r.v[YZ] = a[I] * c[YZ] + a[Z] * c[Y] + a[Y] * c[Z] + a[YZ] * c[I];
-        r.v[XZ] = a[I] * c[XZ] + a[Z] * c[X] + a[X] * c[Z] + a[XZ] * c[I];
-        r.v[YY] = a[I] * c[YY] + a[Y] * c[Y] + a[YY] * c[I];
-        r.v[XY] = a[I] * c[XY] + a[Y] * c[X] + a[X] * c[Y] + a[XY] * c[I];
-        r.v[XX] = a[I] * c[XX] + a[X] * c[X] + a[XX] * c[I];
-        r.v[ZZZ] = a[I] * c[ZZZ] + a[Z] * c[ZZ] + a[ZZ] * c[Z] + a[ZZZ] * c[I];
-        r.v[YZZ] = a[I] * c[YZZ] + a[Z] * c[YZ] + a[Y] * c[ZZ] + a[ZZ] * c[Y] + a[YZ] * c[Z] + a[YZZ] * c[I];
-        r.v[XZZ] = a[I] * c[XZZ] + a[Z] * c[XZ] + a[X] * c[ZZ] + a[ZZ] * c[X] + a[XZ] * c[Z] + a[XZZ] * c[I];
-        r.v[YYZ] = a[I] * c[YYZ] + a[Z] * c[YY] + a[Y] * c[YZ] + a[YZ] * c[Y] + a[YY] * c[Z] + a[YYZ] * c[I];
-        r.v[XYZ] = a[I] * c[XYZ] + a[Z] * c[XY] + a[Y] * c[XZ] + a[X] * c[YZ] + a[YZ] * c[X] + a[XZ] * c[Y] +
-                   a[XY] * c[Z] + a[XYZ] * c[I];
-        r.v[XXZ] = a[I] * c[XXZ] + a[Z] * c[XX] + a[X] * c[XZ] + a[XZ] * c[X] + a[XX] * c[Z] + a[XXZ] * c[I];
-        r.v[YYY] = a[I] * c[YYY] + a[Y] * c[YY] + a[YY] * c[Y] + a[YYY] * c[I];
-        r.v[XYY] = a[I] * c[XYY] + a[Y] * c[XY] + a[X] * c[YY] + a[YY] * c[X] + a[XY] * c[Y] + a[XYY] * c[I];
-        r.v[XXY] = a[I] * c[XXY] + a[Y] * c[XX] + a[X] * c[XY] + a[XY] * c[X] + a[XX] * c[Y] + a[XXY] * c[I];
-        r.v[XXX] = a[I] * c[XXX] + a[X] * c[XX] + a[XX] * c[X] + a[XXX] * c[I];
-        return r;
-    }
-};
-}  // namespace five_point
-
+// The solver is csrc/hypo_solvers.hpp (hypo::essential5), the same source the device kernels run -- here with the serial executor.
 inline std::vector<M3> solve_essential_5pt(const std::array<V2, 5> &pts1, const std::array<V2, 5> &pts2) {
-    using namespace five_point;
-    // null space of the 5 x 9 epipolar constraint matrix (essential.cpp:119-131): rows h = p1 p2^T flattened row-wise
-    double A[5][9];
+    double p1[10], p2[10], models[90];
     for (int i = 0; i < 5; ++i) {
-        const double a[3] = {pts1[i].x, pts1[i].y, 1.0}, b[3] = {pts2[i].x, pts2[i].y, 1.0};
-        for (int j = 0; j < 3; ++j)
-            for (int k = 0; k < 3; ++k) A[i][3 * j + k] = a[j] * b[k];
+        p1[2 * i] = pts1[i].x; p1[2 * i + 1] = pts1[i].y;
+        p2[2 * i] = pts2[i].x; p2[2 * i + 1] = pts2[i].y;
     }
-    double AtA[81], Vv[81], lam[9];
-    for (int i = 0; i < 9; ++i)
-        for (int j = 0; j < 9; ++j) {
-            double s = 0;
-            for (int k = 0; k < 5; ++k) s += A[k][i] * A[k][j];
-            AtA[9 * i + j] = s;
-        }
-    sym_eigen(9, AtA, Vv, lam);
-    const std::vector<int> ord = ascending_order(9, lam);
-    // basis columns: singular vectors 5..8 in JacobiSVD's descending order = ascending eigenvalues 3, 2, 1, 0
-    double basis[9][4];
-    for (int c = 0; c < 4; ++c)
-        for (int r = 0; r < 9; ++r) basis[r][c] = Vv[9 * r + ord[3 - c]];
-    // E(x, y, z) = x Ex + y Ey + z Ez + Ew with E_c = to_matrix(basis.col(c)) (COLUMNS of E are the 3-segments)
-    Poly Ep[3][3];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) Ep[i][j] = Poly::linear(basis[3 * j + i][0], basis[3 * j + i][1], basis[3 * j + i][2], basis[3 * j + i][3]);
-    Poly EEt[3][3];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            Poly s;
-            for (int k = 0; k < 3; ++k) s = s + Ep[i][k] * Ep[j][k];
-            EEt[i][j] = s;
-        }
-    const Poly half_trace = (EEt[0][0] + EEt[1][1] + EEt[2][2]).scaled(0.5);
-    std::vector<double> polys(10 * 20);
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            Poly s;
-            for (int k = 0; k < 3; ++k) s = s + EEt[i][k] * Ep[k][j];
-            s = s - half_trace * Ep[i][j];
-            for (int c = 0; c < 20; ++c) polys[(3 * i + j) * 20 + c] = s.v[c];
-        }
-    {
-        const Poly d = Ep[0][0] * (Ep[1][1] * Ep[2][2] - Ep[1][2] * Ep[2][1]) - Ep[0][1] * (Ep[1][0] * Ep[2][2] - Ep[1][2] * Ep[2][0]) +
-                       Ep[0][2] * (Ep[1][0] * Ep[2][1] - Ep[1][1] * Ep[2][0]);
-        for (int c = 0; c < 20; ++c) polys[9 * 20 + c] = d.v[c];
-    }
-    // Gauss-Jordan with the reference's row-permutation bookkeeping (essential.cpp:167-190)
-    auto P = [&](int r, int c) -> double & { return polys[(size_t)r * 20 + c]; };
-    int perm[10];
-    for (int i = 0; i < 10; ++i) perm[i] = i;
-    for (int i = 0; i < 10; ++i) {
-        for (int j = i + 1; j < 10; ++j)
-            if (std::fabs(P(perm[i], i)) < std::fabs(P(perm[j], i))) std::swap(perm[i], perm[j]);
-        if (P(perm[i], i) == 0.0) continue;
-        const double d = P(perm[i], i);
-        for (int c = 0; c < 20; ++c) P(perm[i], c) /= d;
-        for (int j = i + 1; j < 10; ++j) {
-            const double f = P(perm[j], i);
-            for (int c = 0; c < 20; ++c) P(perm[j], c) -= P(perm[i], c) * f;
-        }
-    }
-    for (int i = 9; i > 0; --i)
-        for (int j = 0; j < i; ++j) {
-            const double f = P(perm[j], i);
-            for (int c = 0; c < 20; ++c) P(perm[j], c) -= P(perm[i], c) * f;
-        }
-    std::vector<double> action(100, 0.0);
-    const int rows[6] = {XXX, XXY, XYY, XXZ, XYZ, XZZ};
-    for (int r = 0; r < 6; ++r)
-        for (int c = 0; c < 10; ++c) action[r * 10 + c] = -P(perm[rows[r]], XX + c);
-    action[6 * 10 + (XX - XX)] = 1.0;
-    action[7 * 10 + (XY - XX)] = 1.0;
-    action[8 * 10 + (XZ - XX)] = 1.0;
-    action[9 * 10 + (X - XX)] = 1.0;
-    std::vector<double> wr, wi;
-    std::vector<M3> results;
-    if (!real_eigenvalues(10, action, wr, wi)) return results;
-    for (int i = 0; i < 10; ++i) {
-        if (std::fabs(wi[i]) >= 1.0e-10) continue;
-        const std::vector<double> h = eigenvector_for(10, action, wr[i]);
-        const double w = h[I - XX];
-        const double sx = h[X - XX] / w, sy = h[Y - XX] / w, sz = h[Z - XX] / w;
-        M3 E;
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) {
-                const int k = 3 * c + r;  // to_matrix: column c = segment c
-                E.m[3 * r + c] = basis[k][0] * sx + basis[k][1] * sy + basis[k][2] * sz + basis[k][3];
-            }
-        results.push_back(E);
-    }
+    int n = 0;
+    hypo::Ess5Work work;
+    hypo::essential5(hypo::SerialExec{}, &work, p1, p2, models, &n);
+    std::vector<M3> results((size_t)n);
+    for (int k = 0; k < n; ++k)
+        for (int q = 0; q < 9; ++q) results[(size_t)k].m[q] = models[9 * k + q];
     return results;
 }
 

@@ -92,6 +92,11 @@ int parsac_fetch(void *user, int model, uint8_t *mask, int32_t *bin_inliers) {
     return rdvio_hip_parsac_fetch(static_cast<HipBackend *>(user)->ctx, model, mask, bin_inliers);
 }
 
+int parsac_generate_score(void *user, const rdvio_parsac_batch *batch, int n_iter, const int32_t *samples, int32_t *per_iter, double *models,
+                          rdvio_parsac_result *results) {
+    return rdvio_hip_parsac_generate_score(static_cast<HipBackend *>(user)->ctx, batch, n_iter, samples, per_iter, models, results);
+}
+
 const char *last_error(void *user) { return rdvio_hip_last_error(static_cast<HipBackend *>(user)->ctx); }
 
 void destroy(void *user) { delete static_cast<HipBackend *>(user); }
@@ -122,6 +127,7 @@ extern "C" int rdvio_pipeline_create_hip(rdvio_pipeline **out, const rdvio_pipel
     fn.parsac_fetch = parsac_fetch;
     fn.preintegrate_estimator = preintegrate_estimator;
     fn.thread_attach = thread_attach;
+    fn.parsac_generate_score = parsac_generate_score;
     const int rc = rdvio_pipeline_create(out, cfg, &fn);
     if (rc != RDVIO_OK) delete b;
     return rc;

@@ -9,7 +9,8 @@
 // solve_pnp_6pt calls cv::solvePnP(..., CV_EPNP) on float32 points with an identity camera matrix and round-trips the
 // pose through a float32 Rodrigues vector; OpenCV is not available, so EPnP (Lepetit, Moreno-Noguer, Fua 2009 -- control
 // points, 12-dim null space, three beta initialisations + Gauss-Newton, Arun alignment, lowest reprojection error wins) is
-// restated here with the same float32 rounding points.  PARITY UNPINNED (no reference fixtures; OpenCV version unpinned).
+// restated (csrc/hypo_solvers.hpp, shared with the device) with the same float32 rounding points.  PARITY UNPINNED (no
+// reference fixtures; OpenCV version unpinned).
 //
 // Kept quirks: the weighted sampler returns a BIN index that the caller uses as a DATA index (parsac.h:120-126,
 // imu_parsac.h:83-91); it draws from the C library's rand() re-seeded with srand(0) per solve (parsac.h:10-13); scores are
@@ -19,11 +20,13 @@
 #pragma once
 
 #include <cfloat>
+#include <chrono>
 #include <cstdlib>
 
 #include <stdexcept>
 
 #include "../../../include/rdvio_pipeline.h"
+#include "../../csrc/hypo_solvers.hpp"
 #include "geom.hpp"
 
 namespace rdvio_pipe {
@@ -39,231 +42,19 @@ inline double pnp_reproject_error(const Pose4 &T, const V3 &P1, const V2 &p2) {
     return sqnorm(p2 - V2{q.x / q.z, q.y / q.z});
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// EPnP for n >= 4 points, camera matrix = identity
-// ---------------------------------------------------------------------------------------------------------------------
-namespace epnp {
-
-inline void control_points(const std::vector<V3> &pw, V3 cws[4]) {
-    const int n = (int)pw.size();
-    cws[0] = V3{0, 0, 0};
-    for (const V3 &p : pw) cws[0] = cws[0] + p;
-    cws[0] = cws[0] / (double)n;
-    double C[9] = {0}, V[9], lam[3];
-    for (const V3 &p : pw) {
-        const double d[3] = {p.x - cws[0].x, p.y - cws[0].y, p.z - cws[0].z};
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) C[3 * i + j] += d[i] * d[j];
-    }
-    sym_eigen(3, C, V, lam);
-    std::vector<int> ord = ascending_order(3, lam);
-    std::reverse(ord.begin(), ord.end());
-    for (int i = 1; i < 4; ++i) {
-        const int c = ord[i - 1];
-        const double k = std::sqrt(std::max(lam[c], 0.0) / n);
-        cws[i] = cws[0] + k * V3{V[0 * 3 + c], V[1 * 3 + c], V[2 * 3 + c]};
-    }
-}
-
-inline bool barycentric(const std::vector<V3> &pw, const V3 cws[4], std::vector<double> &alphas) {
-    M3 CC;
-    for (int i = 0; i < 3; ++i) {
-        const double c0 = i == 0 ? cws[0].x : (i == 1 ? cws[0].y : cws[0].z);
-        for (int j = 1; j < 4; ++j) CC.m[3 * i + j - 1] = (i == 0 ? cws[j].x : (i == 1 ? cws[j].y : cws[j].z)) - c0;
-    }
-    if (!(std::fabs(det(CC)) > 0.0)) return false;
-    const M3 Ci = inverse3(CC);
-    alphas.resize(4 * pw.size());
-    for (size_t i = 0; i < pw.size(); ++i) {
-        const V3 d = pw[i] - cws[0];
-        const V3 a = Ci * d;
-        alphas[4 * i + 1] = a.x; alphas[4 * i + 2] = a.y; alphas[4 * i + 3] = a.z;
-        alphas[4 * i] = 1.0 - a.x - a.y - a.z;
-    }
-    return true;
-}
-
-// rows of L (6 x 10) from the four null-space vectors v[0..3] (each 12 = 4 control points x 3)
-inline void compute_L(const double *const v[4], double L[6][10]) {
-    const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
-    double dv[4][6][3];
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 6; ++j)
-            for (int k = 0; k < 3; ++k) dv[i][j][k] = v[i][3 * pa[j] + k] - v[i][3 * pb[j] + k];
-    auto d = [&](int a, int b, int j) { return dv[a][j][0] * dv[b][j][0] + dv[a][j][1] * dv[b][j][1] + dv[a][j][2] * dv[b][j][2]; };
-    for (int j = 0; j < 6; ++j) {
-        L[j][0] = d(0, 0, j); L[j][1] = 2 * d(0, 1, j); L[j][2] = d(1, 1, j); L[j][3] = 2 * d(0, 2, j); L[j][4] = 2 * d(1, 2, j);
-        L[j][5] = d(2, 2, j); L[j][6] = 2 * d(0, 3, j); L[j][7] = 2 * d(1, 3, j); L[j][8] = 2 * d(2, 3, j); L[j][9] = d(3, 3, j);
-    }
-}
-
-inline void gauss_newton(const double L[6][10], const double rho[6], double b[4]) {
-    for (int it = 0; it < 5; ++it) {
-        std::vector<double> A(24), r(6);
-        for (int i = 0; i < 6; ++i) {
-            const double *l = L[i];
-            A[4 * i + 0] = 2 * l[0] * b[0] + l[1] * b[1] + l[3] * b[2] + l[6] * b[3];
-            A[4 * i + 1] = l[1] * b[0] + 2 * l[2] * b[1] + l[4] * b[2] + l[7] * b[3];
-            A[4 * i + 2] = l[3] * b[0] + l[4] * b[1] + 2 * l[5] * b[2] + l[8] * b[3];
-            A[4 * i + 3] = l[6] * b[0] + l[7] * b[1] + l[8] * b[2] + 2 * l[9] * b[3];
-            r[i] = rho[i] - (l[0] * b[0] * b[0] + l[1] * b[0] * b[1] + l[2] * b[1] * b[1] + l[3] * b[0] * b[2] + l[4] * b[1] * b[2] +
-                             l[5] * b[2] * b[2] + l[6] * b[0] * b[3] + l[7] * b[1] * b[3] + l[8] * b[2] * b[3] + l[9] * b[3] * b[3]);
-        }
-        const std::vector<double> x = least_squares(6, 4, A, r);
-        for (int k = 0; k < 4; ++k) b[k] += x[k];
-    }
-}
-
-// camera-frame points from the betas, sign fix, Arun alignment; returns the mean reprojection error
-inline double pose_from_betas(const double *const v[4], const double b[4], const std::vector<double> &alphas, const std::vector<V3> &pw,
-                              const std::vector<V2> &us, Pose4 &out) {
-    const int n = (int)pw.size();
-    V3 ccs[4];
-    for (int i = 0; i < 4; ++i) {
-        ccs[i] = V3{0, 0, 0};
-        for (int k = 0; k < 4; ++k) ccs[i] = ccs[i] + b[k] * V3{v[k][3 * i], v[k][3 * i + 1], v[k][3 * i + 2]};
-    }
-    std::vector<V3> pc(n);
-    for (int i = 0; i < n; ++i) {
-        pc[i] = V3{0, 0, 0};
-        for (int j = 0; j < 4; ++j) pc[i] = pc[i] + alphas[4 * i + j] * ccs[j];
-    }
-    if (pc[0].z < 0.0)
-        for (V3 &p : pc) p = -p;
-    V3 pc0{0, 0, 0}, pw0{0, 0, 0};
-    for (int i = 0; i < n; ++i) { pc0 = pc0 + pc[i]; pw0 = pw0 + pw[i]; }
-    pc0 = pc0 / (double)n;
-    pw0 = pw0 / (double)n;
-    M3 ABt;
-    for (double &x : ABt.m) x = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const double a[3] = {pc[i].x - pc0.x, pc[i].y - pc0.y, pc[i].z - pc0.z}, c[3] = {pw[i].x - pw0.x, pw[i].y - pw0.y, pw[i].z - pw0.z};
-        for (int r = 0; r < 3; ++r)
-            for (int q = 0; q < 3; ++q) ABt.m[3 * r + q] += a[r] * c[q];
-    }
-    M3 U, V;
-    double sv[3];
-    svd3(ABt, U, sv, V);
-    M3 R = U * transpose(V);
-    if (det(R) < 0) {
-        R.m[6] = -R.m[6]; R.m[7] = -R.m[7]; R.m[8] = -R.m[8];
-    }
-    out.R = R;
-    out.t = pc0 - R * pw0;
-    double err = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const V3 q = R * pw[i] + out.t;
-        const double du = us[i].x - q.x / q.z, dv = us[i].y - q.y / q.z;
-        err += std::sqrt(du * du + dv * dv);
-    }
-    return err / n;
-}
-
-inline bool solve(const std::vector<V3> &pw, const std::vector<V2> &us, Pose4 &best) {
-    const int n = (int)pw.size();
-    if (n < 4) return false;
-    V3 cws[4];
-    control_points(pw, cws);
-    std::vector<double> alphas;
-    if (!barycentric(pw, cws, alphas)) return false;
-    std::vector<double> MtM(144, 0.0), Vv(144), lam(12);
-    for (int i = 0; i < n; ++i) {
-        double r1[12], r2[12];
-        for (int j = 0; j < 4; ++j) {
-            const double a = alphas[4 * i + j];
-            r1[3 * j] = a; r1[3 * j + 1] = 0.0; r1[3 * j + 2] = a * (0.0 - us[i].x);
-            r2[3 * j] = 0.0; r2[3 * j + 1] = a; r2[3 * j + 2] = a * (0.0 - us[i].y);
-        }
-        for (int p = 0; p < 12; ++p)
-            for (int q = 0; q < 12; ++q) MtM[12 * p + q] += r1[p] * r1[q] + r2[p] * r2[q];
-    }
-    sym_eigen(12, MtM.data(), Vv.data(), lam.data());
-    const std::vector<int> ord = ascending_order(12, lam.data());
-    double vbuf[4][12];
-    const double *v[4];
-    for (int k = 0; k < 4; ++k) {  // v[0] = smallest eigenvalue's vector ... v[3] = fourth smallest
-        for (int i = 0; i < 12; ++i) vbuf[k][i] = Vv[12 * i + ord[k]];
-        v[k] = vbuf[k];
-    }
-    double L[6][10], rho[6];
-    compute_L(v, L);
-    const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
-    for (int j = 0; j < 6; ++j) {
-        const V3 d = cws[pa[j]] - cws[pb[j]];
-        rho[j] = dot(d, d);
-    }
-    auto sub_solve = [&](std::initializer_list<int> cols) {
-        const int nc = (int)cols.size();
-        std::vector<double> A(6 * nc), r(rho, rho + 6);
-        int c = 0;
-        for (int col : cols) {
-            for (int j = 0; j < 6; ++j) A[nc * j + c] = L[j][col];
-            ++c;
-        }
-        return least_squares(6, nc, A, r);
-    };
-    double betas[3][4];
-    {   // N = 4 approximation: betas from [B11 B12 B13 B14]
-        const std::vector<double> b4 = sub_solve({0, 1, 3, 6});
-        double *b = betas[0];
-        if (b4[0] < 0) { b[0] = std::sqrt(-b4[0]); b[1] = -b4[1] / b[0]; b[2] = -b4[2] / b[0]; b[3] = -b4[3] / b[0]; }
-        else { b[0] = std::sqrt(b4[0]); b[1] = b4[1] / b[0]; b[2] = b4[2] / b[0]; b[3] = b4[3] / b[0]; }
-    }
-    {   // N = 2: [B11 B12 B22]
-        const std::vector<double> b3 = sub_solve({0, 1, 2});
-        double *b = betas[1];
-        if (b3[0] < 0) { b[0] = std::sqrt(-b3[0]); b[1] = (b3[2] < 0) ? std::sqrt(-b3[2]) : 0.0; }
-        else { b[0] = std::sqrt(b3[0]); b[1] = (b3[2] > 0) ? std::sqrt(b3[2]) : 0.0; }
-        if (b3[1] < 0) b[0] = -b[0];
-        b[2] = b[3] = 0.0;
-    }
-    {   // N = 3: [B11 B12 B22 B13 B23]
-        const std::vector<double> b5 = sub_solve({0, 1, 2, 3, 4});
-        double *b = betas[2];
-        if (b5[0] < 0) { b[0] = std::sqrt(-b5[0]); b[1] = (b5[2] < 0) ? std::sqrt(-b5[2]) : 0.0; }
-        else { b[0] = std::sqrt(b5[0]); b[1] = (b5[2] > 0) ? std::sqrt(b5[2]) : 0.0; }
-        if (b5[1] < 0) b[0] = -b[0];
-        b[2] = b5[3] / b[0];
-        b[3] = 0.0;
-    }
-    double best_err = DBL_MAX;
-    bool ok = false;
-    for (int c = 0; c < 3; ++c) {
-        if (!std::isfinite(betas[c][0]) || !std::isfinite(betas[c][1]) || !std::isfinite(betas[c][2]) || !std::isfinite(betas[c][3])) continue;
-        gauss_newton(L, rho, betas[c]);
-        Pose4 cand;
-        const double err = pose_from_betas(v, betas[c], alphas, pw, us, cand);
-        if (std::isfinite(err) && err < best_err) {
-            best_err = err;
-            best = cand;
-            ok = true;
-        }
-    }
-    return ok;
-}
-
-}  // namespace epnp
-
-// pnp.h:11-48: EPnP on float32 copies of the points, pose round-tripped through a float32 Rodrigues vector
+// pnp.h:11-48: EPnP on float32 copies of the six correspondences, the pose round-tripped through a float32 Rodrigues vector.
+// The solver is csrc/hypo_solvers.hpp (hypo::epnp6), the same source the device kernel runs -- here with the serial executor.
 inline std::vector<Pose4> solve_pnp_6pt(const std::array<V3, 6> &Xs, const std::array<V2, 6> &xs) {
-    std::vector<V3> pw(6);
-    std::vector<V2> us(6);
+    double X[18], u[12], model[12];
     for (int i = 0; i < 6; ++i) {
-        pw[i] = V3{(double)(float)Xs[i].x, (double)(float)Xs[i].y, (double)(float)Xs[i].z};
-        us[i] = V2{(double)(float)xs[i].x, (double)(float)xs[i].y};
+        X[3 * i] = Xs[i].x; X[3 * i + 1] = Xs[i].y; X[3 * i + 2] = Xs[i].z;
+        u[2 * i] = xs[i].x; u[2 * i + 1] = xs[i].y;
     }
-    Pose4 P;
-    if (!epnp::solve(pw, us, P)) {
-        // cv::solvePnP leaves rvec / tvec at whatever EPnP produced; a degenerate sample gives an unusable pose, which the
-        // inlier test then rejects.  An identity pose plays that role here.
-        P = Pose4{};
-    }
-    const V3 rv = logmap(from_mat(P.R));
-    const V3 rvf{(double)(float)rv.x, (double)(float)rv.y, (double)(float)rv.z};
+    hypo::EpnpWork work;
+    hypo::epnp6(hypo::SerialExec{}, &work, X, u, model);
     Pose4 out;
-    out.R = to_mat(expmap(rvf));
-    for (double &m : out.R.m) m = (double)(float)m;
-    out.t = V3{(double)(float)P.t.x, (double)(float)P.t.y, (double)(float)P.t.z};
+    for (int k = 0; k < 9; ++k) out.R.m[k] = model[k];
+    out.t = V3{model[9], model[10], model[11]};
     return {out};
 }
 
@@ -408,6 +199,10 @@ struct ParsacDeviceScorer {
     void *user = nullptr;
     int kind = 0;
     const double *pa = nullptr, *pb = nullptr;
+    // optional: hypotheses GENERATED on the device from the sample indices (rdvio_backend::parsac_generate_score) and scored
+    // in the same call; NULL = models come from the host solvers
+    int (*generate)(void *user, const rdvio_parsac_batch *batch, int n_iterations, const int32_t *samples, int32_t *models_per_iteration,
+                    double *models, rdvio_parsac_result *results) = nullptr;
 };
 inline void parsac_flatten(const M3 &E, double *out) {
     for (int q = 0; q < 9; ++q) out[q] = E.m[q];
@@ -415,6 +210,13 @@ inline void parsac_flatten(const M3 &E, double *out) {
 inline void parsac_flatten(const Pose4 &T, double *out) {
     for (int q = 0; q < 9; ++q) out[q] = T.R.m[q];
     out[9] = T.t.x; out[10] = T.t.y; out[11] = T.t.z;
+}
+inline void parsac_unflatten(const double *in, M3 &E) {
+    for (int q = 0; q < 9; ++q) E.m[q] = in[q];
+}
+inline void parsac_unflatten(const double *in, Pose4 &T) {
+    for (int q = 0; q < 9; ++q) T.R.m[q] = in[q];
+    T.t = V3{in[9], in[10], in[11]};
 }
 
 // Parsac<DoF>::solve (parsac.h:74-171) / IMU_Parsac<DoF>::solve (imu_parsac.h:28-163).
@@ -428,6 +230,31 @@ inline void parsac_flatten(const Pose4 &T, double *out) {
 // replayed on the results in iteration order; hypotheses beyond the iteration at which the loop ends are simply ignored.
 // Both roads run this same control flow and produce bit-identical scores, masks and bin confidences.
 constexpr size_t PARSAC_BATCH = 8;
+// with device generation a batch is one launch whatever its size (one workgroup per hypothesis): the typical solve ends within
+// its first batch
+constexpr size_t PARSAC_BATCH_GENERATED_PNP = 16, PARSAC_BATCH_GENERATED_ESSENTIAL = 8;
+
+// diagnostic accumulators (RDVIO_PIPELINE_PROF): where a PARSAC solve spends its time
+struct ParsacProf {
+    bool on = false;
+    double t_setup = 0, t_models = 0, t_score = 0, t_fetch = 0;
+    long solves = 0, batches = 0, iterations = 0, models = 0, fetches = 0;
+};
+inline ParsacProf &parsac_prof() {
+    static ParsacProf p;
+    return p;
+}
+struct ParsacTick {
+    double &acc;
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    explicit ParsacTick(double &a) : acc(a), on(parsac_prof().on) {
+        if (on) t0 = std::chrono::steady_clock::now();
+    }
+    ~ParsacTick() {
+        if (on) acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
 
 template <size_t DoF, class Model, class SolveFn, class ErrorFn>
 struct ParsacResult {
@@ -452,11 +279,16 @@ ParsacResult<DoF, Model, SolveFn, ErrorFn> parsac_solve(size_t size, const std::
         out.inlier_mask.assign(size, 0);
         return out;
     }
+    ParsacProf &prof = parsac_prof();
+    prof.solves++;
     ParsacGrid grid;
     grid.norm_scale = norm_scale;
     grid.use_lens = imu_prior != nullptr;
     grid.dynamic_probability = dynamic_probability;
-    grid.setup(pts2, lens, binConfidences);
+    {
+        ParsacTick tick(prof.t_setup);
+        grid.setup(pts2, lens, binConfidences);
+    }
     WeightedBinSampler sampler(grid.validConfAccPrior);
     std::vector<char> prior_mask;
     if (imu_prior) {  // ComputePriorDistribution (imu_parsac.h:176-201)
@@ -499,33 +331,34 @@ ParsacResult<DoF, Model, SolveFn, ErrorFn> parsac_solve(size_t size, const std::
     size_t iter_max = max_iteration;
     float scoreMax = imu_prior ? -FLT_MAX : 0.0f;
     bool first_batch = true;
-    for (size_t iter0 = 0; iter0 < iter_max; iter0 += PARSAC_BATCH) {
+    const bool generated = on_device && dev->generate;
+    const size_t batch = !generated ? PARSAC_BATCH : (MD == 12 ? PARSAC_BATCH_GENERATED_PNP : PARSAC_BATCH_GENERATED_ESSENTIAL);
+    for (size_t iter0 = 0; iter0 < iter_max; iter0 += batch) {
         // ---- hypotheses of iterations iter0 .. iter0 + B - 1
-        const size_t B = std::min(PARSAC_BATCH, iter_max - iter0);
+        const size_t B = std::min(batch, iter_max - iter0);
         std::vector<Model> models;
         std::vector<size_t> first_of(B + 1, 0);
+        std::vector<int32_t> samples(generated ? B * DoF : 0);
+        prof.batches++;
+        ParsacTick *tick_models = new ParsacTick(prof.t_models);
         for (size_t b = 0; b < B; ++b) {
             std::array<size_t, DoF> sample;
             lotbox.refill_all();
             sampler.refill_all();
             for (size_t si = 0; si < DoF; ++si)
                 sample[si] = grid.nValidBins > 20 ? sampler.draw_by_weight() : lotbox.draw_without_replacement();  // (bin index used as data index)
+            if (generated) {
+                for (size_t si = 0; si < DoF; ++si) samples[b * DoF + si] = (int32_t)sample[si];
+                continue;
+            }
             const std::vector<Model> ms = solve(sample);
             models.insert(models.end(), ms.begin(), ms.end());
             first_of[b + 1] = models.size();
         }
-        const size_t nm = models.size();
-        // ---- scores
-        std::vector<size_t> counts(nm, 0), effs(nm, 0);
-        std::vector<float> scores(nm, 0.0f);
-        std::vector<std::vector<char>> masks;           // host road only
-        std::vector<std::vector<size_t>> bin_inl;       // host road only
-        if (on_device && nm > 0) {
-            std::vector<double> flat(nm * MD);
-            for (size_t k = 0; k < nm; ++k) parsac_flatten(models[k], &flat[k * MD]);
-            // the device kernel takes at most RDVIO_PARSAC_MAX_MODELS hypotheses per launch (8 iterations x 10 essential
-            // matrices = 80 at most)
-            rdvio_parsac_batch pb{};
+        delete tick_models;
+        // the batch descriptor of the device road
+        rdvio_parsac_batch pb{};
+        if (on_device) {
             pb.kind = dev->kind;
             pb.n_points = (int32_t)size;
             pb.points_changed = first_batch ? 1 : 0;
@@ -538,6 +371,49 @@ ParsacResult<DoF, Model, SolveFn, ErrorFn> parsac_solve(size_t size, const std::
             pb.bin_xy = bin_xy.data();
             pb.lens_weight = grid.use_lens ? lens_w.data() : nullptr;
             pb.prior_mask = imu_prior ? prior_u8.data() : nullptr;
+        }
+        std::vector<size_t> counts, effs;
+        std::vector<float> scores;
+        if (generated) {
+            // one call: the device solves the minimal problems of the B samples (hypo_solvers.hpp, the code solve() runs on the
+            // host) and scores what it found; models come back for the replay below
+            ParsacTick tick(prof.t_score);
+            const size_t per = MD == 12 ? 1 : 10;
+            std::vector<int32_t> per_iter(B);
+            std::vector<double> flat(B * per * MD);
+            std::vector<rdvio_parsac_result> res(B * per);
+            if (dev->generate(dev->user, &pb, (int)B, samples.data(), per_iter.data(), flat.data(), res.data()) != RDVIO_OK)
+                throw std::runtime_error("backend parsac_generate_score failed");
+            first_batch = false;
+            for (size_t b = 0; b < B; ++b) first_of[b + 1] = first_of[b] + (size_t)per_iter[b];
+            const size_t nmg = first_of[B];
+            models.resize(nmg);
+            counts.resize(nmg); effs.resize(nmg); scores.resize(nmg);
+            for (size_t k = 0; k < nmg; ++k) {
+                parsac_unflatten(&flat[k * MD], models[k]);
+                counts[k] = (size_t)res[k].count;
+                effs[k] = (size_t)res[k].effective;
+                scores[k] = res[k].score;
+            }
+        }
+        const size_t nm = models.size();
+        prof.models += (long)nm;
+        ParsacTick *tick_score = new ParsacTick(prof.t_score);
+        // ---- scores
+        if (!generated) {
+            counts.assign(nm, 0);
+            effs.assign(nm, 0);
+            scores.assign(nm, 0.0f);
+        }
+        std::vector<std::vector<char>> masks;           // host road only
+        std::vector<std::vector<size_t>> bin_inl;       // host road only
+        if (generated) {
+            // (scored above)
+        } else if (on_device && nm > 0) {
+            std::vector<double> flat(nm * MD);
+            for (size_t k = 0; k < nm; ++k) parsac_flatten(models[k], &flat[k * MD]);
+            // the device kernel takes at most RDVIO_PARSAC_MAX_MODELS hypotheses per launch (8 iterations x 10 essential
+            // matrices = 80 at most)
             pb.n_models = (int32_t)nm;
             pb.models = flat.data();
             std::vector<rdvio_parsac_result> res(nm);
@@ -572,9 +448,10 @@ ParsacResult<DoF, Model, SolveFn, ErrorFn> parsac_solve(size_t size, const std::
                 scores[k] = grid.score(bin_inl[k]);
             }
         }
+        delete tick_score;
         // ---- replay of the reference's loop body on the results, in iteration order
         long best_in_batch = -1;
-        for (size_t b = 0; b < B && iter0 + b < iter_max; ++b)
+        for (size_t b = 0; b < B && iter0 + b < iter_max; ++b, prof.iterations++)
             for (size_t k = first_of[b]; k < first_of[b + 1]; ++k) {
                 const size_t effective = effs[k];
                 if (imu_prior && effective < DoF) continue;
@@ -590,6 +467,8 @@ ParsacResult<DoF, Model, SolveFn, ErrorFn> parsac_solve(size_t size, const std::
                 }
             }
         if (best_in_batch >= 0) {
+            ParsacTick tick(prof.t_fetch);
+            prof.fetches++;
             if (on_device) {
                 std::vector<uint8_t> m8(size);
                 std::vector<int32_t> bi(grid.nValidBins);

@@ -946,6 +946,7 @@ bool SlidingWindowTracker::filter_parsac_2d2d(Frame *frame_i, Frame *frame_j, st
         }
     if (pts1.size() < 10) return false;
     ParsacDeviceScorer dev{sh.backend.fn.parsac_score, sh.backend.fn.parsac_fetch, sh.backend.fn.user};
+    dev.generate = sh.backend.fn.parsac_generate_score;
     (void)find_essential_matrix_parsac(pts1, pts2, mask, sh.essential_bin_confidences, m_th / frame_i->K[0], 0.999, 1000, 0,
                                        sh.backend.fn.parsac_score ? &dev : nullptr);
     return true;
@@ -978,6 +979,7 @@ bool SlidingWindowTracker::judge_track_status() {
     const M3 Rcw = to_mat(conj(pose.q));
     const V3 tcw = -(Rcw * pose.p);
     ParsacDeviceScorer dev{sh.backend.fn.parsac_score, sh.backend.fn.parsac_fetch, sh.backend.fn.user};
+    dev.generate = sh.backend.fn.parsac_generate_score;
     (void)find_pnp_matrix_parsac_imu(P3D, P2D, lens, Rcw, tcw, 0.20, 1.0, mask, sh.pnp_bin_confidences, 1.0 / curr_frame->K[0], 0.999, 1000, 0,
                                      sh.backend.fn.parsac_score ? &dev : nullptr);
     mask.resize(P2D.size(), 0);
@@ -1240,6 +1242,8 @@ int rdvio_pipeline_create(rdvio_pipeline **out, const rdvio_pipeline_config *cfg
     p->shared.cfg = *cfg;
     p->shared.backend.fn = *backend;
     if (const char *e = std::getenv("RDVIO_PIPELINE_PROF")) p->shared.prof.on = e[0] == '1';
+    parsac_prof() = ParsacProf{};
+    parsac_prof().on = p->shared.prof.on;
     p->handler = std::make_unique<Handler>(p->shared);
     *out = p;
     return RDVIO_OK;
@@ -1257,6 +1261,12 @@ void rdvio_pipeline_destroy(rdvio_pipeline *p) {
                 std::fprintf(stderr, "  %-32s %8.4f  (%ld calls, %.1f us each)\n", HostProf::names[k], 1e3 * p->shared.prof.seconds[k] / std::max<long>(c.frames_tracked, 1),
                              p->shared.prof.calls[k], 1e6 * p->shared.prof.seconds[k] / p->shared.prof.calls[k]);
         static const char *bn[7] = {"preprocess", "detect", "track", "preintegrate", "ba_solve", "marginalize", "image_create"};
+        const ParsacProf &pp = parsac_prof();
+        if (pp.solves)
+            std::fprintf(stderr, "  parsac: %ld solves, %ld batches, %ld iterations, %ld models, %ld fetches; ms per frame: setup %.4f models %.4f score %.4f fetch %.4f\n",
+                         pp.solves, pp.batches, pp.iterations, pp.models, pp.fetches, 1e3 * pp.t_setup / std::max<long>(c.frames_tracked, 1),
+                         1e3 * pp.t_models / std::max<long>(c.frames_tracked, 1), 1e3 * pp.t_score / std::max<long>(c.frames_tracked, 1),
+                         1e3 * pp.t_fetch / std::max<long>(c.frames_tracked, 1));
         for (int k = 0; k < 7; ++k)
             std::fprintf(stderr, "  backend %-24s %8.4f  (%ld calls)\n", bn[k], 1e3 * c.backend_seconds[k] / std::max<long>(c.frames_tracked, 1), (long)c.backend_calls[k]);
     }

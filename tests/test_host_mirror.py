@@ -30,7 +30,7 @@ def test_host_mirror_runs_on_gpu():
     _compile()
     out = subprocess.run([EXE], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.startswith("OK")
+    assert "OK" in out.stdout
 
 
 ODO_SRC = os.path.join(ROOT, "tests", "cpp", "odometry_mirror_test.cpp")
@@ -54,7 +54,7 @@ def test_odometry_mirror_runs_on_gpu():
     _compile_odometry()
     out = subprocess.run([ODO_EXE], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.startswith("OK")
+    assert "OK" in out.stdout
 
 
 PARSAC_SRC = os.path.join(ROOT, "tests", "cpp", "parsac_device_test.cpp")
@@ -80,4 +80,4 @@ def test_parsac_device_scoring_matches_host_scoring():
     _compile_parsac()
     out = subprocess.run([PARSAC_EXE], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.startswith("OK")
+    assert "OK" in out.stdout
