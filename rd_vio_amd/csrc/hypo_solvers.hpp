@@ -128,6 +128,7 @@ HYPO_HD double atan_pos(double x) {  // x >= 0 (inf allowed)
 // cyclic Jacobi on a symmetric n x n matrix (row-major, destroyed), n <= 5; V columns = eigenvectors
 HYPO_HD void jacobi_small(int n, double *A, double *V, double *lam) {
     for (int i = 0; i < n * n; ++i) V[i] = (i / n == i % n) ? 1.0 : 0.0;
+    double prev = 0.0;
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = 0, dg = 0;
         for (int i = 0; i < n; ++i)
@@ -136,7 +137,9 @@ HYPO_HD void jacobi_small(int n, double *A, double *V, double *lam) {
                 if (i == j) dg += a * a;
                 else off += a * a;
             }
-        if (off <= 1e-300 || off <= 1e-32 * dg) break;
+        // converged, or stagnating at the round-off floor (a rank-deficient matrix never gets below it)
+        if (off <= 1e-300 || off <= 1e-32 * dg || (sweep > 0 && off <= 1e-24 * dg && off >= 0.25 * prev)) break;
+        prev = off;
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) {
                 const double apq = A[p * n + q];
@@ -342,20 +345,22 @@ HYPO_HD void rodrigues_float_round_trip(const double *Rin, double *Rout) {
 
 // ------------------------------------------------------------------------------------------------------------ wave-parallel Jacobi
 // Round-robin ("chess tournament") ordering: n even, round r in [0, n - 1), pair k in [0, n / 2) -> (p < q), every pair once a sweep
-HYPO_HD void rr_pair(int n, int r, int k, int &p, int &q) {
-    const int m = n - 1;
+template <int n>
+HYPO_HD void rr_pair(int r, int k, int &p, int &q) {
+    constexpr int m = n - 1;
     const int a = k == 0 ? m : (r + k) % m, b = k == 0 ? r : (r - k + m) % m;
     p = a < b ? a : b;
     q = a < b ? b : a;
 }
 
-// Eigen-decomposition of a symmetric n x n matrix (row-major, destroyed; n <= 12) by Jacobi rotations in round-robin order:
+// Eigen-decomposition of a symmetric n x n matrix (row-major, destroyed; n <= 12, a template parameter so that the index
+// arithmetic of the work items is by constants) by Jacobi rotations in round-robin order:
 // the n/2 rotations of a round act on disjoint index pairs, so a round is three steps of independent items -- the rotation
 // parameters (one item per pair), J^T A (one item per pair and column), (J^T A) J and V J (one item per pair and row).
 // cs: 2 * 6 doubles, flag: 1 int of scratch.
-template <class X>
-HYPO_HD void jacobi_rr(const X &x, int n, double *A, double *V, double *lam, double *cs, int *flag) {
-    const int ne = (n + 1) & ~1, half = ne / 2, rounds = ne - 1;
+template <int n, class X>
+HYPO_HD void jacobi_rr(const X &x, double *A, double *V, double *lam, double *cs, int *flag) {
+    constexpr int ne = (n + 1) & ~1, half = ne / 2, rounds = ne - 1;
     x.each(n * n, [=](int i) { V[i] = (i / n == i % n) ? 1.0 : 0.0; });
     for (int sweep = 0; sweep < 40; ++sweep) {
         x.one([=]() {
@@ -366,13 +371,16 @@ HYPO_HD void jacobi_rr(const X &x, int n, double *A, double *V, double *lam, dou
                     if (i == j) dg += a * a;
                     else off += a * a;
                 }
-            *flag = (off <= 1e-300 || off <= 1e-32 * dg) ? 1 : 0;
+            // converged, or stagnating at the round-off floor (a rank-deficient matrix never gets below it); lam[0] carries
+            // the previous sweep's off-diagonal mass until the eigenvalues are written
+            *flag = (off <= 1e-300 || off <= 1e-32 * dg || (sweep > 0 && off <= 1e-24 * dg && off >= 0.25 * lam[0])) ? 1 : 0;
+            lam[0] = off;
         });
         if (*flag) break;
         for (int r = 0; r < rounds; ++r) {
             x.each(half, [=](int k) {
                 int p, q;
-                rr_pair(ne, r, k, p, q);
+                rr_pair<ne>(r, k, p, q);
                 double c = 1.0, s = 0.0;
                 if (q < n) {
                     const double apq = A[p * n + q];
@@ -389,7 +397,7 @@ HYPO_HD void jacobi_rr(const X &x, int n, double *A, double *V, double *lam, dou
             x.each(half * n, [=](int idx) {   // rows p, q of A
                 const int k = idx / n, j = idx % n;
                 int p, q;
-                rr_pair(ne, r, k, p, q);
+                rr_pair<ne>(r, k, p, q);
                 if (q >= n) return;
                 const double c = cs[2 * k], s = cs[2 * k + 1];
                 const double apj = A[p * n + j], aqj = A[q * n + j];
@@ -401,7 +409,7 @@ HYPO_HD void jacobi_rr(const X &x, int n, double *A, double *V, double *lam, dou
                 const int e = idx < half * n ? idx : idx - half * n;
                 const int k = e / n, i = e % n;
                 int p, q;
-                rr_pair(ne, r, k, p, q);
+                rr_pair<ne>(r, k, p, q);
                 if (q >= n) return;
                 const double c = cs[2 * k], s = cs[2 * k + 1];
                 const double mip = M[i * n + p], miq = M[i * n + q];
@@ -482,7 +490,7 @@ HYPO_HD void epnp6(const X &x, EpnpWork *w, const double *Xs /* 6 x 3 */, const 
             }
             w->MtM[e] = s;
         });
-        jacobi_rr(x, 12, w->MtM, w->Vv, w->lam, w->cs, &w->flag);
+        jacobi_rr<12>(x, w->MtM, w->Vv, w->lam, w->cs, &w->flag);
         x.one([=]() { ascending(12, w->lam, w->ord); });
         x.each(48, [=](int e) {  // v[0] = the smallest eigenvalue's vector ... v[3] = the fourth smallest
             const int k = e / 12, i = e % 12;
@@ -896,7 +904,7 @@ HYPO_HD void essential5(const X &x, Ess5Work *w, const double *p1, const double 
         for (int k = 0; k < 5; ++k) s += w->A[k][i] * w->A[k][j];
         w->AtA[e] = s;
     });
-    jacobi_rr(x, 9, w->AtA, w->Vv, w->lam, w->cs, &w->flag);
+    jacobi_rr<9>(x, w->AtA, w->Vv, w->lam, w->cs, &w->flag);
     x.one([=]() { ascending(9, w->lam, w->ord); });
     // basis columns: singular vectors 5..8 in JacobiSVD's descending order = ascending eigenvalues 3, 2, 1, 0
     x.each(36, [=](int e) {
