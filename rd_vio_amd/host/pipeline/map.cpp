@@ -37,10 +37,15 @@ std::vector<char> PreIntegrator::integrate_batch(Backend &be, CallerLane lane, c
     std::vector<int32_t> off(1, 0);
     std::vector<double> imu, t_end, bg, ba;
     std::vector<size_t> which;
+    auto same = [](const V3 &a, const V3 &b) { return a.x == b.x && a.y == b.y && a.z == b.z; };
     for (size_t j = 0; j < jobs.size(); ++j) {
         const std::vector<ImuData> &data = jobs[j].pre->data;
         if (data.empty()) continue;  // preintegrator.cpp:80-81
         ok[j] = 1;
+        const Key &k = jobs[j].pre->key;
+        if (k.valid && k.n == data.size() && k.t == jobs[j].t && k.t_first == data.front().t && k.t_last == data.back().t && same(k.bg, jobs[j].bg) &&
+            same(k.ba, jobs[j].ba) && k.cj == compute_jacobian && k.cc == compute_covariance)
+            continue;  // `delta` already holds exactly this integration
         which.push_back(j);
         for (const ImuData &d : data) imu.insert(imu.end(), {d.t, d.w.x, d.w.y, d.w.z, d.a.x, d.a.y, d.a.z});
         off.push_back((int32_t)(imu.size() / 7));
@@ -67,9 +72,11 @@ std::vector<char> PreIntegrator::integrate_batch(Backend &be, CallerLane lane, c
                     compute_jacobian ? 1 : 0, compute_covariance ? 1 : 0, out.data()),
                  "preintegrate");
     }
-    for (size_t k = 0; k < which.size(); ++k)
-        std::copy(out.begin() + (std::ptrdiff_t)(k * RDVIO_PREINT_SIZE), out.begin() + (std::ptrdiff_t)((k + 1) * RDVIO_PREINT_SIZE),
-                  jobs[which[k]].pre->delta.begin());
+    for (size_t k = 0; k < which.size(); ++k) {
+        const Job &job = jobs[which[k]];
+        std::copy(out.begin() + (std::ptrdiff_t)(k * RDVIO_PREINT_SIZE), out.begin() + (std::ptrdiff_t)((k + 1) * RDVIO_PREINT_SIZE), job.pre->delta.begin());
+        job.pre->key = Key{job.pre->data.size(), job.t, job.pre->data.front().t, job.pre->data.back().t, job.bg, job.ba, compute_jacobian, compute_covariance, true};
+    }
     return ok;
 }
 

@@ -87,6 +87,15 @@ struct PreIntegrator {
     // flags); ok[i] = false where data is empty
     struct Job { PreIntegrator *pre; double t; V3 bg, ba; };
     static std::vector<char> integrate_batch(Backend &be, CallerLane lane, const std::vector<Job> &jobs, bool compute_jacobian, bool compute_covariance);
+    // key of the integration `delta` holds (samples, end time, biases, flags): integrate() with the same key is a no-op --
+    // the reference integrates the new frame in mirror_frame and again, from identical inputs, in judge_track_status
+    // (sliding_window_tracker.cpp:73-76, 586-590)
+    struct Key {
+        size_t n = 0;
+        double t = 0, t_first = 0, t_last = 0;
+        V3 bg, ba;
+        bool cj = false, cc = false, valid = false;
+    } key;
     double dt() const { return delta[PRE_T]; }
     Q4 dq() const { return {delta[PRE_Q], delta[PRE_Q + 1], delta[PRE_Q + 2], delta[PRE_Q + 3]}; }
     V3 dp() const { return {delta[PRE_P], delta[PRE_P + 1], delta[PRE_P + 2]}; }

@@ -259,6 +259,7 @@ void FeatureTracker::track_keypoints(Frame *frame, Frame *next_frame) {
         next_h[i] = hnormalized(next_bearings[i]);
     }
     // epipolar gate over ALL points, survivors or not (frame.cpp:108-114)
+    HostTimer gates_timer__(sh.prof, 15);
     std::vector<char> mask;
     (void)find_essential_matrix(curr_h, next_h, mask, 1.0);
     mask.resize(n, 0);  // (the reference indexes an empty mask when no model was found; treated as "no inliers")
@@ -320,16 +321,21 @@ void FeatureTracker::run() {
     const bool is_initialized = latest_optimized_frame_id != nil;
     const bool sliding_window_frame_tag = !is_initialized || frame->id() % (size_t)sh.cfg.sliding_window_tracker_frequent == 0;
     if (map->frame_num() > 0) {
+        // The integrations of this step -- every frame after the latest optimised one (feature_tracker.cpp:45-61) and the new
+        // frame (:82-84) -- read only the bias of the frame before them, and predict() copies the bias forward unchanged
+        // (preintegrator.cpp:104-105): all of them integrate with the latest optimised bias and none depends on another's
+        // result, so they travel to the device as ONE batch; the predictions then run in the reference's order.
+        std::vector<PreIntegrator::Job> jobs;
+        size_t idx = nil;
         if (is_initialized) {
-            const size_t idx = map->frame_index_by_id(latest_optimized_frame_id);
+            idx = map->frame_index_by_id(latest_optimized_frame_id);
             if (idx != nil) {
                 Frame *latest = map->get_frame(idx);
                 latest->pose = latest_optimized_pose;
                 latest->motion = latest_optimized_motion;
                 for (size_t j = idx + 1; j < map->frame_num(); ++j) {
-                    Frame *frame_i = map->get_frame(j - 1), *frame_j = map->get_frame(j);
-                    frame_j->preintegration.integrate(be, LANE_TRACKER, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba, false, false);
-                    frame_j->preintegration.predict(frame_i, frame_j);
+                    Frame *frame_j = map->get_frame(j);
+                    jobs.push_back({&frame_j->preintegration, frame_j->image->t, latest->motion.bg, latest->motion.ba});
                 }
             } else {
                 latest_state.reset();  // the sliding window cannot catch up (feature_tracker.cpp:62-68)
@@ -343,7 +349,13 @@ void FeatureTracker::run() {
                 frame->preintegration.data.insert(frame->preintegration.data.begin(), imu);
             }
         }
-        frame->preintegration.integrate(be, LANE_TRACKER, frame->image->t, last_frame->motion.bg, last_frame->motion.ba, false, false);
+        // the new frame integrates with last_frame's bias as it will stand after the predictions below
+        const bool last_repropagated = idx != nil && idx + 1 < map->frame_num();
+        const MotionState &bias_src = last_repropagated ? map->get_frame(idx)->motion : last_frame->motion;
+        jobs.push_back({&frame->preintegration, frame->image->t, bias_src.bg, bias_src.ba});
+        (void)PreIntegrator::integrate_batch(be, LANE_TRACKER, jobs, false, false);
+        if (idx != nil)
+            for (size_t j = idx + 1; j < map->frame_num(); ++j) map->get_frame(j)->preintegration.predict(map->get_frame(j - 1), map->get_frame(j));
         track_keypoints(last_frame, frame.get());
         if (is_initialized) {
             frame->preintegration.predict(last_frame, frame.get());
@@ -425,6 +437,7 @@ void Frontend::drain() {
 
 // the frontend's step proper: everything of Frontend::run's tracking branch that does not touch the feature-tracking map
 void Frontend::execute(FrontendJob &j) {
+    HostTimer host_timer__(sh.prof, 12);
     try {
         if (j.mirrored) sliding_window_tracker->mirror_frame_finish(j);
         j.ok = sliding_window_tracker->track(j);
@@ -464,8 +477,14 @@ void Frontend::run() {
     HostTimer host_timer__(sh.prof, 3);
     const int mode = sh.cfg.threading;
     // the hand-over: the previous step has finished and (pipelined schedule) its results become visible to the tracker
-    drain();
-    if (mode != 0) publish();
+    {
+        HostTimer wait_timer__(sh.prof, 13);
+        drain();
+    }
+    {
+        HostTimer handover_timer__(sh.prof, 14);
+        if (mode != 0) publish();
+    }
     if (initializer) {
         // initialisation reads the whole feature-tracking map and runs once: always inline
         const size_t pending_frame_id = pending_frame_ids.front();
@@ -480,7 +499,10 @@ void Frontend::run() {
         job = std::make_unique<FrontendJob>();
         job->frame_id = pending_frame_ids.front();
         pending_frame_ids.pop_front();
-        sliding_window_tracker->mirror_frame_maps(feature_tracker->map.get(), *job);
+        {
+            HostTimer handover_timer__(sh.prof, 14);
+            sliding_window_tracker->mirror_frame_maps(feature_tracker->map.get(), *job);
+        }
         if (mode == 2) {
             {
                 std::lock_guard<std::mutex> lk(mtx);
