@@ -266,7 +266,7 @@ int rdvio_hip_marginalize_fetch(rdvio_hip_ctx *ctx, double *S_out, double *f_out
  * occupied bin), lens_weight (1 - dynamic_probability^(0.1 mean track length) per occupied bin, NULL for plain PARSAC),
  * prior_mask (inliers of the IMU prior model, NULL for plain PARSAC).  Runs on RDVIO_LANE_SOLVER. */
 #define RDVIO_PARSAC_MAX_BINS 400
-#define RDVIO_PARSAC_MAX_MODELS 128
+#define RDVIO_PARSAC_MAX_MODELS 320 /* e.g. 32 five-point samples x 10 essential matrices */
 typedef struct {
     int32_t kind, n_points;
     int32_t points_changed;        /* != 0: pa / pb / grid / prior_mask differ from the previous call (re-upload) */

@@ -160,7 +160,10 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
         CTX_ALLOC(ctx->ps_masks, (size_t)RDVIO_PARSAC_MAX_MODELS * n);
         CTX_ALLOC(ctx->ps_bins, (size_t)RDVIO_PARSAC_MAX_MODELS * RDVIO_PARSAC_MAX_BINS * sizeof(int32_t));
         CTX_ALLOC(ctx->ps_results, (size_t)RDVIO_PARSAC_MAX_MODELS * sizeof(rdvio_parsac_result));
-        if (hipHostMalloc(&ctx->ps_host, ctx->ps_in_bytes + n + 65536, hipHostMallocDefault) != hipSuccess) {
+        // behind the inputs: the results of a batch -- per-model records, generated models, and (when small enough to ride along)
+        // every model's inlier mask and bin counts
+        ctx->ps_down_bytes = (size_t)RDVIO_PARSAC_MAX_MODELS * (sizeof(rdvio_parsac_result) + 12 * 8 + 4) + n + (size_t)RDVIO_PARSAC_MASKS_INLINE + 65536;
+        if (hipHostMalloc(&ctx->ps_host, ctx->ps_in_bytes + ctx->ps_down_bytes, hipHostMallocDefault) != hipSuccess) {
             rdvio_fail(ctx, RDVIO_ERR_HIP, "hipHostMalloc(parsac blob) failed");
             *out = ctx;
             return RDVIO_ERR_HIP;

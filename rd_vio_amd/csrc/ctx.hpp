@@ -12,6 +12,7 @@
 #include "solver_ws.hpp"
 
 #define RDVIO_NUM_SLOTS 2
+#define RDVIO_PARSAC_MASKS_INLINE (256 * 1024)  // masks + bin counts of a whole batch travel with its results up to this size
 #define RDVIO_MAX_TILES 256  // CLAHE tile grid (8x8 in configs/setting.yaml:17-19)
 
 struct ImageSlot {
@@ -98,6 +99,9 @@ struct rdvio_hip_ctx {
     rdvio_parsac_result *ps_results = nullptr;
     int ps_n = 0, ps_kind = -1, ps_nv = 0, ps_nm = 0;
     int ps_slot_of[RDVIO_PARSAC_MAX_MODELS] = {0};   // model index of the last batch (as the caller counts) -> device slot
+    size_t ps_down_bytes = 0;
+    // masks and bin counts of the last batch on the host already (they rode along with the results): offsets into ps_host, 0 = no
+    size_t ps_masks_host = 0, ps_bins_host = 0;
     bool ps_has_prior = false, ps_has_lens = false;
 
     // pinned host staging

@@ -34,6 +34,7 @@ namespace hypo {
 
 // ------------------------------------------------------------------------------------------------------------ executors
 struct SerialExec {
+    static constexpr bool lanes = false;  // items run one after the other: a value several items need is computed once
     template <class F>
     void each(int n, F f) const {
         for (int i = 0; i < n; ++i) f(i);
@@ -45,6 +46,7 @@ struct SerialExec {
 };
 #if defined(__HIPCC__)
 struct WaveExec {  // one workgroup of 64 lanes; every array a step touches lives in LDS
+    static constexpr bool lanes = true;   // items run side by side: recomputing a shared value per item costs nothing, a step does
     int lane;
     template <class F>
     __device__ void each(int n, F f) const {
@@ -124,6 +126,20 @@ HYPO_HD double atan_pos(double x) {  // x >= 0 (inf allowed)
     return hi[id] - ((x * (s1 + s2) - lo[id]) - x);
 }
 
+// Jacobi rotation (c, s) that annihilates a_pq of the symmetric 2 x 2 block [[app, apq], [apq, aqq]]: tan = sgn(theta) /
+// (|theta| + sqrt(theta^2 + 1)) with theta = (aqq - app) / (2 apq), written with h = |d| + sqrt(d^2 + 4 apq^2) so that it costs
+// two square roots and one division in a row instead of five long operations
+HYPO_HD void jacobi_cs(double app, double aqq, double apq, double &c, double &s) {
+    c = 1.0;
+    s = 0.0;
+    if (apq == 0.0) return;
+    const double d = aqq - app, a2 = 2.0 * apq;
+    const double h = dabs(d) + sqrt(d * d + a2 * a2);
+    const double inv = 1.0 / sqrt(h * h + a2 * a2);
+    c = h * inv;
+    s = (d >= 0 ? a2 : -a2) * inv;
+}
+
 // ------------------------------------------------------------------------------------------------------------ small dense pieces (one lane)
 // cyclic Jacobi on a symmetric n x n matrix (row-major, destroyed), n <= 5; V columns = eigenvectors
 HYPO_HD void jacobi_small(int n, double *A, double *V, double *lam) {
@@ -144,9 +160,8 @@ HYPO_HD void jacobi_small(int n, double *A, double *V, double *lam) {
             for (int q = p + 1; q < n; ++q) {
                 const double apq = A[p * n + q];
                 if (apq == 0.0) continue;
-                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (dabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                double c, s;
+                jacobi_cs(A[p * n + p], A[q * n + q], apq, c, s);
                 for (int k = 0; k < n; ++k) {
                     const double akp = A[k * n + p], akq = A[k * n + q];
                     A[k * n + p] = c * akp - s * akq;
@@ -354,23 +369,33 @@ HYPO_HD void rr_pair(int r, int k, int &p, int &q) {
 }
 
 // Eigen-decomposition of a symmetric n x n matrix (row-major, destroyed; n <= 12, a template parameter so that the index
-// arithmetic of the work items is by constants) by Jacobi rotations in round-robin order:
-// the n/2 rotations of a round act on disjoint index pairs, so a round is three steps of independent items -- the rotation
-// parameters (one item per pair), J^T A (one item per pair and column), (J^T A) J and V J (one item per pair and row).
-// cs: 2 * 6 doubles, flag: 1 int of scratch.
+// arithmetic of the work items is by constants) by Jacobi rotations in round-robin order: the n/2 rotations of a round act on
+// disjoint index pairs, so a round is two steps of independent items --
+//   rows:    B = J^T A, one item per (pair, column); the item computes its pair's rotation itself (from A, which this step only
+//            reads) -- the same value on every item of the pair -- and the column-0 item files it for the next step;
+//   columns: A = B J and V = V J, one item per (pair, row).
+// B: n x n scratch, cs: 2 * 6 doubles, red: 2 * 12 doubles, flag: 1 int of scratch.
 template <int n, class X>
-HYPO_HD void jacobi_rr(const X &x, double *A, double *V, double *lam, double *cs, int *flag) {
+HYPO_HD void jacobi_rr(const X &x, double *A, double *B, double *V, double *lam, double *cs, double *red, int *flag) {
     constexpr int ne = (n + 1) & ~1, half = ne / 2, rounds = ne - 1;
     x.each(n * n, [=](int i) { V[i] = (i / n == i % n) ? 1.0 : 0.0; });
     for (int sweep = 0; sweep < 40; ++sweep) {
+        x.each(n, [=](int j) {   // column sums of squares, then their total in column order
+            double off = 0, dg = 0;
+            for (int i = 0; i < n; ++i) {
+                const double a = A[i * n + j];
+                if (i == j) dg += a * a;
+                else off += a * a;
+            }
+            red[2 * j] = off;
+            red[2 * j + 1] = dg;
+        });
         x.one([=]() {
             double off = 0, dg = 0;
-            for (int i = 0; i < n; ++i)
-                for (int j = 0; j < n; ++j) {
-                    const double a = A[i * n + j];
-                    if (i == j) dg += a * a;
-                    else off += a * a;
-                }
+            for (int j = 0; j < n; ++j) {
+                off += red[2 * j];
+                dg += red[2 * j + 1];
+            }
             // converged, or stagnating at the round-off floor (a rank-deficient matrix never gets below it); lam[0] carries
             // the previous sweep's off-diagonal mass until the eigenvalues are written
             *flag = (off <= 1e-300 || off <= 1e-32 * dg || (sweep > 0 && off <= 1e-24 * dg && off >= 0.25 * lam[0])) ? 1 : 0;
@@ -378,43 +403,51 @@ HYPO_HD void jacobi_rr(const X &x, double *A, double *V, double *lam, double *cs
         });
         if (*flag) break;
         for (int r = 0; r < rounds; ++r) {
-            x.each(half, [=](int k) {
-                int p, q;
-                rr_pair<ne>(r, k, p, q);
-                double c = 1.0, s = 0.0;
-                if (q < n) {
-                    const double apq = A[p * n + q];
-                    if (apq != 0.0) {
-                        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-                        const double t = (theta >= 0 ? 1.0 : -1.0) / (dabs(theta) + sqrt(theta * theta + 1.0));
-                        c = 1.0 / sqrt(t * t + 1.0);
-                        s = t * c;
-                    }
-                }
-                cs[2 * k] = c;
-                cs[2 * k + 1] = s;
-            });
-            x.each(half * n, [=](int idx) {   // rows p, q of A
+            if constexpr (!X::lanes)   // (serial executor: the rotations once per pair instead of once per item -- same values)
+                x.each(half, [=](int k) {
+                    int p, q;
+                    rr_pair<ne>(r, k, p, q);
+                    if (q < n) jacobi_cs(A[p * n + p], A[q * n + q], A[p * n + q], cs[2 * k], cs[2 * k + 1]);
+                });
+            x.each(half * n, [=](int idx) {   // B = J^T A
                 const int k = idx / n, j = idx % n;
                 int p, q;
                 rr_pair<ne>(r, k, p, q);
-                if (q >= n) return;
-                const double c = cs[2 * k], s = cs[2 * k + 1];
+                if (q >= n) {   // the pair of the padding index (odd n): row p passes through
+                    B[p * n + j] = A[p * n + j];
+                    return;
+                }
+                double c, s;
+                if constexpr (X::lanes) {
+                    jacobi_cs(A[p * n + p], A[q * n + q], A[p * n + q], c, s);
+                    if (j == 0) {
+                        cs[2 * k] = c;
+                        cs[2 * k + 1] = s;
+                    }
+                } else {
+                    c = cs[2 * k];
+                    s = cs[2 * k + 1];
+                }
                 const double apj = A[p * n + j], aqj = A[q * n + j];
-                A[p * n + j] = c * apj - s * aqj;
-                A[q * n + j] = s * apj + c * aqj;
+                B[p * n + j] = c * apj - s * aqj;
+                B[q * n + j] = s * apj + c * aqj;
             });
-            x.each(2 * half * n, [=](int idx) {   // columns p, q of A (first half of the items) and of V (second half)
-                double *M = idx < half * n ? A : V;
-                const int e = idx < half * n ? idx : idx - half * n;
+            x.each(2 * half * n, [=](int idx) {   // A = B J (first half of the items), V = V J (second half)
+                const bool first = idx < half * n;
+                const int e = first ? idx : idx - half * n;
                 const int k = e / n, i = e % n;
                 int p, q;
                 rr_pair<ne>(r, k, p, q);
-                if (q >= n) return;
+                if (q >= n) {
+                    if (first) A[i * n + p] = B[i * n + p];
+                    return;
+                }
                 const double c = cs[2 * k], s = cs[2 * k + 1];
-                const double mip = M[i * n + p], miq = M[i * n + q];
-                M[i * n + p] = c * mip - s * miq;
-                M[i * n + q] = s * mip + c * miq;
+                const double *S = first ? B : V;
+                double *D = first ? A : V;
+                const double mip = S[i * n + p], miq = S[i * n + q];
+                D[i * n + p] = c * mip - s * miq;
+                D[i * n + q] = s * mip + c * miq;
             });
         }
     }
@@ -425,7 +458,7 @@ HYPO_HD void jacobi_rr(const X &x, double *A, double *V, double *lam, double *cs
 struct EpnpWork {  // scratch of one hypothesis (LDS on the device)
     double pw[6][3], us[6][2];  // float32-rounded copies of the sample
     double cws[4][3], alphas[6][4];
-    double MtM[144], Vv[144], lam[12], cs[12];
+    double MtM[144], Vv[144], Bw[144], lam[12], cs[12], red[24];
     double v[4][12], L[6][10], rho[6];
     double cand[3][13];  // per beta initialisation: R (9), t (3), mean reprojection error
     int ord[12], flag, ok;
@@ -490,7 +523,7 @@ HYPO_HD void epnp6(const X &x, EpnpWork *w, const double *Xs /* 6 x 3 */, const 
             }
             w->MtM[e] = s;
         });
-        jacobi_rr<12>(x, w->MtM, w->Vv, w->lam, w->cs, &w->flag);
+        jacobi_rr<12>(x, w->MtM, w->Bw, w->Vv, w->lam, w->cs, w->red, &w->flag);
         x.one([=]() { ascending(12, w->lam, w->ord); });
         x.each(48, [=](int e) {  // v[0] = the smallest eigenvalue's vector ... v[3] = the fourth smallest
             const int k = e / 12, i = e % 12;
@@ -880,7 +913,7 @@ HYPO_HD void eigenvector10(const double *a, double lambda, double *x) {
 }
 
 struct Ess5Work {  // scratch of one hypothesis
-    double A[5][9], AtA[81], Vv[81], lam[9], cs[12];
+    double A[5][9], AtA[81], Vv[81], Bw[81], lam[9], cs[12], red[24];
     double basis[9][4];
     double Ep[9][20], EEt[9][20], half_trace[20];
     double polys[10][20];
@@ -904,7 +937,7 @@ HYPO_HD void essential5(const X &x, Ess5Work *w, const double *p1, const double 
         for (int k = 0; k < 5; ++k) s += w->A[k][i] * w->A[k][j];
         w->AtA[e] = s;
     });
-    jacobi_rr<9>(x, w->AtA, w->Vv, w->lam, w->cs, &w->flag);
+    jacobi_rr<9>(x, w->AtA, w->Bw, w->Vv, w->lam, w->cs, w->red, &w->flag);
     x.one([=]() { ascending(9, w->lam, w->ord); });
     // basis columns: singular vectors 5..8 in JacobiSVD's descending order = ascending eigenvalues 3, 2, 1, 0
     x.each(36, [=](int e) {

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64) void parsac_score_kernel(PsArgs a) {
         eff += __shfl_xor(eff, off);
     }
     __syncthreads();
-    for (int i = lane; i < a.n_valid; i += 64) a.bin_inliers[(size_t)m * RDVIO_PARSAC_MAX_BINS + i] = bins[i];
+    for (int i = lane; i < a.n_valid; i += 64) a.bin_inliers[(size_t)m * a.n_valid + i] = bins[i];
     if (lane != 0) return;
     // score (parsac.h:215-262 / imu_parsac.h:233-280), float recurrences in bin order
     float cs = 0.f, cs2 = 0.f;
@@ -261,6 +261,17 @@ static int parsac_run(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, rdvio_par
     const size_t gen_bytes = gen ? (o_models + (size_t)nm * mdim * sizeof(double)) - o_counts : 0;
     uint8_t *down_gen = down0 + (((size_t)nm * sizeof(rdvio_parsac_result) + 15) & ~(size_t)15);
     if (gen) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down_gen, db + o_counts, gen_bytes, hipMemcpyDeviceToHost, st));   // counts | models, one copy
+    // the winner's inlier mask and bin counts are what the caller asks for next (rdvio_hip_parsac_fetch): a small batch brings
+    // everybody's along now instead of paying a second round trip then
+    const size_t mask_bytes = (size_t)nm * n, bins_bytes = (size_t)nm * nv * sizeof(int32_t);
+    ctx->ps_masks_host = ctx->ps_bins_host = 0;
+    if (mask_bytes + bins_bytes <= RDVIO_PARSAC_MASKS_INLINE) {
+        uint8_t *dm = down_gen + ((gen_bytes + 15) & ~(size_t)15), *dbins = dm + ((mask_bytes + 15) & ~(size_t)15);
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(dm, ctx->ps_masks, mask_bytes, hipMemcpyDeviceToHost, st));
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(dbins, ctx->ps_bins, bins_bytes, hipMemcpyDeviceToHost, st));
+        ctx->ps_masks_host = (size_t)(dm - (uint8_t *)ctx->ps_host);
+        ctx->ps_bins_host = (size_t)(dbins - (uint8_t *)ctx->ps_host);
+    }
     RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));
     if (!gen) {
         memcpy(results, down, (size_t)nm * sizeof(rdvio_parsac_result));
@@ -299,13 +310,19 @@ int rdvio_hip_parsac_generate_score(rdvio_hip_ctx *ctx, const rdvio_parsac_batch
 int rdvio_hip_parsac_fetch(rdvio_hip_ctx *ctx, int model, uint8_t *mask, int32_t *bin_inliers) {
     if (!ctx) return RDVIO_ERR_INVALID;
     if (model < 0 || model >= ctx->ps_nm) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "PARSAC model %d was not in the last scored batch", model);
+    model = ctx->ps_slot_of[model];   // a generated batch leaves unoccupied slots between its models
+    if (ctx->ps_masks_host) {         // already on the host (parsac_run)
+        if (mask) memcpy(mask, (const uint8_t *)ctx->ps_host + ctx->ps_masks_host + (size_t)model * ctx->ps_n, (size_t)ctx->ps_n);
+        if (bin_inliers)
+            memcpy(bin_inliers, (const uint8_t *)ctx->ps_host + ctx->ps_bins_host + (size_t)model * ctx->ps_nv * sizeof(int32_t), (size_t)ctx->ps_nv * sizeof(int32_t));
+        return RDVIO_OK;
+    }
     hipStream_t st = ctx->lane[RDVIO_LANE_SOLVER];
     uint8_t *down = (uint8_t *)ctx->ps_host + ctx->ps_in_bytes;
     const size_t mb = ((size_t)ctx->ps_n + 15) & ~(size_t)15;
-    model = ctx->ps_slot_of[model];   // a generated batch leaves unoccupied slots between its models
     if (mask) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, ctx->ps_masks + (size_t)model * ctx->ps_n, (size_t)ctx->ps_n, hipMemcpyDeviceToHost, st));
     if (bin_inliers)
-        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down + mb, ctx->ps_bins + (size_t)model * RDVIO_PARSAC_MAX_BINS, (size_t)ctx->ps_nv * sizeof(int32_t),
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down + mb, ctx->ps_bins + (size_t)model * ctx->ps_nv, (size_t)ctx->ps_nv * sizeof(int32_t),
                                             hipMemcpyDeviceToHost, st));
     RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));
     if (mask) memcpy(mask, down, (size_t)ctx->ps_n);

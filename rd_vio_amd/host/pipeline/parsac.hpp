@@ -232,7 +232,7 @@ inline void parsac_unflatten(const double *in, Pose4 &T) {
 constexpr size_t PARSAC_BATCH = 8;
 // with device generation a batch is one launch whatever its size (one workgroup per hypothesis): the typical solve ends within
 // its first batch
-constexpr size_t PARSAC_BATCH_GENERATED_PNP = 16, PARSAC_BATCH_GENERATED_ESSENTIAL = 8;
+constexpr size_t PARSAC_BATCH_GENERATED_PNP = 32, PARSAC_BATCH_GENERATED_ESSENTIAL = 24;
 
 // diagnostic accumulators (RDVIO_PIPELINE_PROF): where a PARSAC solve spends its time
 struct ParsacProf {
