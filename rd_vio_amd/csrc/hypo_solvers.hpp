@@ -30,6 +30,11 @@
 #define HYPO_HD inline
 #endif
 
+// diagnostic hook (scripts/microbench/hypo_bench.hip defines it to record a clock per stage); nothing in product builds
+#ifndef HYPO_STAMP
+#define HYPO_STAMP(k)
+#endif
+
 namespace hypo {
 
 // ------------------------------------------------------------------------------------------------------------ executors
@@ -468,6 +473,7 @@ struct EpnpWork {  // scratch of one hypothesis (LDS on the device)
 // degenerate sample ends in the identity pose (cv::solvePnP would leave an unusable pose; the inlier test rejects either).
 template <class X>
 HYPO_HD void epnp6(const X &x, EpnpWork *w, const double *Xs /* 6 x 3 */, const double *xs /* 6 x 2 */, double *model /* 12 */) {
+    HYPO_STAMP(0);
     x.each(6, [=](int i) {
         for (int k = 0; k < 3; ++k) w->pw[i][k] = (double)(float)Xs[3 * i + k];
         for (int k = 0; k < 2; ++k) w->us[i][k] = (double)(float)xs[2 * i + k];
@@ -508,6 +514,7 @@ HYPO_HD void epnp6(const X &x, EpnpWork *w, const double *Xs /* 6 x 3 */, const 
             }
         }
     });
+    HYPO_STAMP(1);
     if (w->ok) {
         // M^T M of the 12 x 12 system (two rows per point)
         x.each(144, [=](int e) {
@@ -523,7 +530,9 @@ HYPO_HD void epnp6(const X &x, EpnpWork *w, const double *Xs /* 6 x 3 */, const 
             }
             w->MtM[e] = s;
         });
+        HYPO_STAMP(2);
         jacobi_rr<12>(x, w->MtM, w->Bw, w->Vv, w->lam, w->cs, w->red, &w->flag);
+        HYPO_STAMP(3);
         x.one([=]() { ascending(12, w->lam, w->ord); });
         x.each(48, [=](int e) {  // v[0] = the smallest eigenvalue's vector ... v[3] = the fourth smallest
             const int k = e / 12, i = e % 12;
@@ -548,6 +557,7 @@ HYPO_HD void epnp6(const X &x, EpnpWork *w, const double *Xs /* 6 x 3 */, const 
             for (int k = 0; k < 3; ++k) d += (w->v[a][3 * pa[j] + k] - w->v[a][3 * pb[j] + k]) * (w->v[b][3 * pa[j] + k] - w->v[b][3 * pb[j] + k]);
             w->L[j][col] = a == b ? d : 2 * d;
         });
+        HYPO_STAMP(4);
         // the three beta initialisations, each refined by Gauss-Newton and turned into a pose (one item each)
         x.each(3, [=](int c) {
             double b[4] = {0, 0, 0, 0};
@@ -642,6 +652,7 @@ HYPO_HD void epnp6(const X &x, EpnpWork *w, const double *Xs /* 6 x 3 */, const 
             out[12] = dfinite(mean) ? mean : -1.0;
         });
     }
+    HYPO_STAMP(5);
     x.one([=]() {
         double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
         if (w->ok) {
@@ -658,6 +669,7 @@ HYPO_HD void epnp6(const X &x, EpnpWork *w, const double *Xs /* 6 x 3 */, const 
         rodrigues_float_round_trip(R, model);
         for (int k = 0; k < 3; ++k) model[9 + k] = (double)(float)t[k];
     });
+    HYPO_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------------------------ five-point essential

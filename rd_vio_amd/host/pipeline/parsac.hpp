@@ -13,7 +13,7 @@
 // reference fixtures; OpenCV version unpinned).
 //
 // Kept quirks: the weighted sampler returns a BIN index that the caller uses as a DATA index (parsac.h:120-126,
-// imu_parsac.h:83-91); it draws from the C library's rand() re-seeded with srand(0) per solve (parsac.h:10-13); scores are
+// imu_parsac.h:83-91); it draws rand()'s sequence after srand(0) per solve (parsac.h:10-13; GlibcRand below); scores are
 // float.  One deviation: a point outside [-norm_scale, norm_scale) would index past the 400 bins in the reference
 // (undefined behaviour); its bin coordinate is clamped here.  The reference's function-local static bin confidences
 // (process-global, pnp.h:195, stereo.cpp:147) are passed in by the caller (per pipeline).
@@ -61,13 +61,48 @@ inline std::vector<Pose4> solve_pnp_6pt(const std::array<V3, 6> &Xs, const std::
 // ---------------------------------------------------------------------------------------------------------------------
 // PARSAC / IMU-PARSAC
 // ---------------------------------------------------------------------------------------------------------------------
+// The reference's sampler draws from the C library's rand() after srand(0) (parsac.h:10-13).  rand()'s state is process-global:
+// another thread that draws from it (a second pipeline, a runtime library) would silently change the hypotheses.  This is glibc's
+// generator (random_r.c, TYPE_3: the additive feedback x_i = x_{i-31} + x_{i-3} over 32-bit words, seeded by the Lehmer
+// sequence 16807 x mod 2^31 - 1, the first 310 outputs discarded, an output is the word shifted right by one) as a private
+// object: the same sequence as srand(seed); rand(); ... draw for draw (tests/cpp/geom_test.cpp compares them), owned by one solve.
+class GlibcRand {
+  public:
+    static constexpr uint32_t max = 2147483647u;  // RAND_MAX
+    explicit GlibcRand(unsigned seed) {
+        int32_t word = seed == 0 ? 1 : (int32_t)seed;
+        r_[0] = (uint32_t)word;
+        for (int i = 1; i < 31; ++i) {
+            const long hi = word / 127773, lo = word % 127773;
+            long w = 16807 * lo - 2836 * hi;
+            if (w < 0) w += 2147483647;
+            word = (int32_t)w;
+            r_[i] = (uint32_t)word;
+        }
+        f_ = 3;
+        b_ = 0;
+        for (int i = 0; i < 310; ++i) (void)next();
+    }
+    uint32_t next() {
+        r_[f_] += r_[b_];
+        const uint32_t out = r_[f_] >> 1;
+        f_ = f_ == 30 ? 0 : f_ + 1;
+        b_ = b_ == 30 ? 0 : b_ + 1;
+        return out;
+    }
+
+  private:
+    uint32_t r_[31];
+    int f_, b_;
+};
+
 class WeightedBinSampler {  // parsac.h:9-52
   public:
-    explicit WeightedBinSampler(const std::vector<float> &acc) : acc_(acc) { std::srand(0); }
+    explicit WeightedBinSampler(const std::vector<float> &acc) : acc_(acc), rand_(0) {}
     size_t draw_by_weight() {
         size_t index;
         do {
-            const float r = std::rand() / (float)RAND_MAX;
+            const float r = rand_.next() / (float)GlibcRand::max;
             index = (size_t)(std::upper_bound(acc_.begin() + 1, acc_.end(), r) - acc_.begin() - 1);
         } while (std::find(sampled_.begin(), sampled_.end(), index) != sampled_.end());
         sampled_.push_back(index);
@@ -77,6 +112,7 @@ class WeightedBinSampler {  // parsac.h:9-52
 
   private:
     const std::vector<float> &acc_;
+    GlibcRand rand_;  // srand(0) per solve, as the reference's Sampler constructor does
     std::vector<size_t> sampled_;
 };
 

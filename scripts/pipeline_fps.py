@@ -37,6 +37,7 @@ def main():
     lib = pr.load_pipeline_lib()
     init = gt if args.bootstrap == "gt" else None
     res = {}
+    runs = []
     for mode in [int(m) for m in args.modes.split(",")]:
         for rep in range(args.repeat):
             cfg, over = pr.baseline_config(lib, args.window, args.features, threading=mode)
@@ -53,6 +54,7 @@ def main():
             rep_.update(threading=mode, fps_all=round(len(d) / r["elapsed_s"], 1), first_tracking_frame=i0,
                         fps_tracking=round((len(d) - 1 - i0) / (d[-1] - d[i0]), 1), ms_per_frame_tracking=round(1e3 * (d[-1] - d[i0]) / (len(d) - 1 - i0), 4))
             res[mode] = (r, rep_)
+            runs.append((mode, r))
             print(json.dumps(rep_))
     if args.cpu:
         import oracle
@@ -63,7 +65,7 @@ def main():
 
         cfg, over = pr.baseline_config(lib, args.window, args.features, threading=1)
         c = pr.run_pipeline(lib, pu.oracle_pipeline_factory(lib, shim, cfg), frames, ts, imu, init, kp_capacity=2048)
-        for mode, (r, _) in res.items():
+        for mode, r in runs:
             if mode == 0:
                 continue
             same = len(r["keypoints"]) == len(c["keypoints"]) and all(np.array_equal(a[0], b[0]) for a, b in zip(r["keypoints"], c["keypoints"]))
@@ -72,7 +74,9 @@ def main():
             both = ~np.isnan(sg[:, 0]) & ~np.isnan(sc[:, 0])
             print(json.dumps({"vs_cpu_path": mode, "indices_identical": bool(same), "pixels_identical": bool(samexy),
                               "max_pos_diff_mm": float(1e3 * np.abs(sg[both, 5:8] - sc[both, 5:8]).max()),
-                              "cpu_fps": round(len(c["done_s"]) / c["elapsed_s"], 1), "counters_equal": bool((r["counters"][:11] == c["counters"][:11]).all())}))
+                              "cpu_fps": round(len(c["done_s"]) / c["elapsed_s"], 1), "counters_equal": bool((r["counters"][:11] == c["counters"][:11]).all()),
+                              "first_frame_with_different_indices": next((k for k, (a, b) in enumerate(zip(r["keypoints"], c["keypoints"])) if not np.array_equal(a[0], b[0])), None),
+                              "first_frame_with_different_state": next((k for k in range(min(len(sg), len(sc))) if both[k] and not np.array_equal(sg[k], sc[k])), None)}))
 
 
 if __name__ == "__main__":

@@ -23,6 +23,15 @@ static int fails = 0;
 int main() {
     std::mt19937 rng(648);
     std::uniform_real_distribution<double> U(-1.0, 1.0);
+    // --- the PARSAC sampler's private generator is the C library's rand() after srand(seed), draw for draw
+    for (unsigned seed : {0u, 1u, 648u, 123456789u}) {
+        std::srand(seed);
+        GlibcRand g(seed);
+        int bad = 0;
+        for (int i = 0; i < 20000; ++i) bad += (uint32_t)std::rand() != g.next();
+        CHECK(bad == 0, "GlibcRand(%u) differs from rand() in %d of 20000 draws", seed, bad);
+        CHECK(GlibcRand::max == (uint32_t)RAND_MAX, "RAND_MAX is not 2^31 - 1 here");
+    }
     // --- real eigenvalues / eigenvectors of a non-symmetric matrix with a known spectrum
     {
         const int n = 6;
