@@ -26,9 +26,13 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define HYPO_HD __host__ __device__ inline
+#define HYPO_UNROLL _Pragma("unroll")
 #else
 #define HYPO_HD inline
+#define HYPO_UNROLL _Pragma("GCC unroll 16")
 #endif
+// (fixed trip counts + full unrolling keep the small arrays of the one-lane sections in registers on the device: a dynamically
+// indexed private array lives in scratch memory, a round trip to HBM per access)
 
 // diagnostic hook (scripts/microbench/hypo_bench.hip defines it to record a clock per stage); nothing in product builds
 #ifndef HYPO_STAMP
@@ -147,44 +151,65 @@ HYPO_HD void jacobi_cs(double app, double aqq, double apq, double &c, double &s)
 
 // ------------------------------------------------------------------------------------------------------------ small dense pieces (one lane)
 // cyclic Jacobi on a symmetric n x n matrix (row-major, destroyed), n <= 5; V columns = eigenvectors
-HYPO_HD void jacobi_small(int n, double *A, double *V, double *lam) {
+template <int n>
+HYPO_HD void jacobi_small(double *A, double *V, double *lam) {
+    HYPO_UNROLL
     for (int i = 0; i < n * n; ++i) V[i] = (i / n == i % n) ? 1.0 : 0.0;
     double prev = 0.0;
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = 0, dg = 0;
-        for (int i = 0; i < n; ++i)
+        HYPO_UNROLL
+        for (int i = 0; i < n; ++i) {
+            HYPO_UNROLL
             for (int j = 0; j < n; ++j) {
                 const double a = A[i * n + j];
                 if (i == j) dg += a * a;
                 else off += a * a;
             }
+        }
         // converged, or stagnating at the round-off floor (a rank-deficient matrix never gets below it)
-        if (off <= 1e-300 || off <= 1e-32 * dg || (sweep > 0 && off <= 1e-24 * dg && off >= 0.25 * prev)) break;
+        if (off <= 1e-300 || off <= 1e-28 * dg || (sweep > 0 && off <= 1e-24 * dg && off >= 0.25 * prev)) break;
         prev = off;
-        for (int p = 0; p < n - 1; ++p)
+        HYPO_UNROLL
+        for (int p = 0; p < n - 1; ++p) {
+            HYPO_UNROLL
             for (int q = p + 1; q < n; ++q) {
                 const double apq = A[p * n + q];
                 if (apq == 0.0) continue;
                 double c, s;
                 jacobi_cs(A[p * n + p], A[q * n + q], apq, c, s);
+                HYPO_UNROLL
                 for (int k = 0; k < n; ++k) {
                     const double akp = A[k * n + p], akq = A[k * n + q];
                     A[k * n + p] = c * akp - s * akq;
                     A[k * n + q] = s * akp + c * akq;
                 }
+                HYPO_UNROLL
                 for (int k = 0; k < n; ++k) {
                     const double apk = A[p * n + k], aqk = A[q * n + k];
                     A[p * n + k] = c * apk - s * aqk;
                     A[q * n + k] = s * apk + c * aqk;
                 }
+                HYPO_UNROLL
                 for (int k = 0; k < n; ++k) {
                     const double vkp = V[k * n + p], vkq = V[k * n + q];
                     V[k * n + p] = c * vkp - s * vkq;
                     V[k * n + q] = s * vkp + c * vkq;
                 }
             }
+        }
     }
+    HYPO_UNROLL
     for (int i = 0; i < n; ++i) lam[i] = A[i * n + i];
+}
+
+// indices 0..2 of lam in ascending order (stable), without a dynamically indexed write
+HYPO_HD void ascending3(const double *lam, int *ord) {
+    const bool b10 = lam[1] < lam[0], b20 = lam[2] < lam[0], b21 = lam[2] < lam[1];
+    const int r0 = (b10 ? 1 : 0) + (b20 ? 1 : 0), r1 = (b10 ? 0 : 1) + (b21 ? 1 : 0);   // ranks of elements 0 and 1 (element 2 has the third)
+    ord[0] = r0 == 0 ? 0 : (r1 == 0 ? 1 : 2);
+    ord[1] = r0 == 1 ? 0 : (r1 == 1 ? 1 : 2);
+    ord[2] = r0 == 2 ? 0 : (r1 == 2 ? 1 : 2);
 }
 
 // indices of lam[0..n) in ascending order, stable (insertion sort)
@@ -228,9 +253,9 @@ HYPO_HD void svd3(const double *A, double *U, double *s, double *V) {
     double AtA[9], Vv[9], lam[3];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) AtA[3 * i + j] = A[i] * A[j] + A[3 + i] * A[3 + j] + A[6 + i] * A[6 + j];
-    jacobi_small(3, AtA, Vv, lam);
+    jacobi_small<3>(AtA, Vv, lam);
     int asc[3], ord[3];
-    ascending(3, lam, asc);
+    ascending3(lam, asc);
     ord[0] = asc[2]; ord[1] = asc[1]; ord[2] = asc[0];
     double v[3][3], u[3][3];
     for (int c = 0; c < 3; ++c) {
@@ -274,38 +299,50 @@ HYPO_HD void svd3(const double *A, double *U, double *s, double *V) {
         }
 }
 
-// least squares x = argmin |A x - b| (rows x nc row-major, nc <= 5) through the normal equations, Gaussian elimination with
-// partial pivoting; a singular system yields non-finite values (the callers test for them)
-HYPO_HD void ls_solve(int rows, int nc, const double *A, const double *b, double *x) {
-    double G[5][6];
-    for (int i = 0; i < nc; ++i) {
-        for (int j = 0; j < nc; ++j) {
+// least squares x = argmin |A x - b| (ROWS x NC row-major, NC <= 5) through the normal equations, Gaussian elimination with
+// row exchanges that bring the larger pivot up (compare-and-exchange: no dynamically indexed row); a singular system yields
+// non-finite values (the callers test for them)
+template <int ROWS, int NC>
+HYPO_HD void ls_solve(const double *A, const double *b, double *x) {
+    double G[NC][NC + 1];
+    HYPO_UNROLL
+    for (int i = 0; i < NC; ++i) {
+        HYPO_UNROLL
+        for (int j = 0; j < NC; ++j) {
             double s = 0;
-            for (int r = 0; r < rows; ++r) s += A[r * nc + i] * A[r * nc + j];
+            HYPO_UNROLL
+            for (int r = 0; r < ROWS; ++r) s += A[r * NC + i] * A[r * NC + j];
             G[i][j] = s;
         }
         double s = 0;
-        for (int r = 0; r < rows; ++r) s += A[r * nc + i] * b[r];
-        G[i][nc] = s;
+        HYPO_UNROLL
+        for (int r = 0; r < ROWS; ++r) s += A[r * NC + i] * b[r];
+        G[i][NC] = s;
     }
-    for (int c = 0; c < nc; ++c) {
-        int p = c;
-        for (int r = c + 1; r < nc; ++r)
-            if (dabs(G[r][c]) > dabs(G[p][c])) p = r;
-        if (p != c)
-            for (int j = 0; j <= nc; ++j) {
-                const double t = G[c][j];
-                G[c][j] = G[p][j];
-                G[p][j] = t;
+    HYPO_UNROLL
+    for (int c = 0; c < NC; ++c) {
+        HYPO_UNROLL
+        for (int r = c + 1; r < NC; ++r) {
+            const bool up = dabs(G[r][c]) > dabs(G[c][c]);
+            HYPO_UNROLL
+            for (int j = 0; j <= NC; ++j) {
+                const double gc = G[c][j], gr = G[r][j];
+                G[c][j] = up ? gr : gc;
+                G[r][j] = up ? gc : gr;
             }
-        for (int r = c + 1; r < nc; ++r) {
+        }
+        HYPO_UNROLL
+        for (int r = c + 1; r < NC; ++r) {
             const double f = G[r][c] / G[c][c];
-            for (int j = c; j <= nc; ++j) G[r][j] -= f * G[c][j];
+            HYPO_UNROLL
+            for (int j = c; j <= NC; ++j) G[r][j] -= f * G[c][j];
         }
     }
-    for (int c = nc - 1; c >= 0; --c) {
-        double s = G[c][nc];
-        for (int j = c + 1; j < nc; ++j) s -= G[c][j] * x[j];
+    HYPO_UNROLL
+    for (int c = NC - 1; c >= 0; --c) {
+        double s = G[c][NC];
+        HYPO_UNROLL
+        for (int j = c + 1; j < NC; ++j) s -= G[c][j] * x[j];
         x[c] = s / G[c][c];
     }
 }
@@ -379,10 +416,11 @@ HYPO_HD void rr_pair(int r, int k, int &p, int &q) {
 //   rows:    B = J^T A, one item per (pair, column); the item computes its pair's rotation itself (from A, which this step only
 //            reads) -- the same value on every item of the pair -- and the column-0 item files it for the next step;
 //   columns: A = B J and V = V J, one item per (pair, row).
+// Convergence: off-diagonal mass <= 1e-28 of the diagonal's (norm ratio 1e-14; the sweep that gets there squares it once more).
 // B: n x n scratch, cs: 2 * 6 doubles, red: 2 * 12 doubles, flag: 1 int of scratch.
 template <int n, class X>
 HYPO_HD void jacobi_rr(const X &x, double *A, double *B, double *V, double *lam, double *cs, double *red, int *flag) {
-    constexpr int ne = (n + 1) & ~1, half = ne / 2, rounds = ne - 1;
+    constexpr int ne = (n + 1) & ~1, half = ne / 2, rounds = ne - 1, cstep = (n + 1) / 2;
     x.each(n * n, [=](int i) { V[i] = (i / n == i % n) ? 1.0 : 0.0; });
     for (int sweep = 0; sweep < 40; ++sweep) {
         x.each(n, [=](int j) {   // column sums of squares, then their total in column order
@@ -403,7 +441,7 @@ HYPO_HD void jacobi_rr(const X &x, double *A, double *B, double *V, double *lam,
             }
             // converged, or stagnating at the round-off floor (a rank-deficient matrix never gets below it); lam[0] carries
             // the previous sweep's off-diagonal mass until the eigenvalues are written
-            *flag = (off <= 1e-300 || off <= 1e-32 * dg || (sweep > 0 && off <= 1e-24 * dg && off >= 0.25 * lam[0])) ? 1 : 0;
+            *flag = (off <= 1e-300 || off <= 1e-28 * dg || (sweep > 0 && off <= 1e-24 * dg && off >= 0.25 * lam[0])) ? 1 : 0;
             lam[0] = off;
         });
         if (*flag) break;
@@ -414,18 +452,21 @@ HYPO_HD void jacobi_rr(const X &x, double *A, double *B, double *V, double *lam,
                     rr_pair<ne>(r, k, p, q);
                     if (q < n) jacobi_cs(A[p * n + p], A[q * n + q], A[p * n + q], cs[2 * k], cs[2 * k + 1]);
                 });
-            x.each(half * n, [=](int idx) {   // B = J^T A
-                const int k = idx / n, j = idx % n;
+            // an item carries two columns (rows) so that a 64-lane wavefront covers a step in ONE pass, with independent
+            // rotations in flight per lane
+            x.each(half * cstep, [=](int idx) {   // B = J^T A: item = (pair, columns jj and jj + cstep)
+                const int k = idx / cstep, jj = idx % cstep;
                 int p, q;
                 rr_pair<ne>(r, k, p, q);
                 if (q >= n) {   // the pair of the padding index (odd n): row p passes through
-                    B[p * n + j] = A[p * n + j];
+                    B[p * n + jj] = A[p * n + jj];
+                    if (jj + cstep < n) B[p * n + jj + cstep] = A[p * n + jj + cstep];
                     return;
                 }
                 double c, s;
                 if constexpr (X::lanes) {
                     jacobi_cs(A[p * n + p], A[q * n + q], A[p * n + q], c, s);
-                    if (j == 0) {
+                    if (jj == 0) {
                         cs[2 * k] = c;
                         cs[2 * k + 1] = s;
                     }
@@ -433,26 +474,40 @@ HYPO_HD void jacobi_rr(const X &x, double *A, double *B, double *V, double *lam,
                     c = cs[2 * k];
                     s = cs[2 * k + 1];
                 }
-                const double apj = A[p * n + j], aqj = A[q * n + j];
-                B[p * n + j] = c * apj - s * aqj;
-                B[q * n + j] = s * apj + c * aqj;
+                const double ap0 = A[p * n + jj], aq0 = A[q * n + jj];
+                B[p * n + jj] = c * ap0 - s * aq0;
+                B[q * n + jj] = s * ap0 + c * aq0;
+                if (jj + cstep < n) {
+                    const double ap1 = A[p * n + jj + cstep], aq1 = A[q * n + jj + cstep];
+                    B[p * n + jj + cstep] = c * ap1 - s * aq1;
+                    B[q * n + jj + cstep] = s * ap1 + c * aq1;
+                }
             });
-            x.each(2 * half * n, [=](int idx) {   // A = B J (first half of the items), V = V J (second half)
-                const bool first = idx < half * n;
-                const int e = first ? idx : idx - half * n;
-                const int k = e / n, i = e % n;
+            x.each(half * cstep, [=](int idx) {   // A = B J and V = V J: item = (pair, rows ii and ii + cstep)
+                const int k = idx / cstep, ii = idx % cstep;
                 int p, q;
                 rr_pair<ne>(r, k, p, q);
                 if (q >= n) {
-                    if (first) A[i * n + p] = B[i * n + p];
+                    A[ii * n + p] = B[ii * n + p];
+                    if (ii + cstep < n) A[(ii + cstep) * n + p] = B[(ii + cstep) * n + p];
                     return;
                 }
                 const double c = cs[2 * k], s = cs[2 * k + 1];
-                const double *S = first ? B : V;
-                double *D = first ? A : V;
-                const double mip = S[i * n + p], miq = S[i * n + q];
-                D[i * n + p] = c * mip - s * miq;
-                D[i * n + q] = s * mip + c * miq;
+                {
+                    const double bp = B[ii * n + p], bq = B[ii * n + q], vp = V[ii * n + p], vq = V[ii * n + q];
+                    A[ii * n + p] = c * bp - s * bq;
+                    A[ii * n + q] = s * bp + c * bq;
+                    V[ii * n + p] = c * vp - s * vq;
+                    V[ii * n + q] = s * vp + c * vq;
+                }
+                if (ii + cstep < n) {
+                    const int i1 = ii + cstep;
+                    const double bp = B[i1 * n + p], bq = B[i1 * n + q], vp = V[i1 * n + p], vq = V[i1 * n + q];
+                    A[i1 * n + p] = c * bp - s * bq;
+                    A[i1 * n + q] = s * bp + c * bq;
+                    V[i1 * n + p] = c * vp - s * vq;
+                    V[i1 * n + q] = s * vp + c * vq;
+                }
             });
         }
     }
@@ -490,9 +545,9 @@ HYPO_HD void epnp6(const X &x, EpnpWork *w, const double *Xs /* 6 x 3 */, const 
             for (int a = 0; a < 3; ++a)
                 for (int b = 0; b < 3; ++b) C[3 * a + b] += d[a] * d[b];
         }
-        jacobi_small(3, C, Ve, le);
+        jacobi_small<3>(C, Ve, le);
         int asc[3];
-        ascending(3, le, asc);
+        ascending3(le, asc);
         for (int k = 0; k < 3; ++k) w->cws[0][k] = c0[k];
         for (int i = 1; i < 4; ++i) {
             const int c = asc[3 - i];  // descending eigenvalues
@@ -561,30 +616,45 @@ HYPO_HD void epnp6(const X &x, EpnpWork *w, const double *Xs /* 6 x 3 */, const 
         // the three beta initialisations, each refined by Gauss-Newton and turned into a pose (one item each)
         x.each(3, [=](int c) {
             double b[4] = {0, 0, 0, 0};
-            {
-                const int ncs[3] = {4, 3, 5};
-                const int cols[3][5] = {{0, 1, 3, 6, 0}, {0, 1, 2, 0, 0}, {0, 1, 2, 3, 4}};
-                const int nc = ncs[c];
-                double A[30], sol[5];
-                for (int j = 0; j < 6; ++j)
-                    for (int k = 0; k < nc; ++k) A[nc * j + k] = w->L[j][cols[c][k]];
-                ls_solve(6, nc, A, w->rho, sol);
-                if (c == 0) {  // N = 4: [B11 B12 B13 B14]
-                    if (sol[0] < 0) { b[0] = sqrt(-sol[0]); b[1] = -sol[1] / b[0]; b[2] = -sol[2] / b[0]; b[3] = -sol[3] / b[0]; }
-                    else { b[0] = sqrt(sol[0]); b[1] = sol[1] / b[0]; b[2] = sol[2] / b[0]; b[3] = sol[3] / b[0]; }
-                } else {       // N = 2: [B11 B12 B22]; N = 3: [B11 B12 B22 B13 B23]
-                    if (sol[0] < 0) { b[0] = sqrt(-sol[0]); b[1] = (sol[2] < 0) ? sqrt(-sol[2]) : 0.0; }
-                    else { b[0] = sqrt(sol[0]); b[1] = (sol[2] > 0) ? sqrt(sol[2]) : 0.0; }
-                    if (sol[1] < 0) b[0] = -b[0];
-                    b[2] = c == 2 ? sol[3] / b[0] : 0.0;
-                    b[3] = 0.0;
+            if (c == 0) {  // N = 4: [B11 B12 B13 B14] from columns 0 1 3 6 of L
+                double A[24], sol[4];
+                HYPO_UNROLL
+                for (int j = 0; j < 6; ++j) {
+                    A[4 * j] = w->L[j][0]; A[4 * j + 1] = w->L[j][1]; A[4 * j + 2] = w->L[j][3]; A[4 * j + 3] = w->L[j][6];
                 }
+                ls_solve<6, 4>(A, w->rho, sol);
+                if (sol[0] < 0) { b[0] = sqrt(-sol[0]); b[1] = -sol[1] / b[0]; b[2] = -sol[2] / b[0]; b[3] = -sol[3] / b[0]; }
+                else { b[0] = sqrt(sol[0]); b[1] = sol[1] / b[0]; b[2] = sol[2] / b[0]; b[3] = sol[3] / b[0]; }
+            } else {       // N = 2: [B11 B12 B22] from columns 0 1 2; N = 3: [B11 B12 B22 B13 B23] from columns 0..4
+                double sol[5] = {0, 0, 0, 0, 0};
+                if (c == 1) {
+                    double A[18];
+                    HYPO_UNROLL
+                    for (int j = 0; j < 6; ++j) {
+                        A[3 * j] = w->L[j][0]; A[3 * j + 1] = w->L[j][1]; A[3 * j + 2] = w->L[j][2];
+                    }
+                    ls_solve<6, 3>(A, w->rho, sol);
+                } else {
+                    double A[30];
+                    HYPO_UNROLL
+                    for (int j = 0; j < 6; ++j) {
+                        HYPO_UNROLL
+                        for (int k = 0; k < 5; ++k) A[5 * j + k] = w->L[j][k];
+                    }
+                    ls_solve<6, 5>(A, w->rho, sol);
+                }
+                if (sol[0] < 0) { b[0] = sqrt(-sol[0]); b[1] = (sol[2] < 0) ? sqrt(-sol[2]) : 0.0; }
+                else { b[0] = sqrt(sol[0]); b[1] = (sol[2] > 0) ? sqrt(sol[2]) : 0.0; }
+                if (sol[1] < 0) b[0] = -b[0];
+                b[2] = c == 2 ? sol[3] / b[0] : 0.0;
+                b[3] = 0.0;
             }
             double *out = w->cand[c];
             out[12] = -1.0;  // unusable until proven otherwise
             if (!(dfinite(b[0]) && dfinite(b[1]) && dfinite(b[2]) && dfinite(b[3]))) return;
             for (int it = 0; it < 5; ++it) {  // Gauss-Newton on the six distance constraints
                 double A[24], r[6], dx[4];
+                HYPO_UNROLL
                 for (int i = 0; i < 6; ++i) {
                     const double *l = w->L[i];
                     A[4 * i + 0] = 2 * l[0] * b[0] + l[1] * b[1] + l[3] * b[2] + l[6] * b[3];
@@ -594,44 +664,68 @@ HYPO_HD void epnp6(const X &x, EpnpWork *w, const double *Xs /* 6 x 3 */, const 
                     r[i] = w->rho[i] - (l[0] * b[0] * b[0] + l[1] * b[0] * b[1] + l[2] * b[1] * b[1] + l[3] * b[0] * b[2] + l[4] * b[1] * b[2] +
                                         l[5] * b[2] * b[2] + l[6] * b[0] * b[3] + l[7] * b[1] * b[3] + l[8] * b[2] * b[3] + l[9] * b[3] * b[3]);
                 }
-                ls_solve(6, 4, A, r, dx);
+                ls_solve<6, 4>(A, r, dx);
+                HYPO_UNROLL
                 for (int k = 0; k < 4; ++k) b[k] += dx[k];
             }
             // camera-frame points from the betas, sign fix, Arun alignment, mean reprojection error
             double ccs[4][3], pc[6][3];
-            for (int i = 0; i < 4; ++i)
+            HYPO_UNROLL
+            for (int i = 0; i < 4; ++i) {
+                HYPO_UNROLL
                 for (int k = 0; k < 3; ++k) {
                     double s = 0.0;
+                    HYPO_UNROLL
                     for (int m = 0; m < 4; ++m) s = s + b[m] * w->v[m][3 * i + k];
                     ccs[i][k] = s;
                 }
-            for (int i = 0; i < 6; ++i)
+            }
+            HYPO_UNROLL
+            for (int i = 0; i < 6; ++i) {
+                HYPO_UNROLL
                 for (int k = 0; k < 3; ++k) {
                     double s = 0.0;
+                    HYPO_UNROLL
                     for (int j = 0; j < 4; ++j) s = s + w->alphas[i][j] * ccs[j][k];
                     pc[i][k] = s;
                 }
-            if (pc[0][2] < 0.0)
-                for (int i = 0; i < 6; ++i)
-                    for (int k = 0; k < 3; ++k) pc[i][k] = -pc[i][k];
+            }
+            const bool flip = pc[0][2] < 0.0;
+            HYPO_UNROLL
+            for (int i = 0; i < 6; ++i) {
+                HYPO_UNROLL
+                for (int k = 0; k < 3; ++k) pc[i][k] = flip ? -pc[i][k] : pc[i][k];
+            }
             double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
-            for (int i = 0; i < 6; ++i)
+            HYPO_UNROLL
+            for (int i = 0; i < 6; ++i) {
+                HYPO_UNROLL
                 for (int k = 0; k < 3; ++k) {
                     pc0[k] = pc0[k] + pc[i][k];
                     pw0[k] = pw0[k] + w->pw[i][k];
                 }
+            }
+            HYPO_UNROLL
             for (int k = 0; k < 3; ++k) {
                 pc0[k] = pc0[k] / 6.0;
                 pw0[k] = pw0[k] / 6.0;
             }
             double ABt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            for (int i = 0; i < 6; ++i)
-                for (int r = 0; r < 3; ++r)
+            HYPO_UNROLL
+            for (int i = 0; i < 6; ++i) {
+                HYPO_UNROLL
+                for (int r = 0; r < 3; ++r) {
+                    HYPO_UNROLL
                     for (int q = 0; q < 3; ++q) ABt[3 * r + q] += (pc[i][r] - pc0[r]) * (w->pw[i][q] - pw0[q]);
+                }
+            }
             double U[9], V[9], sv[3], R[9];
             svd3(ABt, U, sv, V);
-            for (int r = 0; r < 3; ++r)
+            HYPO_UNROLL
+            for (int r = 0; r < 3; ++r) {
+                HYPO_UNROLL
                 for (int q = 0; q < 3; ++q) R[3 * r + q] = U[3 * r] * V[3 * q] + U[3 * r + 1] * V[3 * q + 1] + U[3 * r + 2] * V[3 * q + 2];
+            }
             if (det3(R) < 0) {
                 R[6] = -R[6]; R[7] = -R[7]; R[8] = -R[8];
             }
