@@ -218,6 +218,13 @@ int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int slot, int max_iterations
 int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double *inv_depth_out,
                        rdvio_ba_summary *summary);
 
+/* Measurement: live timing of the dominant kernel.  With timing on, every ba_solve_kernel launch is bracketed by HIP events on
+ * the solver lane and read at the fetch that follows; get returns the sums since timing was switched on:
+ * out4 = { launches, kernel milliseconds, algorithmic FP64 flops (SURVEY.md 8d per-unit figures x the units of each launch:
+ * (successful steps + 1) linearisations + iterations cost evaluations), solver iterations }. */
+int rdvio_hip_ctx_set_kernel_timing(rdvio_hip_ctx *ctx, int on);
+int rdvio_hip_ctx_get_kernel_timing(rdvio_hip_ctx *ctx, double *out4);
+
 /* MarginalizationFactor::marginalize(0) (marginalization_factor.h:9-12; ceres/marginalization_factor.h:74-475;
  * called by Map::marginalize_frame, map.cpp:50-62).  Frame 0 of `states` is the victim.  The caller passes the
  * current prior, keyframe_preintegration of frame 1 (NULL if none), and the reprojection factors of every

@@ -182,8 +182,15 @@ typedef struct rdvio_replay {
     double *done_s;               /* n_frames */
     int32_t frames_processed;     /* out */
     double elapsed_s;             /* out: whole call */
+    /* A stream can be replayed in segments (warm-up, then a timed region): after the last frame of the segment IMU samples are
+     * pushed until the feature tracker has consumed every frame pushed so far (flush == 1: only until then; flush == 2: all of
+     * them, the end of the stream), and imu_consumed says where the next segment's IMU starts.  flush == 0: none. */
+    int32_t flush;
+    int32_t imu_consumed;         /* out */
 } rdvio_replay;
 int rdvio_pipeline_replay(rdvio_pipeline *p, rdvio_replay *r);
+/* waits until the frontend's step in flight (threading == 2) has finished; every frame pushed so far is then fully processed */
+int rdvio_pipeline_drain(rdvio_pipeline *p);
 
 #ifdef __cplusplus
 }

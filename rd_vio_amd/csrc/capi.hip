@@ -210,6 +210,8 @@ void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
     if (ctx->marg.host) (void)hipHostFree(ctx->marg.host);
     (void)hipFree(ctx->marg.arena);
     for (int s = 0; s < RDVIO_BA_SLOTS; ++s) {
+        if (ctx->ba[s].ev0) (void)hipEventDestroy(ctx->ba[s].ev0);
+        if (ctx->ba[s].ev1) (void)hipEventDestroy(ctx->ba[s].ev1);
         if (ctx->ba[s].host) (void)hipHostFree(ctx->ba[s].host);
         (void)hipFree(ctx->ba[s].arena);
     }

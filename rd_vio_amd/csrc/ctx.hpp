@@ -84,6 +84,11 @@ struct rdvio_hip_ctx {
         SolverWs ws{};
         size_t in_states_off = 0, in_invd_off = 0, in_bytes = 0, host_bytes = 0;
         bool ready = false;
+        // SURVEY 8(d) algorithmic flops of the problem: per linearisation / per trial-step cost evaluation (rdvio_ba_prepare)
+        double flops_lin = 0.0, flops_eval = 0.0;
+        // live kernel timing (rdvio_hip_ctx_set_kernel_timing): events around the launch in flight
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        bool timed_launch = false;
     } ba[RDVIO_BA_SLOTS];
     size_t ba_host_bytes = 0, ba_arena_bytes = 0;
     // marginalisation: a solver slot of its own (the linearisation is shared with the solver) + tail scratch
@@ -107,6 +112,11 @@ struct rdvio_hip_ctx {
     // pinned host staging
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
+
+    // live kernel timing of the dominant kernel (ba_solve_kernel): HIP events on the solver lane around every launch,
+    // read at the fetch that follows; sums since the last reset
+    bool kernel_timing = false;
+    double kt_launches = 0.0, kt_ms = 0.0, kt_flops = 0.0, kt_iterations = 0.0;
 
     char err[512] = {0};
 };

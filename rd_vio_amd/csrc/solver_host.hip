@@ -281,6 +281,19 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     }
 #undef DP
 #undef IP
+    {
+        // algorithmic FP64 flops from SURVEY.md 8(d)'s per-unit figures: per linearisation 0.5 kflop per reprojection factor
+        // + 15 kflop per preintegration factor + 2 D^2 16 W for the prior's Jacobian product + 182 MAC per factor and 36 m^2 MAC
+        // per free landmark with m observations (normal equations + landmark Schur) + n^3 / 3 for the reduced Cholesky (n = 15 x
+        // free frames); per trial-step cost evaluation 0.2 kflop per reprojection factor + 2 kflop per preintegration factor +
+        // 2 D^2 for the prior
+        double m2 = 0.0;
+        for (int l = 0; l < nl; ++l)
+            if (lm_count[l] > 0 && !pb->lm_fixed[l]) m2 += (double)lm_count[l] * lm_count[l];
+        const double F = nf, P = npre, Dd = D, Wp = np, n3 = (double)N * N * N;
+        slot.flops_lin = 500.0 * F + 15000.0 * P + 2.0 * Dd * Dd * 16.0 * Wp + 2.0 * 182.0 * F + 2.0 * 36.0 * m2 + n3 / 3.0;
+        slot.flops_eval = 200.0 * F + 2000.0 * P + 2.0 * Dd * Dd;
+    }
     slot.in_states_off = o_states;
     slot.in_invd_off = o_invd;
     slot.in_bytes = in_bytes;
@@ -313,8 +326,17 @@ int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int slot, int max_iterations
     w.max_iter = max_iterations;
     // the kernel (re)starts from the uploaded initial values (SolverWs::x0 / xd0): no host traffic, no extra copies
     if (w.n_wg > 1) RDVIO_HIP_CHECK(ctx, hipMemsetAsync(w.sync, 0, 8 * sizeof(double), ctx->lane[RDVIO_LANE_SOLVER]));
+    S.timed_launch = ctx->kernel_timing;
+    if (S.timed_launch) {
+        if (!S.ev0) {
+            RDVIO_HIP_CHECK(ctx, hipEventCreate(&S.ev0));
+            RDVIO_HIP_CHECK(ctx, hipEventCreate(&S.ev1));
+        }
+        RDVIO_HIP_CHECK(ctx, hipEventRecord(S.ev0, ctx->lane[RDVIO_LANE_SOLVER]));
+    }
     rdvio_launch_ba_solve(ctx->lane[RDVIO_LANE_SOLVER], w);
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
+    if (S.timed_launch) RDVIO_HIP_CHECK(ctx, hipEventRecord(S.ev1, ctx->lane[RDVIO_LANE_SOLVER]));
     return RDVIO_OK;
 }
 
@@ -333,6 +355,16 @@ int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double 
     if (states_out) memcpy(states_out, down, (size_t)w.nfr * 16 * sizeof(double));
     if (inv_depth_out && w.nl > 0) memcpy(inv_depth_out, down + (w.xd - w.x), (size_t)w.nl * sizeof(double));
     const double *sum = down + (w.summary - w.x);
+    if (S.timed_launch) {   // the lane has just been waited for: both events are complete
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, S.ev0, S.ev1) == hipSuccess) {
+            ctx->kt_launches += 1.0;
+            ctx->kt_ms += (double)ms;
+            ctx->kt_flops += (sum[1] + 1.0) * S.flops_lin + sum[0] * S.flops_eval;
+            ctx->kt_iterations += sum[0];
+        }
+        S.timed_launch = false;
+    }
     if (summary) {
         summary->iterations = (int32_t)sum[0];
         summary->successful_steps = (int32_t)sum[1];
@@ -344,6 +376,22 @@ int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double 
     // point and termination FAILURE, and the caller is told
     if (sum[6] != 0.0) return rdvio_fail(ctx, RDVIO_ERR_HIP, "solver wavefronts disagreed on the trust-region loop's scalars (internal error)");
     if (sum[5] != 0.0) return rdvio_fail(ctx, RDVIO_ERR_TIMEOUT, "a solver helper workgroup did not answer within the spin limit");
+    return RDVIO_OK;
+}
+
+int rdvio_hip_ctx_set_kernel_timing(rdvio_hip_ctx *ctx, int on) {
+    if (!ctx) return RDVIO_ERR_INVALID;
+    ctx->kernel_timing = on != 0;
+    ctx->kt_launches = ctx->kt_ms = ctx->kt_flops = ctx->kt_iterations = 0.0;
+    return RDVIO_OK;
+}
+
+int rdvio_hip_ctx_get_kernel_timing(rdvio_hip_ctx *ctx, double *out4) {
+    if (!ctx || !out4) return RDVIO_ERR_INVALID;
+    out4[0] = ctx->kt_launches;
+    out4[1] = ctx->kt_ms;
+    out4[2] = ctx->kt_flops;
+    out4[3] = ctx->kt_iterations;
     return RDVIO_OK;
 }
 

@@ -1452,6 +1452,9 @@ int rdvio_pipeline_replay(rdvio_pipeline *p, rdvio_replay *r) {
     const auto t0 = std::chrono::steady_clock::now();
     const double nan = std::nan("");
     int64_t seen = p->shared.counters.frames_tracked;
+    // frames pushed before this call and not yet consumed are consumed (and recorded) here as well: count from what the
+    // tracker HAS consumed plus what the handler still queues
+    const int64_t seen0 = seen + (int64_t)p->handler->queued_frames();
     int rows = 0;
     auto record = [&]() {   // the feature tracker consumed another frame
         if (rows >= r->n_frames) return;
@@ -1486,10 +1489,19 @@ int rdvio_pipeline_replay(rdvio_pipeline *p, rdvio_replay *r) {
         while (ii < r->n_imu && r->imu[7 * (size_t)ii] <= r->frame_t[k] && rc == RDVIO_OK) rc = push_imu(r->imu + 7 * (size_t)ii++);
         if (rc == RDVIO_OK) rc = rdvio_pipeline_add_frame(p, r->frame_t[k], r->frames[k], r->width, r->height, r->stride, nullptr);
     }
-    while (ii < r->n_imu && rc == RDVIO_OK) rc = push_imu(r->imu + 7 * (size_t)ii++);
+    const int64_t pushed = seen0 + r->n_frames;
+    while (ii < r->n_imu && rc == RDVIO_OK && (r->flush == 2 || (r->flush == 1 && p->shared.counters.frames_tracked < pushed)))
+        rc = push_imu(r->imu + 7 * (size_t)ii++);
+    r->imu_consumed = ii;
     r->frames_processed = rows;
     r->elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return rc;
+}
+
+int rdvio_pipeline_drain(rdvio_pipeline *p) {
+    if (!p) return RDVIO_ERR_INVALID;
+    PIPE_GUARD(p->handler->frontend.drain())
+    return RDVIO_OK;
 }
 
 int rdvio_pipeline_counters(const rdvio_pipeline *p, int64_t *out) {

@@ -252,6 +252,7 @@ class Handler {
     PoseState track_accelerometer(double t, double x, double y, double z);
     PoseState track_camera(std::shared_ptr<ImageRef> image);
     std::tuple<double, PoseState> get_latest_state() const;
+    size_t queued_frames() const { return frames.size(); }   // pushed, waiting for the IMU sample that releases them
     FeatureTracker feature_tracker;
     Frontend frontend;
 

@@ -118,13 +118,14 @@ class Replay(ctypes.Structure):
                 ("frames", ctypes.POINTER(ctypes.c_void_p)), ("frame_t", ctypes.c_void_p), ("n_imu", ctypes.c_int32), ("imu", ctypes.c_void_p),
                 ("kp_capacity", ctypes.c_int32), ("kp_ids", ctypes.c_void_p), ("kp_xy", ctypes.c_void_p), ("kp_n", ctypes.c_void_p),
                 ("latest", ctypes.c_void_p), ("window", ctypes.c_void_p), ("sys_state", ctypes.c_void_p), ("done_s", ctypes.c_void_p),
-                ("frames_processed", ctypes.c_int32), ("elapsed_s", ctypes.c_double)]
+                ("frames_processed", ctypes.c_int32), ("elapsed_s", ctypes.c_double), ("flush", ctypes.c_int32), ("imu_consumed", ctypes.c_int32)]
 
 
-def replay_stream(lib, handle, frames, ts, imu, kp_capacity=0):
-    """rdvio_pipeline_replay: the whole stream in one native call (the test_euroc loop inside the library).  Returns a dict:
-    window (n x 17), latest (n x 8), sys_state, done_s (seconds since the start of the replay at which each frame was done),
-    keypoints [(ids, xy)] when kp_capacity > 0, frames_processed, elapsed_s."""
+def replay_stream(lib, handle, frames, ts, imu, kp_capacity=0, flush=2):
+    """rdvio_pipeline_replay: a stream (or a segment of one: flush = 1, continue with imu[imu_consumed:]) in one native call (the
+    test_euroc loop inside the library).  Returns a dict: window (rows x 17), latest (rows x 8), sys_state, done_s (seconds since the
+    start of the call at which each frame was done), keypoints [(ids, xy)] when kp_capacity > 0, frames_processed, elapsed_s,
+    imu_consumed.  Rows: one per frame the feature tracker consumed during the call."""
     n = len(ts)
     imgs = [np.ascontiguousarray(f) for f in frames]
     h, w = imgs[0].shape
@@ -135,7 +136,7 @@ def replay_stream(lib, handle, frames, ts, imu, kp_capacity=0):
     sys_state, done = np.zeros(n, dtype=np.int32), np.zeros(n)
     rp = Replay(n_frames=n, width=w, height=h, stride=w, frames=ctypes.cast(ptrs, ctypes.POINTER(ctypes.c_void_p)), frame_t=ts.ctypes.data,
                 n_imu=len(imu), imu=imu.ctypes.data, kp_capacity=kp_capacity, window=window.ctypes.data, latest=latest.ctypes.data,
-                sys_state=sys_state.ctypes.data, done_s=done.ctypes.data)
+                sys_state=sys_state.ctypes.data, done_s=done.ctypes.data, flush=flush)
     if kp_capacity > 0:
         ids = np.zeros((n, kp_capacity), dtype=np.int64)
         xy = np.zeros((n, kp_capacity, 2))
@@ -145,7 +146,8 @@ def replay_stream(lib, handle, frames, ts, imu, kp_capacity=0):
     if rc != 0:
         raise RuntimeError(lib.rdvio_pipeline_last_error(handle).decode())
     m = rp.frames_processed
-    out = dict(window=window[:m], latest=latest[:m], sys_state=sys_state[:m], done_s=done[:m], frames_processed=m, elapsed_s=rp.elapsed_s)
+    out = dict(window=window[:m], latest=latest[:m], sys_state=sys_state[:m], done_s=done[:m], frames_processed=m, elapsed_s=rp.elapsed_s,
+               imu_consumed=int(rp.imu_consumed))
     if kp_capacity > 0:
         out["keypoints"] = [(ids[k, :min(kn[k], kp_capacity)].copy(), xy[k, :min(kn[k], kp_capacity)].copy()) for k in range(m)]
     return out

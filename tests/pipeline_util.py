@@ -25,7 +25,7 @@ PIPELINE_EXPORTS = [
     "rdvio_pipeline_last_error", "rdvio_pipeline_set_init_states", "rdvio_pipeline_add_frame", "rdvio_pipeline_add_motion",
     "rdvio_pipeline_add_gyro", "rdvio_pipeline_add_acc", "rdvio_pipeline_state", "rdvio_pipeline_latest_state",
     "rdvio_pipeline_window_state", "rdvio_pipeline_transform_world_cam", "rdvio_pipeline_local_map",
-    "rdvio_pipeline_last_frame_keypoints", "rdvio_pipeline_counters", "rdvio_pipeline_replay",
+    "rdvio_pipeline_last_frame_keypoints", "rdvio_pipeline_counters", "rdvio_pipeline_replay", "rdvio_pipeline_drain",
 ]
 
 
