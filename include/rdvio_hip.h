@@ -105,6 +105,11 @@ int rdvio_hip_image_preprocess(rdvio_hip_ctx *ctx, int slot, const uint8_t *gray
                                int stride, double clahe_clip, int tiles_x, int tiles_y);
 int rdvio_hip_image_preprocess_dev(rdvio_hip_ctx *ctx, int slot, const uint8_t *gray_dev, int width,
                                    int height, int stride, double clahe_clip, int tiles_x, int tiles_y);
+/* The same in two halves, for a caller that receives the image before the tracker asks for it (Odometry::addFrame only enqueues,
+ * handler.cpp:113-138): upload copies the pixels into the slot's pinned staging buffer (the caller's buffer is free when the call
+ * returns) and enqueues the copy to the device; preprocess_uploaded enqueues the kernels on what was uploaded.  Neither waits. */
+int rdvio_hip_image_upload(rdvio_hip_ctx *ctx, int slot, const uint8_t *gray, int width, int height, int stride);
+int rdvio_hip_image_preprocess_uploaded(rdvio_hip_ctx *ctx, int slot, double clahe_clip, int tiles_x, int tiles_y);
 /* copy a slot's arenas back (parity tests) */
 int rdvio_hip_image_download(rdvio_hip_ctx *ctx, int slot, uint8_t *pyr_img, int16_t *pyr_deriv);
 

@@ -14,7 +14,7 @@ MAX_LEVELS = 4
 # every symbol include/rdvio_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "rdvio_hip_version", "rdvio_hip_pyr_layout_init", "rdvio_hip_ctx_create", "rdvio_hip_ctx_destroy",
-    "rdvio_hip_last_error", "rdvio_hip_sync", "rdvio_hip_ctx_set_lane_stream", "rdvio_hip_ctx_set_wait_mode", "rdvio_hip_lane_wait", "rdvio_hip_lane_sync", "rdvio_hip_image_preprocess", "rdvio_hip_image_preprocess_dev",
+    "rdvio_hip_last_error", "rdvio_hip_sync", "rdvio_hip_ctx_set_lane_stream", "rdvio_hip_ctx_set_wait_mode", "rdvio_hip_lane_wait", "rdvio_hip_lane_sync", "rdvio_hip_image_preprocess", "rdvio_hip_image_upload", "rdvio_hip_image_preprocess_uploaded", "rdvio_hip_image_preprocess_dev",
     "rdvio_hip_image_download", "rdvio_hip_track_keypoints", "rdvio_hip_track_keypoints_dev", "rdvio_hip_lk_flow",
     "rdvio_hip_detect_keypoints", "rdvio_hip_harris_response", "rdvio_hip_image_release", "rdvio_hip_preintegrate",
     "rdvio_hip_preintegrate_dev", "rdvio_hip_preintegrate_estimator", "rdvio_hip_ctx_attach_thread", "rdvio_hip_ctx_ensure_lane_streams",

@@ -89,6 +89,15 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
         CTX_ALLOC(ctx->slots[s].pyr_deriv, (size_t)ctx->maxL.deriv_elems * sizeof(int16_t));
     }
     CTX_ALLOC(ctx->gray, (size_t)max_w * max_h);
+    for (int sl = 0; sl < RDVIO_NUM_SLOTS; ++sl) {
+        CTX_ALLOC(ctx->gray_slot[sl], (size_t)max_w * max_h);
+        if (hipHostMalloc((void **)&ctx->gray_pinned[sl], (size_t)max_w * max_h, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->gray_ev[sl], hipEventDisableTiming) != hipSuccess) {
+            rdvio_fail(ctx, RDVIO_ERR_HIP, "image staging allocation failed");
+            *out = ctx;
+            return RDVIO_ERR_HIP;
+        }
+    }
     CTX_ALLOC(ctx->clahe_lut, (size_t)RDVIO_MAX_TILES * 256);
     CTX_ALLOC(ctx->harris, (size_t)max_w * max_h * sizeof(float));
     CTX_ALLOC(ctx->harris_scalars, 4 * sizeof(uint32_t));
@@ -197,6 +206,9 @@ void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
     for (int s = 0; s < RDVIO_NUM_SLOTS; ++s) {
         (void)hipFree(ctx->slots[s].pyr_img);
         (void)hipFree(ctx->slots[s].pyr_deriv);
+        (void)hipFree(ctx->gray_slot[s]);
+        if (ctx->gray_pinned[s]) (void)hipHostFree(ctx->gray_pinned[s]);
+        if (ctx->gray_ev[s]) (void)hipEventDestroy(ctx->gray_ev[s]);
     }
     void *bufs[] = {ctx->gray, ctx->clahe_lut, ctx->harris, ctx->harris_scalars, ctx->harris_cand, ctx->sel_hdr, ctx->sel_corners, ctx->sel_existing, ctx->ps_dev, ctx->ps_masks, ctx->ps_bins, ctx->ps_results,
                     ctx->lk_curr,
@@ -304,11 +316,35 @@ int rdvio_hip_image_preprocess_dev(rdvio_hip_ctx *ctx, int slot, const uint8_t *
     return rdvio_launch_preprocess(ctx, slot, gray_dev, w, h, stride, clip, tiles_x, tiles_y);
 }
 
+int rdvio_hip_image_upload(rdvio_hip_ctx *ctx, int slot, const uint8_t *gray, int w, int h, int stride) {
+    if (int rc = check_image_args(ctx, slot, gray, w, h, stride, 1, 1)) return rc;
+    // the pinned buffer of this slot may still feed the previous upload
+    RDVIO_HIP_CHECK(ctx, hipEventSynchronize(ctx->gray_ev[slot]));
+    uint8_t *pin = ctx->gray_pinned[slot];
+    if (stride == w) memcpy(pin, gray, (size_t)w * h);
+    else
+        for (int y = 0; y < h; ++y) memcpy(pin + (size_t)y * w, gray + (size_t)y * stride, (size_t)w);
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->gray_slot[slot], pin, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
+    RDVIO_HIP_CHECK(ctx, hipEventRecord(ctx->gray_ev[slot], ctx->stream));
+    ctx->gray_w[slot] = w;
+    ctx->gray_h[slot] = h;
+    return RDVIO_OK;
+}
+
+int rdvio_hip_image_preprocess_uploaded(rdvio_hip_ctx *ctx, int slot, double clip, int tiles_x, int tiles_y) {
+    if (!ctx || slot < 0 || slot >= RDVIO_NUM_SLOTS) return RDVIO_ERR_INVALID;
+    if (ctx->gray_w[slot] <= 0) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "no image uploaded for slot %d", slot);
+    if (int rc = check_image_args(ctx, slot, ctx->gray_slot[slot], ctx->gray_w[slot], ctx->gray_h[slot], ctx->gray_w[slot], tiles_x, tiles_y)) return rc;
+    return rdvio_launch_preprocess(ctx, slot, ctx->gray_slot[slot], ctx->gray_w[slot], ctx->gray_h[slot], ctx->gray_w[slot], clip, tiles_x, tiles_y);
+}
+
 int rdvio_hip_image_preprocess(rdvio_hip_ctx *ctx, int slot, const uint8_t *gray, int w, int h, int stride, double clip,
                                int tiles_x, int tiles_y) {
     if (int rc = check_image_args(ctx, slot, gray, w, h, stride, tiles_x, tiles_y)) return rc;
-    RDVIO_HIP_CHECK(ctx, hipMemcpy2DAsync(ctx->gray, w, gray, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
-    return rdvio_launch_preprocess(ctx, slot, ctx->gray, w, h, w, clip, tiles_x, tiles_y);
+    // through the slot's pinned staging buffer: when this returns the caller's pixels have been read (an asynchronous copy
+    // straight out of pageable memory could still be reading them)
+    if (int rc = rdvio_hip_image_upload(ctx, slot, gray, w, h, stride)) return rc;
+    return rdvio_launch_preprocess(ctx, slot, ctx->gray_slot[slot], w, h, w, clip, tiles_x, tiles_y);
 }
 
 int rdvio_hip_image_download(rdvio_hip_ctx *ctx, int slot, uint8_t *pyr_img, int16_t *pyr_deriv) {

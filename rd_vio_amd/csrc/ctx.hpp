@@ -49,7 +49,14 @@ struct rdvio_hip_ctx {
     rdvio_pyr_layout maxL{};
 
     ImageSlot slots[RDVIO_NUM_SLOTS];
-    uint8_t *gray = nullptr;       // staging for host-side uploads (max_w*max_h)
+    uint8_t *gray = nullptr;       // device staging of a slot-less upload (max_w*max_h)
+    // host images travel through pinned memory, one staging pair per image slot: the copy out of the caller's buffer is
+    // synchronous (the caller may free it when the call returns), the copy to the device asynchronous (gray_ev[s] says when the
+    // pinned buffer may be overwritten)
+    uint8_t *gray_pinned[RDVIO_NUM_SLOTS] = {nullptr, nullptr};
+    uint8_t *gray_slot[RDVIO_NUM_SLOTS] = {nullptr, nullptr};
+    hipEvent_t gray_ev[RDVIO_NUM_SLOTS] = {nullptr, nullptr};
+    int gray_w[RDVIO_NUM_SLOTS] = {0, 0}, gray_h[RDVIO_NUM_SLOTS] = {0, 0};
     uint8_t *clahe_lut = nullptr;  // RDVIO_MAX_TILES x 256
     float *harris = nullptr;       // max_w*max_h
     uint32_t *harris_scalars = nullptr;  // [0] ordered-uint max, [1] candidate count

@@ -1,6 +1,7 @@
 // The product backend of the orchestration: every seam call goes to librdvio_hip.so (include/rdvio_hip.h).
 // Images live in the context's two pyramid slots -- the tracker keeps exactly two consecutive frames alive
 // (feature_tracker.cpp:94), so frame k uses slot k % 2.
+#include <atomic>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -10,34 +11,69 @@
 namespace {
 
 struct HipImage {
-    std::vector<uint8_t> gray;  // OpenCvImage::image (a private copy until preprocess uploads it)
+    std::vector<uint8_t> gray;  // OpenCvImage::image: a private copy, only while the image could not go to the device at once
     int width, height, slot;
+    bool preprocessed = false;
+    double clip = 0.0;
+    int tx = 0, ty = 0;
 };
 
 struct HipBackend {
     rdvio_hip_ctx *ctx;
+    // CLAHE parameters of the configuration: what the prefetch at image_create applies (preprocess re-runs if asked otherwise)
+    double clip;
+    int tx, ty;
     int next_slot = 0;
+    // which image holds each pyramid slot (nullptr = free).  image_destroy can run on the estimator's thread (the last clone of
+    // a frame dies there), everything else on the tracker's.
+    std::atomic<HipImage *> owner[2] = {nullptr, nullptr};
 };
 
+// Odometry::addFrame hands the image over before the tracker asks for it (handler.cpp:113-138 only enqueues): when the slot this
+// frame will use is free -- the frame two before it was released at the end of the previous tracker step -- the pixels go to
+// the device and CLAHE + pyramid are enqueued right away, behind whatever the frontend lane still has to do; the tracker's
+// preprocess call then finds the work done (or under way).  Otherwise the image waits in a private host copy, as before.
 int image_create(void *user, const uint8_t *gray, int width, int height, int stride, void **out) {
-    (void)user;
+    auto *b = static_cast<HipBackend *>(user);
     auto *img = new HipImage();
     img->width = width;
     img->height = height;
     img->slot = -1;
+    *out = img;
+    const int slot = b->next_slot;
+    HipImage *expected = nullptr;
+    if (b->owner[slot].compare_exchange_strong(expected, img)) {
+        b->next_slot ^= 1;
+        img->slot = slot;
+        int rc = rdvio_hip_image_upload(b->ctx, slot, gray, width, height, stride);
+        if (rc == RDVIO_OK) rc = rdvio_hip_image_preprocess_uploaded(b->ctx, slot, b->clip, b->tx, b->ty);
+        img->preprocessed = rc == RDVIO_OK;
+        img->clip = b->clip; img->tx = b->tx; img->ty = b->ty;
+        return rc;
+    }
     img->gray.resize((size_t)width * height);
     for (int y = 0; y < height; ++y) std::memcpy(&img->gray[(size_t)y * width], gray + (size_t)y * stride, (size_t)width);
-    *out = img;
     return RDVIO_OK;
 }
 
 int image_preprocess(void *user, void *image, double clip, int tx, int ty) {
     auto *b = static_cast<HipBackend *>(user);
     auto *img = static_cast<HipImage *>(image);
-    img->slot = b->next_slot;
+    if (img->preprocessed) {
+        if (img->clip == clip && img->tx == tx && img->ty == ty) return RDVIO_OK;
+        // other parameters than the prefetch assumed: the pixels are still in the slot's device staging buffer
+        img->clip = clip; img->tx = tx; img->ty = ty;
+        return rdvio_hip_image_preprocess_uploaded(b->ctx, img->slot, clip, tx, ty);
+    }
+    if (img->gray.empty()) return RDVIO_ERR_INVALID;
+    const int slot = b->next_slot;
     b->next_slot ^= 1;
-    const int rc = rdvio_hip_image_preprocess(b->ctx, img->slot, img->gray.data(), img->width, img->height, img->width, clip, tx, ty);
-    std::vector<uint8_t>().swap(img->gray);  // the pyramid is resident in HBM from here on
+    b->owner[slot].store(img);   // (the tracker keeps two consecutive frames alive: whoever held the slot is done with it)
+    img->slot = slot;
+    const int rc = rdvio_hip_image_preprocess(b->ctx, slot, img->gray.data(), img->width, img->height, img->width, clip, tx, ty);
+    std::vector<uint8_t>().swap(img->gray);  // rdvio_hip_image_preprocess has read the pixels when it returns
+    img->preprocessed = rc == RDVIO_OK;
+    img->clip = clip; img->tx = tx; img->ty = ty;
     return rc;
 }
 
@@ -55,13 +91,22 @@ int image_track(void *user, void *curr, void *next, int n, const double *curr_xy
 void image_release(void *user, void *image) {
     auto *b = static_cast<HipBackend *>(user);
     auto *img = static_cast<HipImage *>(image);
-    if (img->slot >= 0) (void)rdvio_hip_image_release(b->ctx, img->slot);
+    if (img->slot >= 0) {
+        HipImage *expected = img;
+        if (b->owner[img->slot].compare_exchange_strong(expected, nullptr)) (void)rdvio_hip_image_release(b->ctx, img->slot);
+    }
     img->slot = -1;
 }
 
 void image_destroy(void *user, void *image) {
-    (void)user;
-    delete static_cast<HipImage *>(image);
+    auto *b = static_cast<HipBackend *>(user);
+    auto *img = static_cast<HipImage *>(image);
+    // (an image that still holds its slot -- never released by the tracker -- gives it back; no device call from this thread)
+    for (int s = 0; s < 2; ++s) {
+        HipImage *expected = img;
+        (void)b->owner[s].compare_exchange_strong(expected, nullptr);
+    }
+    delete img;
 }
 
 int preintegrate(void *user, int nseg, const int32_t *seg_off, const double *imu, const double *t_end, const double *bg, const double *ba,
@@ -109,7 +154,7 @@ extern "C" int rdvio_pipeline_create_hip(rdvio_pipeline **out, const rdvio_pipel
     // one thread wait for the other's kernels)
     if (cfg->threading == 2)
         if (int rc = rdvio_hip_ctx_ensure_lane_streams(ctx)) return rc;
-    auto *b = new HipBackend{ctx};
+    auto *b = new HipBackend{ctx, cfg->feature_tracker_clahe_clip_limit, cfg->feature_tracker_clahe_width, cfg->feature_tracker_clahe_height};
     rdvio_backend fn;
     fn.user = b;
     fn.image_create = image_create;
