@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of rd_vio's per-frame hot path on MI355X (BASELINE.json metric).
 
-A "step" is one camera frame of the hot path on a synthetic EuRoC-shaped stream (there is no EuRoC data on
-the box): CLAHE + 4-level pyramid + Scharr (A1) -> fused forward/backward pyramidal LK (A2) -> GFTT-Harris
-detection (A3) -> IMU preintegration of the frame segment and the W keyframe segments (A7) ->
-localize_newframe solve, refine_window solve (A8-A14) and marginalisation of the oldest frame (A13), with every
-input resident in HBM before the timed
-region.  Multi-GPU = one independent replica (one stream) per GPU, no collective on the data path
-(SURVEY.md 8e); torch.distributed is used only for the barrier / max-over-ranks timing.
+`value`: camera frames per second of the PRODUCT PIPELINE (librdvio_pipeline.so over librdvio_hip.so: feature tracker on the
+caller's thread, sliding-window estimator on the worker thread -- rdvio_pipeline_config::threading = 2) in its tracking phase,
+fed like test_euroc feeds rdvio::Odometry (IMU samples and camera frames in timestamp order, rdvio_pipeline_replay) with a
+synthetic EuRoC-shaped stream (there is no EuRoC data on the box) that is resident in host memory, on the BASELINE
+configuration: configs/baseline_setting.yaml (the reference's shipped settings, restated) with only sliding_window.size and
+feature_tracker.max_keypoint_detection overridden, bootstrapped by the full initializer.  A "step" is one camera frame: LK
+tracker + two-view gates + detection (A1-A6), preintegration (A7), RD dynamic-outlier path (A19), localisation / window /
+subwindow solves and marginalisation (A8-A16).  The W warm-up frames and the K timed frames are tracking-phase frames; the
+bootstrap frames before them are not timed.  This rate is PCIe-inclusive (host images in, host-built BA graphs in, states out).
 
-Prints ONE JSON line (see the round contract): metric/value/unit + `roofline` (dominant kernel, measured with
-HIP events on the launch stream) + `cpu_baseline` (the CPU oracle timed on this box, rank 0, N=1 only).
+Beside it: `kernel_loop` (the resident per-frame kernel sequence of rounds 1-2, every input in HBM, with per-stage HIP-event
+times and the image kernels' HBM rooflines), `roofline` (dominant kernel ba_solve_kernel: algorithmic flops per launch over its
+HIP-event duration inside the timed region), `cpu_baseline` (the same orchestration over the CPU oracle backend on the same
+stream, one pinned core, this box), `end_to_end` (feature-index / trajectory agreement of the two paths).
+Multi-GPU = one independent replica (one stream) per GPU, no collective on the data path; torch.distributed is
+used only for the barrier / max-over-ranks timing.  Prints ONE JSON line.
 """
 import argparse
 import json
@@ -29,7 +35,7 @@ CONFIGS = {
                        name="EuRoC V1_01_easy-shaped synthetic stream 752x480, 150 features, window 8, LK + BA on GPU"),
     # configs[2]: MH_03_medium shape, 300 features, window 10, RD dynamic-outlier path on (end-to-end leg: a mapped object
     # starts to move, parsac_flag = 1)
-    "euroc_mh03_rd": dict(width=752, height=480, features=300, window=10, landmarks=300, iters=30, parsac=True,
+    "euroc_mh03_rd": dict(width=752, height=480, features=300, window=10, landmarks=300, iters=30, parsac_stream=True,
                           name="EuRoC MH_03_medium-shaped synthetic stream 752x480, 300 features, window 10, RD path"),
     # configs[4]: roofline run
     "synthetic_720p": dict(width=1280, height=720, features=1000, window=16, landmarks=1000, iters=30,
@@ -71,7 +77,7 @@ def ba_algorithmic_flops(pb, iterations, successful_steps):
     return (successful_steps + 1) * lin + iterations * cost
 
 
-PMC_TAG = "r02"
+PMC_TAG = "r03"
 
 
 def kernel_source_hash():
@@ -326,211 +332,301 @@ def multi_sequence(cfg, torch, dev, device_index, host, n_seq, steps, warmup, ov
                     "per-frame step as `value`; wall time from the common start to the last sequence's last frame"}
 
 
-CPU_STAGES = ["preprocess", "lk_track", "detect", "preintegrate", "ba_localize", "ba_window", "marginalize"]
+BOOT_FRAMES = 44   # the initializer (8 keyframes, gap 5) hands over at frame 36 of the synthetic stream; margin for other cameras
 
 
-def cpu_baseline_loop(cfg, wl, budget_s, max_frames):
-    """The CPU oracle (single thread) on the same per-frame workload; bounded sample; per-stage wall time."""
-    import oracle
-    from rd_vio_amd import synth
-
-    oracle.build()
-    frames = wl["frames_host"]
-    kp = wl["kp_host"]
-    pyr = oracle.preprocess(frames[0])
-    n = 0
-    stage = np.zeros(len(CPU_STAGES))
-    t0 = time.perf_counter()
-    while True:
-        img = frames[(n + 1) % len(frames)]
-        a = time.perf_counter()
-        nxt = oracle.preprocess(img)
-        b = time.perf_counter()
-        oracle.track_keypoints(pyr[0], (pyr[1], pyr[2]), (nxt[1], nxt[2]), kp)
-        c = time.perf_counter()
-        lvl0 = np.ascontiguousarray(oracle.level_view(nxt[0], nxt[1], 0))
-        oracle.detect_keypoints(lvl0, np.zeros((0, 2)), cfg["features"], 10.0)
-        d = time.perf_counter()
-        for i, s in enumerate(wl["imu_segs"]):
-            p = wl["imu_par"][i]
-            oracle.preintegrate(s, p[0], p[1:4], p[4:7], synth.EUROC_NOISE, jac=i > 0, cov=i > 0)
-        e = time.perf_counter()
-        oracle.ba_solve(wl["localize_pb"], cfg["iters"])
-        f = time.perf_counter()
-        oracle.ba_solve(wl["window_pb"], cfg["iters"])
-        g = time.perf_counter()
-        oracle.marginalize(*wl["marg_args"])
-        h = time.perf_counter()
-        stage += np.diff([a, b, c, d, e, f, g, h])
-        pyr = nxt
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= max_frames:
-            break
-    return n, el, stage / n * 1e3
-
-
-def cpu_baseline_worker(args):
-    """child process of cpu_baseline(): loads the oracle build named by RDVIO_ORACLE_LIB (set by the parent), runs the
-    bounded loop on the pickled workload, prints one JSON line.  Never touches the GPU."""
-    import pickle
-
-    with open(args.cpu_baseline_worker, "rb") as fh:
-        cfg, wl = pickle.load(fh)
-    n, el, stage = cpu_baseline_loop(cfg, wl, args.cpu_budget, 400)
-    print(json.dumps({"frames": n, "seconds": el, "stage_ms": [float(x) for x in stage]}))
-
-
-def cpu_baseline(cfg, wl, budget_s=10.0):
-    """SURVEY.md 8(d) / BASELINE.md section 3: the CPU restatement of the same per-frame work on one pinned host core, in the
-    two builds the survey names -- `-O3 -march=native` (strong baseline; the >= 200x target is quoted against it) and the
-    reference's own flags `-Og -msse -msse2 -msse3 -ffast-math -mtune=native` (/root/reference/CMakeLists.txt:10,17-18) --
-    each compiled on THIS host and timed in a child process (one thread, pinned to one core), with per-stage milliseconds.
-    The parity build (-O2, no contraction, no fast-math) is timed too, for continuity with round 1."""
-    import pickle
-    import subprocess
-    import tempfile
-
-    import oracle
-
-    keep = ("frames_host", "kp_host", "imu_segs", "imu_par", "localize_pb", "window_pb", "marg_args")
-    with tempfile.NamedTemporaryFile(suffix=".pkl", delete=False) as fh:
-        pickle.dump((cfg, {k: wl[k] for k in keep}), fh)
-        path = fh.name
-    builds = {}
-    try:
-        for name in ("O3_native", "Og_fastmath", "O2_parity"):
-            env = dict(os.environ)
-            if name == "O2_parity":
-                env.pop("RDVIO_ORACLE_LIB", None)
-                flags = "-O2 -ffp-contract=off -fno-fast-math"
-            else:
-                env["RDVIO_ORACLE_LIB"] = oracle.build_variant(name)
-                flags = " ".join(oracle.VARIANTS[name])
-            cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", path, "--cpu-budget", str(budget_s)]
-            try:
-                core = sorted(os.sched_getaffinity(0))[-1]
-                cmd = ["taskset", "-c", str(core)] + cmd
-            except (AttributeError, OSError):
-                pass
-            out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=20 * budget_s + 120)
-            if out.returncode != 0:
-                builds[name] = {"error": (out.stderr or out.stdout)[-300:], "flags": flags}
-                continue
-            rep = json.loads(out.stdout.strip().splitlines()[-1])
-            builds[name] = {"value": round(rep["frames"] / rep["seconds"], 3), "unit": "frames/s", "flags": "gcc " + flags,
-                            "frames": rep["frames"], "seconds": round(rep["seconds"], 2),
-                            "stage_ms": {k: round(v, 4) for k, v in zip(CPU_STAGES, rep["stage_ms"])}}
-    finally:
-        os.unlink(path)
-    head = builds.get("O3_native", {})
-    if "value" not in head:
-        head = builds.get("O2_parity", {})
-    return dict(value=head.get("value"), unit="frames/s", cores=1, kind="port",
-                sample=f"{head.get('frames')} frames of the same synthetic per-frame work through the CPU oracle (oracle/*.c), gcc -O3 "
-                       f"-march=native, 1 thread pinned to one core, {head.get('seconds')} s; other builds under `builds`",
-                stage_ms=head.get("stage_ms"), builds=builds)
-
-
-def end_to_end(cfg, ctx, n_frames, with_cpu_path):
-    """SURVEY.md 8d metric (1)-(3) on a geometrically consistent synthetic stream: the product pipeline
-    (librdvio_pipeline.so: feature tracker + sliding-window tracker over the HIP backend) fed like test_euroc feeds
-    rdvio::Odometry.  This rate is PCIe-inclusive (host images in, host-built BA graphs in, states out every frame), so
-    it is reported beside `value`, never as `value`.  With `with_cpu_path` the same orchestration runs over the CPU
-    oracle backend (cpu_baseline leg) for the trajectory / feature-index comparison."""
-    import ctypes
-
-    from rd_vio_amd import pipeline_run as pr
+def make_stream(cfg, n_frames):
     from rd_vio_amd import synth
 
     w, h = cfg["width"], cfg["height"]
     K = synth.EUROC_K.copy()
     if (w, h) != (752, 480):
         K = np.array([[900.0, 0, w / 2.0], [0, 900.0, h / 2.0], [0, 0, 1.0]])
-    frames, ts, imu, gt = synth.make_stream(n_frames, w, h, K, mover=bool(cfg.get("parsac")))
-    lib = pr.load_pipeline_lib()
-    pcfg = pr.default_config(lib, K, w, h, synth.EUROC_EXTR, synth.EUROC_NOISE, sliding_window_size=cfg["window"],
-                             feature_tracker_max_keypoint_detection=cfg["features"], feature_tracker_min_keypoint_distance=10.0,
-                             solver_iteration_limit=cfg["iters"], feature_tracker_max_frames=20,
-                             sliding_window_force_keyframe_landmarks=50, sliding_window_subframe_size=3,
-                             rotation_misalignment_threshold=0.02, parsac_flag=1 if cfg.get("parsac") else 0, parsac_keyframe_check_size=1)
-    gt_c = np.ascontiguousarray(gt)
+    frames, ts, imu, gt = synth.make_stream(n_frames, w, h, K, mover=bool(cfg.get("parsac_stream")))
+    return dict(frames=frames, ts=np.ascontiguousarray(ts), imu=np.ascontiguousarray(imu), gt=np.ascontiguousarray(gt), K=K, w=w, h=h)
 
-    def run(handle):
-        states, kps, stamps = [], [], []
-        ids = np.zeros(4096, dtype=np.int64)
-        xy = np.zeros((4096, 2))
-        st16 = np.zeros(16)
-        tt = ctypes.c_double(0)
-        t_start = time.perf_counter()
 
-        def snap(_n):
-            n = lib.rdvio_pipeline_last_frame_keypoints(handle, ids.ctypes.data_as(ctypes.c_void_p), xy.ctypes.data_as(ctypes.c_void_p), 4096)
-            kps.append((ids[:n].copy(), xy[:n].copy()))
-            ok = lib.rdvio_pipeline_window_state(handle, ctypes.byref(tt), st16.ctypes.data_as(ctypes.c_void_p))
-            states.append(np.concatenate([[tt.value], st16]) if ok else np.full(17, np.nan))
-            stamps.append(time.perf_counter() - t_start)
+def pipeline_config(lib, cfg, threading):
+    from rd_vio_amd import pipeline_run as pr
 
-        assert lib.rdvio_pipeline_set_init_states(handle, len(gt_c), gt_c.ctypes.data_as(ctypes.c_void_p)) == 0
-        spent = pr.feed_stream(lib, handle, frames, ts, imu, per_frame=snap)
+    kw = {}
+    if (cfg["width"], cfg["height"]) != (752, 480):
+        kw = dict(width=cfg["width"], height=cfg["height"], K=np.array([[900.0, 0, cfg["width"] / 2.0], [0, 900.0, cfg["height"] / 2.0], [0, 0, 1.0]]))
+    return pr.baseline_config(lib, cfg["window"], cfg["features"], threading=threading, **kw)
+
+
+class PipelineRun:
+    """One pipeline over one stream, replayed in segments: bootstrap + warm-up (untimed), then the timed frames."""
+
+    def __init__(self, lib, make_pipeline, stream, init_states=None, kp_capacity=0):
+        import ctypes
+
+        from rd_vio_amd import pipeline_run as pr
+
+        self.lib, self.pr, self.stream, self.kp_capacity, self.ct = lib, pr, stream, kp_capacity, ctypes
+        self.h = ctypes.c_void_p()
+        rc = make_pipeline(ctypes.byref(self.h))
+        if rc != 0:
+            raise RuntimeError(f"pipeline creation failed ({rc})")
+        if init_states is not None and len(init_states):
+            g = np.ascontiguousarray(init_states, dtype=np.float64)
+            assert lib.rdvio_pipeline_set_init_states(self.h, len(g), g.ctypes.data_as(ctypes.c_void_p)) == 0
+        self.frame0 = 0
+        self.imu0 = 0
+        self.rows = []
+
+    def segment(self, n, last=False):
+        s = self.stream
+        a, b = self.frame0, self.frame0 + n
+        out = self.pr.replay_stream(self.lib, self.h, s["frames"][a:b], s["ts"][a:b], s["imu"][self.imu0:], kp_capacity=self.kp_capacity,
+                                    flush=2 if last else 1)
+        if self.lib.rdvio_pipeline_drain(self.h) != 0:
+            raise RuntimeError(self.lib.rdvio_pipeline_last_error(self.h).decode())
+        self.frame0, self.imu0 = b, self.imu0 + out["imu_consumed"]
+        self.rows.append(out)
+        return out
+
+    def counters(self):
         cnt = np.zeros(29, dtype=np.int64)
-        lib.rdvio_pipeline_counters(handle, cnt.ctypes.data_as(ctypes.c_void_p))
-        lib.rdvio_pipeline_destroy(handle)
-        return np.array(states), kps, np.array(stamps), spent, cnt
+        self.lib.rdvio_pipeline_counters(self.h, cnt.ctypes.data_as(self.ct.c_void_p))
+        return cnt
 
-    sg, kg, stamps, spent, cnt = run(pr.create_hip_pipeline(lib, ctx, pcfg))
-    tracking = ~np.isnan(sg[:, 0])
-    out = {"frames": int(cnt[0]), "frames_tracking": int(tracking.sum()), "fps": round(float(cnt[0] / spent), 2),
-           "window_solves": int(cnt[1]), "marginalizations": int(cnt[3]), "localizations": int(cnt[4]), "subwindow_solves": int(cnt[5]),
-           "largest_solve": {"frames": int(cnt[8]), "factors": int(cnt[9])}, "solver_iterations": int(cnt[10]),
-           "rd_path": {"imu_parsac_judgements": int(cnt[27]), "tracks_marked_dynamic": int(cnt[28])},
-           "backend_ms_per_frame": {name: round(float(cnt[11 + 2 * k]) / 1e3 / max(int(cnt[0]), 1), 4) for k, name in enumerate(
-               ("preprocess", "detect", "track", "preintegrate", "ba_solve", "marginalize", "image_create"))},
-           "backend_calls": {name: int(cnt[12 + 2 * k]) for k, name in enumerate(
-               ("preprocess", "detect", "track", "preintegrate", "ba_solve", "marginalize", "image_create"))},
-           "ms_per_frame": round(1e3 * spent / max(int(cnt[0]), 1), 4),
-           "note": "product pipeline over the HIP backend, host buffers in/out every frame (PCIe-inclusive)"}
-    if tracking.sum() >= 2:
-        i0 = int(np.argmax(tracking))
-        out["fps_tracking_phase"] = round(float((len(stamps) - 1 - i0) / (stamps[-1] - stamps[i0])), 2)
-        p_gt = np.array([synth.traj_pose(t)[1] for t in sg[tracking, 0]])
-        out["position_error_vs_ground_truth_m"] = {"max": round(float(np.linalg.norm(sg[tracking, 5:8] - p_gt, axis=1).max()), 4),
-                                                   "final": round(float(np.linalg.norm(sg[tracking, 5:8][-1] - p_gt[-1])), 4)}
-    if with_cpu_path:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import pipeline_util as pu
+    def close(self):
+        if self.h:
+            self.lib.rdvio_pipeline_destroy(self.h)
+            self.h = None
 
-        shim = pu.build_oracle_backend()
-        hc = ctypes.c_void_p()
-        assert pu.oracle_pipeline_factory(lib, shim, pcfg)(ctypes.byref(hc)) == 0
-        sc, kc, stamps_c, spent_c, cnt_c = run(hc)
-        same_idx = len(kc) == len(kg) and all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(kg, kc))
-        both = tracking & ~np.isnan(sc[:, 0]) if len(sc) == len(sg) else np.zeros(0, dtype=bool)
-        out["cpu_path"] = {"fps": round(float(cnt_c[0] / spent_c), 2),
-                           "feature_indices_identical": bool(same_idx),
-                           "ate_rmse_gpu_vs_cpu_path_mm": float(f"{1e3 * pu.ate_rmse(sg[both, 5:8], sc[both, 5:8]):.3g}") if both.sum() >= 3 else None,
-                           "max_position_difference_mm": float(f"{1e3 * float(np.abs(sg[both, 5:8] - sc[both, 5:8]).max()):.3g}") if both.sum() else None,
-                           "kind": "the same orchestration over the CPU oracle backend (tests/cpp/oracle_backend.c), 1 thread"}
+    def table(self, key):
+        return np.concatenate([r[key] for r in self.rows]) if self.rows else np.zeros((0,))
+
+    def keypoints(self):
+        return [kp for r in self.rows for kp in r.get("keypoints", [])]
+
+
+def bootstrap_and_warm_up(run, warmup, n_total):
+    """replays until the pipeline has been tracking for `warmup` frames; returns the number of frames consumed"""
+    run.segment(BOOT_FRAMES)
+    while True:
+        st = run.table("sys_state")
+        tracking = int((st == 1).sum())
+        if tracking >= warmup:
+            return run.frame0
+        more = max(warmup - tracking, 1) if tracking > 0 else 8
+        if run.frame0 + more > n_total:
+            raise RuntimeError(f"the pipeline did not reach its tracking phase within {run.frame0} frames")
+        run.segment(more)
+
+
+def cpu_path_worker(args):
+    """child process of cpu_baseline(): the orchestration (the pipeline library build named on the command line) over the CPU
+    oracle backend (the oracle build named by RDVIO_ORACLE_VARIANT), threading = 1 (the pipelined schedule on ONE thread), on
+    the pickled stream, segmented exactly like the GPU run.  Prints one JSON line, saves the per-frame tables.  Never touches
+    the GPU."""
+    import pickle
+
+    import oracle
+    from rd_vio_amd import pipeline_run as pr
+
+    with open(args.cpu_path_worker, "rb") as fh:
+        cfg, stream, n_pre, steps, variant, lib_path = pickle.load(fh)
+    lib = pr.load_pipeline_lib(lib_path)
+    shim = oracle.build_backend(variant)
+    pcfg, _ = pipeline_config(lib, cfg, threading=1)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes
+
+    class Backend(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_void_p) for n in ("user", "image_create", "image_preprocess", "image_detect", "image_track", "image_release",
+                                                   "image_destroy", "preintegrate", "ba_solve", "marginalize", "last_error", "destroy", "parsac_score",
+                                                   "parsac_fetch", "preintegrate_estimator", "thread_attach", "parsac_generate_score")]
+
+    be = Backend()
+    shim.rdvio_oracle_backend_fill(ctypes.byref(be))
+    run = PipelineRun(lib, lambda out: lib.rdvio_pipeline_create(out, ctypes.byref(pcfg), ctypes.byref(be)), stream, kp_capacity=2048)
+    run.segment(n_pre)
+    c0 = run.counters()
+    t = run.segment(steps)
+    c1 = run.counters()
+    names = ("preprocess", "detect", "track", "preintegrate", "ba_solve", "marginalize", "image_create")
+    stage = {n: round(float(c1[11 + 2 * k] - c0[11 + 2 * k]) / 1e3 / steps, 4) for k, n in enumerate(names)}
+    np.savez(args.cpu_path_out, window=run.table("window"), kp_n=np.array([len(k[0]) for k in run.keypoints()]),
+             kp_ids=np.concatenate([k[0] for k in run.keypoints()] + [np.zeros(0, dtype=np.int64)]),
+             kp_xy=np.concatenate([k[1].reshape(-1, 2) for k in run.keypoints()] + [np.zeros((0, 2))]), counters=c1)
+    run.close()
+    print(json.dumps({"frames": steps, "seconds": t["elapsed_s"], "backend_ms_per_frame": stage}))
+
+
+CPU_BUILDS = {
+    # strong baseline: what the >= 200x target is quoted against
+    "O3_native": (["-O3", "-march=native"], "O3_native"),
+    # the reference's own flags, /root/reference/CMakeLists.txt:10,17-18
+    "Og_fastmath": (["-Og", "-msse", "-msse2", "-msse3", "-mtune=native"], "Og_fastmath"),
+    # the parity checker's build (what the trajectory / feature-index comparison runs on)
+    "O2_parity": (None, None),
+}
+
+
+def cpu_baseline(cfg, stream, n_pre, steps, builds=("O3_native", "Og_fastmath", "O2_parity")):
+    """SURVEY.md 8(d) / BASELINE.md section 3: the CPU path -- the same host orchestration over the CPU oracle backend -- on the
+    same stream and the same frames as `value`, one thread pinned to one core, in the builds the survey names: `-O3
+    -march=native` (strong baseline; the >= 200x target is quoted against it), the reference's own flags (`-Og ...
+    -ffast-math -mtune=native` for the oracle; the orchestration, whose results must not change, without -ffast-math), and the
+    parity build.  Each build is compiled on THIS host and timed in a child process."""
+    import pickle
+    import subprocess
+    import tempfile
+
+    import oracle
+    from rd_vio_amd import build as rbuild
+
+    out = {}
+    tables = None
+    with tempfile.TemporaryDirectory() as td:
+        for name in builds:
+            flags, variant = CPU_BUILDS[name]
+            try:
+                lib_path = rbuild.build_pipeline_variant(name, flags) if flags else rbuild.PIPE_LIB
+                if variant:
+                    oracle.build_backend(variant)
+                pk = os.path.join(td, f"{name}.pkl")
+                with open(pk, "wb") as fh:
+                    pickle.dump((cfg, stream, n_pre, steps, variant, lib_path), fh)
+                npz = os.path.join(td, f"{name}.npz")
+                cmd = [sys.executable, os.path.abspath(__file__), "--cpu-path-worker", pk, "--cpu-path-out", npz]
+                try:
+                    core = sorted(os.sched_getaffinity(0))[-1]
+                    cmd = ["taskset", "-c", str(core)] + cmd
+                except (AttributeError, OSError):
+                    pass
+                res = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
+                if res.returncode != 0:
+                    out[name] = {"error": (res.stderr or res.stdout)[-300:]}
+                    continue
+                rep = json.loads(res.stdout.strip().splitlines()[-1])
+                oflags = " ".join(oracle.VARIANTS[variant]) if variant else "-O2 -ffp-contract=off -fno-fast-math"
+                out[name] = {"value": round(rep["frames"] / rep["seconds"], 3), "unit": "frames/s", "frames": rep["frames"], "seconds": round(rep["seconds"], 2),
+                             "flags": {"oracle": "gcc " + oflags, "orchestration": "g++ " + (" ".join(flags) if flags else "-O2") + " -ffp-contract=off"},
+                             "backend_ms_per_frame": rep["backend_ms_per_frame"]}
+                if name == "O2_parity":
+                    tables = dict(np.load(npz))
+            except Exception as exc:  # noqa: BLE001
+                out[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    head = out.get("O3_native") if "value" in out.get("O3_native", {}) else out.get("O2_parity", {})
+    rep = dict(value=head.get("value"), unit="frames/s", cores=1, kind="port",
+               sample=f"the {steps} timed frames of the same stream (after the same {n_pre} bootstrap + warm-up frames) through the same host orchestration "
+                      f"over the CPU oracle backend (oracle/*.c, oracle/backend/), pipelined schedule on one thread pinned to one core, gcc -O3 "
+                      f"-march=native for oracle and orchestration, {head.get('seconds')} s; other builds under `builds`",
+               builds=out)
+    return rep, tables
+
+
+def compare_paths(gpu_run, cpu_tables, stream, cfg):
+    """SURVEY.md 8d metrics (2) and (3): per-frame feature index sets / pixel positions and trajectories of the two paths"""
+    from rd_vio_amd import pipeline_run as pr
+    from rd_vio_amd import synth
+
+    sg = gpu_run.table("window")
+    kg = gpu_run.keypoints()
+    sc = cpu_tables["window"]
+    off = np.concatenate([[0], np.cumsum(cpu_tables["kp_n"])])
+    kc = [(cpu_tables["kp_ids"][off[i]:off[i + 1]], cpu_tables["kp_xy"][off[i]:off[i + 1]]) for i in range(len(cpu_tables["kp_n"]))]
+    n = min(len(kg), len(kc))
+    same_idx = len(kg) == len(kc) and all(np.array_equal(kg[i][0], kc[i][0]) for i in range(n))
+    same_px = same_idx and all(np.array_equal(kg[i][1], kc[i][1]) for i in range(n))
+    m = min(len(sg), len(sc))
+    both = ~np.isnan(sg[:m, 0]) & ~np.isnan(sc[:m, 0])
+    out = {"frames_compared": int(n), "feature_indices_identical": bool(same_idx), "pixel_positions_identical": bool(same_px)}
+    if both.sum() >= 3:
+        a, b = sg[:m][both, 5:8], sc[:m][both, 5:8]
+        out["ate_rmse_gpu_vs_cpu_path_mm"] = float(f"{1e3 * ate_rmse(a, b):.3g}")
+        out["max_position_difference_mm"] = float(f"{1e3 * float(np.abs(a - b).max()):.3g}")
+        p_gt = np.array([synth.traj_pose(t)[1] for t in sg[:m][both, 0]])
+        out["ate_rmse_vs_ground_truth_m"] = {"gpu_path": round(ate_rmse(a, p_gt), 4), "cpu_path": round(ate_rmse(b, p_gt), 4),
+                                             "note": "after rigid alignment (the initializer fixes its own world frame)"}
     return out
+
+
+def ate_rmse(p_est, p_ref):
+    """position RMSE after the best rigid (Umeyama, no scale) alignment of p_est onto p_ref"""
+    a, b = np.asarray(p_est), np.asarray(p_ref)
+    ma, mb = a.mean(0), b.mean(0)
+    H = (a - ma).T @ (b - mb)
+    U, _, Vt = np.linalg.svd(H)
+    D = np.diag([1, 1, np.sign(np.linalg.det(Vt.T @ U.T))])
+    R = Vt.T @ D @ U.T
+    return float(np.sqrt(np.mean(np.sum(((a - ma) @ R.T + mb - b) ** 2, axis=1))))
+
+
+def kernel_loop_leg(cfg, torch, dev, device_index, steps, warmup, serial, stream):
+    """The resident kernel loop (rounds 1-2's `value`): one camera frame of the hot path on a fixed synthetic problem set with
+    every input in HBM -- preprocess -> LK -> detect -> preintegration -> localize_newframe solve -> refine_window solve ->
+    marginalisation, one host wait per frame, no host orchestration.  Per-stage times from HIP events on the launch streams."""
+    import rd_vio_amd
+
+    seq = Sequence(cfg, torch, dev, device_index, overlap=not serial, first_stream=stream)
+    ctx, wl = seq.ctx, seq.wl
+    for k in range(warmup):
+        seq.step(k)
+    N_EV, EV_PAIRS, names = Sequence.N_EV, Sequence.EV_PAIRS, Sequence.STAGES
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(N_EV)] for _ in range(steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        seq.step(warmup + k, evs[k])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    stage_ms = np.zeros(len(names))
+    for e in evs:
+        for i, (a, b) in enumerate(EV_PAIRS):
+            stage_ms[i] += e[a].elapsed_time(e[b])
+    stage_ms /= steps
+    _, _, sm_win = ctx.ba_fetch(0)
+    _, _, sm_loc = ctx.ba_fetch(1)
+
+    def hbm_row(kernel, nbytes, ms):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return dict(kernel=kernel, bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 6),
+                    algorithmic_bytes=int(nbytes), avg_stage_us=round(ms * 1e3, 2))
+
+    P0 = wl["L"].w[0] * wl["L"].h[0]
+    image_roof = [hbm_row("clahe_lut_kernel+pyr_level_kernel", preprocess_algorithmic_bytes(wl["L"]), stage_ms[0]),
+                  hbm_row("lk_track_kernel", lk_algorithmic_bytes(cfg["features"]), stage_ms[1]),
+                  hbm_row("harris_kernel+harris_candidates_kernel+gftt_select_kernel+poisson_filter_kernel (selection on the device)", 9 * P0, stage_ms[2])]
+    pmc, pmc_note = pmc_traffic_bytes() if cfg is CONFIGS["euroc_v101"] else ({}, "PMC passes are taken on the default config only")
+    if pmc:
+        image_roof[0]["traffic"] = pmc.get("clahe_lut_kernel", 0) + pmc.get("pyr_level_kernel<true>", 0) + 3 * pmc.get("pyr_level_kernel<false>", 0)
+        image_roof[1]["traffic"] = pmc.get("lk_track_kernel")
+        image_roof[2]["traffic"] = pmc.get("harris_kernel", 0) + pmc.get("harris_candidates_kernel", 0)
+    out = {"fps": round(steps / el, 2), "ms_per_step": round(1e3 * el / steps, 4), "steps": steps, "warmup": warmup,
+           "schedule": "serial" if serial else "frontend lane overlapped with solver and marginalisation lanes, one host wait per frame",
+           "stages_ms": {n: round(float(v), 4) for n, v in zip(names, stage_ms)},
+           "ba_window": {"factors": int(len(wl["window_pb"]["tgt"])), "iterations": int(sm_win.iterations), "successful_steps": int(sm_win.successful_steps)},
+           "ba_localize": {"factors": int(len(wl["localize_pb"]["tgt"])), "iterations": int(sm_loc.iterations)},
+           "note": "fixed problem set: every frame is a keyframe whose window solve runs to the iteration limit -- the worst case of the cadence; "
+                   "no host orchestration, no uploads",
+           "image_kernels_roofline": image_roof}
+    ctx.close()
+    return out, pmc, pmc_note
 
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="euroc_v101", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--end-to-end-frames", type=int, default=100, help="frames of the pipeline run (0 = skip)")
-    ap.add_argument("--sequences", type=int, default=16,
-                    help="extra leg (1 GPU, rank 0): this many independent sequences sharing the GPU, aggregate frames/s reported beside `value` (0 = skip)")
-    ap.add_argument("--sequence-wait", type=int, default=-1, choices=(-1, 0, 1), help="host waits of the multi-sequence leg: 0 spin, 1 block, -1 auto")
-    ap.add_argument("--sequence-lanes", type=int, default=1, choices=(1, 3),
-                    help="streams per sequence in the multi-sequence leg: 1 = stages back to back (the device overlaps ACROSS sequences), 3 = the lanes of `value`")
-    ap.add_argument("--serial", action="store_true", help="one stream, stages back to back (the round-1 step); default: frontend / estimator streams overlapped")
+    ap.add_argument("--no-kernel-loop", action="store_true", help="skip the resident kernel loop leg")
+    ap.add_argument("--no-variants", action="store_true", help="skip the schedule / bootstrap variants of the pipeline leg")
+    ap.add_argument("--threading", type=int, default=2, choices=(0, 1, 2), help="schedule of the timed pipeline (default: the product's, 2)")
+    ap.add_argument("--sequences", type=int, default=0,
+                    help="extra leg (1 GPU, rank 0): this many independent sequences sharing the GPU through the resident kernel loop (0 = skip)")
+    ap.add_argument("--sequence-wait", type=int, default=-1, choices=(-1, 0, 1))
+    ap.add_argument("--sequence-lanes", type=int, default=1, choices=(1, 3))
+    ap.add_argument("--serial", action="store_true", help="kernel loop leg: one stream, stages back to back")
     # internal modes
-    ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-budget", type=float, default=10.0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-path-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-path-out", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--stub-step-ms", type=float, default=None,
                     help="test mode: no GPU, a step is a sleep of this many ms (exercises the replica launcher and the timing protocol on CPU)")
     return ap.parse_args(argv)
@@ -586,8 +682,8 @@ def run_stub(args):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
-    if args.cpu_baseline_worker:
-        return cpu_baseline_worker(args)
+    if args.cpu_path_worker:
+        return cpu_path_worker(args)
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # torchrun (the driver's N > 1 launch) or launch_replicas
     if args.gpus > 1 and not under_launcher:
         return launch_replicas(args, argv)
@@ -595,9 +691,9 @@ def main(argv=None):
         return run_stub(args)
     cfg = CONFIGS[args.config]
     if args.sequences > 1:
-        # the multi-sequence leg runs one HIP stream per sequence: the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues
-        # (default 4), and streams that share a queue run one after the other -- ask for one queue per sequence before HIP starts
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(max(4, 2 * args.sequences * args.sequence_lanes), 32)))
+
+    import ctypes
 
     import torch
 
@@ -613,106 +709,139 @@ def main(argv=None):
     # which gloo carries on the host -- no RCCL communicator is created for a path that has no collective
     rank, _lr, world, dist = replica.init_distributed("gloo")
 
-    from rd_vio_amd import build as rbuild
     import rd_vio_amd
+    from rd_vio_amd import build as rbuild
+    from rd_vio_amd import pipeline_run as pr
 
     rbuild.build()
-    # explicit (non-default) streams: the context enqueues on them and torch.cuda.Event records on them, so the HIP events
-    # below bracket exactly the kernels of each stage.  Lanes (include/rdvio_hip.h): the frontend (image side +
-    # preintegration), the solver and the marginalisation each get their own stream unless --serial.
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    seq = Sequence(cfg, torch, dev, local_rank, overlap=not args.serial, first_stream=stream)
-    ctx, wl, step, overlap = seq.ctx, seq.wl, seq.step, seq.overlap
-    nfeat, iters = cfg["features"], cfg["iters"]
-    stage_names, NS, EV_PAIRS, N_EV = Sequence.STAGES, len(Sequence.STAGES), Sequence.EV_PAIRS, Sequence.N_EV
+    lib = pr.load_pipeline_lib()
+    steps, warmup = args.steps, args.warmup
+    n_total = BOOT_FRAMES + 24 + warmup + steps
+    stream = make_stream(cfg, n_total)
 
-    # slot 1 holds frame 0 (build_workload); warm up
-    for k in range(args.warmup):
-        step(k)
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(N_EV)] for _ in range(args.steps)]
-    elapsed, per_rank = replica.timed_region(lambda k: step(k, evs[k - args.warmup]), args.steps, sync=torch.cuda.synchronize,
-                                             dist=dist, first_index=args.warmup, per_rank=True)
-    stage_ms = np.zeros(NS)
-    for e in evs:
-        for i, (a, b) in enumerate(EV_PAIRS):
-            stage_ms[i] += e[a].elapsed_time(e[b])
-    stage_ms /= args.steps
-    _, _, sm_win = ctx.ba_fetch(0)
-    _, _, sm_loc = ctx.ba_fetch(1)
+    def hip_context():
+        return rd_vio_amd.Context(max_width=cfg["width"], max_height=cfg["height"], max_features=max(1024, 4 * cfg["features"]),
+                                  max_window=cfg["window"] + 8, max_factors=40000, device=local_rank)
+
+    def hip_run(threading, init_states=None, kp_capacity=0):
+        ctx = hip_context()
+        pcfg, applied = pipeline_config(lib, cfg, threading)
+        run = PipelineRun(lib, lambda out: lib.rdvio_pipeline_create_hip(out, ctypes.byref(pcfg), ctx._h), stream, init_states, kp_capacity)
+        return ctx, run, applied
+
+    # ---- the timed pipeline
+    ctx, run, applied = hip_run(args.threading, kp_capacity=2048)
+    n_pre = bootstrap_and_warm_up(run, warmup, n_total - steps)
+    c0 = run.counters()
+    ctx._check(ctx._lib.rdvio_hip_ctx_set_kernel_timing(ctx._h, 1))
+    timed = {}
+
+    def block(_first, k):
+        timed["out"] = run.segment(k)   # exactly k frames: replay + drain of the estimator's last step
+
+    elapsed, per_rank = replica.timed_region(None, steps, sync=torch.cuda.synchronize, dist=dist, first_index=n_pre, per_rank=True, block=block)
+    kt = np.zeros(4)
+    ctx._check(ctx._lib.rdvio_hip_ctx_get_kernel_timing(ctx._h, kt.ctypes.data_as(ctypes.c_void_p)))
+    c1 = run.counters()
+    assert timed["out"]["frames_processed"] == steps, timed["out"]["frames_processed"]
 
     if rank == 0:
-        value = world * args.steps / elapsed
-        stages = {n: round(float(v), 4) for n, v in zip(stage_names, stage_ms)}
-        dom = int(np.argmax(stage_ms))
-
-        def hbm_row(kernel, nbytes, ms):
-            gbs = nbytes / (ms * 1e-3) / 1e9
-            return dict(kernel=kernel, bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(gbs / HBM_PEAK_GBS, 6), algorithmic_bytes=int(nbytes), avg_stage_us=round(ms * 1e3, 2))
-
-        # the dominant kernel is ba_solve_kernel (two launches per frame: localize_newframe and refine_window): FP64,
-        # one workgroup, bounded by dependent-latency chains rather than by either roofline; it is priced against
-        # the FP64 matrix peak because its dense pieces run on MFMA
-        fl = (ba_algorithmic_flops(wl["window_pb"], sm_win.iterations, sm_win.successful_steps)
-              + ba_algorithmic_flops(wl["localize_pb"], sm_loc.iterations, sm_loc.successful_steps))
-        ba_ms = stage_ms[4] + stage_ms[5]
-        tfl = fl / (ba_ms * 1e-3) / 1e12
-        pmc, pmc_note = pmc_traffic_bytes() if args.config == "euroc_v101" else ({}, "PMC passes are taken on the default config only")
-        roof = dict(kernel="ba_solve_kernel", bound="mfma", achieved=round(tfl, 5), peak=FP64_PEAK_TFLOPS,
-                    unit="TFLOP/s", frac=round(tfl / FP64_PEAK_TFLOPS, 7), traffic=pmc.get("ba_solve_kernel"),
-                    traffic_unit=pmc_note,
-                    algorithmic_flops_per_launch=int(fl / 2), avg_launch_us=round(float(ba_ms) * 1e3 / 2, 2),
-                    launches_per_frame=2, dominant_stage=stage_names[dom],
-                    note="single-workgroup latency-bound trust-region loop; see DESIGN.md section 4 for the phase table")
-        # image-side kernels against the HBM roofline (algorithmic bytes from SURVEY.md 8d)
-        P0 = wl["L"].w[0] * wl["L"].h[0]
-        image_roof = [hbm_row("clahe_lut_kernel+pyr_level_kernel", preprocess_algorithmic_bytes(wl["L"]), stage_ms[0]),
-                      hbm_row("lk_track_kernel", lk_algorithmic_bytes(nfeat), stage_ms[1]),
-                      hbm_row("harris_kernel+harris_candidates_kernel (+host selection)", 9 * P0, stage_ms[2])]
-        if pmc:
-            image_roof[0]["traffic"] = pmc.get("clahe_lut_kernel", 0) + pmc.get("pyr_level_kernel<true>", 0) + 3 * pmc.get("pyr_level_kernel<false>", 0)
-            image_roof[1]["traffic"] = pmc.get("lk_track_kernel")
-            image_roof[2]["traffic"] = pmc.get("harris_kernel", 0) + pmc.get("harris_candidates_kernel", 0)
+        value = world * steps / elapsed
+        names = pr.COUNTER_NAMES
+        dc = c1 - c0
+        backend_ms = {n: round(float(dc[11 + 2 * k]) / 1e3 / steps, 4) for k, n in enumerate(names)}
+        launches, k_ms, k_flops = float(kt[0]), float(kt[1]), float(kt[2])
+        tfl = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         out = {
-            "metric": "VIO frames/sec per GPU (hot path: LK tracker + sliding-window BA), synthetic EuRoC-shaped stream",
-            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "metric": "VIO frames/sec per GPU (product pipeline: LK tracker + RD path + sliding-window BA), synthetic EuRoC-shaped stream",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int64 (image, LK) + f64 (estimation)", "data": "synthetic",
-            "config": {"workload": cfg["name"], "features": nfeat, "window": cfg["window"],
-                       "solver_iteration_limit": iters, "replicas": world,
-                       "schedule": ("frontend lane (image side + preintegration of frame k+1) overlapped with the solver lane (localisation + "
-                                    "window solve of frame k) and the marginalisation lane; one host wait per frame on frontend + solver"
-                                    if overlap else "serial: all stages back to back on one stream, one host wait per frame"),
-                       "fixed_problem_note": "every frame is a keyframe whose window solve runs to the iteration limit (27 of 30 trial steps "
-                                             "rejected through the reference's live bias-linearisation, DESIGN.md section 2) -- a reading of "
-                                             "Ceres that no reference fixture pins",
-                       "ba_window": {"factors": int(len(wl["window_pb"]["tgt"])), "iterations": int(sm_win.iterations),
-                                     "successful_steps": int(sm_win.successful_steps)},
-                       "ba_localize": {"factors": int(len(wl["localize_pb"]["tgt"])), "iterations": int(sm_loc.iterations)}},
-            "stages_ms": stages,
-            "per_replica_fps": [round(args.steps / e, 2) for e in per_rank],
-            "roofline": roof,
-            "image_kernels_roofline": image_roof,
+            "config": {"workload": cfg["name"], "features": cfg["features"], "window": cfg["window"], "replicas": world,
+                       "settings": "configs/baseline_setting.yaml (the reference's configs/setting.yaml values) with only sliding_window.size and "
+                                   "feature_tracker.max_keypoint_detection overridden; configs/synthetic_euroc_sensor.yaml",
+                       "settings_applied": {k: (v if not isinstance(v, (list, tuple, np.ndarray)) else [float(x) for x in v]) for k, v in applied.items()},
+                       "bootstrap": "full initializer (SfM + IMU alignment), no supplied states",
+                       "schedule": {0: "inline (the reference's THREADING=OFF)", 1: "pipelined tracker / frontend schedule on one thread",
+                                    2: "tracker on the caller's thread, frontend's step on a worker thread (frontend lane || solver lane), "
+                                       "deterministic hand-over"}[args.threading],
+                       "frames": {"bootstrap_and_warmup_untimed": int(n_pre), "timed": steps},
+                       "timed_region": {"window_solves": int(dc[1]), "marginalizations": int(dc[3]), "localizations": int(dc[4]), "subwindow_solves": int(dc[5]),
+                                        "solver_iterations": int(dc[10]), "imu_parsac_judgements": int(dc[27]), "tracks_marked_dynamic": int(dc[28]),
+                                        "largest_solve": {"frames": int(c1[8]), "factors": int(c1[9])}}},
+            "backend_ms_per_frame": backend_ms,
+            "per_replica_fps": [round(steps / e, 2) for e in per_rank],
+            # dominant kernel: ba_solve_kernel (FP64, one persistent workgroup per solve: a dependent-latency chain, neither roofline
+            # binds it -- DESIGN.md section 4).  achieved = SURVEY 8(d) algorithmic flops of the launches of the timed region / their
+            # HIP-event durations (events on the solver lane, the stream the kernel is launched on)
+            "roofline": dict(kernel="ba_solve_kernel", bound="mfma", achieved=round(tfl, 6), peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+                             frac=round(tfl / FP64_PEAK_TFLOPS, 8), traffic=None,
+                             launches=int(launches), launches_per_frame=round(launches / steps, 3),
+                             avg_launch_us=round(1e3 * k_ms / max(launches, 1), 2),
+                             algorithmic_flops_per_launch=int(k_flops / max(launches, 1)), solver_iterations=int(kt[3]),
+                             kernel_ms_per_frame=round(k_ms / steps, 4),
+                             note="measured live over the timed region: localize_newframe, refine_window and refine_subwindow launches as the stream "
+                                  "produced them; single-workgroup latency-bound trust-region loop (phase table: DESIGN.md section 4)"),
         }
-        # the legs beside `value`: a failure in one of them is recorded in its own field and never costs the line
-        def leg(name, fn):
+
+        def leg(name, fn):   # the legs beside `value`: a failure in one of them is recorded in its own field and never costs the line
             try:
                 out[name] = fn()
             except Exception as exc:  # noqa: BLE001
                 out[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
+        cpu_tables = None
         if world == 1 and not args.no_cpu_baseline:
-            leg("cpu_baseline", lambda: cpu_baseline(cfg, wl))
-            if out["cpu_baseline"].get("value"):
+            def _cpu():
+                nonlocal cpu_tables
+                rep, cpu_tables = cpu_baseline(cfg, stream, n_pre, steps)
+                return rep
+            leg("cpu_baseline", _cpu)
+            if isinstance(out.get("cpu_baseline"), dict) and out["cpu_baseline"].get("value"):
                 out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 2)
-        if world == 1 and args.end_to_end_frames > 0:
-            leg("end_to_end", lambda: end_to_end(cfg, ctx, args.end_to_end_frames, with_cpu_path=not args.no_cpu_baseline))
-        if world == 1 and args.sequences > 1 and not args.serial:
-            leg("multi_sequence", lambda: multi_sequence(cfg, torch, dev, local_rank, wl, args.sequences, steps=min(args.steps, 100), warmup=10,
-                                                         overlap=args.sequence_lanes == 3, wait_mode=args.sequence_wait))
-        print(json.dumps(out))
+            if cpu_tables is not None:
+                leg("end_to_end", lambda: compare_paths(run, cpu_tables, stream, cfg))
+    run.close()
     ctx.close()
+
+    if rank == 0 and world == 1:
+        if not args.no_variants:
+            def _variants():
+                rep = {}
+                for label, thr, init in (("inline_schedule", 0, None), ("groundtruth_bootstrap", args.threading, stream["gt"])):
+                    c2, r2, _ = hip_run(thr, init_states=init)
+                    try:
+                        n2 = bootstrap_and_warm_up(r2, warmup, n_total - steps)
+                        t2 = r2.segment(min(steps, n_total - n2))
+                        rep[label] = {"fps": round(t2["frames_processed"] / t2["elapsed_s"], 2), "frames": int(t2["frames_processed"]),
+                                      "bootstrap_and_warmup_frames": int(n2)}
+                    finally:
+                        r2.close()
+                        c2.close()
+                return rep
+            leg("pipeline_variants", _variants)
+        if not args.no_kernel_loop:
+            def _kl():
+                s2 = torch.cuda.Stream(device=dev)
+                torch.cuda.set_stream(s2)
+                rep, pmc, pmc_note = kernel_loop_leg(cfg, torch, dev, local_rank, min(steps, 100), 10, args.serial, s2)
+                out["roofline"]["traffic"] = pmc.get("ba_solve_kernel")
+                out["roofline"]["traffic_unit"] = pmc_note
+                return rep
+            leg("kernel_loop", _kl)
+        if args.sequences > 1:
+            def _ms():
+                s3 = torch.cuda.Stream(device=dev)
+                torch.cuda.set_stream(s3)
+                first = Sequence(cfg, torch, dev, local_rank, overlap=True, first_stream=s3)
+                try:
+                    return multi_sequence(cfg, torch, dev, local_rank, first.wl, args.sequences, steps=min(steps, 100), warmup=10,
+                                          overlap=args.sequence_lanes == 3, wait_mode=args.sequence_wait)
+                finally:
+                    first.ctx.close()
+            leg("multi_sequence", _ms)
+    if rank == 0:
+        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -44,6 +44,28 @@ def build_pipeline(force=False, verbose=False):
     return PIPE_LIB
 
 
+def build_pipeline_variant(name, flags):
+    """librdvio_pipeline.so compiled with other optimisation flags (bench.py's CPU-baseline builds: the orchestration is part
+    of the CPU path that is timed) into rd_vio_amd/_build/; -ffp-contract=off stays, so results do not change."""
+    import hashlib
+
+    try:
+        key = "".join(l for l in open("/proc/cpuinfo").read().splitlines() if l.startswith(("model name", "flags")))[:20000]
+    except OSError:
+        key = "unknown"
+    out_dir = os.path.join(HERE, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, f"librdvio_pipeline_{name}_{hashlib.sha1(key.encode()).hexdigest()[:10]}.so")
+    deps = [os.path.join(PIPE_DIR, f) for f in os.listdir(PIPE_DIR)] + [os.path.join(HERE, "..", "include", f) for f in ("rdvio_hip.h", "rdvio_pipeline.h")] + \
+           [os.path.join(CSRC, "hypo_solvers.hpp"), LIB]
+    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    cmd = [os.environ.get("CXX", "g++")] + list(flags) + ["-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread", "-o", out] + \
+          [os.path.join(PIPE_DIR, s) for s in PIPE_SOURCES] + ["-L" + HERE, "-lrdvio_hip", "-Wl,-rpath," + HERE]
+    subprocess.check_call(cmd)
+    return out
+
+
 EUROC_EXE = os.path.join(HERE, "test_euroc")
 
 

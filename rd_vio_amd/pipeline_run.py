@@ -35,10 +35,10 @@ class PipelineConfig(ctypes.Structure):
     ]
 
 
-def load_pipeline_lib():
+def load_pipeline_lib(path=None):
     from rd_vio_amd import build as rbuild
     rbuild.build()
-    lib = ctypes.CDLL(rbuild.PIPE_LIB)
+    lib = ctypes.CDLL(path or rbuild.PIPE_LIB)
     lib.rdvio_pipeline_last_error.restype = ctypes.c_char_p
     return lib
 

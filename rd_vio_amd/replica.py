@@ -24,17 +24,21 @@ def init_distributed(backend=None, device_id=None):
     return rank, local_rank, world, dist
 
 
-def timed_region(step, steps, sync, dist=None, device=None, first_index=0, per_rank=False):
-    """barrier + sync, EXACTLY `steps` calls of step(k), sync + barrier; returns the MAX elapsed seconds over ranks
-    (with per_rank: also every rank's own time between the barriers' release and its own last sync, rank order)."""
+def timed_region(step, steps, sync, dist=None, device=None, first_index=0, per_rank=False, block=None):
+    """barrier + sync, EXACTLY `steps` calls of step(k) -- or ONE call of block(first_index, steps), which must perform
+    exactly `steps` steps (a native loop) --, sync + barrier; returns the MAX elapsed seconds over ranks (with per_rank:
+    also every rank's own time between the barriers' release and its own last sync, rank order)."""
     import torch
 
     sync()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    for k in range(steps):
-        step(first_index + k)
+    if block is not None:
+        block(first_index, steps)
+    else:
+        for k in range(steps):
+            step(first_index + k)
     sync()
     own = time.perf_counter() - t0
     if dist is not None:
