@@ -189,6 +189,17 @@ typedef struct {
     const double *prior_lin;       /* n_prior x 16 linearisation states */
     const double *prior_S;         /* (15 n_prior)^2 sqrt information */
     const double *prior_f;         /* 15 n_prior */
+    /* Optional, fused PreIntegrator::integrate (preintegrator.cpp:78-95) of the records this solve uses: refine_window re-integrates
+     * every keyframe interval and refine_subwindow every subframe interval right before their solve
+     * (sliding_window_tracker.cpp:283-301, 379-384).  With n_pre_jobs == n_preint > 0 the records are not read from `preint` (may be
+     * NULL) but integrated on the device from the raw samples (covariance and bias Jacobians on) into the solve's own record slots --
+     * no host hop between the two kernels -- and handed back through job_preint_out by rdvio_hip_ba_fetch / rdvio_hip_ba_solve. */
+    int32_t n_pre_jobs;            /* 0 or n_preint */
+    const int32_t *job_seg_off;    /* n_pre_jobs + 1 sample offsets into job_imu */
+    const double *job_imu;         /* samples x 7 (t, gyro, acc) */
+    const double *job_par;         /* n_pre_jobs x 7: t_end, bg(3), ba(3) */
+    const double *job_noise;       /* 36: cov_w cov_a cov_bg cov_ba */
+    double *job_preint_out;        /* n_pre_jobs x RDVIO_PREINT_SIZE (host) */
 } rdvio_ba_problem;
 
 typedef struct {

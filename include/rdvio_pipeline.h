@@ -71,6 +71,11 @@ typedef struct rdvio_backend {
     int (*preintegrate_estimator)(void *user, int nseg, const int32_t *seg_off, const double *imu, const double *t_end, const double *bg,
                                   const double *ba, const double *noise, int compute_jacobian, int compute_covariance, double *preint_out);
     int (*thread_attach)(void *user);
+    /* optional pair (NULL = marginalize): the same call in two halves -- begin enqueues, end waits and copies out.  The new prior
+     * is first read by the NEXT refine_window (sliding_window_tracker.cpp:339-347, 226-300), several frames later: the
+     * orchestration calls end only then, so the marginalisation runs beside the frames in between. */
+    int (*marginalize_begin)(void *user, const rdvio_marg_problem *pb);
+    int (*marginalize_end)(void *user, double *S_out, double *f_out, double *lin_out);
     /* optional (NULL = the orchestration's host solvers generate the hypotheses): rdvio_hip_parsac_generate_score */
     int (*parsac_generate_score)(void *user, const rdvio_parsac_batch *batch, int n_iterations, const int32_t *samples,
                                  int32_t *models_per_iteration, double *models, rdvio_parsac_result *results);

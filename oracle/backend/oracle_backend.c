@@ -92,6 +92,12 @@ static int ob_ba_solve(void *user, const rdvio_ba_problem *pb, int max_iter, dou
     q.n_factors = pb->n_factors; q.tgt = pb->tgt; q.ref = pb->ref; q.lm = pb->lm; q.tangent = pb->tangent;
     q.n_rot = pb->n_rot; q.rot_tgt = pb->rot_tgt; q.rot_ref = pb->rot_ref; q.rot_zref = pb->rot_zref; q.rot_tangent = pb->rot_tangent;
     q.n_preint = pb->n_preint; q.pre_i = pb->pre_i; q.pre_j = pb->pre_j; q.preint = pb->preint;
+    if (pb->n_pre_jobs > 0) { /* the fused form: integrate the records first (PreIntegrator::integrate with covariance and Jacobians) */
+        for (int k = 0; k < pb->n_pre_jobs; ++k)
+            ro_preintegrate(pb->job_seg_off[k + 1] - pb->job_seg_off[k], pb->job_imu + 7 * (size_t)pb->job_seg_off[k], pb->job_par[7 * k],
+                            pb->job_par + 7 * k + 1, pb->job_par + 7 * k + 4, pb->job_noise, 1, 1, pb->job_preint_out + (size_t)RO_PREINT_SIZE * k);
+        q.preint = pb->job_preint_out;
+    }
     q.np = pb->n_prior; q.prior_frames = pb->prior_frames; q.lin = pb->prior_lin; q.S = pb->prior_S; q.f = pb->prior_f;
     memcpy(states, pb->states, sizeof(double) * 16 * (size_t)pb->n_frames);
     if (pb->n_landmarks > 0) memcpy(invd, pb->inv_depth, sizeof(double) * (size_t)pb->n_landmarks);
@@ -140,5 +146,7 @@ void rdvio_oracle_backend_fill(rdvio_backend *b) {
     b->parsac_fetch = NULL;
     b->preintegrate_estimator = NULL; /* ro_preintegrate keeps no state: safe from both threads */
     b->thread_attach = NULL;
+    b->marginalize_begin = NULL;
+    b->marginalize_end = NULL;
     b->parsac_generate_score = NULL;
 }

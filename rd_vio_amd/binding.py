@@ -76,6 +76,8 @@ class BaProblem(ctypes.Structure):
         ("preint", ctypes.c_void_p),
         ("n_prior", ctypes.c_int32), ("prior_frames", ctypes.c_void_p), ("prior_lin", ctypes.c_void_p),
         ("prior_S", ctypes.c_void_p), ("prior_f", ctypes.c_void_p),
+        ("n_pre_jobs", ctypes.c_int32), ("job_seg_off", ctypes.c_void_p), ("job_imu", ctypes.c_void_p), ("job_par", ctypes.c_void_p),
+        ("job_noise", ctypes.c_void_p), ("job_preint_out", ctypes.c_void_p),
     ]
 
 

@@ -91,6 +91,12 @@ struct rdvio_hip_ctx {
         SolverWs ws{};
         size_t in_states_off = 0, in_invd_off = 0, in_bytes = 0, host_bytes = 0;
         bool ready = false;
+        // fused preintegration jobs of the uploaded problem (rdvio_ba_problem::n_pre_jobs): device views of the raw samples and
+        // where the records go back to
+        int n_jobs = 0;
+        const int32_t *job_off = nullptr;
+        const double *job_imu = nullptr, *job_par = nullptr, *job_noise = nullptr;
+        double *job_out_host = nullptr;
         // SURVEY 8(d) algorithmic flops of the problem: per linearisation / per trial-step cost evaluation (rdvio_ba_prepare)
         double flops_lin = 0.0, flops_eval = 0.0;
         // live kernel timing (rdvio_hip_ctx_set_kernel_timing): events around the launch in flight

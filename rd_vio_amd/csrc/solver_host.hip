@@ -52,7 +52,18 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     if (nl > 0 && (!pb->z_ref || !pb->inv_depth || !pb->lm_fixed)) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null landmark arrays");
     if (nf > 0 && (!pb->tgt || !pb->ref || !pb->lm || !pb->tangent)) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null factor arrays");
     if (nrot > 0 && (!pb->rot_tgt || !pb->rot_ref || !pb->rot_zref || !pb->rot_tangent)) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null rotation-prior arrays");
-    if (npre > 0 && (!pb->pre_i || !pb->pre_j || !pb->preint)) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null preintegration arrays");
+    const int njobs = pb->n_pre_jobs;
+    if (njobs != 0 && (njobs != npre || with_marg_tail)) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "n_pre_jobs must be 0 or n_preint");
+    if (npre > 0 && (!pb->pre_i || !pb->pre_j || (!pb->preint && njobs == 0))) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null preintegration arrays");
+    int job_samples = 0;
+    if (njobs > 0) {
+        if (!pb->job_seg_off || !pb->job_imu || !pb->job_par || !pb->job_noise || !pb->job_preint_out) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null preintegration job arrays");
+        if (pb->job_seg_off[0] != 0) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "job_seg_off[0] must be 0");
+        for (int k = 0; k < njobs; ++k)
+            if (pb->job_seg_off[k + 1] < pb->job_seg_off[k]) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "job_seg_off must be non-decreasing");
+        job_samples = pb->job_seg_off[njobs];
+        if (job_samples > ctx->pre_max_samples) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d samples exceed capacity %d", job_samples, ctx->pre_max_samples);
+    }
     if (np > 0 && (!pb->prior_frames || !pb->prior_lin || !pb->prior_S || !pb->prior_f)) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "null prior arrays");
     // every index is range-checked here so that the kernel can never read out of bounds
     for (int k = 0; k < nf; ++k) {
@@ -187,7 +198,9 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     const size_t o_rt = P.put(pb->rot_tgt, (size_t)nrot), o_rr = P.put(pb->rot_ref, (size_t)nrot);
     const size_t o_rz = P.put(pb->rot_zref, (size_t)nrot * 3), o_rtan = P.put(pb->rot_tangent, (size_t)nrot * 9);
     const size_t o_pi = P.put(pb->pre_i, (size_t)npre), o_pj = P.put(pb->pre_j, (size_t)npre);
-    const size_t o_pre = P.put(pb->preint, (size_t)npre * RDVIO_PREINT_SIZE);
+    const size_t o_pre = P.put(njobs > 0 ? (const double *)nullptr : pb->preint, (size_t)npre * RDVIO_PREINT_SIZE);
+    const size_t o_joff = P.put(pb->job_seg_off, njobs > 0 ? (size_t)njobs + 1 : 0), o_jimu = P.put(pb->job_imu, (size_t)job_samples * 7);
+    const size_t o_jpar = P.put(pb->job_par, (size_t)njobs * 7), o_jnoise = P.put(pb->job_noise, njobs > 0 ? 36 : 0);
     const size_t o_pf = P.put(pb->prior_frames, (size_t)np), o_lin = P.put(pb->prior_lin, (size_t)np * 16);
     const size_t o_S = P.put(pb->prior_S, (size_t)D * D), o_f = P.put(pb->prior_f, (size_t)D);
     const size_t o_fcol = P.put(fcol.data(), (size_t)nfr);
@@ -294,6 +307,12 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
         slot.flops_lin = 500.0 * F + 15000.0 * P + 2.0 * Dd * Dd * 16.0 * Wp + 2.0 * 182.0 * F + 2.0 * 36.0 * m2 + n3 / 3.0;
         slot.flops_eval = 200.0 * F + 2000.0 * P + 2.0 * Dd * Dd;
     }
+    slot.n_jobs = njobs;
+    slot.job_off = (const int32_t *)(B + o_joff);
+    slot.job_imu = (const double *)(B + o_jimu);
+    slot.job_par = (const double *)(B + o_jpar);
+    slot.job_noise = (const double *)(B + o_jnoise);
+    slot.job_out_host = pb->job_preint_out;
     slot.in_states_off = o_states;
     slot.in_invd_off = o_invd;
     slot.in_bytes = in_bytes;
@@ -314,6 +333,11 @@ int rdvio_hip_ba_upload(rdvio_hip_ctx *ctx, int slot, const rdvio_ba_problem *pb
     RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->lane[RDVIO_LANE_SOLVER]));
     if (int rc = rdvio_ba_prepare(ctx, S, pb, ctx->ba_arena_bytes, false)) return rc;
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(S.arena, S.host, S.in_bytes, hipMemcpyHostToDevice, ctx->lane[RDVIO_LANE_SOLVER]));
+    // fused PreIntegrator::integrate: the records of this solve's preintegration factors, straight into their slots of the arena
+    if (S.n_jobs > 0)
+        if (int rc = rdvio_launch_preintegrate(ctx, ctx->lane[RDVIO_LANE_SOLVER], S.n_jobs, S.job_off, S.job_imu, S.job_par, S.job_noise, 1, 1,
+                                               const_cast<double *>(S.ws.preint)))
+            return rc;
     return RDVIO_OK;
 }
 
@@ -351,7 +375,14 @@ int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double 
     if (host_off + n_out * sizeof(double) > S.host_bytes) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "result does not fit the pinned blob");
     double *down = (double *)((uint8_t *)S.host + host_off);
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, w.x, n_out * sizeof(double), hipMemcpyDeviceToHost, ctx->lane[RDVIO_LANE_SOLVER]));
+    double *down_pre = down + ((n_out + 7) & ~(size_t)7);
+    const size_t pre_doubles = (size_t)S.n_jobs * RDVIO_PREINT_SIZE;
+    if (S.n_jobs > 0) {
+        if ((size_t)((uint8_t *)(down_pre + pre_doubles) - (uint8_t *)S.host) > S.host_bytes) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "records do not fit the pinned blob");
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down_pre, w.preint, pre_doubles * sizeof(double), hipMemcpyDeviceToHost, ctx->lane[RDVIO_LANE_SOLVER]));
+    }
     RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->lane[RDVIO_LANE_SOLVER]));
+    if (S.n_jobs > 0 && S.job_out_host) memcpy(S.job_out_host, down_pre, pre_doubles * sizeof(double));
     if (states_out) memcpy(states_out, down, (size_t)w.nfr * 16 * sizeof(double));
     if (inv_depth_out && w.nl > 0) memcpy(inv_depth_out, down + (w.xd - w.x), (size_t)w.nl * sizeof(double));
     const double *sum = down + (w.summary - w.x);

@@ -129,6 +129,16 @@ int marginalize(void *user, const rdvio_marg_problem *pb, double *S, double *f, 
     return rdvio_hip_marginalize(static_cast<HipBackend *>(user)->ctx, pb, 0, S, f, lin, nullptr, nullptr, nullptr);
 }
 
+int marginalize_begin(void *user, const rdvio_marg_problem *pb) {
+    rdvio_hip_ctx *ctx = static_cast<HipBackend *>(user)->ctx;
+    if (int rc = rdvio_hip_marginalize_upload(ctx, pb)) return rc;
+    return rdvio_hip_marginalize_resident(ctx, 0);
+}
+
+int marginalize_end(void *user, double *S, double *f, double *lin) {
+    return rdvio_hip_marginalize_fetch(static_cast<HipBackend *>(user)->ctx, S, f, lin, nullptr, nullptr, nullptr);
+}
+
 int parsac_score(void *user, const rdvio_parsac_batch *batch, rdvio_parsac_result *results) {
     return rdvio_hip_parsac_score(static_cast<HipBackend *>(user)->ctx, batch, results);
 }
@@ -173,6 +183,8 @@ extern "C" int rdvio_pipeline_create_hip(rdvio_pipeline **out, const rdvio_pipel
     fn.preintegrate_estimator = preintegrate_estimator;
     fn.thread_attach = thread_attach;
     fn.parsac_generate_score = parsac_generate_score;
+    fn.marginalize_begin = marginalize_begin;
+    fn.marginalize_end = marginalize_end;
     const int rc = rdvio_pipeline_create(out, cfg, &fn);
     if (rc != RDVIO_OK) delete b;
     return rc;

@@ -27,6 +27,12 @@ std::array<double, 9> tangent_frame(const V3 &x) {
     return {b1.x, b2.x, x.x, b1.y, b2.y, x.y, b1.z, b2.z, x.z};
 }
 
+void MarginalizationPrior::ready(Backend &be) {
+    if (!pending) return;
+    pending = false;
+    be.check(be.fn.marginalize_end(be.fn.user, S.data(), f.data(), lin.data()), "marginalize (end)");
+}
+
 // ---------------------------------------------------------------------------------------------- PreIntegrator
 bool PreIntegrator::integrate(Backend &be, CallerLane lane, double t, const V3 &bg, const V3 &ba, bool compute_jacobian, bool compute_covariance) {
     return integrate_batch(be, lane, {Job{this, t, bg, ba}}, compute_jacobian, compute_covariance)[0] != 0;

@@ -190,6 +190,10 @@ struct MarginalizationPrior {
     std::vector<Frame *> frames;
     std::vector<double> lin;  // frames x 16
     std::vector<double> S, f; // (15 frames)^2, 15 frames
+    // a marginalisation is under way behind the backend (marginalize_begin): S / f / lin hold their new sizes and get their
+    // values at the first read (ready())
+    bool pending = false;
+    void ready(Backend &be);
 };
 
 class Map {

@@ -93,7 +93,17 @@ void BaBuilder::add_preintegration(Frame *frame_i, Frame *frame_j, const PreInte
     if (i < 0) i = add_constant_frame(frame_i);
     int j = frame_index(frame_j);
     if (j < 0) j = add_constant_frame(frame_j);
-    pres.push_back({i, j, pre.delta.data()});
+    pres.push_back({i, j, pre.delta.data(), nullptr, 0.0, V3{}, V3{}});
+}
+
+bool BaBuilder::add_integrated_preintegration(Frame *frame_i, Frame *frame_j, PreIntegrator &pre, double t, const V3 &bg, const V3 &ba) {
+    if (pre.data.empty()) return false;
+    int i = frame_index(frame_i);
+    if (i < 0) i = add_constant_frame(frame_i);
+    int j = frame_index(frame_j);
+    if (j < 0) j = add_constant_frame(frame_j);
+    pres.push_back({i, j, pre.delta.data(), &pre, t, bg, ba});
+    return true;
 }
 
 bool BaBuilder::solve(rdvio_ba_summary *summary_out) {
@@ -122,13 +132,33 @@ bool BaBuilder::solve(rdvio_ba_summary *summary_out) {
         rot_zref[3 * k] = rots[k].zref.x; rot_zref[3 * k + 1] = rots[k].zref.y; rot_zref[3 * k + 2] = rots[k].zref.z;
         std::copy(rots[k].tangent, rots[k].tangent + 9, &rot_tangent[9 * (size_t)k]);
     }
+    // integrations that ride inside the solve call: only when EVERY preintegration factor asks for it (the records then fill
+    // the solve's slots in order); a mixed solve integrates through the separate entry first
+    int njobs = 0;
+    for (const Pre &p : pres) njobs += p.job != nullptr;
+    if (njobs > 0 && njobs != npre) {
+        std::vector<PreIntegrator::Job> jobs;
+        for (const Pre &p : pres)
+            if (p.job) jobs.push_back({p.job, p.t, p.bg, p.ba});
+        (void)PreIntegrator::integrate_batch(sh.backend, LANE_ESTIMATOR, jobs, true, true);
+        njobs = 0;
+    }
     std::vector<int32_t> pre_i(std::max(npre, 1)), pre_j(std::max(npre, 1));
     std::vector<double> preint((size_t)std::max(npre, 1) * RDVIO_PREINT_SIZE);
+    std::vector<int32_t> job_off(1, 0);
+    std::vector<double> job_imu, job_par;
     for (int k = 0; k < npre; ++k) {
         pre_i[k] = pres[k].i; pre_j[k] = pres[k].j;
-        std::copy(pres[k].delta, pres[k].delta + RDVIO_PREINT_SIZE, &preint[(size_t)k * RDVIO_PREINT_SIZE]);
+        if (njobs > 0) {
+            for (const ImuData &d : pres[k].job->data) job_imu.insert(job_imu.end(), {d.t, d.w.x, d.w.y, d.w.z, d.a.x, d.a.y, d.a.z});
+            job_off.push_back((int32_t)(job_imu.size() / 7));
+            job_par.insert(job_par.end(), {pres[k].t, pres[k].bg.x, pres[k].bg.y, pres[k].bg.z, pres[k].ba.x, pres[k].ba.y, pres[k].ba.z});
+        } else {
+            std::copy(pres[k].delta, pres[k].delta + RDVIO_PREINT_SIZE, &preint[(size_t)k * RDVIO_PREINT_SIZE]);
+        }
     }
     std::vector<int32_t> prior_frames;
+    if (prior) const_cast<MarginalizationPrior *>(prior)->ready(sh.backend);   // a marginalisation begun frames ago lands here
     if (prior)
         for (Frame *f : prior->frames) {
             const int i = frame_index(f);
@@ -161,6 +191,14 @@ bool BaBuilder::solve(rdvio_ba_summary *summary_out) {
     pb.rot_zref = rot_zref.data(); pb.rot_tangent = rot_tangent.data();
     pb.n_preint = npre;
     pb.pre_i = pre_i.data(); pb.pre_j = pre_j.data(); pb.preint = preint.data();
+    if (njobs > 0) {
+        pb.n_pre_jobs = njobs;
+        pb.job_seg_off = job_off.data();
+        pb.job_imu = job_imu.data();
+        pb.job_par = job_par.data();
+        pb.job_noise = pres[0].job->noise;
+        pb.job_preint_out = preint.data();
+    }
     pb.n_prior = (int)prior_frames.size();
     if (prior) {
         pb.prior_frames = prior_frames.data();
@@ -176,10 +214,22 @@ bool BaBuilder::solve(rdvio_ba_summary *summary_out) {
     std::memset(&sm, 0, sizeof sm);
     {
         BackendTimer timer(sh.counters, 4);
+        const auto t0 = std::chrono::steady_clock::now();
         sh.backend.check(sh.backend.fn.ba_solve(sh.backend.fn.user, &pb, sh.cfg.solver_iteration_limit, states_out.data(), invd_out.data(), &sm),
                          "ba_solve");
+        if (sh.prof.on) {
+            SolveProf &sp = sh.solve_prof;
+            sp.calls[kind]++; sp.iterations[kind] += sm.iterations; sp.factors[kind] += nf; sp.frames[kind] += nfr;
+            sp.seconds[kind] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
     }
     sh.counters.solver_iterations += sm.iterations;
+    if (njobs > 0)   // the integrators keep their records, like after PreIntegrator::integrate
+        for (int k = 0; k < npre; ++k) {
+            PreIntegrator &pre = *pres[k].job;
+            std::copy(&preint[(size_t)k * RDVIO_PREINT_SIZE], &preint[(size_t)(k + 1) * RDVIO_PREINT_SIZE], pre.delta.begin());
+            pre.key = PreIntegrator::Key{pre.data.size(), pres[k].t, pre.data.front().t, pre.data.back().t, pres[k].bg, pres[k].ba, true, true, true};
+        }
     // the reference's parameter blocks ARE the Frame / Track members (solver.cpp:88-114): copy the result back
     for (int i = 0; i < nfr; ++i)
         if (frame_fixed[i] != 1) frames[i]->set_state(&states_out[16 * (size_t)i]);
@@ -595,6 +645,7 @@ void SlidingWindowTracker::localize_newframe() {
     for (size_t k = 0; k < frame_j->keypoint_num(); ++k)
         if (Track *track = frame_j->get_track(k))
             if (track->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) solver.add_reprojection_prior(frame_j, track);
+    solver.kind = 0;
     solver.solve();
     sh.counters.localizations++;
 }
@@ -700,8 +751,7 @@ void SlidingWindowTracker::refine_window() {
             solver.add_reprojection_error(frame, j);
         }
     }
-    // keyframe_preintegration of every interval (:283-301); the W independent integrations go to the device as one batch
-    std::vector<PreIntegrator::Job> jobs;
+    // keyframe_preintegration of every interval (:283-301): the W independent integrations ride inside the solve call
     for (size_t j = 1; j < map->frame_num(); ++j) {
         Frame *frame_i = map->get_frame(j - 1), *frame_j = map->get_frame(j);
         frame_j->keyframe_preintegration = frame_j->preintegration;
@@ -710,11 +760,10 @@ void SlidingWindowTracker::refine_window() {
             for (const auto &sub : frame_i->subframes) imu_data.insert(imu_data.end(), sub->preintegration.data.begin(), sub->preintegration.data.end());
             frame_j->keyframe_preintegration.data.insert(frame_j->keyframe_preintegration.data.begin(), imu_data.begin(), imu_data.end());
         }
-        jobs.push_back({&frame_j->keyframe_preintegration, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba});
+        frame_j->keyframe_preintegration.key.valid = false;   // (the copied record belongs to other samples)
+        (void)solver.add_integrated_preintegration(frame_i, frame_j, frame_j->keyframe_preintegration, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba);
     }
-    const std::vector<char> integrated = PreIntegrator::integrate_batch(sh.backend, LANE_ESTIMATOR, jobs, true, true);
-    for (size_t j = 1; j < map->frame_num(); ++j)
-        if (integrated[j - 1]) solver.add_preintegration(map->get_frame(j - 1), map->get_frame(j), map->get_frame(j)->keyframe_preintegration, false);
+    solver.kind = 1;
     solver.solve();
     sh.counters.window_solves++;
     sh.counters.keyframes++;
@@ -763,6 +812,7 @@ void SlidingWindowTracker::slide_window() {
 void SlidingWindowTracker::marginalize_frame0() {
     HostTimer host_timer__(sh.prof, 8);
     MarginalizationPrior &prior = *map->marginalization_factor;
+    prior.ready(sh.backend);
     const int nfm = (int)map->frame_num();
     std::unordered_map<const Frame *, int> index;
     std::vector<double> states((size_t)nfm * 16);
@@ -827,31 +877,27 @@ void SlidingWindowTracker::marginalize_frame0() {
     pb.tangent = tangent.data();
     const size_t R = 15 * (size_t)(nfm - 1);
     std::vector<double> S(R * R), f(R), lin(16 * (size_t)(nfm - 1));
+    bool pending = false;
     {
         BackendTimer timer(sh.counters, 5);
-        sh.backend.check(sh.backend.fn.marginalize(sh.backend.fn.user, &pb, S.data(), f.data(), lin.data()), "marginalize");
+        if (sh.backend.fn.marginalize_begin && sh.backend.fn.marginalize_end) {
+            // the new prior is read by the next refine_window: enqueue now, collect then (MarginalizationPrior::ready)
+            sh.backend.check(sh.backend.fn.marginalize_begin(sh.backend.fn.user, &pb), "marginalize (begin)");
+            pending = true;
+        } else {
+            sh.backend.check(sh.backend.fn.marginalize(sh.backend.fn.user, &pb, S.data(), f.data(), lin.data()), "marginalize");
+        }
     }
     prior.frames.clear();
     for (int i = 1; i < nfm; ++i) prior.frames.push_back(map->get_frame(i));
     prior.S.swap(S);
     prior.f.swap(f);
     prior.lin.swap(lin);
+    prior.pending = pending;
     for (size_t i = 0; i < victim->keypoint_num(); ++i)
         if (Track *track = victim->get_track(i)) track->remove_keypoint(victim);
     map->drop_front_frame();
     sh.counters.marginalizations++;
-}
-
-// every subframe interval re-integrated with the previous frame's biases (:379-384, :416-421); the intervals are independent
-// (no state changes inside the loop), so they go to the device as one batch
-void SlidingWindowTracker::integrate_subframes(Frame *frame) {
-    std::vector<PreIntegrator::Job> jobs;
-    for (size_t i = 0; i < frame->subframes.size(); ++i) {
-        Frame *subframe = frame->subframes[i].get();
-        const Frame *prev_frame = (i == 0 ? frame : frame->subframes[i - 1].get());
-        jobs.push_back({&subframe->preintegration, subframe->image->t, prev_frame->motion.bg, prev_frame->motion.ba});
-    }
-    (void)PreIntegrator::integrate_batch(sh.backend, LANE_ESTIMATOR, jobs, true, true);
 }
 
 void SlidingWindowTracker::refine_subwindow() {
@@ -877,12 +923,13 @@ void SlidingWindowTracker::refine_subwindow() {
         frame->set_tag(FT_FIX_POSE, true);
         frame->set_tag(FT_FIX_MOTION, true);
         solver.add_frame_states(frame);
-        integrate_subframes(frame);
         for (size_t i = 0; i < frame->subframes.size(); ++i) {
             Frame *subframe = frame->subframes[i].get();
             solver.add_frame_states(subframe);
             Frame *prev_frame = (i == 0 ? frame : frame->subframes[i - 1].get());
-            solver.add_preintegration(prev_frame, subframe, subframe->preintegration, false);
+            // every subframe interval re-integrated with the previous frame's biases (:379-384) -- inside the solve call
+            if (!solver.add_integrated_preintegration(prev_frame, subframe, subframe->preintegration, subframe->image->t, prev_frame->motion.bg, prev_frame->motion.ba))
+                solver.add_preintegration(prev_frame, subframe, subframe->preintegration, false);
         }
         Frame *last_subframe = frame->subframes.back().get();
         for (size_t k = 0; k < last_subframe->keypoint_num(); ++k)
@@ -894,6 +941,7 @@ void SlidingWindowTracker::refine_subwindow() {
                         solver.add_rotation_prior(last_subframe, track);
                     }
                 }
+        solver.kind = 2;
         solver.solve();
         frame->set_tag(FT_FIX_POSE, false);
         frame->set_tag(FT_FIX_MOTION, false);
@@ -902,12 +950,13 @@ void SlidingWindowTracker::refine_subwindow() {
         frame->set_tag(FT_FIX_POSE, true);
         frame->set_tag(FT_FIX_MOTION, true);
         solver.add_frame_states(frame);
-        integrate_subframes(frame);
         for (size_t i = 0; i < frame->subframes.size(); ++i) {
             Frame *subframe = frame->subframes[i].get();
             solver.add_frame_states(subframe);
             Frame *prev_frame = (i == 0 ? frame : frame->subframes[i - 1].get());
-            solver.add_preintegration(prev_frame, subframe, subframe->preintegration, false);
+            // (:416-421)
+            if (!solver.add_integrated_preintegration(prev_frame, subframe, subframe->preintegration, subframe->image->t, prev_frame->motion.bg, prev_frame->motion.ba))
+                solver.add_preintegration(prev_frame, subframe, subframe->preintegration, false);
             for (size_t k = 0; k < subframe->keypoint_num(); ++k)
                 if (Track *track = subframe->get_track(k))
                     if (track->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) {
@@ -917,6 +966,7 @@ void SlidingWindowTracker::refine_subwindow() {
                         // entry; that access is not reproduced ("deliberate deviations")
                     }
         }
+        solver.kind = 2;
         solver.solve();
         frame->set_tag(FT_FIX_POSE, false);
         frame->set_tag(FT_FIX_MOTION, false);
@@ -1283,6 +1333,12 @@ void rdvio_pipeline_destroy(rdvio_pipeline *p) {
                 std::fprintf(stderr, "  %-32s %8.4f  (%ld calls, %.1f us each)\n", HostProf::names[k], 1e3 * p->shared.prof.seconds[k] / std::max<long>(c.frames_tracked, 1),
                              p->shared.prof.calls[k], 1e6 * p->shared.prof.seconds[k] / p->shared.prof.calls[k]);
         static const char *bn[7] = {"preprocess", "detect", "track", "preintegrate", "ba_solve", "marginalize", "image_create"};
+        static const char *kn[4] = {"localize_newframe", "refine_window", "refine_subwindow", "other"};
+        for (int k = 0; k < 4; ++k)
+            if (const SolveProf &sp = p->shared.solve_prof; sp.calls[k])
+                std::fprintf(stderr, "  solves %-18s %5ld calls: %.1f iterations, %.0f factors, %.1f frames, %.1f us per call\n", kn[k], sp.calls[k],
+                             (double)sp.iterations[k] / sp.calls[k], (double)sp.factors[k] / sp.calls[k], (double)sp.frames[k] / sp.calls[k],
+                             1e6 * sp.seconds[k] / sp.calls[k]);
         const ParsacProf &pp = parsac_prof();
         if (pp.solves)
             std::fprintf(stderr, "  parsac: %ld solves, %ld batches, %ld iterations, %ld models, %ld fetches; ms per frame: setup %.4f models %.4f score %.4f fetch %.4f\n",

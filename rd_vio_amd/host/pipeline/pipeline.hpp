@@ -80,8 +80,15 @@ struct HostTimer {
     }
 };
 
+// diagnostic (RDVIO_PIPELINE_PROF): solver work by call site -- 0 localize_newframe, 1 refine_window, 2 refine_subwindow, 3 other
+struct SolveProf {
+    long calls[4] = {0, 0, 0, 0}, iterations[4] = {0, 0, 0, 0}, factors[4] = {0, 0, 0, 0}, frames[4] = {0, 0, 0, 0};
+    double seconds[4] = {0, 0, 0, 0};
+};
+
 struct Shared {  // what every stage needs
     HostProf prof;
+    SolveProf solve_prof;
     rdvio_pipeline_config cfg;
     Backend backend;
     IdGenerator ids;
@@ -104,13 +111,18 @@ class BaBuilder {
     void add_reprojection_prior(Frame *frame, Track *track);            // create_reprojection_prior_factor
     void add_rotation_prior(Frame *frame, Track *track);                // create_rotation_prior_factor
     void add_preintegration(Frame *frame_i, Frame *frame_j, const PreIntegrator &pre, bool prior);
+    // PreIntegrator::integrate(t, bg, ba, true, true) + add_preintegration in one: the integration runs inside the solve call
+    // (rdvio_ba_problem::n_pre_jobs) when every preintegration factor of the solve comes this way, through the backend's
+    // separate entry otherwise.  false: no samples, no factor (preintegrator.cpp:80-81)
+    bool add_integrated_preintegration(Frame *frame_i, Frame *frame_j, PreIntegrator &pre, double t, const V3 &bg, const V3 &ba);
     void add_marginalization(const MarginalizationPrior *prior) { this->prior = prior; }
     bool solve(rdvio_ba_summary *summary = nullptr);                    // Solver::solve + in-place state update
+    int kind = 3;                                                       // call site, for the diagnostic profile
 
   private:
     struct Fac { int tgt, ref, lm; const double *tangent; };
     struct Rot { int tgt, ref; V3 zref; const double *tangent; };
-    struct Pre { int i, j; const double *delta; };
+    struct Pre { int i, j; const double *delta; PreIntegrator *job; double t; V3 bg, ba; };
     int frame_index(Frame *frame) const;
     Shared &sh;
     std::vector<Frame *> frames;
@@ -159,7 +171,6 @@ class SlidingWindowTracker {
     void refine_window();
     void slide_window();
     void refine_subwindow();
-    void integrate_subframes(Frame *frame);
     void marginalize_frame0();
     // RD dynamic-outlier path (parsac_flag; sliding_window_tracker.cpp:487-769)
     bool judge_track_status();
