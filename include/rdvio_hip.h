@@ -234,6 +234,29 @@ int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int slot, int max_iterations
 int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double *inv_depth_out,
                        rdvio_ba_summary *summary);
 
+/* Unit parity of the estimation kernels' inner pieces (SURVEY.md 8b's `build_normal_schur`): ONE linearisation of the problem at
+ * its initial values with the device routines the solver runs -- every factor's Evaluate, J^T J / J^T r assembly, landmark
+ * elimination -- and the pieces copied out.  lin_states (n_frames x 16, may be NULL = the initial states) are the states whose
+ * biases the preintegration factors are linearised about (the reference reads them live from the frames,
+ * ceres/preintegration_factor.h:37-38).  robust_loss != 0 keeps CauchyLoss(1.0) on the reprojection / rotation factors
+ * (residual and Jacobian scaled by sqrt(rho')), 0 evaluates them plain.  Any output pointer may be NULL.
+ *   r_preint / J_preint  CeresPreIntegrationErrorFactor::Evaluate (ceres/preintegration_factor.h:19-160): whitened residual (15) and
+ *                        Jacobians wrt the 15-dim tangents (theta p v bg ba) of frame i and frame j (two row-major 15 x 15 per factor)
+ *   r_prior / J_prior    CeresMarginalizationFactor::Evaluate (ceres/marginalization_factor.h:27-72): D = 15 n_prior
+ *   H, g                 J^T J and J^T r over the free frames' 15-dim blocks (N = 15 x free frames, frame order), all factors
+ *   lm_info, lm_grad     the landmarks' scalar blocks of the same system
+ *   S_reduced, c_reduced the landmark-eliminated (Schur) system H - A^T W A, g - A^T W g_l */
+typedef struct {
+    double *r_preint, *J_preint;
+    double *r_prior, *J_prior;
+    double *H, *g;
+    double *lm_info, *lm_grad;
+    double *S_reduced, *c_reduced;
+    int32_t N; /* out */
+} rdvio_ba_linearization;
+int rdvio_hip_ba_linearize(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, const double *lin_states, int robust_loss,
+                           rdvio_ba_linearization *out);
+
 /* Measurement: live timing of the dominant kernel.  With timing on, every ba_solve_kernel launch is bracketed by HIP events on
  * the solver lane and read at the fetch that follows; get returns the sums since timing was switched on:
  * out4 = { launches, kernel milliseconds, algorithmic FP64 flops (SURVEY.md 8d per-unit figures x the units of each launch:

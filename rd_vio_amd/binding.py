@@ -19,7 +19,7 @@ EXPORTS = [
     "rdvio_hip_detect_keypoints", "rdvio_hip_harris_response", "rdvio_hip_image_release", "rdvio_hip_preintegrate",
     "rdvio_hip_preintegrate_dev", "rdvio_hip_preintegrate_estimator", "rdvio_hip_ctx_attach_thread", "rdvio_hip_ctx_ensure_lane_streams",
     "rdvio_hip_reprojection_eval", "rdvio_hip_rotation_prior_eval", "rdvio_hip_ba_solve", "rdvio_hip_ba_upload", "rdvio_hip_ba_solve_resident",
-    "rdvio_hip_ba_fetch", "rdvio_hip_ctx_set_kernel_timing", "rdvio_hip_ctx_get_kernel_timing", "rdvio_hip_marginalize", "rdvio_hip_marginalize_upload", "rdvio_hip_marginalize_resident",
+    "rdvio_hip_ba_fetch", "rdvio_hip_ba_linearize", "rdvio_hip_ctx_set_kernel_timing", "rdvio_hip_ctx_get_kernel_timing", "rdvio_hip_marginalize", "rdvio_hip_marginalize_upload", "rdvio_hip_marginalize_resident",
     "rdvio_hip_marginalize_fetch", "rdvio_hip_parsac_score", "rdvio_hip_parsac_generate_score", "rdvio_hip_parsac_fetch",
     "rdvio_hip_frame_step", "rdvio_hip_run_sequences",
 ]
@@ -91,6 +91,12 @@ class MargProblem(ctypes.Structure):
         ("inv_depth", ctypes.c_void_p), ("n_factors", ctypes.c_int32), ("tgt", ctypes.c_void_p),
         ("ref", ctypes.c_void_p), ("lm", ctypes.c_void_p), ("tangent", ctypes.c_void_p),
     ]
+
+
+class BaLinearization(ctypes.Structure):
+    """rdvio_ba_linearization (include/rdvio_hip.h)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("r_preint", "J_preint", "r_prior", "J_prior", "H", "g", "lm_info", "lm_grad", "S_reduced",
+                                               "c_reduced")] + [("N", ctypes.c_int32)]
 
 
 class BaSummary(ctypes.Structure):
@@ -295,6 +301,23 @@ class Context:
         self._check(self._lib.rdvio_hip_ba_solve(self._h, ctypes.byref(c), int(max_iterations), states.ctypes.data,
                                                  invd.ctypes.data, ctypes.byref(sm)), sm)
         return states, invd, sm
+
+    def ba_linearize(self, pb, lin_states=None, robust_loss=True):
+        """rdvio_hip_ba_linearize: one linearisation with the solver's device routines -> dict of the pieces"""
+        c, keep = self._ba_problem(pb)
+        npre, D, nl = c.n_preint, 15 * c.n_prior, c.n_landmarks
+        nfree = int((keep["frame_fixed"] != 1).sum())
+        N = 15 * nfree
+        out = dict(r_preint=np.zeros((npre, 15)), J_preint=np.zeros((npre, 2, 15, 15)), r_prior=np.zeros(D), J_prior=np.zeros((D, D)),
+                   H=np.zeros((N, N)), g=np.zeros(N), lm_info=np.zeros(nl), lm_grad=np.zeros(nl), S_reduced=np.zeros((N, N)), c_reduced=np.zeros(N))
+        lin = BaLinearization()
+        for k, v in out.items():
+            setattr(lin, k, v.ctypes.data if v.size else None)
+        ls = _f64(lin_states).reshape(-1, 16) if lin_states is not None else None
+        self._check(self._lib.rdvio_hip_ba_linearize(self._h, ctypes.byref(c), ls.ctypes.data_as(ctypes.c_void_p) if ls is not None else None,
+                                                     1 if robust_loss else 0, ctypes.byref(lin)))
+        assert lin.N == N
+        return out
 
     def ba_upload(self, pb, slot=0):
         c, keep = self._ba_problem(pb)

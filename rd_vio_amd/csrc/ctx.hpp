@@ -93,6 +93,7 @@ struct rdvio_hip_ctx {
         bool ready = false;
         // fused preintegration jobs of the uploaded problem (rdvio_ba_problem::n_pre_jobs): device views of the raw samples and
         // where the records go back to
+        size_t user0_off = 0;
         int n_jobs = 0;
         const int32_t *job_off = nullptr;
         const double *job_imu = nullptr, *job_par = nullptr, *job_noise = nullptr;

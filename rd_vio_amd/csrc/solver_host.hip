@@ -203,6 +203,7 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
     const size_t o_jpar = P.put(pb->job_par, (size_t)njobs * 7), o_jnoise = P.put(pb->job_noise, njobs > 0 ? 36 : 0);
     const size_t o_pf = P.put(pb->prior_frames, (size_t)np), o_lin = P.put(pb->prior_lin, (size_t)np * 16);
     const size_t o_S = P.put(pb->prior_S, (size_t)D * D), o_f = P.put(pb->prior_f, (size_t)D);
+    const size_t o_user0 = P.put((const double *)nullptr, (size_t)nfr * 16);   // (rdvio_hip_ba_linearize fills it)
     const size_t o_fcol = P.put(fcol.data(), (size_t)nfr);
     const size_t o_ffix = P.put(pb->frame_fixed, (size_t)nfr);
     const size_t o_lmf = P.put(lm_first.data(), (size_t)nl), o_lmc = P.put(lm_count.data(), (size_t)nl);
@@ -307,6 +308,7 @@ int rdvio_ba_prepare(rdvio_hip_ctx *ctx, rdvio_hip_ctx::BaSlot &slot, const rdvi
         slot.flops_lin = 500.0 * F + 15000.0 * P + 2.0 * Dd * Dd * 16.0 * Wp + 2.0 * 182.0 * F + 2.0 * 36.0 * m2 + n3 / 3.0;
         slot.flops_eval = 200.0 * F + 2000.0 * P + 2.0 * Dd * Dd;
     }
+    slot.user0_off = o_user0;
     slot.n_jobs = njobs;
     slot.job_off = (const int32_t *)(B + o_joff);
     slot.job_imu = (const double *)(B + o_jimu);
@@ -407,6 +409,65 @@ int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double 
     // point and termination FAILURE, and the caller is told
     if (sum[6] != 0.0) return rdvio_fail(ctx, RDVIO_ERR_HIP, "solver wavefronts disagreed on the trust-region loop's scalars (internal error)");
     if (sum[5] != 0.0) return rdvio_fail(ctx, RDVIO_ERR_TIMEOUT, "a solver helper workgroup did not answer within the spin limit");
+    return RDVIO_OK;
+}
+
+int rdvio_hip_ba_linearize(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, const double *lin_states, int robust_loss, rdvio_ba_linearization *out) {
+    if (!ctx || !pb || !out) return RDVIO_ERR_INVALID;
+    if (pb->n_pre_jobs != 0) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "rdvio_hip_ba_linearize takes integrated records");
+    rdvio_hip_ctx::BaSlot &S = ctx->ba[0];
+    S.ready = false;
+    hipStream_t st = ctx->lane[RDVIO_LANE_SOLVER];
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));
+    // helper workgroups off: this entry is one workgroup whatever the size
+    const int wgs = ctx->solver_wgs;
+    ctx->solver_wgs = 1;
+    const int rc = rdvio_ba_prepare(ctx, S, pb, ctx->ba_arena_bytes, false);
+    ctx->solver_wgs = wgs;
+    if (rc) return rc;
+    SolverWs &w = S.ws;
+    if (lin_states) {
+        memcpy((uint8_t *)S.host + S.user0_off, lin_states, (size_t)w.nfr * 16 * sizeof(double));
+        w.user0 = (const double *)((uint8_t *)S.arena + S.user0_off);
+    }
+    w.no_loss = robust_loss ? 0 : 1;
+    w.max_iter = 0;
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(S.arena, S.host, S.in_bytes, hipMemcpyHostToDevice, st));
+    rdvio_launch_ba_linearize(st, w);
+    RDVIO_HIP_CHECK(ctx, hipGetLastError());
+    const int N = w.N, D = w.D, nl = w.nl, npre = w.npre, np = w.np;
+    std::vector<double> Jri((size_t)std::max(np, 1) * 9), Sm((size_t)(N + 1) * std::max(N, 1));
+    auto down = [&](double *dst, const double *src, size_t n) -> hipError_t {
+        return (dst && n) ? hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, st) : hipSuccess;
+    };
+    RDVIO_HIP_CHECK(ctx, down(out->r_preint, w.r_p, (size_t)npre * 15));
+    RDVIO_HIP_CHECK(ctx, down(out->J_preint, w.Jp, (size_t)npre * 450));
+    RDVIO_HIP_CHECK(ctx, down(out->r_prior, w.r_m, (size_t)D));
+    RDVIO_HIP_CHECK(ctx, down(out->J_prior ? Jri.data() : nullptr, w.Jri, (size_t)np * 9));
+    RDVIO_HIP_CHECK(ctx, down(out->H, w.H, (size_t)N * N));
+    RDVIO_HIP_CHECK(ctx, down(out->g, w.g, (size_t)N));
+    RDVIO_HIP_CHECK(ctx, down(out->lm_info, w.lm_m, (size_t)nl));
+    RDVIO_HIP_CHECK(ctx, down(out->lm_grad, w.lm_g, (size_t)nl));
+    RDVIO_HIP_CHECK(ctx, down((out->S_reduced || out->c_reduced) ? Sm.data() : nullptr, w.Sm, (size_t)(N + 1) * N));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));
+    if (out->S_reduced)   // lower triangle -> full symmetric
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j <= i; ++j) out->S_reduced[(size_t)i * N + j] = out->S_reduced[(size_t)j * N + i] = Sm[(size_t)i * N + j];
+    if (out->c_reduced) memcpy(out->c_reduced, &Sm[(size_t)N * N], (size_t)N * sizeof(double));
+    if (out->J_prior) {
+        // ceres/marginalization_factor.h:46-67: d r / d theta_i = S[:, 15 i .. +3] Jr^-1(log(q0^-1 q)), every other column block is S's
+        for (int r = 0; r < D; ++r)
+            for (int c = 0; c < D; ++c) {
+                const int fi = c / 15, a = c % 15;
+                double v = pb->prior_S[(size_t)r * D + c];
+                if (a < 3) {
+                    v = 0.0;
+                    for (int k = 0; k < 3; ++k) v += pb->prior_S[(size_t)r * D + 15 * fi + k] * Jri[9 * (size_t)fi + 3 * k + a];
+                }
+                out->J_prior[(size_t)r * D + c] = v;
+            }
+    }
+    out->N = N;
     return RDVIO_OK;
 }
 

@@ -1173,7 +1173,7 @@ __device__ __attribute__((noinline)) void solver_setup(LdsWs &w, Shared &sh, lds
     for (int i = t; i < w.nfr * 16; i += T) {
         const double v = w.x0[i];
         w.x[i] = v;
-        w.user[i] = v;
+        w.user[i] = w.user0 ? w.user0[i] : v;
     }
     for (int l = t; l < nl; l += T) w.xd[l] = w.xd0[l];
     for (int l = t; l < nl; l += T) w.lfree[l] = (w.lm_count[l] > 0 && !w.lm_fixed[l]) ? 1 : 0;
@@ -2284,7 +2284,48 @@ __global__ __launch_bounds__(T) void marginalize_kernel(SolverWs w) {
     STAMP(3);
 }
 
+// Unit-parity entry (rdvio_hip_ba_linearize): ONE linearisation of the problem with the solver's own device routines -- setup,
+// factor evaluation with Jacobians, normal equations, landmark elimination with unit scaling and zero damping (so that the
+// reduced system is plainly H - A^T W A, g - A^T W g_l) -- and nothing else; the host copies the workspace arrays out.
+__global__ __launch_bounds__(T) void linearize_kernel(SolverWs w) {
+    __shared__ BlockShared<T> sh_store;
+    Shared &sh = *(Shared *)&sh_store;
+    constexpr int NMAX = 15 * RDVIO_LDS_CHOL_MAX_FRAMES;
+    constexpr size_t LDS_CAP = (NMAX + 1) * (NMAX + 2) / 2 + 225 * RDVIO_LDS_CHOL_MAX_FRAMES;
+    __shared__ __attribute__((aligned(16))) double lds_buf[LDS_CAP];
+    __shared__ SolverWs w_lds;
+    const int t = threadIdx.x;
+    for (int i = t; i < (int)(sizeof(SolverWs) / 8); i += T)
+        ((__attribute__((address_space(3))) unsigned long long *)&w_lds)[i] = ((const unsigned long long *)&w)[i];
+    __syncthreads();
+    LdsWs &wl = *(LdsWs *)&w_lds;
+    int phase = 0;
+    unsigned long long prof_last = 0;
+    solver_setup(wl, sh, RDVIO_LDS(lds_buf), LDS_CAP, prof_last);
+    (void)evaluate<true>(wl, sh, phase, w.x, w.xd, prof_last);
+    phase ^= 1;
+    build_normal_equations(wl, sh, prof_last);
+    for (int i = t; i < w.N; i += T) { w.sig_p[i] = 1.0; w.diag_p[i] = 1.0; }
+    for (int l = t; l < w.nl; l += T) { w.sig_l[l] = 1.0; w.diag_l[l] = 1.0; }
+    __syncthreads();
+    schur_reduce(wl, sh, RDVIO_LDS(lds_buf), LDS_CAP, 0.0, prof_last);
+    if (w.lds_chol) {   // the packed LDS triangle (+ right-hand-side row) -> the global matrix the host reads (ld N, row N = rhs)
+        const int N = w.N;
+        for (int o = t; o < (N + 1) * N; o += T) {
+            const int i = o / N, j = o - i * N;
+            if (j <= i || i == N) w.Sm[(size_t)i * N + j] = lds_buf[tri(i) + j];
+        }
+    }
+}
+
 }  // namespace
+
+void rdvio_launch_ba_linearize(hipStream_t stream, const SolverWs &w0) {
+    SolverWs w = w0;
+    w.n_wg = 1;
+    w.wg_stride = 1;
+    hipLaunchKernelGGL(linearize_kernel, dim3(1), dim3(T), 0, stream, w);
+}
 
 void rdvio_launch_marginalize(hipStream_t stream, const SolverWs &w0) {
     SolverWs w = w0;

@@ -42,6 +42,7 @@ struct SolverWs {
     double *partial;                     // per-workgroup partial costs
     // ---- state
     const double *x0, *xd0;              // uploaded initial values (every launch restarts from them)
+    const double *user0;                 // unit-parity entry only: the bias linearisation states (NULL: x0, as Solver::solve starts)
     double *x, *xd;                      // in/out: frame states, inverse depths
     double *xc, *xdc, *user;
     uint8_t *lfree;
@@ -83,3 +84,4 @@ typedef const __attribute__((address_space(3))) SolverWs LdsWs;
 
 void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w);
 void rdvio_launch_marginalize(hipStream_t stream, const SolverWs &w);
+void rdvio_launch_ba_linearize(hipStream_t stream, const SolverWs &w);

@@ -510,3 +510,99 @@ def test_results_do_not_depend_on_initial_lds_contents(ctx, oracle, monkeypatch)
             assert np.array_equal(a[k][0], b[k][0]) and np.array_equal(a[k][1], b[k][1])
             assert (a[k][2].iterations, a[k][2].successful_steps, a[k][2].final_cost) == (b[k][2].iterations, b[k][2].successful_steps, b[k][2].final_cost)
         assert np.array_equal(a[2][0], b[2][0]) and np.array_equal(a[2][1], b[2][1])
+
+
+def _dense_normal_equations(oracle, pb, lin_states, robust):
+    """H, g over the free frames' 15-dim tangents and the landmarks' inverse depths from the ORACLE's factor evaluations, assembled
+    densely in numpy, and the landmark-eliminated system -- the independent build rdvio_hip_ba_linearize is checked against"""
+    st = pb["states"]
+    nfr, nl = len(st), len(pb["inv_depth"])
+    fixed = pb["frame_fixed"]
+    col = -np.ones(nfr, dtype=int)
+    col[fixed != 1] = np.arange((fixed != 1).sum())
+    N = 15 * (fixed != 1).sum()
+    M = N + nl
+    H, g = np.zeros((M, M)), np.zeros(M)
+
+    def add(J_blocks, r):   # J_blocks: [(start column or -1, J)]
+        for ca, Ja in J_blocks:
+            if ca < 0:
+                continue
+            g[ca:ca + Ja.shape[1]] += Ja.T @ r
+            for cb, Jb in J_blocks:
+                if cb >= 0:
+                    H[ca:ca + Ja.shape[1], cb:cb + Jb.shape[1]] += Ja.T @ Jb
+    r, Jt, Jr, Jd = oracle.reprojection_eval(pb["tgt"], pb["ref"], pb["lm"], pb["tangent"], pb["z_ref"], pb["inv_depth"], st, pb["extr"], pb["sqrt_inv_cov"])
+    for k in range(len(pb["tgt"])):
+        rk, w = r[k], 1.0
+        if robust:   # CauchyLoss(1.0), Ceres' Corrector with rho'' < 0: residual and Jacobian scaled by sqrt(rho'), rho'(s) = 1 / (1 + s)
+            w = np.sqrt(1.0 / (1.0 + rk @ rk))
+        t, rf, l = pb["tgt"][k], pb["ref"][k], pb["lm"][k]
+        blocks = [(15 * col[t] if col[t] >= 0 else -1, w * Jt[k].reshape(2, 6)), (15 * col[rf] if col[rf] >= 0 else -1, w * Jr[k].reshape(2, 6)),
+                  (N + l if not pb["lm_fixed"][l] else -1, w * Jd[k].reshape(2, 1))]
+        add(blocks, w * rk)
+    r_pre, J_pre = [], []
+    for k in range(len(pb.get("pre_i", []))):
+        i, j = pb["pre_i"][k], pb["pre_j"][k]
+        rk, Ji, Jj = oracle.preintegration_eval(st[i], st[j], pb["preint"][k], lin_states[i, 10:16], pb["extr"])
+        r_pre.append(rk)
+        J_pre.append(np.stack([Ji, Jj]))
+        add([(15 * col[i] if col[i] >= 0 else -1, Ji), (15 * col[j] if col[j] >= 0 else -1, Jj)], rk)
+    r_m = J_m = None
+    if len(pb.get("prior_frames", [])):
+        pf = pb["prior_frames"]
+        r_m, J_m = oracle.marginalization_eval(st[pf], pb["lin"], pb["S"], pb["f"])
+        add([(15 * col[f] if col[f] >= 0 else -1, J_m[:, 15 * a:15 * a + 15]) for a, f in enumerate(pf)], r_m)
+    # frames with frame_fixed == 2 keep their columns with the pose part zeroed
+    for f in np.nonzero(fixed == 2)[0]:
+        c0 = 15 * col[f]
+        H[c0:c0 + 6, :] = 0
+        H[:, c0:c0 + 6] = 0
+        g[c0:c0 + 6] = 0
+    Hpp, Hpl, Hll, gp, gl = H[:N, :N], H[:N, N:], np.diag(H[N:, N:]).copy(), g[:N], g[N:]
+    free = Hll > 0
+    Winv = np.where(free, 1.0 / np.where(free, Hll, 1.0), 0.0)
+    S = Hpp - (Hpl * Winv) @ Hpl.T
+    c = gp - Hpl @ (Winv * gl)
+    return dict(H=Hpp, g=gp, lm_info=Hll, lm_grad=gl, S_reduced=S, c_reduced=c, r_preint=np.array(r_pre), J_preint=np.array(J_pre), r_prior=r_m, J_prior=J_m)
+
+
+@pytest.mark.parametrize("nfr,nl,seed,robust,kw", [(9, 150, 648, True, {}), (11, 300, 649, True, {}), (9, 150, 650, False, {}),
+                                                    (6, 60, 654, True, dict(with_prior=False)), (17, 400, 655, True, {})])
+def test_ba_linearize_unit_parity(big_ctx, oracle, nfr, nl, seed, robust, kw):
+    """rows A11 / A12 and the normal equations (SURVEY 8b's build_normal_schur): the device's preintegration-factor and
+    marginalisation-prior evaluations against ro_preintegration_eval / ro_marginalization_eval, and H, g, the landmark scalars and
+    the Schur-reduced system against a dense numpy build from the oracle's factor evaluations, at 1e-11 of each array's scale."""
+    pb = synth.make_window_problem(nfr, nl, seed, preintegrate=_oracle_pre(oracle), **kw)
+    rng = np.random.default_rng(seed)
+    # the window away from its linearisation points: the prior's error vector and the bias correction terms are exercised
+    lin_states = pb["states"].copy()
+    lin_states[:, 10:16] += 1e-3 * rng.standard_normal((nfr, 6))
+    if "lin" in pb:
+        pb["lin"] = pb["lin"] + 1e-3 * rng.standard_normal(pb["lin"].shape)
+        pb["lin"][:, :4] /= np.linalg.norm(pb["lin"][:, :4], axis=1, keepdims=True)
+        D = len(pb["f"])
+        A = rng.standard_normal((D, D))
+        pb["S"] = pb["S"] + 10.0 * np.triu(A)          # a dense sqrt information behind the 1e15 pin
+        pb["f"] = rng.standard_normal(D)
+    ref = _dense_normal_equations(oracle, pb, lin_states, robust)
+    got = big_ctx.ba_linearize(pb, lin_states, robust_loss=robust)
+    for key in ("r_preint", "J_preint", "r_prior", "J_prior", "H", "g", "lm_info", "lm_grad", "S_reduced", "c_reduced"):
+        a, b = got[key], ref[key]
+        if b is None or np.size(b) == 0:
+            continue
+        b = np.asarray(b).reshape(a.shape)
+        if key in ("H", "S_reduced", "J_prior"):
+            # entries span 30 orders of magnitude (the 1e15 pin squared): measure every entry against the scale of its row and column
+            d = np.sqrt(np.maximum(np.abs(np.diag(b @ b.T if key == "J_prior" else b)), 1e-300)) if key != "J_prior" else None
+            if key == "J_prior":
+                scale = np.maximum(np.abs(b).max(axis=1, keepdims=True), 1e-300) * np.ones_like(b)
+            else:
+                scale = np.outer(d, d)
+            err = np.abs(a - b) / np.maximum(scale, 1e-300)
+            assert err.max() <= 1e-11, (key, err.max())
+        elif key in ("g", "c_reduced"):
+            d = np.sqrt(np.maximum(np.abs(np.diag(ref["H"] if key == "g" else ref["S_reduced"])), 1e-300))
+            assert (np.abs(a - b) / (d * max(1.0, np.abs(b / d).max()))).max() <= 1e-11, key
+        else:
+            assert np.abs(a - b).max() <= 1e-11 * max(np.abs(b).max(), 1.0), (key, np.abs(a - b).max(), np.abs(b).max())
