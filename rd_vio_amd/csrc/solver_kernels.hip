@@ -2304,6 +2304,7 @@ __global__ __launch_bounds__(T) void linearize_kernel(SolverWs w) {
     solver_setup(wl, sh, RDVIO_LDS(lds_buf), LDS_CAP, prof_last);
     (void)evaluate<true>(wl, sh, phase, w.x, w.xd, prof_last);
     phase ^= 1;
+    for (int i = t; i < 9 * w.np; i += T) w.Jri[i] = sh.Jri[i];   // (the prior's Jr^-1 blocks live in LDS; the host assembles S E from them)
     build_normal_equations(wl, sh, prof_last);
     for (int i = t; i < w.N; i += T) { w.sig_p[i] = 1.0; w.diag_p[i] = 1.0; }
     for (int l = t; l < w.nl; l += T) { w.sig_l[l] = 1.0; w.diag_l[l] = 1.0; }
