@@ -28,8 +28,31 @@ DM unsigned long long rdvio_uniform64(unsigned long long v) {
 }
 // ONLY for operands that always live in global memory: the solver redirects its small vectors (g, yp, sig / diag / grad / gn, the
 // landmark scalars, x / xd and their candidates, user, lfree) into LDS when there is room -- those stay generic pointers.
+#ifndef RDVIO_CHECK_UG
 #define RDVIO_UG(p) ((cgdouble *)rdvio_uniform64((unsigned long long)(p)))
 #define RDVIO_UGW(p) ((gdouble *)rdvio_uniform64((unsigned long long)(p)))
+#else
+// Checking build (RDVIO_CHECK_UG=1 python rd_vio_amd/build.py --force; never a timed build): a generic pointer into LDS turned
+// global-typed reads the LDS aperture's address as a global one -- round 2's HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.  Here
+// such a pointer is REFUSED instead: the violation is counted in a device word the host reads at the next fetch
+// (rdvio_hip_ba_fetch / rdvio_hip_marginalize_fetch return RDVIO_ERR_HIP) and the access goes to a scratch line.
+__device__ unsigned g_rdvio_ug_violations;
+__device__ double g_rdvio_ug_sink[64];
+DM unsigned long long rdvio_ug_checked(const void *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool in_lds = __builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)p);
+#else
+    const bool in_lds = false;
+#endif
+    if (in_lds) {
+        atomicAdd(&g_rdvio_ug_violations, 1u);
+        return (unsigned long long)g_rdvio_ug_sink;
+    }
+    return rdvio_uniform64((unsigned long long)p);
+}
+#define RDVIO_UG(p) ((cgdouble *)rdvio_ug_checked((const void *)(p)))
+#define RDVIO_UGW(p) ((gdouble *)rdvio_ug_checked((const void *)(p)))
+#endif
 // Lane-masked load WITHOUT an exec-masked block: `ok ? p[i] : 0.0` compiles to v_cmp / s_and_saveexec / s_cbranch_execz / load /
 // s_or exec -- two scalar mask operations and a branch per load, ~60-90 cycles of a lone wavefront's issue (measured: the
 // group products spent 3.8 of 8.4 us issuing 96 such loads).  Here every lane loads (a masked lane reads entry `safe`, which

@@ -84,6 +84,7 @@ int rdvio_hip_marginalize_fetch(rdvio_hip_ctx *ctx, double *S_out, double *f_out
     if (Lambda_out) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(Lambda_out, w.Lambda_out, R * R * sizeof(double), hipMemcpyDeviceToHost, st));
     if (eta_out) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(eta_out, w.eta_out, R * sizeof(double), hipMemcpyDeviceToHost, st));
     RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));
+    if (const unsigned ug = rdvio_ug_violations()) return rdvio_fail(ctx, RDVIO_ERR_HIP, "RDVIO_UG was applied to an LDS address %u times (checking build)", ug);
     if (S_out) memcpy(S_out, down, R * R * sizeof(double));
     if (f_out) memcpy(f_out, down + (w.f_out - w.S_out), R * sizeof(double));
     if (lin_out) memcpy(lin_out, down + (w.lin_out - w.S_out), (size_t)(w.nfr - 1) * 16 * sizeof(double));

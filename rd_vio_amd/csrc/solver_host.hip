@@ -407,6 +407,7 @@ int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double 
     }
     // a helper workgroup that never answered (solver_kernels.hip, collect_partials): the outputs hold the last accepted
     // point and termination FAILURE, and the caller is told
+    if (const unsigned ug = rdvio_ug_violations()) return rdvio_fail(ctx, RDVIO_ERR_HIP, "RDVIO_UG was applied to an LDS address %u times (checking build)", ug);
     if (sum[6] != 0.0) return rdvio_fail(ctx, RDVIO_ERR_HIP, "solver wavefronts disagreed on the trust-region loop's scalars (internal error)");
     if (sum[5] != 0.0) return rdvio_fail(ctx, RDVIO_ERR_TIMEOUT, "a solver helper workgroup did not answer within the spin limit");
     return RDVIO_OK;

@@ -2321,6 +2321,18 @@ __global__ __launch_bounds__(T) void linearize_kernel(SolverWs w) {
 
 }  // namespace
 
+// checking builds: RDVIO_UG violations since the last call (0 in product builds)
+unsigned rdvio_ug_violations() {
+#ifdef RDVIO_CHECK_UG
+    unsigned v = 0, zero = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_rdvio_ug_violations), sizeof v) != hipSuccess) return 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rdvio_ug_violations), &zero, sizeof zero);
+    return v;
+#else
+    return 0;
+#endif
+}
+
 void rdvio_launch_ba_linearize(hipStream_t stream, const SolverWs &w0) {
     SolverWs w = w0;
     w.n_wg = 1;

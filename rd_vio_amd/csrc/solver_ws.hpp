@@ -85,3 +85,4 @@ typedef const __attribute__((address_space(3))) SolverWs LdsWs;
 void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w);
 void rdvio_launch_marginalize(hipStream_t stream, const SolverWs &w);
 void rdvio_launch_ba_linearize(hipStream_t stream, const SolverWs &w);
+unsigned rdvio_ug_violations();   // RDVIO_CHECK_UG builds: global-typed accesses that were handed an LDS address (else 0)
