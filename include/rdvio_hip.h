@@ -257,6 +257,11 @@ typedef struct {
 int rdvio_hip_ba_linearize(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, const double *lin_states, int robust_loss,
                            rdvio_ba_linearization *out);
 
+/* Large solves run on a team of workgroups whose members must all be resident.  When a member does not answer within the
+ * bounded wait (a device shared with other work), the solve is repeated once on one workgroup inside rdvio_hip_ba_fetch instead of
+ * failing; this counts those repeats.  A process with more than one live context on a device keeps every solve on one workgroup. */
+long rdvio_hip_ctx_team_retries(const rdvio_hip_ctx *ctx);
+
 /* Measurement: live timing of the dominant kernel.  With timing on, every ba_solve_kernel launch is bracketed by HIP events on
  * the solver lane and read at the fetch that follows; get returns the sums since timing was switched on:
  * out4 = { launches, kernel milliseconds, algorithmic FP64 flops (SURVEY.md 8d per-unit figures x the units of each launch:

@@ -115,6 +115,8 @@ typedef struct rdvio_pipeline_config {
      * 1 and 2 produce identical results by construction (the two steps share no mutable state between hand-overs); the
      * CPU path of the comparison runs 1, the product 2. */
     int32_t threading;
+    /* initializer.refine_imu (initializer.cpp:373): 0 skips refine_scale_velocity_via_gravity */
+    int32_t initializer_refine_imu;
 } rdvio_pipeline_config;
 
 void rdvio_pipeline_config_default(rdvio_pipeline_config *cfg);

@@ -12,6 +12,10 @@
 #include "host_select.hpp"
 #include "select_caps.hpp"
 
+#include <atomic>
+static std::atomic<int> g_live_contexts[64];
+int rdvio_live_contexts(int device) { return (device >= 0 && device < 64) ? g_live_contexts[device].load() : 1; }
+
 extern "C" {
 
 const char *rdvio_hip_version(void) { return "rdvio_hip 0.1 (gfx950)"; }
@@ -191,12 +195,17 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
         *out = ctx;
         return RDVIO_ERR_HIP;
     }
+    if (device < 64) {
+        g_live_contexts[device].fetch_add(1);
+        ctx->counted = true;
+    }
     *out = ctx;
     return RDVIO_OK;
 }
 
 void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->counted) g_live_contexts[ctx->device].fetch_sub(1);
     (void)hipSetDevice(ctx->device);
     for (int l = 0; l < 3; ++l) (void)rdvio_wait(ctx, ctx->lane[l]);
     for (int l = 0; l < 3; ++l) {

@@ -93,6 +93,7 @@ struct rdvio_hip_ctx {
         bool ready = false;
         // fused preintegration jobs of the uploaded problem (rdvio_ba_problem::n_pre_jobs): device views of the raw samples and
         // where the records go back to
+        bool retried = false;   // a team solve whose helpers stayed silent was repeated on the leader alone
         size_t user0_off = 0;
         int n_jobs = 0;
         const int32_t *job_off = nullptr;
@@ -129,6 +130,8 @@ struct rdvio_hip_ctx {
 
     // live kernel timing of the dominant kernel (ba_solve_kernel): HIP events on the solver lane around every launch,
     // read at the fetch that follows; sums since the last reset
+    bool counted = false;    // this context is in the device's live-context count
+    long team_retries = 0;   // solves repeated on one workgroup after a helper time-out (rdvio_hip_ctx_team_retries)
     bool kernel_timing = false;
     double kt_launches = 0.0, kt_ms = 0.0, kt_flops = 0.0, kt_iterations = 0.0;
 
@@ -163,6 +166,9 @@ static inline hipError_t rdvio_wait(rdvio_hip_ctx *ctx, hipStream_t st) {
             return rdvio_fail(ctx, RDVIO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
                               __FILE__, __LINE__);                                                     \
     } while (0)
+
+// contexts alive on a device (capi.hip): more than one means the device is shared between sequences
+int rdvio_live_contexts(int device);
 
 // solver_host.hip: validate + index + pack a BA problem into `slot` (capacity `cap` bytes of pinned blob and arena);
 // with_marg_tail also carves the marginalisation tail's scratch and outputs

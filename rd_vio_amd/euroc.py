@@ -54,6 +54,7 @@ def config_overrides(sensor_yaml, setting_yaml=None):
             ("initializer", "keyframe_num"): "initializer_keyframe_num", ("initializer", "keyframe_gap"): "initializer_keyframe_gap",
             ("initializer", "min_matches"): "initializer_min_matches", ("initializer", "min_parallax"): "initializer_min_parallax",
             ("initializer", "min_triangulation"): "initializer_min_triangulation", ("initializer", "min_landmarks"): "initializer_min_landmarks",
+            ("initializer", "refine_imu"): "initializer_refine_imu",
             ("solver", "iteration_limit"): "solver_iteration_limit",
             ("rotation", "misalignment_threshold"): "rotation_misalignment_threshold", ("rotation", "ransac_threshold"): "rotation_ransac_threshold",
             ("parsac", "parsac_flag"): "parsac_flag", ("parsac", "keyframe_check_size"): "parsac_keyframe_check_size",

@@ -243,9 +243,10 @@ bool Initializer::init_imu() {
     solve_gyro_bias();
     solve_gravity_scale_velocity();
     if (scale < 0.001 || scale > 1.0) return false;
-    // initializer.refine_imu defaults to true (config.cpp:52) and both reference settings files keep it
-    refine_scale_velocity_via_gravity();
-    if (scale < 0.001 || scale > 1.0) return false;
+    if (sh.cfg.initializer_refine_imu) {   // initializer.cpp:373 (true by default, config.cpp:52)
+        refine_scale_velocity_via_gravity();
+        if (scale < 0.001 || scale > 1.0) return false;
+    }
     return apply_init();
 }
 

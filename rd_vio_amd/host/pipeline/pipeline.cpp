@@ -1298,6 +1298,7 @@ void rdvio_pipeline_config_default(rdvio_pipeline_config *c) {
     c->parsac_flag = 0;
     c->parsac_keyframe_check_size = 3;
     c->threading = 0;
+    c->initializer_refine_imu = 1;
 }
 
 int rdvio_pipeline_create(rdvio_pipeline **out, const rdvio_pipeline_config *cfg, const rdvio_backend *backend) {

@@ -36,6 +36,7 @@ inline PngImage read_png(const std::string &path) {
         if (pos + 12 + len > buf.size()) throw std::runtime_error("truncated PNG: " + path);
         const size_t data = pos + 8;
         if (type == "IHDR") {
+            if (len != 13) throw std::runtime_error("malformed PNG (IHDR is not 13 bytes): " + path);
             w = (int)be32(data);
             h = (int)be32(data + 4);
             depth = buf[data + 8];
@@ -50,6 +51,8 @@ inline PngImage read_png(const std::string &path) {
     }
     if (w <= 0 || h <= 0 || depth != 8 || interlace != 0 || (ctype != 0 && ctype != 2 && ctype != 4 && ctype != 6))
         throw std::runtime_error("unsupported PNG (need 8-bit, non-interlaced, gray / RGB with optional alpha): " + path);
+    // the header sizes every allocation below: refuse what no camera of this pipeline produces before trusting it
+    if (w > 16384 || h > 16384) throw std::runtime_error("unreasonable PNG dimensions: " + path);
     const int spp = ctype == 0 ? 1 : (ctype == 2 ? 3 : (ctype == 4 ? 2 : 4));
     const size_t stride = (size_t)w * spp;
     std::vector<uint8_t> raw((stride + 1) * (size_t)h);

@@ -299,9 +299,15 @@ inline rdvio_pipeline_config load_yaml_config(const std::string &slam_config_fil
     if (auto n = opt("initializer.min_parallax")) c.initializer_min_parallax = as_double(*n, "initializer.min_parallax");
     if (auto n = opt("initializer.min_triangulation")) c.initializer_min_triangulation = (int32_t)as_size(*n, "initializer.min_triangulation");
     if (auto n = opt("initializer.min_landmarks")) c.initializer_min_landmarks = (int32_t)as_size(*n, "initializer.min_landmarks");
-    if (auto n = opt("initializer.refine_imu")) ex.initializer_refine_imu = as_bool(*n, "initializer.refine_imu") ? 1 : 0;
+    if (auto n = opt("initializer.refine_imu")) ex.initializer_refine_imu = c.initializer_refine_imu = as_bool(*n, "initializer.refine_imu") ? 1 : 0;
     if (auto n = opt("solver.iteration_limit")) c.solver_iteration_limit = (int32_t)as_size(*n, "solver.iteration_limit");
-    if (auto n = opt("solver.time_limit")) ex.solver_time_limit = as_double(*n, "solver.time_limit");
+    if (auto n = opt("solver.time_limit")) {
+        ex.solver_time_limit = as_double(*n, "solver.time_limit");
+        // Ceres' max_solver_time_in_seconds (solver.cpp:188).  The device solver is bounded by solver.iteration_limit only: a limit
+        // that could cut a solve short (the shipped files say 1e6 s) is refused rather than silently ignored
+        if (ex.solver_time_limit < 10.0)
+            throw YamlParseException("config \"solver.time_limit\" below 10 s is not supported: the device solver has no wall-clock limit, bound it with solver.iteration_limit");
+    }
     if (auto n = opt("parsac.parsac_flag")) c.parsac_flag = as_bool(*n, "parsac.parsac_flag") ? 1 : 0;
     if (auto n = opt("parsac.dynamic_probability")) ex.parsac_dynamic_probability = as_double(*n, "parsac.dynamic_probability");
     if (auto n = opt("parsac.threshold")) ex.parsac_threshold = as_double(*n, "parsac.threshold");

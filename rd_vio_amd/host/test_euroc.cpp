@@ -207,6 +207,9 @@ int main(int argc, char **argv) {
                 PngImage png = read_png(mav + "/cam0/data/" + std::to_string(c.ns) + ".png");
                 if (png.width != W || png.height != H) throw std::runtime_error("image size differs from cam0/sensor.yaml");
                 if (png.channels == 3) {  // PNG stores RGB; Odometry::addFrame expects OpenCV's BGR
+                    // the reference undistorts every image, colour or gray (dataset.hpp:585-592); this harness remaps single-channel
+                    // images only, so a colour stream from a distorted camera is refused rather than fed through raw
+                    if (!und.identity) throw std::runtime_error("colour images with lens distortion are not supported by this harness (undistort them first)");
                     for (size_t i = 0; i < (size_t)W * H; ++i) std::swap(png.pixels[3 * i], png.pixels[3 * i + 2]);
                     const auto t0 = std::chrono::steady_clock::now();
                     vio.addFrame(t, png.pixels.data(), W, H, 3, 3 * W);

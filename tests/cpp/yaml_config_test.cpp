@@ -30,13 +30,13 @@ int main(int argc, char **argv) {
                     "\"feature_tracker_predict_keypoints\": %d, \"initializer_keyframe_num\": %d, \"initializer_keyframe_gap\": %d, "
                     "\"initializer_min_matches\": %d, \"initializer_min_triangulation\": %d, \"initializer_min_landmarks\": %d, "
                     "\"initializer_min_parallax\": %.17g, \"solver_iteration_limit\": %d, \"rotation_misalignment_threshold\": %.17g, "
-                    "\"rotation_ransac_threshold\": %.17g, \"random\": %d, \"parsac_flag\": %d, \"parsac_keyframe_check_size\": %d, ",
+                    "\"rotation_ransac_threshold\": %.17g, \"random\": %d, \"parsac_flag\": %d, \"parsac_keyframe_check_size\": %d, \"initializer_refine_imu\": %d, ",
                     c.sliding_window_size, c.sliding_window_subframe_size, c.sliding_window_force_keyframe_landmarks, c.sliding_window_tracker_frequent,
                     c.feature_tracker_min_keypoint_distance, c.feature_tracker_max_keypoint_detection, c.feature_tracker_max_init_frames,
                     c.feature_tracker_max_frames, c.feature_tracker_clahe_clip_limit, c.feature_tracker_clahe_width, c.feature_tracker_clahe_height,
                     c.feature_tracker_predict_keypoints, c.initializer_keyframe_num, c.initializer_keyframe_gap, c.initializer_min_matches,
                     c.initializer_min_triangulation, c.initializer_min_landmarks, c.initializer_min_parallax, c.solver_iteration_limit,
-                    c.rotation_misalignment_threshold, c.rotation_ransac_threshold, c.random, c.parsac_flag, c.parsac_keyframe_check_size);
+                    c.rotation_misalignment_threshold, c.rotation_ransac_threshold, c.random, c.parsac_flag, c.parsac_keyframe_check_size, c.initializer_refine_imu);
         std::printf("\"extras\": {\"camera_distortion_flag\": %d, \"camera_time_offset\": %.17g, \"initializer_refine_imu\": %d, \"solver_time_limit\": %.17g, "
                     "\"parsac_dynamic_probability\": %.17g, \"parsac_threshold\": %.17g, \"parsac_norm_scale\": %.17g, ",
                     ex.camera_distortion_flag, ex.camera_time_offset, ex.initializer_refine_imu, ex.solver_time_limit, ex.parsac_dynamic_probability,

@@ -309,3 +309,22 @@ def test_cpp_test_euroc_matches_run_euroc(mav, tmp_path):
     # the constructor's failure modes surface as the reference's exception messages
     c = subprocess.run([exe, str(d), str(d / "nope.yaml"), str(d / "setting.yaml")], capture_output=True, text=True, timeout=60)
     assert c.returncode == 1 and "cannot load config" in c.stderr
+
+
+def test_yaml_settings_the_pipeline_cannot_ignore(mav, tmp_path):
+    """initializer.refine_imu reaches the pipeline configuration (initializer.cpp:373 skips the gravity refinement when false), and a
+    solver.time_limit that could cut a solve short is refused loudly: the device solver is bounded by the iteration limit only."""
+    import json
+
+    d, *_ = mav
+    tool = _yaml_tool()
+    base = (d / "setting.yaml").read_text()
+    s1 = tmp_path / "no_refine.yaml"
+    s1.write_text(base.replace("initializer:\n", "initializer:\n  refine_imu: false\n"))
+    got = json.loads(tool(s1, d / "sensor.yaml"))
+    assert got["initializer_refine_imu"] == 0 and got["extras"]["initializer_refine_imu"] == 0
+    assert json.loads(tool(d / "setting.yaml", d / "sensor.yaml"))["initializer_refine_imu"] == 1
+    s2 = tmp_path / "time_limit.yaml"
+    s2.write_text(base.replace("solver:\n", "solver:\n  time_limit: 0.01\n"))
+    out = tool(s2, d / "sensor.yaml")
+    assert out.startswith("EXCEPTION parse:") and "solver.time_limit" in out

@@ -1,5 +1,7 @@
 """GPU parity (MI355X): FP64 estimation kernels vs the CPU oracle.  Tolerances are stated per test:
 FP64 results agree to ~1e-12 relative (different summation/FMA order, scan vs sequential recurrence)."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -262,6 +264,7 @@ def test_ba_solve_large_problem_uses_helper_workgroups(ctx, oracle, monkeypatch)
     pb = synth.make_window_problem(17, 1000, 655, preintegrate=_oracle_pre(oracle))
     assert len(pb["tgt"]) >= 4096
     ref_s, ref_d, ref_sm = oracle.ba_solve(pb, 6)
+    monkeypatch.setenv("RDVIO_TEST_FORCE_TEAM", "1")   # (whatever other contexts the module keeps alive)
     got_s, got_d, got_sm = ctx.ba_solve(pb, 6)
     assert (got_sm.iterations, got_sm.successful_steps, got_sm.termination) == (ref_sm.iterations, ref_sm.successful_steps, ref_sm.termination)
     assert abs(got_sm.initial_cost - ref_sm.initial_cost) <= 1e-9 * abs(ref_sm.initial_cost)
@@ -475,20 +478,25 @@ def test_ba_solve_rejects_oversized_prior(big_ctx, oracle):
     assert e.value.code == 3   # RDVIO_ERR_CAPACITY
 
 
-def test_helper_timeout_is_reported_as_failure(ctx, oracle, monkeypatch):
-    """A helper workgroup that never answers (here: all of them exit at once, RDVIO_TEST_MUTE_HELPERS) must not hang the
-    launch nor pass for convergence: the leader's bounded wait expires, the loop ends with termination FAILURE (2), the
-    outputs hold the last accepted point (the initial values here) and rdvio_hip_ba_fetch returns RDVIO_ERR_TIMEOUT."""
+def test_helper_timeout_is_recovered_on_one_workgroup(oracle, monkeypatch):
+    """A helper workgroup that never answers (here: all of them exit at once, RDVIO_TEST_MUTE_HELPERS) must not hang the launch, pass
+    for convergence, or cost the frame its solve: the leader's bounded wait expires, the loop ends with FAILURE, and
+    rdvio_hip_ba_fetch repeats the solve once on the leader alone -- same result as a solve that never had helpers."""
     pb = synth.make_window_problem(17, 1000, 655, preintegrate=_oracle_pre(oracle))
     assert len(pb["tgt"]) >= 4096
-    monkeypatch.setenv("RDVIO_TEST_MUTE_HELPERS", "1")
-    with pytest.raises(rd_vio_amd.RdvioError) as e:
-        ctx.ba_solve(pb, 6)
-    assert e.value.code == rd_vio_amd.binding.ERR_TIMEOUT
-    assert e.value.summary.termination == 2 and e.value.summary.successful_steps == 0
-    monkeypatch.setenv("RDVIO_TEST_MUTE_HELPERS", "0")
-    _, _, sm = ctx.ba_solve(pb, 6)     # the context is usable afterwards
-    assert sm.termination in (0, 1) and np.isfinite(sm.final_cost)
+    with rd_vio_amd.Context(max_width=752, max_height=480, max_features=1024, max_window=16, max_factors=16384) as c:
+        lib = c._lib
+        lib.rdvio_hip_ctx_team_retries.restype = ctypes.c_long
+        monkeypatch.setenv("RDVIO_TEST_MUTE_HELPERS", "1")
+        monkeypatch.setenv("RDVIO_TEST_FORCE_TEAM", "1")   # (other contexts of this module are alive: the library would not launch a team)
+        s1, d1, sm1 = c.ba_solve(pb, 6)
+        assert lib.rdvio_hip_ctx_team_retries(c._h) == 1
+        monkeypatch.setenv("RDVIO_TEST_MUTE_HELPERS", "0")
+        monkeypatch.setenv("RDVIO_SOLVER_WGS", "1")
+    with rd_vio_amd.Context(max_width=752, max_height=480, max_features=1024, max_window=16, max_factors=16384) as c1:
+        s2, d2, sm2 = c1.ba_solve(pb, 6)     # a context that never launches helpers
+    assert (sm1.iterations, sm1.successful_steps, sm1.termination) == (sm2.iterations, sm2.successful_steps, sm2.termination)
+    assert sm1.termination in (0, 1) and np.array_equal(s1, s2) and np.array_equal(d1, d2)
 
 
 def test_results_do_not_depend_on_initial_lds_contents(ctx, oracle, monkeypatch):
