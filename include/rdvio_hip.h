@@ -351,6 +351,26 @@ int rdvio_hip_parsac_generate_score(rdvio_hip_ctx *ctx, const rdvio_parsac_batch
 /* inlier mask (n_points) and per-occupied-bin inlier counts (n_valid) of model `model` of the last scored batch */
 int rdvio_hip_parsac_fetch(rdvio_hip_ctx *ctx, int model, uint8_t *mask, int32_t *bin_inliers);
 
+/* ------------------------------------------------------------------ the tracker's two-view gates */
+/* Frame::track_keypoints (src/rdvio_map/src/frame.cpp:108-161) between the LK kernel and the estimator: the 5-point essential RANSAC
+ * (stereo.cpp:38-66; kind 0: pa = p1, pb = p2 normalised image points n x 2, threshold on the symmetric epipolar error), the
+ * 2-point rotation RANSAC (stereo.cpp:68-91, wahba.h:8-26; kind 2: pa = p1, pb = p2 unit bearings n x 3, threshold = cos of the
+ * angular threshold: a point is an inlier when cos(threshold) <= (R p1) . p2 <= 1, i.e. acos(...) <= threshold) and the
+ * track-length Poisson-disk thinning.  Like the PARSAC entries: the caller draws the samples (std::default_random_engine order,
+ * random.h:79-126) and replays the accept / early-exit decisions of ransac.h:31-76 on the returned inlier counts; one launch solves
+ * the minimal problems of n_iterations samples (5 resp. 2 point indices each) and scores every model.  Out, packed in iteration
+ * order: models (9 doubles each; capacity n_iterations x (10 | 1)), inlier_counts; rdvio_hip_ransac_fetch copies a model's mask.
+ * Frontend lane, staging of its own (a threaded pipeline's estimator may be in rdvio_hip_parsac_* at the same time). */
+int rdvio_hip_ransac_generate_score(rdvio_hip_ctx *ctx, int kind, int n_points, int points_changed, const double *pa, const double *pb,
+                                    double threshold, int n_iterations, const int32_t *samples, int32_t *models_per_iteration, double *models,
+                                    int32_t *inlier_counts);
+int rdvio_hip_ransac_fetch(rdvio_hip_ctx *ctx, int model, uint8_t *mask);
+/* frame.cpp:134-161: xy (n_points x 2 pixels in the next image), the n_order surviving keypoints in processing order (longest track
+ * first -- the caller sorts like the reference's std::sort), trash[i] != 0 for a TT_TRASH track; keep[k] = 1 when order[k] passes
+ * PoissonDiskFilter<2>(radius) against the keypoints kept before it and is not trash. */
+int rdvio_hip_thin_tracks(rdvio_hip_ctx *ctx, int width, int height, double radius, int n_points, const double *xy, int n_order,
+                          const int32_t *order, const uint8_t *trash, uint8_t *keep);
+
 /* ------------------------------------------------------------------ multi-sequence driver */
 /* One camera frame of the hot path over inputs that are resident in HBM, as one call: preprocess -> LK -> detect ->
  * preintegration (frame segment without covariance, then nseg - 1 keyframe segments with) on the frontend lane;

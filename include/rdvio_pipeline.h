@@ -76,6 +76,13 @@ typedef struct rdvio_backend {
      * orchestration calls end only then, so the marginalisation runs beside the frames in between. */
     int (*marginalize_begin)(void *user, const rdvio_marg_problem *pb);
     int (*marginalize_end)(void *user, double *S_out, double *f_out, double *lin_out);
+    /* optional (NULL = the orchestration's host code): the tracker's two-view gates and track-length thinning behind the backend
+     * (rdvio_hip_ransac_generate_score / _ransac_fetch / rdvio_hip_thin_tracks; Frame::track_keypoints, frame.cpp:108-161) */
+    int (*ransac_generate_score)(void *user, int kind, int n_points, int points_changed, const double *pa, const double *pb, double threshold,
+                                 int n_iterations, const int32_t *samples, int32_t *models_per_iteration, double *models, int32_t *inlier_counts);
+    int (*ransac_fetch)(void *user, int model, uint8_t *mask);
+    int (*thin_tracks)(void *user, int width, int height, double radius, int n_points, const double *xy, int n_order, const int32_t *order,
+                       const uint8_t *trash, uint8_t *keep);
     /* optional (NULL = the orchestration's host solvers generate the hypotheses): rdvio_hip_parsac_generate_score */
     int (*parsac_generate_score)(void *user, const rdvio_parsac_batch *batch, int n_iterations, const int32_t *samples,
                                  int32_t *models_per_iteration, double *models, rdvio_parsac_result *results);

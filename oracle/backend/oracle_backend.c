@@ -148,5 +148,8 @@ void rdvio_oracle_backend_fill(rdvio_backend *b) {
     b->thread_attach = NULL;
     b->marginalize_begin = NULL;
     b->marginalize_end = NULL;
+    b->ransac_generate_score = NULL; /* the CPU path runs the gates and the thinning in the orchestration's host code */
+    b->ransac_fetch = NULL;
+    b->thin_tracks = NULL;
     b->parsac_generate_score = NULL;
 }

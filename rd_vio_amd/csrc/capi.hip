@@ -165,19 +165,30 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
             return RDVIO_ERR_HIP;
         }
     }
-    {
-        ctx->ps_max_points = std::max(4096, 4 * max_feat);
-        const size_t n = (size_t)ctx->ps_max_points;
-        ctx->ps_in_bytes = (n * (5 * 8 + 4 + 1) + RDVIO_PARSAC_MAX_BINS * 24 + (size_t)RDVIO_PARSAC_MAX_MODELS * 12 * 8 + 4096 + 15) & ~(size_t)15;
-        CTX_ALLOC(ctx->ps_dev, ctx->ps_in_bytes);
-        CTX_ALLOC(ctx->ps_masks, (size_t)RDVIO_PARSAC_MAX_MODELS * n);
-        CTX_ALLOC(ctx->ps_bins, (size_t)RDVIO_PARSAC_MAX_MODELS * RDVIO_PARSAC_MAX_BINS * sizeof(int32_t));
-        CTX_ALLOC(ctx->ps_results, (size_t)RDVIO_PARSAC_MAX_MODELS * sizeof(rdvio_parsac_result));
+    for (int which = 0; which < 2; ++which) {
+        rdvio_hip_ctx::PsState &P = ctx->ps[which];
+        P.lane = which == 0 ? RDVIO_LANE_SOLVER : RDVIO_LANE_FRONTEND;
+        P.max_points = std::max(4096, 4 * max_feat);
+        const size_t n = (size_t)P.max_points;
+        P.in_bytes = (n * (6 * 8 + 4 + 1) + RDVIO_PARSAC_MAX_BINS * 24 + (size_t)RDVIO_PARSAC_MAX_MODELS * 12 * 8 + 4096 + 15) & ~(size_t)15;
+        CTX_ALLOC(P.dev, P.in_bytes);
+        CTX_ALLOC(P.masks, (size_t)RDVIO_PARSAC_MAX_MODELS * n);
+        CTX_ALLOC(P.bins, (size_t)RDVIO_PARSAC_MAX_MODELS * RDVIO_PARSAC_MAX_BINS * sizeof(int32_t));
+        CTX_ALLOC(P.results, (size_t)RDVIO_PARSAC_MAX_MODELS * sizeof(rdvio_parsac_result));
         // behind the inputs: the results of a batch -- per-model records, generated models, and (when small enough to ride along)
         // every model's inlier mask and bin counts
-        ctx->ps_down_bytes = (size_t)RDVIO_PARSAC_MAX_MODELS * (sizeof(rdvio_parsac_result) + 12 * 8 + 4) + n + (size_t)RDVIO_PARSAC_MASKS_INLINE + 65536;
-        if (hipHostMalloc(&ctx->ps_host, ctx->ps_in_bytes + ctx->ps_down_bytes, hipHostMallocDefault) != hipSuccess) {
+        P.down_bytes = (size_t)RDVIO_PARSAC_MAX_MODELS * (sizeof(rdvio_parsac_result) + 12 * 8 + 4) + n + (size_t)RDVIO_PARSAC_MASKS_INLINE + 65536;
+        if (hipHostMalloc(&P.host, P.in_bytes + P.down_bytes, hipHostMallocDefault) != hipSuccess) {
             rdvio_fail(ctx, RDVIO_ERR_HIP, "hipHostMalloc(parsac blob) failed");
+            *out = ctx;
+            return RDVIO_ERR_HIP;
+        }
+    }
+    {
+        ctx->thin_bytes = (size_t)std::max(4096, 4 * max_feat) * (2 * 8 + 4 + 1 + 1) + 4096;
+        CTX_ALLOC(ctx->thin_dev, ctx->thin_bytes);
+        if (hipHostMalloc(&ctx->thin_host, ctx->thin_bytes, hipHostMallocDefault) != hipSuccess) {
+            rdvio_fail(ctx, RDVIO_ERR_HIP, "hipHostMalloc(thinning blob) failed");
             *out = ctx;
             return RDVIO_ERR_HIP;
         }
@@ -219,7 +230,8 @@ void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
         if (ctx->gray_pinned[s]) (void)hipHostFree(ctx->gray_pinned[s]);
         if (ctx->gray_ev[s]) (void)hipEventDestroy(ctx->gray_ev[s]);
     }
-    void *bufs[] = {ctx->gray, ctx->clahe_lut, ctx->harris, ctx->harris_scalars, ctx->harris_cand, ctx->sel_hdr, ctx->sel_corners, ctx->sel_existing, ctx->ps_dev, ctx->ps_masks, ctx->ps_bins, ctx->ps_results,
+    void *bufs[] = {ctx->gray, ctx->clahe_lut, ctx->harris, ctx->harris_scalars, ctx->harris_cand, ctx->sel_hdr, ctx->sel_corners, ctx->sel_existing, ctx->ps[0].dev, ctx->ps[0].masks, ctx->ps[0].bins, ctx->ps[0].results, ctx->ps[1].dev, ctx->ps[1].masks, ctx->ps[1].bins,
+                    ctx->ps[1].results, ctx->thin_dev,
                     ctx->lk_curr,
                     ctx->lk_next, ctx->lk_prevf, ctx->lk_nextf, ctx->lk_status, ctx->ba_states, ctx->ba_extr,
                     ctx->ba_zref, ctx->ba_invd, ctx->ba_tangent, ctx->ba_idx, ctx->ba_r, ctx->ba_Jt, ctx->ba_Jr,
@@ -227,7 +239,9 @@ void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
     for (void *b : bufs) (void)hipFree(b);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pre2_pinned) (void)hipHostFree(ctx->pre2_pinned);
-    if (ctx->ps_host) (void)hipHostFree(ctx->ps_host);
+    for (int which = 0; which < 2; ++which)
+        if (ctx->ps[which].host) (void)hipHostFree(ctx->ps[which].host);
+    if (ctx->thin_host) (void)hipHostFree(ctx->thin_host);
     if (ctx->marg.host) (void)hipHostFree(ctx->marg.host);
     (void)hipFree(ctx->marg.arena);
     for (int s = 0; s < RDVIO_BA_SLOTS; ++s) {

@@ -110,19 +110,26 @@ struct rdvio_hip_ctx {
     BaSlot marg;
     size_t marg_bytes = 0;
 
-    // PARSAC hypothesis scoring (parsac_kernels.hip; solver lane): pinned blob (inputs | results), device mirror, outputs
-    void *ps_host = nullptr, *ps_dev = nullptr;
-    size_t ps_in_bytes = 0;
-    int ps_max_points = 0;
-    uint8_t *ps_masks = nullptr;           // RDVIO_PARSAC_MAX_MODELS x ps_max_points
-    int32_t *ps_bins = nullptr;            // RDVIO_PARSAC_MAX_MODELS x RDVIO_PARSAC_MAX_BINS
-    rdvio_parsac_result *ps_results = nullptr;
-    int ps_n = 0, ps_kind = -1, ps_nv = 0, ps_nm = 0;
-    int ps_slot_of[RDVIO_PARSAC_MAX_MODELS] = {0};   // model index of the last batch (as the caller counts) -> device slot
-    size_t ps_down_bytes = 0;
-    // masks and bin counts of the last batch on the host already (they rode along with the results): offsets into ps_host, 0 = no
-    size_t ps_masks_host = 0, ps_bins_host = 0;
-    bool ps_has_prior = false, ps_has_lens = false;
+    // Hypothesis generation / scoring state (parsac_kernels.hip): pinned blob (inputs | results), device mirror, outputs.  Two
+    // instances, one per caller: [0] the estimator's PARSAC solves on the solver lane, [1] the tracker's two-view RANSAC gates
+    // on the frontend lane -- they run concurrently in a threaded pipeline and share nothing.
+    struct PsState {
+        int lane = RDVIO_LANE_SOLVER;
+        void *host = nullptr, *dev = nullptr;
+        size_t in_bytes = 0, down_bytes = 0;
+        int max_points = 0;
+        uint8_t *masks = nullptr;           // RDVIO_PARSAC_MAX_MODELS x max_points
+        int32_t *bins = nullptr;            // RDVIO_PARSAC_MAX_MODELS x n_valid
+        rdvio_parsac_result *results = nullptr;
+        int n = 0, kind = -1, nv = 0, nm = 0;
+        bool has_prior = false, has_lens = false;
+        int slot_of[RDVIO_PARSAC_MAX_MODELS] = {0};   // model index of the last batch (as the caller counts) -> device slot
+        // masks and bin counts of the last batch on the host already (they rode along with the results): offsets into host, 0 = no
+        size_t masks_host = 0, bins_host = 0;
+    } ps[2];
+    // track-length thinning (rdvio_hip_thin_tracks; frontend lane)
+    void *thin_host = nullptr, *thin_dev = nullptr;
+    size_t thin_bytes = 0;
 
     // pinned host staging
     void *pinned = nullptr;

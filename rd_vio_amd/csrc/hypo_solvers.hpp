@@ -9,6 +9,7 @@
 //                (null-space basis, ten cubic constraints in GRevLex order, Gauss-Jordan to the action matrix of
 //                multiplication by x, real eigenvectors -> essential matrices; Eigen::JacobiSVD / EigenSolver replaced by a
 //                Jacobi eigensolver on A^T A and Hessenberg-QR + inverse iteration)
+//   rotation2    solve_rotation_2pt       /root/reference/src/rdvio_geometry/include/rdvio/geometry/wahba.h:8-26
 //
 // The same source runs in two shapes.  Every algorithm is a sequence of STEPS; a step is either a set of independent work
 // items (`each`: every item writes locations no other item of the step touches) or a single-lane section (`one`).  The host
@@ -398,6 +399,44 @@ HYPO_HD void rodrigues_float_round_trip(const double *Rin, double *Rout) {
     }
     mat_from_quat(qo, Rout);
     for (int k = 0; k < 9; ++k) Rout[k] = (double)(float)Rout[k];
+}
+
+// wahba.h:8-26 (solve_rotation_2pt): the rotation R with p2_k ~ R p1_k for two bearing pairs -- Kabsch on the 3 x 3 correlation,
+// R = V diag(1, 1, det(V U^T)) U^T; one lane
+HYPO_HD void rotation2(const double *p1 /* 2 x 3 */, const double *p2 /* 2 x 3 */, double *R /* 9 */) {
+    double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, U[9], V[9], s[3], VUt[9];
+    HYPO_UNROLL
+    for (int k = 0; k < 2; ++k) {
+        HYPO_UNROLL
+        for (int i = 0; i < 3; ++i) {
+            HYPO_UNROLL
+            for (int j = 0; j < 3; ++j) cov[3 * i + j] += p1[3 * k + i] * p2[3 * k + j];
+        }
+    }
+    HYPO_UNROLL
+    for (int i = 0; i < 9; ++i) cov[i] *= 0.5;
+    svd3(cov, U, s, V);
+    HYPO_UNROLL
+    for (int r = 0; r < 3; ++r) {
+        HYPO_UNROLL
+        for (int c = 0; c < 3; ++c) VUt[3 * r + c] = V[3 * r] * U[3 * c] + V[3 * r + 1] * U[3 * c + 1] + V[3 * r + 2] * U[3 * c + 2];
+    }
+    const double e = det3(VUt) >= 0.0 ? 1.0 : -1.0;
+    HYPO_UNROLL
+    for (int r = 0; r < 3; ++r) {
+        HYPO_UNROLL
+        for (int c = 0; c < 3; ++c) R[3 * r + c] = V[3 * r] * U[3 * c] + V[3 * r + 1] * U[3 * c + 1] + (V[3 * r + 2] * e) * U[3 * c + 2];
+    }
+}
+
+// the inlier test of find_rotation_matrix (stereo.cpp:82-84): acos((R p1) . p2) <= threshold, decided without the arc cosine:
+// acos(d) is defined for |d| <= 1 (NaN beyond: not an inlier) and decreasing, so the test is cos(threshold) <= d <= 1.  One
+// predicate for host and device (cos_threshold comes from the host's cos()): both roads decide every point alike.
+HYPO_HD bool rotation_inlier(const double *R, const double *p1, const double *p2, double cos_threshold) {
+    double q[3];
+    matvec3(R, p1, q);
+    const double d = dot3(q, p2);
+    return d <= 1.0 && d >= cos_threshold;
 }
 
 // ------------------------------------------------------------------------------------------------------------ wave-parallel Jacobi

@@ -10,6 +10,8 @@
 // independent), and the coverage score -- a float recurrence over the occupied bins in bin order -- runs on lane 0 in the
 // reference's operation order, so scores, masks and counts are bit-identical to the host restatement
 // (host/pipeline/parsac.hpp), which is what the orchestration runs over a backend without this hook.
+#include <vector>
+
 #include "ctx.hpp"
 #include "hypo_solvers.hpp"
 
@@ -53,13 +55,23 @@ __global__ __launch_bounds__(64) void parsac_score_kernel(PsArgs a) {
     }
     for (int i = lane; i < a.n_valid; i += 64) bins[i] = 0;
     __syncthreads();
-    const double *M = a.models + (a.kind == 1 ? 12 : 9) * (size_t)m;
+    const double *M = a.models + (a.kind == 1 ? 12 : 9) * (size_t)m;   // (kinds 0 and 2: nine doubles)
     double Mr[12];
 #pragma unroll
     for (int q = 0; q < 12; ++q) Mr[q] = (q < 9 || a.kind == 1) ? M[q] : 0.0;
     int count = 0, eff = 0;
     for (int i = lane; i < a.n; i += 64) {
         double err;
+        if (a.kind == 2) {   // rotation gate: cos(threshold) <= (R p1) . p2 <= 1  (hypo::rotation_inlier, shared with the host road)
+            const double p1[3] = {a.pa[3 * i], a.pa[3 * i + 1], a.pa[3 * i + 2]}, p2[3] = {a.pb[3 * i], a.pb[3 * i + 1], a.pb[3 * i + 2]};
+            const bool in2 = hypo::rotation_inlier(Mr, p1, p2, a.threshold);
+            a.masks[(size_t)m * a.n + i] = in2 ? 1 : 0;
+            if (in2) {
+                count++;
+                atomicAdd(&bins[a.d2v[i]], 1);
+            }
+            continue;
+        }
         const double bx = a.pb[2 * i], by = a.pb[2 * i + 1];
         if (a.kind == 1) {
             const double X = a.pa[3 * i], Y = a.pa[3 * i + 1], Z = a.pa[3 * i + 2];
@@ -148,6 +160,14 @@ __global__ __launch_bounds__(64) void parsac_generate_kernel(GenArgs a) {
         });
         hypo::epnp6(x, &work.pnp, pts_a, pts_b, a.models + 12 * (size_t)b);
         if (threadIdx.x == 0) a.counts[b] = 1;
+    } else if (a.kind == 2) {
+        const int32_t *smp = a.samples + 2 * (size_t)b;
+        x.each(12, [=](int e) {
+            if (e < 6) pts_a[e] = a.pa[3 * (size_t)smp[e / 3] + e % 3];
+            else pts_b[e - 6] = a.pb[3 * (size_t)smp[(e - 6) / 3] + (e - 6) % 3];
+        });
+        x.one([=]() { hypo::rotation2(pts_a, pts_b, a.models + 9 * (size_t)b); });
+        if (threadIdx.x == 0) a.counts[b] = 1;
     } else {
         const int32_t *smp = a.samples + 5 * (size_t)b;
         x.each(20, [=](int e) {
@@ -172,21 +192,25 @@ size_t put(uint8_t *base, size_t &off, const Tp *src, size_t n) {
 
 extern "C" {
 
+static int parsac_fetch(rdvio_hip_ctx *ctx, int which, int model, uint8_t *mask, int32_t *bin_inliers);
+
 // one scoring launch; n_iter > 0: the hypotheses are generated on the device first (samples: n_iter x dof point indices)
-static int parsac_run(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, rdvio_parsac_result *results, int n_iter, const int32_t *samples,
+static int parsac_run(rdvio_hip_ctx *ctx, int which, const rdvio_parsac_batch *b, rdvio_parsac_result *results, int n_iter, const int32_t *samples,
                       int32_t *models_per_iteration, double *models_out) {
     if (!ctx || !b || !results) return RDVIO_ERR_INVALID;
+    rdvio_hip_ctx::PsState &P = ctx->ps[which];
     const bool gen = n_iter > 0;
     const int n = b->n_points, nv = b->n_valid;
-    const int per_iter = b->kind == 1 ? 1 : 10, dof = b->kind == 1 ? 6 : 5;
+    // kind 0: essential matrix, five correspondences, up to ten models; 1: pose, six; 2: rotation, two bearing pairs
+    const int per_iter = b->kind == 0 ? 10 : 1, dof = b->kind == 0 ? 5 : (b->kind == 1 ? 6 : 2);
     const int nm = gen ? n_iter * per_iter : b->n_models;
-    if ((b->kind != 0 && b->kind != 1) || n <= 0 || nv <= 0 || nm < 0 || !b->pa || !b->pb || !b->data_to_valid || !b->valid_sizes || !b->bin_xy ||
+    if ((b->kind != 0 && b->kind != 1 && b->kind != 2) || n <= 0 || nv <= 0 || nm < 0 || !b->pa || !b->pb || !b->data_to_valid || !b->valid_sizes || !b->bin_xy ||
         (!gen && nm > 0 && !b->models) || (gen && (!samples || !models_per_iteration || !models_out)))
         return rdvio_fail(ctx, RDVIO_ERR_INVALID, "bad PARSAC batch");
-    if (n > ctx->ps_max_points || nv > RDVIO_PARSAC_MAX_BINS || nm > RDVIO_PARSAC_MAX_MODELS)
+    if (n > P.max_points || nv > RDVIO_PARSAC_MAX_BINS || nm > RDVIO_PARSAC_MAX_MODELS)
         return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "PARSAC batch of %d points / %d bins / %d models exceeds capacity (%d / %d / %d)", n, nv, nm,
-                          ctx->ps_max_points, RDVIO_PARSAC_MAX_BINS, RDVIO_PARSAC_MAX_MODELS);
-    if (!b->points_changed && (ctx->ps_n != n || ctx->ps_kind != b->kind || ctx->ps_nv != nv))
+                          P.max_points, RDVIO_PARSAC_MAX_BINS, RDVIO_PARSAC_MAX_MODELS);
+    if (!b->points_changed && (P.n != n || P.kind != b->kind || P.nv != nv))
         return rdvio_fail(ctx, RDVIO_ERR_INVALID, "PARSAC batch reuses points that were never uploaded");
     for (int i = 0; b->points_changed && i < n; ++i)
         if (b->data_to_valid[i] < 0 || b->data_to_valid[i] >= nv) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "PARSAC point %d maps outside the occupied bins", i);
@@ -194,17 +218,17 @@ static int parsac_run(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, rdvio_par
     for (int i = 0; gen && i < n_iter * dof; ++i)
         if (samples[i] < 0 || samples[i] >= n) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "PARSAC sample index %d outside the %d points", samples[i], n);
     if (nm == 0) return RDVIO_OK;
-    hipStream_t st = ctx->lane[RDVIO_LANE_SOLVER];
+    hipStream_t st = ctx->lane[P.lane];
     RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));  // the pinned blob may still be in flight
-    uint8_t *hb = (uint8_t *)ctx->ps_host, *db = (uint8_t *)ctx->ps_dev;
-    const int pdim = b->kind == 1 ? 3 : 2, mdim = b->kind == 1 ? 12 : 9;
+    uint8_t *hb = (uint8_t *)P.host, *db = (uint8_t *)P.dev;
+    const int pdim = b->kind == 0 ? 2 : 3, pbdim = b->kind == 2 ? 3 : 2, mdim = b->kind == 1 ? 12 : 9;
     // (a batch that reuses the uploaded points keeps their layout, whatever optional pointers it passes)
-    const bool has_lens = b->points_changed ? b->lens_weight != nullptr : ctx->ps_has_lens;
-    const bool has_prior = b->points_changed ? b->prior_mask != nullptr : ctx->ps_has_prior;
+    const bool has_lens = b->points_changed ? b->lens_weight != nullptr : P.has_lens;
+    const bool has_prior = b->points_changed ? b->prior_mask != nullptr : P.has_prior;
     // static part (points, grid) at fixed offsets, models (or samples + model slots + counts) behind it; one copy each
     size_t off = 0;
     const size_t o_pa = put(hb, off, b->points_changed ? b->pa : (const double *)nullptr, (size_t)n * pdim);
-    const size_t o_pb = put(hb, off, b->points_changed ? b->pb : (const double *)nullptr, (size_t)n * 2);
+    const size_t o_pb = put(hb, off, b->points_changed ? b->pb : (const double *)nullptr, (size_t)n * pbdim);
     const size_t o_xy = put(hb, off, b->points_changed ? b->bin_xy : (const double *)nullptr, (size_t)nv * 2);
     const size_t o_d2v = put(hb, off, b->points_changed ? b->data_to_valid : (const int32_t *)nullptr, (size_t)n);
     const size_t o_vs = put(hb, off, b->points_changed ? b->valid_sizes : (const int32_t *)nullptr, (size_t)nv);
@@ -222,14 +246,14 @@ static int parsac_run(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, rdvio_par
         o_models = put(hb, off, b->models, (size_t)nm * mdim);
         up_end = off;
     }
-    if (off > ctx->ps_in_bytes) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "PARSAC staging buffer too small");
+    if (off > P.in_bytes) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "PARSAC staging buffer too small");
     if (b->points_changed) {
         RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(db, hb, up_end, hipMemcpyHostToDevice, st));
-        ctx->ps_n = n;
-        ctx->ps_kind = b->kind;
-        ctx->ps_nv = nv;
-        ctx->ps_has_prior = has_prior;
-        ctx->ps_has_lens = has_lens;
+        P.n = n;
+        P.kind = b->kind;
+        P.nv = nv;
+        P.has_prior = has_prior;
+        P.has_lens = has_lens;
     } else {
         RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(db + o_dyn, hb + o_dyn, up_end - o_dyn, hipMemcpyHostToDevice, st));
     }
@@ -244,7 +268,7 @@ static int parsac_run(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, rdvio_par
         RDVIO_HIP_CHECK(ctx, hipGetLastError());
     }
     PsArgs a;
-    a.kind = b->kind; a.n = n; a.n_valid = nv; a.n_models = nm; a.has_prior = ctx->ps_has_prior; a.has_lens = ctx->ps_has_lens;
+    a.kind = b->kind; a.n = n; a.n_valid = nv; a.n_models = nm; a.has_prior = P.has_prior; a.has_lens = P.has_lens;
     a.per_iter = per_iter;
     a.counts = gen ? (const int32_t *)(db + o_counts) : nullptr;
     a.threshold = b->threshold;
@@ -252,31 +276,31 @@ static int parsac_run(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, rdvio_par
     a.models = (const double *)(db + o_models);
     a.d2v = (const int32_t *)(db + o_d2v); a.valid_sizes = (const int32_t *)(db + o_vs);
     a.lens_w = (const float *)(db + o_lw); a.prior = db + o_pm;
-    a.masks = ctx->ps_masks; a.bin_inliers = ctx->ps_bins; a.results = ctx->ps_results;
+    a.masks = P.masks; a.bin_inliers = P.bins; a.results = P.results;
     hipLaunchKernelGGL(parsac_score_kernel, dim3(nm), dim3(64), 0, st, a);
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
-    uint8_t *down0 = (uint8_t *)ctx->ps_host + ctx->ps_in_bytes;
+    uint8_t *down0 = (uint8_t *)P.host + P.in_bytes;
     rdvio_parsac_result *down = (rdvio_parsac_result *)down0;
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, ctx->ps_results, (size_t)nm * sizeof(rdvio_parsac_result), hipMemcpyDeviceToHost, st));
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, P.results, (size_t)nm * sizeof(rdvio_parsac_result), hipMemcpyDeviceToHost, st));
     const size_t gen_bytes = gen ? (o_models + (size_t)nm * mdim * sizeof(double)) - o_counts : 0;
     uint8_t *down_gen = down0 + (((size_t)nm * sizeof(rdvio_parsac_result) + 15) & ~(size_t)15);
     if (gen) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down_gen, db + o_counts, gen_bytes, hipMemcpyDeviceToHost, st));   // counts | models, one copy
     // the winner's inlier mask and bin counts are what the caller asks for next (rdvio_hip_parsac_fetch): a small batch brings
     // everybody's along now instead of paying a second round trip then
     const size_t mask_bytes = (size_t)nm * n, bins_bytes = (size_t)nm * nv * sizeof(int32_t);
-    ctx->ps_masks_host = ctx->ps_bins_host = 0;
+    P.masks_host = P.bins_host = 0;
     if (mask_bytes + bins_bytes <= RDVIO_PARSAC_MASKS_INLINE) {
         uint8_t *dm = down_gen + ((gen_bytes + 15) & ~(size_t)15), *dbins = dm + ((mask_bytes + 15) & ~(size_t)15);
-        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(dm, ctx->ps_masks, mask_bytes, hipMemcpyDeviceToHost, st));
-        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(dbins, ctx->ps_bins, bins_bytes, hipMemcpyDeviceToHost, st));
-        ctx->ps_masks_host = (size_t)(dm - (uint8_t *)ctx->ps_host);
-        ctx->ps_bins_host = (size_t)(dbins - (uint8_t *)ctx->ps_host);
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(dm, P.masks, mask_bytes, hipMemcpyDeviceToHost, st));
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(dbins, P.bins, bins_bytes, hipMemcpyDeviceToHost, st));
+        P.masks_host = (size_t)(dm - (uint8_t *)P.host);
+        P.bins_host = (size_t)(dbins - (uint8_t *)P.host);
     }
     RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));
     if (!gen) {
         memcpy(results, down, (size_t)nm * sizeof(rdvio_parsac_result));
-        for (int k = 0; k < nm; ++k) ctx->ps_slot_of[k] = k;
-        ctx->ps_nm = nm;
+        for (int k = 0; k < nm; ++k) P.slot_of[k] = k;
+        P.nm = nm;
         return RDVIO_OK;
     }
     // pack the occupied slots in iteration order (the order Parsac<>::solve meets the models in)
@@ -290,43 +314,74 @@ static int parsac_run(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, rdvio_par
             const int slot = it * per_iter + k;
             memcpy(models_out + (size_t)packed * mdim, mod + (size_t)slot * mdim, (size_t)mdim * sizeof(double));
             results[packed] = down[slot];
-            ctx->ps_slot_of[packed] = slot;
+            P.slot_of[packed] = slot;
         }
     }
-    ctx->ps_nm = packed;
+    P.nm = packed;
     return RDVIO_OK;
 }
 
 int rdvio_hip_parsac_score(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, rdvio_parsac_result *results) {
-    return parsac_run(ctx, b, results, 0, nullptr, nullptr, nullptr);
+    return parsac_run(ctx, 0, b, results, 0, nullptr, nullptr, nullptr);
 }
 
 int rdvio_hip_parsac_generate_score(rdvio_hip_ctx *ctx, const rdvio_parsac_batch *b, int n_iterations, const int32_t *samples,
                                     int32_t *models_per_iteration, double *models, rdvio_parsac_result *results) {
     if (n_iterations <= 0) return ctx ? rdvio_fail(ctx, RDVIO_ERR_INVALID, "no PARSAC iterations to generate") : RDVIO_ERR_INVALID;
-    return parsac_run(ctx, b, results, n_iterations, samples, models_per_iteration, models);
+    return parsac_run(ctx, 0, b, results, n_iterations, samples, models_per_iteration, models);
 }
 
-int rdvio_hip_parsac_fetch(rdvio_hip_ctx *ctx, int model, uint8_t *mask, int32_t *bin_inliers) {
+int rdvio_hip_parsac_fetch(rdvio_hip_ctx *ctx, int model, uint8_t *mask, int32_t *bin_inliers) { return parsac_fetch(ctx, 0, model, mask, bin_inliers); }
+
+// Frame::track_keypoints' two RANSAC gates (frame.cpp:108-118; ransac.h:31-76): the same machinery on the FRONTEND lane with the
+// tracker's own staging, scored by inlier count alone (one bin holding every point stands in for the grid)
+int rdvio_hip_ransac_generate_score(rdvio_hip_ctx *ctx, int kind, int n_points, int points_changed, const double *pa, const double *pb, double threshold,
+                                    int n_iterations, const int32_t *samples, int32_t *models_per_iteration, double *models, int32_t *inlier_counts) {
+    if (!ctx || n_points <= 0 || n_iterations <= 0 || !inlier_counts) return RDVIO_ERR_INVALID;
+    if (kind != 0 && kind != 2) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "RANSAC gate kind must be 0 (essential) or 2 (rotation)");
+    rdvio_hip_ctx::PsState &P = ctx->ps[1];
+    if (n_points > P.max_points) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d points exceed capacity %d", n_points, P.max_points);
+    static thread_local std::vector<int32_t> d2v;
+    if ((int)d2v.size() < n_points) d2v.assign((size_t)n_points, 0);
+    const int32_t vs = n_points;
+    const double bxy[2] = {0.0, 0.0};
+    rdvio_parsac_batch b{};
+    b.kind = kind; b.n_points = n_points; b.points_changed = points_changed; b.pa = pa; b.pb = pb; b.threshold = threshold;
+    b.n_valid = 1; b.data_to_valid = d2v.data(); b.valid_sizes = &vs; b.bin_xy = bxy;
+    const int per = kind == 0 ? 10 : 1;
+    static thread_local std::vector<rdvio_parsac_result> res;
+    res.resize((size_t)n_iterations * per);
+    if (int rc = parsac_run(ctx, 1, &b, res.data(), n_iterations, samples, models_per_iteration, models)) return rc;
+    int packed = 0;
+    for (int it = 0; it < n_iterations; ++it)
+        for (int k = 0; k < models_per_iteration[it]; ++k, ++packed) inlier_counts[packed] = res[(size_t)packed].count;
+    return RDVIO_OK;
+}
+
+int rdvio_hip_ransac_fetch(rdvio_hip_ctx *ctx, int model, uint8_t *mask) { return parsac_fetch(ctx, 1, model, mask, nullptr); }
+
+
+static int parsac_fetch(rdvio_hip_ctx *ctx, int which, int model, uint8_t *mask, int32_t *bin_inliers) {
     if (!ctx) return RDVIO_ERR_INVALID;
-    if (model < 0 || model >= ctx->ps_nm) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "PARSAC model %d was not in the last scored batch", model);
-    model = ctx->ps_slot_of[model];   // a generated batch leaves unoccupied slots between its models
-    if (ctx->ps_masks_host) {         // already on the host (parsac_run)
-        if (mask) memcpy(mask, (const uint8_t *)ctx->ps_host + ctx->ps_masks_host + (size_t)model * ctx->ps_n, (size_t)ctx->ps_n);
+    rdvio_hip_ctx::PsState &P = ctx->ps[which];
+    if (model < 0 || model >= P.nm) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "PARSAC model %d was not in the last scored batch", model);
+    model = P.slot_of[model];   // a generated batch leaves unoccupied slots between its models
+    if (P.masks_host) {         // already on the host (parsac_run)
+        if (mask) memcpy(mask, (const uint8_t *)P.host + P.masks_host + (size_t)model * P.n, (size_t)P.n);
         if (bin_inliers)
-            memcpy(bin_inliers, (const uint8_t *)ctx->ps_host + ctx->ps_bins_host + (size_t)model * ctx->ps_nv * sizeof(int32_t), (size_t)ctx->ps_nv * sizeof(int32_t));
+            memcpy(bin_inliers, (const uint8_t *)P.host + P.bins_host + (size_t)model * P.nv * sizeof(int32_t), (size_t)P.nv * sizeof(int32_t));
         return RDVIO_OK;
     }
-    hipStream_t st = ctx->lane[RDVIO_LANE_SOLVER];
-    uint8_t *down = (uint8_t *)ctx->ps_host + ctx->ps_in_bytes;
-    const size_t mb = ((size_t)ctx->ps_n + 15) & ~(size_t)15;
-    if (mask) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, ctx->ps_masks + (size_t)model * ctx->ps_n, (size_t)ctx->ps_n, hipMemcpyDeviceToHost, st));
+    hipStream_t st = ctx->lane[P.lane];
+    uint8_t *down = (uint8_t *)P.host + P.in_bytes;
+    const size_t mb = ((size_t)P.n + 15) & ~(size_t)15;
+    if (mask) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, P.masks + (size_t)model * P.n, (size_t)P.n, hipMemcpyDeviceToHost, st));
     if (bin_inliers)
-        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down + mb, ctx->ps_bins + (size_t)model * ctx->ps_nv, (size_t)ctx->ps_nv * sizeof(int32_t),
+        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down + mb, P.bins + (size_t)model * P.nv, (size_t)P.nv * sizeof(int32_t),
                                             hipMemcpyDeviceToHost, st));
     RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));
-    if (mask) memcpy(mask, down, (size_t)ctx->ps_n);
-    if (bin_inliers) memcpy(bin_inliers, down + mb, (size_t)ctx->ps_nv * sizeof(int32_t));
+    if (mask) memcpy(mask, down, (size_t)P.n);
+    if (bin_inliers) memcpy(bin_inliers, down + mb, (size_t)P.nv * sizeof(int32_t));
     return RDVIO_OK;
 }
 

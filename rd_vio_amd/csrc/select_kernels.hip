@@ -336,7 +336,87 @@ __global__ __launch_bounds__(256) void poisson_filter_kernel(const double *__res
     if (t == 0) hdr[3] = total;
 }
 
+// Track-length thinning of Frame::track_keypoints (frame.cpp:134-161): the surviving keypoints, longest track first (the ORDER comes
+// from the host: the reference sorts with std::sort, whose order among equal lengths is the library's), pass through a
+// PoissonDiskFilter<2> in the next image -- a keypoint is kept if no resident point is closer than the radius AND its track is not
+// TT_TRASH, and a kept keypoint becomes resident.  Sequential by nature; one wavefront walks the list, the 25 visited cells of a
+// candidate on 25 lanes, one ballot per candidate (the walk of poisson_filter_kernel's ordered mode).
+__global__ __launch_bounds__(64) void thin_tracks_kernel(const double *__restrict__ xy, const int32_t *__restrict__ order, int n_order,
+                                                        const uint8_t *__restrict__ trash, int w, int h, double radius, uint8_t *__restrict__ keep,
+                                                        int32_t *__restrict__ flag) {
+    __shared__ int grid[RDVIO_SEL_PGRID_MAX];
+    __shared__ __attribute__((aligned(16))) double pts[2 * RDVIO_SEL_PTS_MAX];
+    const int t = threadIdx.x;
+    const double cellp = radius / sqrt(2.0), r2 = radius * radius;
+    constexpr int M = 3;
+    const int gx = (int)floor((double)(w - 1) / cellp) + 1 + 2 * M, gy = (int)floor((double)(h - 1) / cellp) + 1 + 2 * M;
+    if ((long long)gx * gy > RDVIO_SEL_PGRID_MAX || n_order > RDVIO_SEL_PTS_MAX) {
+        if (t == 0) *flag = 1;   // beyond the LDS capacities: the caller takes the host road
+        return;
+    }
+    for (int i = t; i < gx * gy; i += 64) grid[i] = -1;
+    __syncthreads();
+    int npts = 0;
+    for (int k = 0; k < n_order; ++k) {
+        const int idx = order[k];
+        const double x = xy[2 * idx], y = xy[2 * idx + 1];
+        const int cx = (int)floor(x / cellp), cy = (int)floor(y / cellp);
+        bool conflict = false;
+        if (t < 25) {
+            // the reference's walk over [cx-2, cx+2] x [cy-2, cy+2]: it steps BEFORE it looks, so it never visits (cx-2, cy-2) and ends on (cx-2, cy+3)
+            const int pos = t + 1;
+            const int ax = cx - 2 + pos % 5 + M, ay = cy - 2 + pos / 5 + M;
+            if (ax >= 0 && ay >= 0 && ax < gx && ay < gy) {
+                const int p = grid[ay * gx + ax];
+                if (p >= 0) {
+                    const double dx = x - pts[2 * p], dy = y - pts[2 * p + 1];
+                    conflict = dx * dx + dy * dy < r2;
+                }
+            }
+        }
+        const bool kept = __ballot(conflict) == 0ull && !trash[idx];
+        if (kept && t == 0) {
+            const int ax = cx + M, ay = cy + M;
+            if (ax >= 0 && ay >= 0 && ax < gx && ay < gy) grid[ay * gx + ax] = npts;
+            pts[2 * npts] = x;
+            pts[2 * npts + 1] = y;
+        }
+        if (kept) npts++;
+        if (t == 0) keep[k] = kept ? 1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (t == 0) *flag = 0;
+}
+
 }  // namespace
+
+extern "C" int rdvio_hip_thin_tracks(rdvio_hip_ctx *ctx, int width, int height, double radius, int n_points, const double *xy, int n_order,
+                                     const int32_t *order, const uint8_t *trash, uint8_t *keep) {
+    if (!ctx || width <= 0 || height <= 0 || !(radius > 0.0) || n_points < 0 || n_order < 0 || (n_order > 0 && (!xy || !order || !trash || !keep)))
+        return RDVIO_ERR_INVALID;
+    if (n_order == 0) return RDVIO_OK;
+    for (int k = 0; k < n_order; ++k)   // shapes are checked on the host: the kernel never indexes out of bounds
+        if (order[k] < 0 || order[k] >= n_points) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "thinning order entry %d outside the %d points", order[k], n_points);
+    const size_t o_xy = 0, o_ord = (size_t)n_points * 16, o_tr = o_ord + (size_t)n_order * 4, o_keep = (o_tr + (size_t)n_points + 15) & ~(size_t)15,
+                 o_flag = (o_keep + (size_t)n_order + 15) & ~(size_t)15, total = o_flag + 16;
+    if (total > ctx->thin_bytes) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "thinning of %d points exceeds the context's capacity", n_points);
+    hipStream_t st = ctx->stream;
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));   // the pinned blob may still be in flight
+    uint8_t *hb = (uint8_t *)ctx->thin_host, *db = (uint8_t *)ctx->thin_dev;
+    memcpy(hb + o_xy, xy, (size_t)n_points * 16);
+    memcpy(hb + o_ord, order, (size_t)n_order * 4);
+    memcpy(hb + o_tr, trash, (size_t)n_points);
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(db, hb, o_keep, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(thin_tracks_kernel, dim3(1), dim3(64), 0, st, (const double *)(db + o_xy), (const int32_t *)(db + o_ord), n_order,
+                       (const uint8_t *)(db + o_tr), width, height, radius, db + o_keep, (int32_t *)(db + o_flag));
+    RDVIO_HIP_CHECK(ctx, hipGetLastError());
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(hb + o_keep, db + o_keep, total - o_keep, hipMemcpyDeviceToHost, st));
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));
+    if (*(const int32_t *)(hb + o_flag) != 0) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "thinning grid beyond the kernel's LDS capacity");
+    memcpy(keep, hb + o_keep, (size_t)n_order);
+    return RDVIO_OK;
+}
 
 int rdvio_launch_select(rdvio_hip_ctx *ctx, int slot, int max_corners, double gftt_min_dist, double poisson_radius, int n_existing) {
     ImageSlot &S = ctx->slots[slot];

@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <numeric>
 #include <random>
+#include <stdexcept>
 #include <unordered_map>
 #include <vector>
 
@@ -197,20 +198,11 @@ inline void svd3(const M3 &A, M3 &U, double s[3], M3 &V) {
 
 // wahba.h:8-26:  h(p2) = R h(p1)
 inline M3 solve_rotation_2pt(const std::array<V3, 2> &p1, const std::array<V3, 2> &p2) {
-    M3 cov;
-    for (int i = 0; i < 9; ++i) cov.m[i] = 0.0;
-    for (int k = 0; k < 2; ++k) {
-        const double a[3] = {p1[k].x, p1[k].y, p1[k].z}, b[3] = {p2[k].x, p2[k].y, p2[k].z};
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) cov.m[3 * i + j] += a[i] * b[j];
-    }
-    for (int i = 0; i < 9; ++i) cov.m[i] *= 0.5;
-    M3 U, V;
-    double s[3];
-    svd3(cov, U, s, V);
-    M3 E;
-    E.m[8] = (det(V * transpose(U)) >= 0.0) ? 1.0 : -1.0;
-    return V * E * transpose(U);
+    // (csrc/hypo_solvers.hpp: the source the device kernel runs)
+    const double a[6] = {p1[0].x, p1[0].y, p1[0].z, p1[1].x, p1[1].y, p1[1].z}, b[6] = {p2[0].x, p2[0].y, p2[0].z, p2[1].x, p2[1].y, p2[1].z};
+    M3 R;
+    hypo::rotation2(a, b, R.m);
+    return R;
 }
 
 // essential.h:14-19
@@ -446,10 +438,29 @@ class LotBox {
     std::uniform_int_distribution<size_t> distribution{0, std::numeric_limits<size_t>::max()};
 };
 
-// Generic RANSAC loop.  solve(sample indices) -> models; error(model, i) -> double.
-template <size_t DoF, class Model, class SolveFn, class ErrorFn>
-Model ransac(size_t size, double threshold, double confidence, size_t max_iteration, int seed, SolveFn solve, ErrorFn error,
-             std::vector<char> &inlier_mask, Model model = Model()) {
+// Hypothesis generation and scoring of a RANSAC gate behind the backend (rdvio_backend::ransac_generate_score / ransac_fetch; the
+// HIP product implements them: rdvio_hip_ransac_generate_score).  kind / pa / pb / threshold as that entry takes them.
+struct RansacDevice {
+    int (*generate)(void *user, int kind, int n_points, int points_changed, const double *pa, const double *pb, double threshold, int n_iterations,
+                    const int32_t *samples, int32_t *models_per_iteration, double *models, int32_t *inlier_counts) = nullptr;
+    int (*fetch)(void *user, int model, uint8_t *mask) = nullptr;
+    void *user = nullptr;
+    int kind = 0;
+    const double *pa = nullptr, *pb = nullptr;
+    double threshold = 0.0;
+};
+
+// Generic RANSAC loop (ransac.h:31-76).  solve(sample indices) -> models; inlier(model, i) -> bool.
+// Evaluated a batch of iterations at a time: the samples do not depend on the scores (the lot box is seeded per call and draws in
+// a fixed order), only the NUMBER of iterations does, through the adaptive iter_max.  The hypotheses of the next RANSAC_BATCH
+// iterations are generated and scored together -- on the device when `dev` offers the hooks, in place otherwise -- and the
+// reference's accept / early-exit decisions are replayed on the inlier counts in iteration order.  Both roads run this control
+// flow over bit-identical models (csrc/hypo_solvers.hpp) and inlier decisions.
+constexpr size_t RANSAC_BATCH = 8;
+
+template <size_t DoF, class Model, class SolveFn, class InlierFn>
+Model ransac(size_t size, double confidence, size_t max_iteration, int seed, SolveFn solve, InlierFn inlier, std::vector<char> &inlier_mask,
+             Model model = Model(), const RansacDevice *dev = nullptr) {
     LotBox lotbox(size);
     lotbox.seed((unsigned int)seed);
     const double K = std::log(std::max(1 - confidence, 1.0e-5));
@@ -457,27 +468,70 @@ Model ransac(size_t size, double threshold, double confidence, size_t max_iterat
     inlier_mask.assign(size, 0);
     if (size < DoF) return model;
     inlier_mask.clear();  // ransac.h leaves the member mask empty until a model beats zero inliers
+    const bool on_device = dev && dev->generate && dev->fetch;
     size_t iter_max = max_iteration;
-    for (size_t iter = 0; iter < iter_max; ++iter) {
-        std::array<size_t, DoF> sample;
-        lotbox.refill_all();
-        for (size_t si = 0; si < DoF; ++si) sample[si] = lotbox.draw_without_replacement();
-        const std::vector<Model> models = solve(sample);
-        for (const Model &current : models) {
-            size_t count = 0;
-            std::vector<char> mask(size, 0);
-            for (size_t i = 0; i < size; ++i)
-                if (error(current, i) <= threshold) {
-                    count++;
-                    mask[i] = 1;
+    bool first_batch = true;
+    for (size_t iter0 = 0; iter0 < iter_max; iter0 += RANSAC_BATCH) {
+        const size_t B = std::min(RANSAC_BATCH, iter_max - iter0);
+        std::vector<std::array<size_t, DoF>> samples(B);
+        for (size_t b = 0; b < B; ++b) {
+            lotbox.refill_all();
+            for (size_t si = 0; si < DoF; ++si) samples[b][si] = lotbox.draw_without_replacement();
+        }
+        std::vector<Model> models;
+        std::vector<size_t> first_of(B + 1, 0), counts;
+        std::vector<std::vector<char>> masks;   // host road only
+        if (on_device) {
+            std::vector<int32_t> flat_s(B * DoF), per_iter(B), cnt(B * 10);
+            for (size_t b = 0; b < B; ++b)
+                for (size_t si = 0; si < DoF; ++si) flat_s[b * DoF + si] = (int32_t)samples[b][si];
+            std::vector<double> flat_m(B * 10 * 9);
+            if (dev->generate(dev->user, dev->kind, (int)size, first_batch ? 1 : 0, dev->pa, dev->pb, dev->threshold, (int)B, flat_s.data(), per_iter.data(),
+                              flat_m.data(), cnt.data()) != 0)   // (0 = RDVIO_OK)
+                throw std::runtime_error("backend ransac_generate_score failed");
+            first_batch = false;
+            for (size_t b = 0; b < B; ++b) first_of[b + 1] = first_of[b] + (size_t)per_iter[b];
+            models.resize(first_of[B]);
+            counts.resize(first_of[B]);
+            for (size_t k = 0; k < models.size(); ++k) {
+                for (int q = 0; q < 9; ++q) models[k].m[q] = flat_m[9 * k + q];
+                counts[k] = (size_t)cnt[k];
+            }
+        } else {
+            for (size_t b = 0; b < B; ++b) {
+                const std::vector<Model> ms = solve(samples[b]);
+                models.insert(models.end(), ms.begin(), ms.end());
+                first_of[b + 1] = models.size();
+            }
+            counts.assign(models.size(), 0);
+            masks.resize(models.size());
+            for (size_t k = 0; k < models.size(); ++k) {
+                masks[k].assign(size, 0);
+                for (size_t i = 0; i < size; ++i)
+                    if (inlier(models[k], i)) {
+                        counts[k]++;
+                        masks[k][i] = 1;
+                    }
+            }
+        }
+        long best = -1;
+        for (size_t b = 0; b < B && iter0 + b < iter_max; ++b)
+            for (size_t k = first_of[b]; k < first_of[b + 1]; ++k)
+                if (counts[k] > inlier_count) {
+                    model = models[k];
+                    inlier_count = counts[k];
+                    best = (long)k;
+                    const double ratio = inlier_count / (double)size;
+                    const double N = K / std::log(1 - std::pow(ratio, 5));
+                    if (N < (double)iter_max) iter_max = (size_t)std::ceil(N);
                 }
-            if (count > inlier_count) {
-                model = current;
-                inlier_count = count;
-                inlier_mask.swap(mask);
-                const double ratio = inlier_count / (double)size;
-                const double N = K / std::log(1 - std::pow(ratio, 5));
-                if (N < (double)iter_max) iter_max = (size_t)std::ceil(N);
+        if (best >= 0) {
+            if (on_device) {
+                std::vector<uint8_t> m8(size);
+                if (dev->fetch(dev->user, (int)best, m8.data()) != 0) throw std::runtime_error("backend ransac_fetch failed");
+                inlier_mask.assign(m8.begin(), m8.end());
+            } else {
+                inlier_mask.swap(masks[(size_t)best]);
             }
         }
     }
@@ -486,28 +540,51 @@ Model ransac(size_t size, double threshold, double confidence, size_t max_iterat
 
 // stereo.cpp:38-66
 inline M3 find_essential_matrix(const std::vector<V2> &p1, const std::vector<V2> &p2, std::vector<char> &mask, double threshold = 1.0,
-                                double confidence = 0.999, size_t max_iteration = 1000, int seed = 0) {
+                                double confidence = 0.999, size_t max_iteration = 1000, int seed = 0, RansacDevice *dev = nullptr) {
     const double t1 = 3.84;
+    const double thr = 2.0 * t1 * threshold * threshold;
     auto solve = [&](const std::array<size_t, 5> &s) {
         std::array<V2, 5> a, b;
         for (int i = 0; i < 5; ++i) { a[i] = p1[s[i]]; b[i] = p2[s[i]]; }
         return solve_essential_5pt(a, b);
     };
-    auto err = [&](const M3 &E, size_t i) {
-        return essential_geometric_error(E, p1[i], p2[i]) + essential_geometric_error(transpose(E), p2[i], p1[i]);
+    auto inl = [&](const M3 &E, size_t i) {
+        return essential_geometric_error(E, p1[i], p2[i]) + essential_geometric_error(transpose(E), p2[i], p1[i]) <= thr;
     };
-    return ransac<5, M3>(p1.size(), 2.0 * t1 * threshold * threshold, confidence, max_iteration, seed, solve, err, mask);
+    std::vector<double> fa, fb;
+    if (dev) {
+        fa.resize(2 * p1.size());
+        fb.resize(2 * p2.size());
+        for (size_t i = 0; i < p1.size(); ++i) { fa[2 * i] = p1[i].x; fa[2 * i + 1] = p1[i].y; fb[2 * i] = p2[i].x; fb[2 * i + 1] = p2[i].y; }
+        dev->kind = 0; dev->pa = fa.data(); dev->pb = fb.data(); dev->threshold = thr;
+    }
+    return ransac<5, M3>(p1.size(), confidence, max_iteration, seed, solve, inl, mask, M3(), dev);
 }
 
-// stereo.cpp:68-91
+// stereo.cpp:68-91.  The inlier test acos((R p1) . p2) <= threshold is decided as cos(threshold) <= (R p1) . p2 <= 1
+// (hypo::rotation_inlier: the same predicate on the host and on the device)
 inline M3 find_rotation_matrix(const std::vector<V3> &p1, const std::vector<V3> &p2, std::vector<char> &mask, double threshold = 1.0,
-                               double confidence = 0.999, size_t max_iteration = 1000, int seed = 0) {
+                               double confidence = 0.999, size_t max_iteration = 1000, int seed = 0, RansacDevice *dev = nullptr) {
     const double t2 = 5.99;
+    const double cos_thr = std::cos(t2 * threshold * threshold);
     auto solve = [&](const std::array<size_t, 2> &s) {
         return std::vector<M3>{solve_rotation_2pt({p1[s[0]], p1[s[1]]}, {p2[s[0]], p2[s[1]]})};
     };
-    auto err = [&](const M3 &R, size_t i) { return std::acos(dot(R * p1[i], p2[i])); };
-    return ransac<2, M3>(p1.size(), t2 * threshold * threshold, confidence, max_iteration, seed, solve, err, mask);
+    auto inl = [&](const M3 &R, size_t i) {
+        const double a[3] = {p1[i].x, p1[i].y, p1[i].z}, b[3] = {p2[i].x, p2[i].y, p2[i].z};
+        return hypo::rotation_inlier(R.m, a, b, cos_thr);
+    };
+    std::vector<double> fa, fb;
+    if (dev) {
+        fa.resize(3 * p1.size());
+        fb.resize(3 * p2.size());
+        for (size_t i = 0; i < p1.size(); ++i) {
+            fa[3 * i] = p1[i].x; fa[3 * i + 1] = p1[i].y; fa[3 * i + 2] = p1[i].z;
+            fb[3 * i] = p2[i].x; fb[3 * i + 1] = p2[i].y; fb[3 * i + 2] = p2[i].z;
+        }
+        dev->kind = 2; dev->pa = fa.data(); dev->pb = fb.data(); dev->threshold = cos_thr;
+    }
+    return ransac<2, M3>(p1.size(), confidence, max_iteration, seed, solve, inl, mask, M3(), dev);
 }
 
 // stereo.h:83-93: N-view DLT.  Ps: 3x4 row-major projection matrices.  Returns the homogeneous point (smallest right
@@ -693,8 +770,9 @@ inline M3 find_homography_matrix(const std::vector<V2> &p1, const std::vector<V2
     auto solve = [&](const std::array<size_t, 4> &s) {
         return std::vector<M3>{solve_homography_4pt({p1[s[0]], p1[s[1]], p1[s[2]], p1[s[3]]}, {p2[s[0]], p2[s[1]], p2[s[2]], p2[s[3]]})};
     };
-    auto err = [&](const M3 &H, size_t i) { return homography_geometric_error(H, p1[i], p2[i]) + homography_geometric_error(inverse3(H), p2[i], p1[i]); };
-    return ransac<4, M3>(p1.size(), 2.0 * t2 * threshold * threshold, confidence, max_iteration, seed, solve, err, mask);
+    const double thr = 2.0 * t2 * threshold * threshold;
+    auto inl = [&](const M3 &H, size_t i) { return homography_geometric_error(H, p1[i], p2[i]) + homography_geometric_error(inverse3(H), p2[i], p1[i]) <= thr; };
+    return ransac<4, M3>(p1.size(), confidence, max_iteration, seed, solve, inl, mask);
 }
 
 // homography.cpp:5-87.  Returns false for a pure rotation.

@@ -147,6 +147,15 @@ int parsac_fetch(void *user, int model, uint8_t *mask, int32_t *bin_inliers) {
     return rdvio_hip_parsac_fetch(static_cast<HipBackend *>(user)->ctx, model, mask, bin_inliers);
 }
 
+int ransac_generate_score(void *user, int kind, int n, int changed, const double *pa, const double *pb, double thr, int n_iter, const int32_t *samples,
+                          int32_t *per_iter, double *models, int32_t *counts) {
+    return rdvio_hip_ransac_generate_score(static_cast<HipBackend *>(user)->ctx, kind, n, changed, pa, pb, thr, n_iter, samples, per_iter, models, counts);
+}
+int ransac_fetch(void *user, int model, uint8_t *mask) { return rdvio_hip_ransac_fetch(static_cast<HipBackend *>(user)->ctx, model, mask); }
+int thin_tracks(void *user, int w, int h, double radius, int n, const double *xy, int n_order, const int32_t *order, const uint8_t *trash, uint8_t *keep) {
+    return rdvio_hip_thin_tracks(static_cast<HipBackend *>(user)->ctx, w, h, radius, n, xy, n_order, order, trash, keep);
+}
+
 int parsac_generate_score(void *user, const rdvio_parsac_batch *batch, int n_iter, const int32_t *samples, int32_t *per_iter, double *models,
                           rdvio_parsac_result *results) {
     return rdvio_hip_parsac_generate_score(static_cast<HipBackend *>(user)->ctx, batch, n_iter, samples, per_iter, models, results);
@@ -183,6 +192,9 @@ extern "C" int rdvio_pipeline_create_hip(rdvio_pipeline **out, const rdvio_pipel
     fn.preintegrate_estimator = preintegrate_estimator;
     fn.thread_attach = thread_attach;
     fn.parsac_generate_score = parsac_generate_score;
+    fn.ransac_generate_score = ransac_generate_score;
+    fn.ransac_fetch = ransac_fetch;
+    fn.thin_tracks = thin_tracks;
     fn.marginalize_begin = marginalize_begin;
     fn.marginalize_end = marginalize_end;
     const int rc = rdvio_pipeline_create(out, cfg, &fn);

@@ -309,13 +309,17 @@ void FeatureTracker::track_keypoints(Frame *frame, Frame *next_frame) {
         next_h[i] = hnormalized(next_bearings[i]);
     }
     // epipolar gate over ALL points, survivors or not (frame.cpp:108-114)
+    // Both gates generate and score their hypotheses behind the backend when it offers the hooks (the HIP product: one launch per
+    // batch of samples on the frontend lane); sampling and the accept / early-exit replay stay here (geom.hpp, ransac<>).
     HostTimer gates_timer__(sh.prof, 15);
+    RansacDevice gate{be.fn.ransac_generate_score, be.fn.ransac_fetch, be.fn.user};
+    RansacDevice *gate_dev = (be.fn.ransac_generate_score && be.fn.ransac_fetch) ? &gate : nullptr;
     std::vector<char> mask;
-    (void)find_essential_matrix(curr_h, next_h, mask, 1.0);
+    (void)find_essential_matrix(curr_h, next_h, mask, 1.0, 0.999, 1000, 0, gate_dev);
     mask.resize(n, 0);  // (the reference indexes an empty mask when no model was found; treated as "no inliers")
     for (size_t i = 0; i < n; ++i)
         if (!mask[i]) status[i] = 0;
-    const M3 R = find_rotation_matrix(frame->bearings, next_bearings, mask, (M_PI / 180.0) * sh.cfg.rotation_ransac_threshold);
+    const M3 R = find_rotation_matrix(frame->bearings, next_bearings, mask, (M_PI / 180.0) * sh.cfg.rotation_ransac_threshold, 0.999, 1000, 0, gate_dev);
     mask.resize(n, 0);
     std::vector<double> angles;
     for (size_t i = 0; i < n; ++i)
@@ -337,9 +341,30 @@ void FeatureTracker::track_keypoints(Frame *frame, Frame *next_frame) {
         by_length.emplace_back(i, track->keypoint_num());
     }
     std::sort(by_length.begin(), by_length.end(), [](const auto &a, const auto &b) { return a.second > b.second; });
+    bool thinned = false;
+    if (be.fn.thin_tracks && !by_length.empty()) {
+        // the filter itself behind the backend: the order (std::sort's, ties included) and the TT_TRASH flags go in, a keep flag
+        // per entry comes back
+        std::vector<int32_t> order(by_length.size());
+        std::vector<uint8_t> trash(n, 0), keep(by_length.size(), 0);
+        for (size_t k = 0; k < by_length.size(); ++k) {
+            order[k] = (int32_t)by_length[k].first;
+            const Track *track = frame->get_track(by_length[k].first);
+            trash[by_length[k].first] = (track && track->tag(TT_TRASH)) ? 1 : 0;
+        }
+        const int rc = be.fn.thin_tracks(be.fn.user, next_frame->image->width, next_frame->image->height, sh.cfg.feature_tracker_min_keypoint_distance, (int)n,
+                                         next_xy.data(), (int)order.size(), order.data(), trash.data(), keep.data());
+        if (rc == RDVIO_OK) {
+            for (size_t k = 0; k < by_length.size(); ++k)
+                if (!keep[k]) status[by_length[k].first] = 0;
+            thinned = true;
+        } else if (rc != RDVIO_ERR_CAPACITY) {
+            be.check(rc, "thin_tracks");
+        }   // (beyond the kernel's capacities: the host road below)
+    }
     PoissonDisk2 filter(sh.cfg.feature_tracker_min_keypoint_distance);
-    for (const auto &[keypoint_index, track_length] : by_length) {
-        (void)track_length;
+    for (size_t k = 0; k < by_length.size() && !thinned; ++k) {
+        const size_t keypoint_index = by_length[k].first;
         const V2 pt = v2(&next_xy[2 * keypoint_index]);
         Track *track = frame->get_track(keypoint_index);
         if (filter.permit_point(pt) && (!track || !track->tag(TT_TRASH))) filter.preset_point(pt);

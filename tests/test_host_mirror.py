@@ -81,3 +81,29 @@ def test_parsac_device_scoring_matches_host_scoring():
     out = subprocess.run([PARSAC_EXE], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "OK" in out.stdout
+
+
+GATES_SRC = os.path.join(ROOT, "tests", "cpp", "gates_device_test.cpp")
+GATES_EXE = os.path.join(ROOT, "tests", "cpp", "gates_device_test.bin")
+
+
+def _compile_gates():
+    rbuild.build()
+    libdir = os.path.join(ROOT, "rd_vio_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-ffp-contract=off", "-o", GATES_EXE, GATES_SRC, "-L", libdir, "-lrdvio_hip",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
+
+
+def test_gates_device_test_compiles_and_links():
+    _compile_gates()
+    assert os.path.exists(GATES_EXE)
+
+
+@pytest.mark.gpu
+def test_two_view_gates_and_thinning_on_the_device_match_the_host_road():
+    """row N3: rdvio_hip_ransac_generate_score / _ransac_fetch / rdvio_hip_thin_tracks against geom.hpp's host road -- essential and
+    rotation gate models and masks, keep flags of the track-length thinning: bit-identical"""
+    _compile_gates()
+    out = subprocess.run([GATES_EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OK" in out.stdout
