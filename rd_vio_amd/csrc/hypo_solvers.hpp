@@ -841,65 +841,98 @@ HYPO_HD void poly_mul(const double *a, const double *c, double *r) {
     r[XXX] = a[MI] * c[XXX] + a[MX] * c[XX] + a[XX] * c[MX] + a[XXX] * c[MI];
 }
 
-// eigenvalues of a general real 10 x 10 matrix (row-major, destroyed): elimination to Hessenberg form + QR with implicit
-// double shifts (the classic EISPACK elmhes / hqr recipe).  false: no convergence.
-HYPO_HD bool real_eigenvalues10(double *a, double *wr, double *wi) {
-    const int n = 10;
-#define HA(i, j) a[(i) * n + (j)]
+// Eigenvalues of a general real 10 x 10 matrix (row-major, destroyed): elimination to Hessenberg form + QR with implicit double
+// shifts (the classic EISPACK elmhes / hqr recipe), laid out in steps: every decision (pivot, deflation, shift, the reflector of a
+// QR step) is taken in a one-lane section and filed in the shared state, the row and column updates it implies are items over the
+// columns / rows.  ok = 0: no convergence.
+struct Hqr10 {
+    double a[100], wr[10], wi[10], mult[10];
+    double t, p, q, r, x, y, z, w, anorm;
+    int nn, l, m, k, its, mode, apply, ok, piv;
+};
+
+template <class X>
+HYPO_HD void real_eigenvalues10(const X &xq, Hqr10 *h) {
+    constexpr int n = 10;
+#define HA(i, j) h->a[(i) * n + (j)]
+    // ---- elmhes: for every column m - 1 the pivot row comes up, the multipliers y_i = a(i, m-1) / pivot are filed, then
+    // A <- L^-1 A (rows i > m, an item per entry) and A <- A L (column m, an item per row), L = I + sum_i y_i e_i e_m^T
     for (int m = 1; m < n - 1; ++m) {
-        double x = 0.0;
-        int i = m;
-        for (int j = m; j < n; ++j)
-            if (dabs(HA(j, m - 1)) > dabs(x)) {
-                x = HA(j, m - 1);
-                i = j;
-            }
-        if (i != m) {
-            for (int j = m - 1; j < n; ++j) {
-                const double t = HA(i, j);
-                HA(i, j) = HA(m, j);
-                HA(m, j) = t;
-            }
-            for (int j = 0; j < n; ++j) {
-                const double t = HA(j, i);
-                HA(j, i) = HA(j, m);
-                HA(j, m) = t;
-            }
-        }
-        if (x != 0.0)
-            for (i = m + 1; i < n; ++i) {
-                double y = HA(i, m - 1);
-                if (y != 0.0) {
-                    y /= x;
-                    HA(i, m - 1) = y;
-                    for (int j = m; j < n; ++j) HA(i, j) -= y * HA(m, j);
-                    for (int j = 0; j < n; ++j) HA(j, m) += y * HA(j, i);
+        xq.one([=]() {
+            double x = 0.0;
+            int i = m;
+            for (int j = m; j < n; ++j)
+                if (dabs(HA(j, m - 1)) > dabs(x)) {
+                    x = HA(j, m - 1);
+                    i = j;
+                }
+            if (i != m) {
+                for (int j = m - 1; j < n; ++j) {
+                    const double t = HA(i, j);
+                    HA(i, j) = HA(m, j);
+                    HA(m, j) = t;
+                }
+                for (int j = 0; j < n; ++j) {
+                    const double t = HA(j, i);
+                    HA(j, i) = HA(j, m);
+                    HA(j, m) = t;
                 }
             }
+            for (int r = m + 1; r < n; ++r) {
+                double y = 0.0;
+                if (x != 0.0 && HA(r, m - 1) != 0.0) {
+                    y = HA(r, m - 1) / x;
+                    HA(r, m - 1) = y;
+                }
+                h->mult[r] = y;
+            }
+        });
+        xq.each((n - m - 1) * (n - m), [=](int e) {   // rows i = m+1 .. n-1, columns j = m .. n-1
+            const int i = m + 1 + e / (n - m), j = m + e % (n - m);
+            HA(i, j) -= h->mult[i] * HA(m, j);
+        });
+        xq.each(n, [=](int j) {   // column m of every row
+            double s = HA(j, m);
+            for (int i = m + 1; i < n; ++i) s += h->mult[i] * HA(j, i);
+            HA(j, m) = s;
+        });
     }
-    for (int i = 2; i < n; ++i)
-        for (int j = 0; j < i - 1; ++j) HA(i, j) = 0.0;
-    for (int i = 0; i < n; ++i) wr[i] = wi[i] = 0.0;
-    double anorm = 0.0;
-    for (int i = 0; i < n; ++i)
-        for (int j = (i - 1 > 0 ? i - 1 : 0); j < n; ++j) anorm += dabs(HA(i, j));
-    int nn = n - 1;
-    double t = 0.0, p = 0, q = 0, r = 0, s = 0, x = 0, y = 0, z = 0, w = 0, u = 0, v = 0;
-    while (nn >= 0) {
-        int its = 0, l;
-        do {
+    xq.one([=]() {
+        for (int i = 2; i < n; ++i)
+            for (int j = 0; j < i - 1; ++j) HA(i, j) = 0.0;
+        for (int i = 0; i < n; ++i) h->wr[i] = h->wi[i] = 0.0;
+        double anorm = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int j = (i - 1 > 0 ? i - 1 : 0); j < n; ++j) anorm += dabs(HA(i, j));
+        h->anorm = anorm;
+        h->nn = n - 1;
+        h->t = 0.0;
+        h->its = 0;
+        h->ok = 1;
+        h->mode = 0;
+    });
+    // ---- hqr.  mode after the deflation check: 1 one root found, 2 two roots found, 3 a QR step over k = m .. nn-1, 4 failure.
+    // `its` restarts whenever the active block shrinks below the last deflation point (the do-while of the classic code).
+    for (int guard = 0; guard < 2000; ++guard) {
+        if (h->nn < 0 || !h->ok) break;
+        xq.one([=]() {
+            int nn = h->nn, l;
+            double s, x, y, w, p, q, z, r, u, v;
             for (l = nn; l >= 1; --l) {
                 s = dabs(HA(l - 1, l - 1)) + dabs(HA(l, l));
-                if (s == 0.0) s = anorm;
+                if (s == 0.0) s = h->anorm;
                 if (dabs(HA(l, l - 1)) + s == s) {
                     HA(l, l - 1) = 0.0;
                     break;
                 }
             }
+            h->l = l;
             x = HA(nn, nn);
             if (l == nn) {
-                wr[nn] = x + t;
-                wi[nn--] = 0.0;
+                h->wr[nn] = x + h->t;
+                h->wi[nn] = 0.0;
+                h->nn = nn - 1;
+                h->mode = 1;
             } else {
                 y = HA(nn - 1, nn - 1);
                 w = HA(nn, nn - 1) * HA(nn - 1, nn);
@@ -907,28 +940,33 @@ HYPO_HD bool real_eigenvalues10(double *a, double *wr, double *wi) {
                     p = 0.5 * (y - x);
                     q = p * p + w;
                     z = sqrt(dabs(q));
-                    x += t;
+                    x += h->t;
                     if (q >= 0.0) {
-                        z = p + (p < 0 || (p == 0 && 1.0 / p < 0) ? -z : z);  // copysign(z, p), z >= 0
-                        wr[nn - 1] = wr[nn] = x + z;
-                        if (z != 0.0) wr[nn] = x - w / z;
-                        wi[nn - 1] = wi[nn] = 0.0;
+                        z = p + ((p < 0 || (p == 0 && 1.0 / p < 0)) ? -z : z);  // copysign(z, p)
+                        h->wr[nn - 1] = h->wr[nn] = x + z;
+                        if (z != 0.0) h->wr[nn] = x - w / z;
+                        h->wi[nn - 1] = h->wi[nn] = 0.0;
                     } else {
-                        wr[nn - 1] = wr[nn] = x + p;
-                        wi[nn - 1] = -(wi[nn] = z);
+                        h->wr[nn - 1] = h->wr[nn] = x + p;
+                        h->wi[nn] = z;
+                        h->wi[nn - 1] = -z;
                     }
-                    nn -= 2;
+                    h->nn = nn - 2;
+                    h->mode = 2;
+                } else if (h->its == 90) {
+                    h->ok = 0;
+                    h->mode = 4;
                 } else {
-                    if (its == 90) return false;
-                    if (its == 10 || its == 20 || its == 40) {
-                        t += x;
+                    if (h->its == 10 || h->its == 20 || h->its == 40) {   // exceptional shift
+                        h->t += x;
                         for (int i = 0; i <= nn; ++i) HA(i, i) -= x;
                         s = dabs(HA(nn, nn - 1)) + dabs(HA(nn - 1, nn - 2));
                         y = x = 0.75 * s;
                         w = -0.4375 * s * s;
                     }
-                    ++its;
+                    ++h->its;
                     int m;
+                    p = q = r = 0.0;
                     for (m = nn - 2; m >= l; --m) {
                         z = HA(m, m);
                         r = x - z;
@@ -949,59 +987,82 @@ HYPO_HD bool real_eigenvalues10(double *a, double *wr, double *wi) {
                         HA(i, i - 2) = 0.0;
                         if (i != m + 2) HA(i, i - 3) = 0.0;
                     }
-                    for (int k = m; k <= nn - 1; ++k) {
-                        if (k != m) {
-                            p = HA(k, k - 1);
-                            q = HA(k + 1, k - 1);
-                            r = 0.0;
-                            if (k != nn - 1) r = HA(k + 2, k - 1);
-                            if ((x = dabs(p) + dabs(q) + dabs(r)) != 0.0) {
-                                p /= x;
-                                q /= x;
-                                r /= x;
-                            }
-                        }
-                        const double sq = sqrt(p * p + q * q + r * r);
-                        s = (p < 0 || (p == 0 && 1.0 / p < 0)) ? -sq : sq;  // copysign(sq, p)
-                        if (s != 0.0) {
-                            if (k == m) {
-                                if (l != m) HA(k, k - 1) = -HA(k, k - 1);
-                            } else {
-                                HA(k, k - 1) = -s * x;
-                            }
-                            p += s;
-                            x = p / s;
-                            y = q / s;
-                            z = r / s;
-                            q /= p;
-                            r /= p;
-                            for (int j = k; j <= nn; ++j) {
-                                p = HA(k, j) + q * HA(k + 1, j);
-                                if (k != nn - 1) {
-                                    p += r * HA(k + 2, j);
-                                    HA(k + 2, j) -= p * z;
-                                }
-                                HA(k + 1, j) -= p * y;
-                                HA(k, j) -= p * x;
-                            }
-                            const int mmin = nn < k + 3 ? nn : k + 3;
-                            for (int i = l; i <= mmin; ++i) {
-                                p = x * HA(i, k) + y * HA(i, k + 1);
-                                if (k != nn - 1) {
-                                    p += z * HA(i, k + 2);
-                                    HA(i, k + 2) -= p * r;
-                                }
-                                HA(i, k + 1) -= p * q;
-                                HA(i, k) -= p;
-                            }
-                        }
-                    }
+                    h->m = m;
+                    h->p = p;
+                    h->q = q;
+                    h->r = r;
+                    h->x = x;
+                    h->mode = 3;
                 }
             }
-        } while (l < nn - 1);
+            // the do-while of the classic code ends when l >= nn - 1 (with the new nn): the iteration count restarts
+            if (h->mode != 3 && !(h->l < h->nn - 1)) h->its = 0;
+        });
+        if (h->mode != 3) continue;
+        const int nn = h->nn, l = h->l, m0 = h->m;
+        for (int k = m0; k <= nn - 1; ++k) {
+            xq.one([=]() {
+                double p = h->p, q = h->q, r = h->r, x = h->x, s;
+                if (k != m0) {
+                    p = HA(k, k - 1);
+                    q = HA(k + 1, k - 1);
+                    r = 0.0;
+                    if (k != nn - 1) r = HA(k + 2, k - 1);
+                    if ((x = dabs(p) + dabs(q) + dabs(r)) != 0.0) {
+                        const double ix = 1.0 / x;   // (one division where the classic code has three: a long dependent chain on one lane)
+                        p *= ix;
+                        q *= ix;
+                        r *= ix;
+                    }
+                }
+                const double sq = sqrt(p * p + q * q + r * r);
+                s = (p < 0 || (p == 0 && 1.0 / p < 0)) ? -sq : sq;  // copysign(sq, p)
+                h->apply = 0;
+                if (s != 0.0) {
+                    if (k == m0) {
+                        if (l != m0) HA(k, k - 1) = -HA(k, k - 1);
+                    } else {
+                        HA(k, k - 1) = -s * x;
+                    }
+                    p += s;
+                    const double is = 1.0 / s, ip = 1.0 / p;
+                    h->x = p * is;
+                    h->y = q * is;
+                    h->z = r * is;
+                    h->q = q * ip;
+                    h->r = r * ip;
+                    h->apply = 1;
+                } else {
+                    h->x = x;
+                }
+            });
+            if (!h->apply) continue;
+            xq.each(nn - k + 1, [=](int e) {   // rows k, k+1, k+2 at column j
+                const int j = k + e;
+                double p = HA(k, j) + h->q * HA(k + 1, j);
+                if (k != nn - 1) {
+                    p += h->r * HA(k + 2, j);
+                    HA(k + 2, j) -= p * h->z;
+                }
+                HA(k + 1, j) -= p * h->y;
+                HA(k, j) -= p * h->x;
+            });
+            xq.each((nn < k + 3 ? nn : k + 3) - l + 1, [=](int e) {   // columns k, k+1, k+2 at row i
+                const int i = l + e;
+                double p = h->x * HA(i, k) + h->y * HA(i, k + 1);
+                if (k != nn - 1) {
+                    p += h->z * HA(i, k + 2);
+                    HA(i, k + 2) -= p * h->r;
+                }
+                HA(i, k + 1) -= p * h->q;
+                HA(i, k) -= p;
+            });
+        }
     }
+    xq.one([=]() {
+        if (h->nn >= 0) h->ok = 0;   // (the guard ran out)
+    });
 #undef HA
-    return true;
 }
 
 // right eigenvector of `a` (10 x 10 row-major) for the real eigenvalue lambda: inverse iteration with partial-pivot LU
@@ -1062,7 +1123,8 @@ struct Ess5Work {  // scratch of one hypothesis
     double basis[9][4];
     double Ep[9][20], EEt[9][20], half_trace[20];
     double polys[10][20];
-    double action[100], hess[100], wr[10], wi[10];
+    double action[100], mult[10];
+    Hqr10 hq;
     int ord[9], perm[10], flag, ok, n_out;
 };
 
@@ -1071,6 +1133,7 @@ struct Ess5Work {  // scratch of one hypothesis
 template <class X>
 HYPO_HD void essential5(const X &x, Ess5Work *w, const double *p1, const double *p2, double *models /* 10 x 9 */, int *n_models) {
     // null space of the 5 x 9 epipolar constraint matrix (essential.cpp:119-131): rows h = p1 p2^T flattened row-wise
+    HYPO_STAMP(0);
     x.each(45, [=](int e) {
         const int i = e / 9, j = (e % 9) / 3, k = e % 3;
         const double a = j == 0 ? p1[2 * i] : (j == 1 ? p1[2 * i + 1] : 1.0), b = k == 0 ? p2[2 * i] : (k == 1 ? p2[2 * i + 1] : 1.0);
@@ -1082,7 +1145,9 @@ HYPO_HD void essential5(const X &x, Ess5Work *w, const double *p1, const double 
         for (int k = 0; k < 5; ++k) s += w->A[k][i] * w->A[k][j];
         w->AtA[e] = s;
     });
+    HYPO_STAMP(1);
     jacobi_rr<9>(x, w->AtA, w->Bw, w->Vv, w->lam, w->cs, w->red, &w->flag);
+    HYPO_STAMP(2);
     x.one([=]() { ascending(9, w->lam, w->ord); });
     // basis columns: singular vectors 5..8 in JacobiSVD's descending order = ascending eigenvalues 3, 2, 1, 0
     x.each(36, [=](int e) {
@@ -1137,30 +1202,52 @@ HYPO_HD void essential5(const X &x, Ess5Work *w, const double *p1, const double 
             for (int c = 0; c < 20; ++c) w->polys[9][c] = s[c];
         }
     });
-    // Gauss-Jordan with the reference's row-permutation bookkeeping (essential.cpp:167-190); action matrix; its eigenvalues
+    HYPO_STAMP(3);
+    // Gauss-Jordan with the reference's row-permutation bookkeeping (essential.cpp:167-190).  A pivot step is three steps here: the
+    // pivot row is chosen and the column of multipliers filed (one lane); every COLUMN of the 10 x 20 system is then updated by its
+    // own item (the ten row updates of an item are independent loads and stores: they pipeline); the back substitution likewise.
     x.one([=]() {
-        int *perm = w->perm;
-        for (int i = 0; i < 10; ++i) perm[i] = i;
-        for (int i = 0; i < 10; ++i) {
+        for (int i = 0; i < 10; ++i) w->perm[i] = i;
+    });
+    for (int i = 0; i < 10; ++i) {
+        x.one([=]() {
+            int *perm = w->perm;
             for (int j = i + 1; j < 10; ++j)
                 if (dabs(w->polys[perm[i]][i]) < dabs(w->polys[perm[j]][i])) {
                     const int t = perm[i];
                     perm[i] = perm[j];
                     perm[j] = t;
                 }
-            if (w->polys[perm[i]][i] == 0.0) continue;
-            const double d = w->polys[perm[i]][i];
-            for (int c = 0; c < 20; ++c) w->polys[perm[i]][c] /= d;
-            for (int j = i + 1; j < 10; ++j) {
-                const double f = w->polys[perm[j]][i];
-                for (int c = 0; c < 20; ++c) w->polys[perm[j]][c] -= w->polys[perm[i]][c] * f;
-            }
-        }
-        for (int i = 9; i > 0; --i)
-            for (int j = 0; j < i; ++j) {
-                const double f = w->polys[perm[j]][i];
-                for (int c = 0; c < 20; ++c) w->polys[perm[j]][c] -= w->polys[perm[i]][c] * f;
-            }
+            // mult[0] = the pivot (0: the step is skipped), mult[j] = the entry of row perm[j] in the pivot column
+            w->mult[0] = w->polys[perm[i]][i];
+            for (int j = i + 1; j < 10; ++j) w->mult[j] = w->polys[perm[j]][i];
+        });
+        x.each(20, [=](int c) {
+            const double d = w->mult[0];
+            if (d == 0.0) return;
+            const int *perm = w->perm;
+            const double pv = w->polys[perm[i]][c] / d;
+            w->polys[perm[i]][c] = pv;
+            HYPO_UNROLL
+            for (int j = 1; j < 10; ++j)
+                if (j > i) w->polys[perm[j]][c] -= pv * w->mult[j];
+        });
+    }
+    for (int i = 9; i > 0; --i) {
+        x.one([=]() {
+            for (int j = 0; j < i; ++j) w->mult[j] = w->polys[w->perm[j]][i];
+        });
+        x.each(20, [=](int c) {
+            const int *perm = w->perm;
+            const double pv = w->polys[perm[i]][c];
+            HYPO_UNROLL
+            for (int j = 0; j < 9; ++j)
+                if (j < i) w->polys[perm[j]][c] -= pv * w->mult[j];
+        });
+    }
+    // action matrix; its eigenvalues
+    x.one([=]() {
+        int *perm = w->perm;
         for (int i = 0; i < 100; ++i) w->action[i] = 0.0;
         const int rows[6] = {XXX, XXY, XYY, XXZ, XYZ, XZZ};
         for (int r = 0; r < 6; ++r)
@@ -1169,22 +1256,26 @@ HYPO_HD void essential5(const X &x, Ess5Work *w, const double *p1, const double 
         w->action[7 * 10 + (XY - XX)] = 1.0;
         w->action[8 * 10 + (XZ - XX)] = 1.0;
         w->action[9 * 10 + (MX - XX)] = 1.0;
-        for (int i = 0; i < 100; ++i) w->hess[i] = w->action[i];
-        w->ok = real_eigenvalues10(w->hess, w->wr, w->wi) ? 1 : 0;
+        for (int i = 0; i < 100; ++i) w->hq.a[i] = w->action[i];
+    });
+    real_eigenvalues10(x, &w->hq);
+    x.one([=]() {
+        w->ok = w->hq.ok;
         // output slots in eigenvalue order: slot of eigenvalue i = number of real eigenvalues before it
         int n = 0;
         for (int i = 0; i < 10; ++i) {
             w->perm[i] = -1;
-            if (w->ok && dabs(w->wi[i]) < 1.0e-10) w->perm[i] = n++;
+            if (w->ok && dabs(w->hq.wi[i]) < 1.0e-10) w->perm[i] = n++;
         }
         w->n_out = n;
         *n_models = n;
     });
+    HYPO_STAMP(4);
     x.each(10, [=](int i) {   // one real eigenvalue each: eigenvector -> (x, y, z) -> E
         const int slot = w->perm[i];
         if (slot < 0) return;
         double h[10];
-        eigenvector10(w->action, w->wr[i], h);
+        eigenvector10(w->action, w->hq.wr[i], h);
         const double ww = h[MI - XX];
         const double sx = h[MX - XX] / ww, sy = h[MY - XX] / ww, sz = h[MZ - XX] / ww;
         for (int r = 0; r < 3; ++r)
@@ -1193,6 +1284,7 @@ HYPO_HD void essential5(const X &x, Ess5Work *w, const double *p1, const double 
                 models[9 * slot + 3 * r + c] = w->basis[k][0] * sx + w->basis[k][1] * sy + w->basis[k][2] * sz + w->basis[k][3];
             }
     });
+    HYPO_STAMP(5);
 }
 
 }  // namespace hypo

@@ -19,6 +19,14 @@ __global__ __launch_bounds__(64) void epnp_kernel(const double *X, const double 
     hypo::epnp6(x, &work, X + 18 * blockIdx.x, u + 12 * blockIdx.x, models + 12 * blockIdx.x);
 }
 
+__global__ __launch_bounds__(64) void ess_kernel(const double *p1, const double *p2, double *models, int *counts) {
+    __shared__ hypo::Ess5Work work;
+    __shared__ int n_found;
+    const hypo::WaveExec x{(int)threadIdx.x};
+    hypo::essential5(x, &work, p1 + 10 * blockIdx.x, p2 + 10 * blockIdx.x, models + 90 * blockIdx.x, &n_found);
+    if (threadIdx.x == 0) counts[blockIdx.x] = n_found;
+}
+
 int main() {
     const int n = 32;
     std::mt19937 rng(3);
@@ -50,6 +58,34 @@ int main() {
         const char *names[6] = {"control points", "MtM", "jacobi12", "L", "candidates", "select+rodrigues"};
         for (int k = 0; k < 6; ++k) std::printf(" %s %llu", names[k], s[k + 1] - s[k]);
         std::printf(" total %llu\n", s[6] - s[0]);
+    }
+    // ---- five-point essential solver
+    {
+        std::vector<double> a(10 * n), b(10 * n);
+        for (int k = 0; k < n; ++k)
+            for (int i = 0; i < 5; ++i) {
+                const double P[3] = {2 * U(rng), 1.5 * U(rng), 4 + U(rng)};
+                a[10 * k + 2 * i] = P[0] / P[2]; a[10 * k + 2 * i + 1] = P[1] / P[2];
+                b[10 * k + 2 * i] = (P[0] + 0.1) / (P[2] + 0.03); b[10 * k + 2 * i + 1] = (P[1] - 0.05) / (P[2] + 0.03);
+            }
+        double *da, *db, *dmm; int *dc;
+        (void)hipMalloc(&da, a.size() * 8); (void)hipMalloc(&db, b.size() * 8); (void)hipMalloc(&dmm, 90 * n * 8); (void)hipMalloc(&dc, n * 4);
+        (void)hipMemcpy(da, a.data(), a.size() * 8, hipMemcpyHostToDevice);
+        (void)hipMemcpy(db, b.data(), b.size() * 8, hipMemcpyHostToDevice);
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipEventRecord(e0);
+            hipLaunchKernelGGL(ess_kernel, dim3(n), dim3(64), 0, 0, da, db, dmm, dc);
+            (void)hipEventRecord(e1);
+            (void)hipDeviceSynchronize();
+            float ms;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            std::vector<unsigned long long> s(8 * 64);
+            (void)hipMemcpyFromSymbol(s.data(), HIP_SYMBOL(g_stamps), s.size() * 8);
+            std::printf("essential5 x %d: kernel %.1f us; block 0 stages (x 10 ns):", n, 1e3 * ms);
+            const char *names[5] = {"A, AtA", "jacobi9", "polynomials", "gauss-jordan + hqr", "eigenvectors"};
+            for (int k = 0; k < 5; ++k) std::printf(" %s %llu", names[k], s[k + 1] - s[k]);
+            std::printf(" total %llu\n", s[5] - s[0]);
+        }
     }
     return 0;
 }
