@@ -346,12 +346,12 @@ def make_stream(cfg, n_frames):
     return dict(frames=frames, ts=np.ascontiguousarray(ts), imu=np.ascontiguousarray(imu), gt=np.ascontiguousarray(gt), K=K, w=w, h=h)
 
 
-def pipeline_config(lib, cfg, threading):
+def pipeline_config(lib, cfg, threading, **extra):
     from rd_vio_amd import pipeline_run as pr
 
-    kw = {}
+    kw = dict(extra)
     if (cfg["width"], cfg["height"]) != (752, 480):
-        kw = dict(width=cfg["width"], height=cfg["height"], K=np.array([[900.0, 0, cfg["width"] / 2.0], [0, 900.0, cfg["height"] / 2.0], [0, 0, 1.0]]))
+        kw.update(width=cfg["width"], height=cfg["height"], K=np.array([[900.0, 0, cfg["width"] / 2.0], [0, 900.0, cfg["height"] / 2.0], [0, 0, 1.0]]))
     return pr.baseline_config(lib, cfg["window"], cfg["features"], threading=threading, **kw)
 
 
@@ -723,9 +723,9 @@ def main(argv=None):
         return rd_vio_amd.Context(max_width=cfg["width"], max_height=cfg["height"], max_features=max(1024, 4 * cfg["features"]),
                                   max_window=cfg["window"] + 8, max_factors=40000, device=local_rank)
 
-    def hip_run(threading, init_states=None, kp_capacity=0):
+    def hip_run(threading, init_states=None, kp_capacity=0, **extra):
         ctx = hip_context()
-        pcfg, applied = pipeline_config(lib, cfg, threading)
+        pcfg, applied = pipeline_config(lib, cfg, threading, **extra)
         run = PipelineRun(lib, lambda out: lib.rdvio_pipeline_create_hip(out, ctypes.byref(pcfg), ctx._h), stream, init_states, kp_capacity)
         return ctx, run, applied
 
@@ -808,8 +808,9 @@ def main(argv=None):
         if not args.no_variants:
             def _variants():
                 rep = {}
-                for label, thr, init in (("inline_schedule", 0, None), ("groundtruth_bootstrap", args.threading, stream["gt"])):
-                    c2, r2, _ = hip_run(thr, init_states=init)
+                for label, thr, init, extra in (("inline_schedule", 0, None, {}), ("groundtruth_bootstrap", args.threading, stream["gt"], {}),
+                                                ("tracker_gates_on_the_device", args.threading, None, {"tracker_gates_on_backend": 1})):
+                    c2, r2, _ = hip_run(thr, init_states=init, **extra)
                     try:
                         n2 = bootstrap_and_warm_up(r2, warmup, n_total - steps)
                         t2 = r2.segment(min(steps, n_total - n2))

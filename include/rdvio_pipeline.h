@@ -124,6 +124,13 @@ typedef struct rdvio_pipeline_config {
     int32_t threading;
     /* initializer.refine_imu (initializer.cpp:373): 0 skips refine_scale_velocity_via_gravity */
     int32_t initializer_refine_imu;
+    /* Where the feature tracker's two-view RANSAC gates and its track-length thinning run (frame.cpp:108-161):
+     *   0  on the host (geom.hpp) -- the default: at the reference's sizes (<= 150 points, <= 8 five-point hypotheses per
+     *      batch) one host core is faster than a launch + round trip per gate;
+     *   1  behind the backend's ransac_generate_score / ransac_fetch / thin_tracks hooks when it offers them (the HIP
+     *      product: hypothesis generation and scoring on the frontend lane).
+     * Both roads run the same solvers (csrc/hypo_solvers.hpp) and give bit-identical gates. */
+    int32_t tracker_gates_on_backend;
 } rdvio_pipeline_config;
 
 void rdvio_pipeline_config_default(rdvio_pipeline_config *cfg);

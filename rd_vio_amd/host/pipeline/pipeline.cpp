@@ -313,7 +313,8 @@ void FeatureTracker::track_keypoints(Frame *frame, Frame *next_frame) {
     // batch of samples on the frontend lane); sampling and the accept / early-exit replay stay here (geom.hpp, ransac<>).
     HostTimer gates_timer__(sh.prof, 15);
     RansacDevice gate{be.fn.ransac_generate_score, be.fn.ransac_fetch, be.fn.user};
-    RansacDevice *gate_dev = (be.fn.ransac_generate_score && be.fn.ransac_fetch) ? &gate : nullptr;
+    const bool gates_on_backend = sh.cfg.tracker_gates_on_backend != 0;
+    RansacDevice *gate_dev = (gates_on_backend && be.fn.ransac_generate_score && be.fn.ransac_fetch) ? &gate : nullptr;
     std::vector<char> mask;
     (void)find_essential_matrix(curr_h, next_h, mask, 1.0, 0.999, 1000, 0, gate_dev);
     mask.resize(n, 0);  // (the reference indexes an empty mask when no model was found; treated as "no inliers")
@@ -342,7 +343,7 @@ void FeatureTracker::track_keypoints(Frame *frame, Frame *next_frame) {
     }
     std::sort(by_length.begin(), by_length.end(), [](const auto &a, const auto &b) { return a.second > b.second; });
     bool thinned = false;
-    if (be.fn.thin_tracks && !by_length.empty()) {
+    if (gates_on_backend && be.fn.thin_tracks && !by_length.empty()) {
         // the filter itself behind the backend: the order (std::sort's, ties included) and the TT_TRASH flags go in, a keep flag
         // per entry comes back
         std::vector<int32_t> order(by_length.size());
@@ -1324,6 +1325,7 @@ void rdvio_pipeline_config_default(rdvio_pipeline_config *c) {
     c->parsac_keyframe_check_size = 3;
     c->threading = 0;
     c->initializer_refine_imu = 1;
+    c->tracker_gates_on_backend = 0;
 }
 
 int rdvio_pipeline_create(rdvio_pipeline **out, const rdvio_pipeline_config *cfg, const rdvio_backend *backend) {

@@ -31,7 +31,7 @@ class PipelineConfig(ctypes.Structure):
         ("solver_iteration_limit", ctypes.c_int32),
         ("rotation_misalignment_threshold", ctypes.c_double), ("rotation_ransac_threshold", ctypes.c_double),
         ("random", ctypes.c_int32), ("parsac_flag", ctypes.c_int32), ("parsac_keyframe_check_size", ctypes.c_int32),
-        ("threading", ctypes.c_int32), ("initializer_refine_imu", ctypes.c_int32),
+        ("threading", ctypes.c_int32), ("initializer_refine_imu", ctypes.c_int32), ("tracker_gates_on_backend", ctypes.c_int32),
     ]
 
 

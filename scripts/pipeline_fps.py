@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--mover", action="store_true")
     ap.add_argument("--cpu", action="store_true", help="also run the CPU path (oracle backend, threading 1) and compare")
     ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("--gates", type=int, default=0, choices=(0, 1), help="1: the tracker's two-view gates + thinning behind the backend hooks")
     args = ap.parse_args()
 
     import rd_vio_amd
@@ -40,7 +41,7 @@ def main():
     runs = []
     for mode in [int(m) for m in args.modes.split(",")]:
         for rep in range(args.repeat):
-            cfg, over = pr.baseline_config(lib, args.window, args.features, threading=mode)
+            cfg, over = pr.baseline_config(lib, args.window, args.features, threading=mode, tracker_gates_on_backend=args.gates)
             ctx = rd_vio_amd.Context(max_width=W, max_height=H, max_features=max(1024, 4 * args.features), max_window=args.window + 8, max_factors=40000)
             try:
                 r = pr.run_pipeline(lib, lambda out: lib.rdvio_pipeline_create_hip(out, __import__("ctypes").byref(cfg), ctx._h), frames, ts, imu, init, kp_capacity=2048)

@@ -14,13 +14,17 @@ OVER = dict(sliding_window_size=8, feature_tracker_max_keypoint_detection=150, f
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("schedule", ["inline", "threaded"])
+@pytest.mark.parametrize("schedule", ["inline", "threaded", "threaded_device_gates"])
 @pytest.mark.parametrize("case", ["translation_full_res", "rotation_phase_half_res", "full_initializer_half_res", "dynamic_object_parsac",
                                   "dynamic_object_parsac_300_w10", "synthetic_720p_1000_w16"])
 def test_hip_pipeline_reproduces_the_cpu_path(case, schedule):
     """schedule "inline": the reference's THREADING=OFF on both paths.  "threaded": the product's tracker / frontend split --
     the HIP path with the frontend's step on a worker thread (threading = 2: two host threads, frontend lane and solver lane
-    concurrently) against the CPU path running the same pipelined schedule on one thread (threading = 1)."""
+    concurrently) against the CPU path running the same pipelined schedule on one thread (threading = 1).
+    "threaded_device_gates": the same with the tracker's two-view gates and track-length thinning behind the backend hooks
+    (tracker_gates_on_backend = 1, row N3) on the HIP path and on the host in the CPU path."""
+    if schedule == "threaded_device_gates" and case not in ("translation_full_res", "dynamic_object_parsac", "synthetic_720p_1000_w16"):
+        pytest.skip("device gates: three cases cover the sizes")
     if case == "translation_full_res":
         W, H, K = 752, 480, synth.EUROC_K
         frames, ts, imu, gt = synth.make_stream(36, W, H, K)
@@ -68,10 +72,10 @@ def test_hip_pipeline_reproduces_the_cpu_path(case, schedule):
     if case == "synthetic_720p_1000_w16":
         over = dict(OVER, sliding_window_size=16, feature_tracker_max_keypoint_detection=1000)
     max_kp = 4096
-    threaded = schedule == "threaded"
+    threaded = schedule != "inline"
     cfg = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **dict(over, threading=1 if threaded else 0))
     cpu = pu.run_stream(lib, pu.oracle_pipeline_factory(lib, shim, cfg), frames, ts, imu, gt, max_kp=max_kp)
-    cfg_gpu = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **dict(over, threading=2 if threaded else 0))
+    cfg_gpu = pu.default_config(lib, K, W, H, synth.EUROC_EXTR, synth.EUROC_NOISE, **dict(over, threading=2 if threaded else 0, tracker_gates_on_backend=1 if schedule == "threaded_device_gates" else 0))
     ctx = rd_vio_amd.Context(max_width=W, max_height=H, max_features=4096, max_window=over["sliding_window_size"] + 8, max_factors=20000)
     try:
         gpu = pu.run_stream(lib, pu.hip_pipeline_factory(lib, ctx, cfg_gpu), frames, ts, imu, gt, max_kp=max_kp)
