@@ -244,7 +244,8 @@ size_t Map::frame_index_by_id(size_t id) const {
 }
 
 Track *Map::create_track() {
-    std::unique_ptr<Track> track = std::make_unique<Track>(ids, this);
+    std::unique_ptr<Track> track = reserved_track_ids[0] < reserved_track_ids[1] ? std::make_unique<Track>(reserved_track_ids[0]++, this)
+                                                                                 : std::make_unique<Track>(ids, this);
     track->map_index = tracks.size();
     tracks.emplace_back(std::move(track));
     return tracks.back().get();

@@ -149,6 +149,7 @@ class Frame {
 class Track {
   public:
     Track(IdGenerator &ids, Map *m) : map(m), id_(++ids.next_track) { set_tag(TT_STATIC, true); }  // track.cpp:7
+    Track(size_t reserved_id, Map *m) : map(m), id_(reserved_id) { set_tag(TT_STATIC, true); }   // an id taken from the generator earlier (Map::reserved_track_ids)
     size_t id() const { return id_; }
     bool tag(TrackTag f) const { return (tags_ >> f) & 1u; }
     void set_tag(TrackTag f, bool v) { tags_ = v ? (tags_ | (1u << f)) : (tags_ & ~(1u << f)); }
@@ -216,6 +217,10 @@ class Map {
     void drop_front_frame();  // frames.erase(begin) after a marginalisation (map.cpp:61)
 
     IdGenerator &ids;
+    // ids set aside for the tracks this map creates next (first, one past the last): the sliding-window map creates its tracks
+    // inside the frontend's step, concurrently with the feature tracker's own -- the ids it may use were drawn at the hand-over,
+    // in the order a single thread would have drawn them
+    size_t reserved_track_ids[2] = {0, 0};
     std::unique_ptr<MarginalizationPrior> marginalization_factor;
 
   private:

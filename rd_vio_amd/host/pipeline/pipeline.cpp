@@ -515,9 +515,11 @@ void Frontend::drain() {
 void Frontend::execute(FrontendJob &j) {
     HostTimer host_timer__(sh.prof, 12);
     try {
+        sliding_window_tracker->mirror_frame_apply(j);
         if (j.mirrored) sliding_window_tracker->mirror_frame_finish(j);
         j.ok = sliding_window_tracker->track(j);
         j.latest_state = sliding_window_tracker->get_latest_state();
+        sliding_window_tracker->newest_frame_summary(j.newest_id, j.newest_flags);
     } catch (...) {
         j.error = std::current_exception();
     }
@@ -531,10 +533,14 @@ void Frontend::publish() {
     if (done->ok) {
         auto [t, pose, motion] = done->latest_state;
         latest_state = std::make_tuple(t, done->frame_id, pose, motion);
+        newest_id = done->newest_id;
+        newest_flags.swap(done->newest_flags);
     } else {
         latest_state = std::make_tuple(0.0, nil, PoseState{}, MotionState{});
         initializer = std::make_unique<Initializer>(sh);
         sliding_window_tracker.reset();
+        newest_id = nil;
+        newest_flags.clear();
     }
     // update_track_status's writes to the feature-tracking map's tracks (sliding_window_tracker.cpp:751-756)
     if (!done->old_tracks_nonstatic.empty()) {
@@ -552,6 +558,16 @@ void Frontend::run() {
     if (pending_frame_ids.empty()) return;
     HostTimer host_timer__(sh.prof, 3);
     const int mode = sh.cfg.threading;
+    // What the next step needs from the feature-tracking map is gathered BEFORE waiting for the step in flight: it depends on
+    // that step only through the id of the frame the sliding-window map will end with -- as a rule the step's own frame.  (A
+    // wrong guess is noticed after the hand-over and the packet gathered again.)
+    std::unique_ptr<FrontendJob> next;
+    if (!initializer && sliding_window_tracker) {
+        HostTimer gather_timer__(sh.prof, 16);
+        next = std::make_unique<FrontendJob>();
+        next->frame_id = pending_frame_ids.front();
+        SlidingWindowTracker::gather_mirror_packet(feature_tracker->map.get(), job ? job->frame_id : newest_id, next->frame_id, next->packet);
+    }
     // the hand-over: the previous step has finished and (pipelined schedule) its results become visible to the tracker
     {
         HostTimer wait_timer__(sh.prof, 13);
@@ -569,15 +585,18 @@ void Frontend::run() {
         if ((sliding_window_tracker = initializer->initialize())) {
             auto [t, pose, motion] = sliding_window_tracker->get_latest_state();
             latest_state = std::make_tuple(t, pending_frame_id, pose, motion);
+            sliding_window_tracker->newest_frame_summary(newest_id, newest_flags);
             initializer.reset();
         }
     } else if (sliding_window_tracker) {
-        job = std::make_unique<FrontendJob>();
+        job = next ? std::move(next) : std::make_unique<FrontendJob>();
         job->frame_id = pending_frame_ids.front();
         pending_frame_ids.pop_front();
         {
             HostTimer handover_timer__(sh.prof, 14);
-            sliding_window_tracker->mirror_frame_maps(feature_tracker->map.get(), *job);
+            if (job->packet.frame_i_id != newest_id || job->packet.frame_j_id != job->frame_id)
+                SlidingWindowTracker::gather_mirror_packet(feature_tracker->map.get(), newest_id, job->frame_id, job->packet);
+            SlidingWindowTracker::mirror_frame_handover(sh.ids, newest_flags, feature_tracker->map.get(), sh.cfg.parsac_flag != 0, *job);
         }
         if (mode == 2) {
             {
@@ -602,40 +621,84 @@ SlidingWindowTracker::SlidingWindowTracker(std::unique_ptr<Map> keyframe_map, Sh
     }
 }
 
-void SlidingWindowTracker::mirror_frame_maps(Map *ftmap, FrontendJob &job) {
-    HostTimer host_timer__(sh.prof, 4);
-    Frame *keyframe = map->get_frame(map->frame_num() - 1);
-    Frame *new_frame_i = keyframe;
-    if (!keyframe->subframes.empty()) new_frame_i = keyframe->subframes.back().get();
-    const size_t index_i = ftmap->frame_index_by_id(new_frame_i->id()), index_j = ftmap->frame_index_by_id(job.frame_id);
+// mirror_frame (sliding_window_tracker.cpp:29-78), the feature-tracking map's side.  Reads that map only.
+void SlidingWindowTracker::gather_mirror_packet(const Map *ftmap, size_t frame_i_id, size_t frame_j_id, MirrorPacket &pk) {
+    pk = MirrorPacket{};
+    pk.frame_i_id = frame_i_id;
+    pk.frame_j_id = frame_j_id;
+    if (frame_i_id == nil || frame_j_id == nil) return;
+    const size_t index_i = ftmap->frame_index_by_id(frame_i_id), index_j = ftmap->frame_index_by_id(frame_j_id);
     if (index_i == nil || index_j == nil) return;
-    Frame *old_frame_i = ftmap->get_frame(index_i), *old_frame_j = ftmap->get_frame(index_j);
-    std::unique_ptr<Frame> curr_frame = old_frame_j->clone();
-    std::vector<ImuData> &new_data = curr_frame->preintegration.data;
+    const Frame *old_frame_i = ftmap->get_frame(index_i), *old_frame_j = ftmap->get_frame(index_j);
+    pk.curr_frame = old_frame_j->clone();
+    std::vector<ImuData> &new_data = pk.curr_frame->preintegration.data;
     for (size_t index = index_j - 1; index > index_i; --index) {
         const std::vector<ImuData> &old_data = ftmap->get_frame(index)->preintegration.data;
         new_data.insert(new_data.begin(), old_data.begin(), old_data.end());
     }
-    map->attach_frame(std::move(curr_frame));
-    Frame *new_frame_j = map->get_frame(map->frame_num() - 1);
     for (size_t ki = 0; ki < old_frame_i->keypoint_num(); ++ki)
         if (Track *track = old_frame_i->get_track(ki))
             if (size_t kj = track->get_keypoint_index(old_frame_j); kj != nil) {
-                Track *new_track = new_frame_i->get_track(ki, map.get());
-                new_track->add_keypoint(new_frame_j, kj);
-                track->set_tag(TT_TRASH, new_track->tag(TT_TRASH) && !new_track->tag(TT_STATIC));
+                pk.matches.emplace_back((uint32_t)ki, (uint32_t)kj);
+                pk.ft_tracks.push_back(track);
             }
-    map->prune_tracks([](const Track *track) { return track->tag(TT_TRASH) && !track->tag(TT_STATIC); });
-    job.mirrored = true;
-    job.new_frame_i = new_frame_i;
-    job.new_frame_j = new_frame_j;
-    if (sh.cfg.parsac_flag) {
+    pk.found = true;
+}
+
+// The hand-over's share: what mirror_frame writes INTO the feature-tracking map (TT_TRASH of the continued tracks, from the
+// sliding-window map's flags as the finished step left them), what update_track_status will read of it, and the ids of the tracks
+// the sliding-window map is about to create (drawn here, between the tracker's frames, as a single thread would draw them).
+void SlidingWindowTracker::mirror_frame_handover(IdGenerator &ids, const std::vector<uint8_t> &newest_flags, const Map *ftmap, bool parsac, FrontendJob &job) {
+    MirrorPacket &pk = job.packet;
+    job.mirrored = pk.found;
+    if (!pk.found) return;
+    size_t created = 0;
+    for (size_t m = 0; m < pk.matches.size(); ++m) {
+        const uint32_t ki = pk.matches[m].first;
+        const uint8_t fl = ki < newest_flags.size() ? newest_flags[ki] : 0;
+        if (!(fl & 1u)) ++created;   // (a new track: neither TT_TRASH nor anything but TT_STATIC)
+        pk.ft_tracks[m]->set_tag(TT_TRASH, (fl & 2u) != 0);
+    }
+    job.track_ids[0] = ids.next_track + 1;
+    job.track_ids[1] = ids.next_track + 1 + created;
+    ids.next_track += created;
+    if (parsac) {
         // what update_track_status will read of the feature-tracking map (nobody writes these bits before the step's own
         // deferred writes are published: Track::Track is the only other writer of TT_STATIC on that map)
+        const Frame *old_frame_j = ftmap->get_frame(ftmap->frame_index_by_id(pk.frame_j_id));
         job.old_track_flags.assign(old_frame_j->keypoint_num(), 0);
         for (size_t j = 0; j < old_frame_j->keypoint_num(); ++j)
             if (const Track *old_track = old_frame_j->get_track(j)) job.old_track_flags[j] = (uint8_t)(1u | (old_track->tag(TT_STATIC) ? 2u : 0u));
     }
+}
+
+// ... and the sliding-window map's side (the frontend's step)
+void SlidingWindowTracker::mirror_frame_apply(FrontendJob &job) {
+    HostTimer host_timer__(sh.prof, 4);
+    if (!job.mirrored) return;
+    MirrorPacket &pk = job.packet;
+    Frame *keyframe = map->get_frame(map->frame_num() - 1);
+    Frame *new_frame_i = keyframe;
+    if (!keyframe->subframes.empty()) new_frame_i = keyframe->subframes.back().get();
+    if (new_frame_i->id() != pk.frame_i_id) throw std::logic_error("mirror_frame: the packet was gathered against another frame");
+    map->attach_frame(std::move(pk.curr_frame));
+    Frame *new_frame_j = map->get_frame(map->frame_num() - 1);
+    map->reserved_track_ids[0] = job.track_ids[0];
+    map->reserved_track_ids[1] = job.track_ids[1];
+    for (const auto &[ki, kj] : pk.matches) new_frame_i->get_track(ki, map.get())->add_keypoint(new_frame_j, kj);
+    if (map->reserved_track_ids[0] != map->reserved_track_ids[1]) throw std::logic_error("mirror_frame: track ids drawn at the hand-over do not match the tracks created");
+    map->prune_tracks([](const Track *track) { return track->tag(TT_TRASH) && !track->tag(TT_STATIC); });
+    job.new_frame_i = new_frame_i;
+    job.new_frame_j = new_frame_j;
+}
+
+void SlidingWindowTracker::newest_frame_summary(size_t &id, std::vector<uint8_t> &flags) const {
+    const Frame *keyframe = map->get_frame(map->frame_num() - 1);
+    const Frame *newest = keyframe->subframes.empty() ? keyframe : keyframe->subframes.back().get();
+    id = newest->id();
+    flags.assign(newest->keypoint_num(), 0);
+    for (size_t k = 0; k < newest->keypoint_num(); ++k)
+        if (const Track *track = newest->get_track(k)) flags[k] = (uint8_t)(1u | ((track->tag(TT_TRASH) && !track->tag(TT_STATIC)) ? 2u : 0u));
 }
 
 void SlidingWindowTracker::mirror_frame_finish(FrontendJob &job) {

@@ -55,12 +55,12 @@ struct BackendTimer {
 // host-side stage profile (diagnostic: RDVIO_PIPELINE_PROF=1 prints it to stderr when the pipeline is destroyed): inclusive
 // wall time of the orchestration's stages, backend calls included -- subtract the backend counters for the host share
 struct HostProf {
-    static constexpr int N = 16;
+    static constexpr int N = 17;
     static constexpr const char *names[N] = {"tracker.run", "tracker.track_keypoints", "tracker.detect_keypoints", "frontend.run", "swt.mirror_frame",
                                              "swt.localize_newframe", "swt.refine_window", "swt.refine_subwindow", "swt.marginalize_frame0",
                                              "swt.track_landmark+manage", "ba.solve (assembly + backend)", "rd path",
-                                             "frontend step (either thread)", "hand-over: wait for the step", "hand-over: publish + mirror maps",
-                                             "tracker.gates (host)"};
+                                             "frontend step (either thread)", "hand-over: wait for the step", "hand-over: publish + tags",
+                                             "tracker.gates (host)", "mirror packet (tracker's side, ahead of the hand-over)"};
     double seconds[N] = {};
     long calls[N] = {};
     bool on = false;
@@ -139,9 +139,23 @@ class BaBuilder {
 
 // One step of the frontend (Frontend::run's tracking branch, frontend.cpp:47-66) as a unit of work: prepared at the
 // hand-over (both maps quiescent), executed inline or on the worker, its results published at the next hand-over.
+// What mirror_frame (sliding_window_tracker.cpp:29-78) takes from the FEATURE-TRACKING map for one new frame, gathered on the
+// tracker's side: the frame's clone with the IMU samples since the sliding-window map's newest frame, and which keypoints of
+// that newest frame continue into the new one.  Depends on the feature-tracking map and the newest frame's id only, so the
+// tracker builds it while the previous step is still running.
+struct MirrorPacket {
+    size_t frame_i_id = nil, frame_j_id = nil;
+    bool found = false;                                  // both frames are in the feature-tracking map
+    std::unique_ptr<Frame> curr_frame;
+    std::vector<std::pair<uint32_t, uint32_t>> matches;  // (keypoint of frame i, keypoint of frame j)
+    std::vector<Track *> ft_tracks;                      // the feature-tracking map's track of each match
+};
+
 struct FrontendJob {
     size_t frame_id = nil;
     bool mirrored = false;                   // mirror_frame found both frames (sliding_window_tracker.cpp:33-36)
+    MirrorPacket packet;
+    size_t track_ids[2] = {0, 0};            // ids drawn at the hand-over for the tracks the step creates while mirroring
     Frame *new_frame_i = nullptr, *new_frame_j = nullptr;
     // update_track_status reads, per keypoint of the new frame, whether the FEATURE-TRACKING map's track exists (bit 0) and
     // is TT_STATIC (bit 1) (sliding_window_tracker.cpp:731-757); taken at the hand-over
@@ -150,6 +164,10 @@ struct FrontendJob {
     bool ok = true;
     std::tuple<double, PoseState, MotionState> latest_state;
     std::vector<size_t> old_tracks_nonstatic;  // keypoints of the new frame whose feature-tracking-map track loses TT_STATIC
+    // the sliding-window map's newest frame when the step ended, for the next hand-over: its id and, per keypoint, whether it has
+    // a track (bit 0) and whether that track is TT_TRASH and not TT_STATIC (bit 1)
+    size_t newest_id = nil;
+    std::vector<uint8_t> newest_flags;
     std::exception_ptr error;
 };
 
@@ -158,8 +176,14 @@ class SlidingWindowTracker {
     SlidingWindowTracker(std::unique_ptr<Map> keyframe_map, Shared &sh);
     // mirror_frame (sliding_window_tracker.cpp:29-78) in two halves: the part that reads and tags the feature-tracking map
     // (hand-over, caller's thread) and the preintegration + prediction of the new frame (the frontend's step)
-    void mirror_frame_maps(Map *feature_tracking_map, FrontendJob &job);
+    //   gather (tracker's side, any time after the tracker finished the frame)  ->  mirror_frame_handover (hand-over: the tags
+    //   mirror_frame writes INTO the feature-tracking map, ids for the tracks to come)  ->  mirror_frame_apply + _finish (the
+    //   frontend's step: the sliding-window map's side, preintegration, prediction)
+    static void gather_mirror_packet(const Map *feature_tracking_map, size_t frame_i_id, size_t frame_j_id, MirrorPacket &out);
+    static void mirror_frame_handover(IdGenerator &ids, const std::vector<uint8_t> &newest_flags, const Map *feature_tracking_map, bool parsac, FrontendJob &job);
+    void mirror_frame_apply(FrontendJob &job);
     void mirror_frame_finish(FrontendJob &job);
+    void newest_frame_summary(size_t &id, std::vector<uint8_t> &flags) const;
     bool track(FrontendJob &job);
     std::tuple<double, PoseState, MotionState> get_latest_state() const;
     std::unique_ptr<Map> map;
@@ -231,6 +255,9 @@ class Frontend {
     std::tuple<double, size_t, PoseState, MotionState> latest_state;
     // the step in flight / finished but not yet published
     std::unique_ptr<FrontendJob> job;
+    // the sliding-window map's newest frame as of the last published step (FrontendJob::newest_id / newest_flags)
+    size_t newest_id = nil;
+    std::vector<uint8_t> newest_flags;
     // worker (threading == 2): one slot, phase 0 idle, 1 posted, 2 done, 3 quit; waits spin briefly, then sleep
     std::thread worker;
     std::atomic<int> phase{0};
