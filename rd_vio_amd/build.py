@@ -97,6 +97,8 @@ def _build_hip(force=False, verbose=False):
     extra = ["-DRDVIO_PROF"] if os.environ.get("RDVIO_PROF") else []  # diagnostic phase stamps (never timed builds)
     if os.environ.get("RDVIO_CHECK_UG"):
         extra.append("-DRDVIO_CHECK_UG")    # RDVIO_UG refuses LDS addresses and reports them at the next fetch (never a timed build)
+    if os.environ.get("RDVIO_SOLVER_THREADS"):
+        extra.append("-DRDVIO_SOLVER_THREADS=" + os.environ["RDVIO_SOLVER_THREADS"])   # experiment switch (block size of the solver kernels)
     if os.environ.get("RDVIO_PROF_CHOL"):
         extra.append("-DRDVIO_PROF_CHOL")   # stamps inside cholesky_lds (summary[72..76]; not together with RDVIO_PROF_HBLK)
     if os.environ.get("RDVIO_PROF_HBLK"):

@@ -2,7 +2,9 @@
 #pragma once
 #include <cstdint>
 
+#ifndef RDVIO_SOLVER_THREADS
 #define RDVIO_SOLVER_THREADS 512
+#endif
 // per-factor record of the stored linearisation: Jt[12] Jr[12] Jd[2] r[2] ht[6] hr[6] m g
 #define RDVIO_FAC_STRIDE 42
 #define RDVIO_REC_STRIDE 26

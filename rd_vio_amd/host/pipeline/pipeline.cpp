@@ -801,6 +801,7 @@ void SlidingWindowTracker::track_landmark() {
 
 void SlidingWindowTracker::refine_window() {
     HostTimer host_timer__(sh.prof, 6);
+    std::optional<HostTimer> part_timer__(std::in_place, sh.prof, 17);
     BaBuilder solver(sh);
     if (!map->marginalization_factor) {
         // MarginalizationFactor::MarginalizationFactor (marginalization_factor.h:16-32): every frame but the newest, the
@@ -853,9 +854,11 @@ void SlidingWindowTracker::refine_window() {
         (void)solver.add_integrated_preintegration(frame_i, frame_j, frame_j->keyframe_preintegration, frame_j->image->t, frame_i->motion.bg, frame_i->motion.ba);
     }
     solver.kind = 1;
+    part_timer__.reset();
     solver.solve();
     sh.counters.window_solves++;
     sh.counters.keyframes++;
+    part_timer__.emplace(sh.prof, 18);
 
     // depth / reprojection culling (:304-336)
     for (size_t k = 0; k < map->track_num(); ++k) {

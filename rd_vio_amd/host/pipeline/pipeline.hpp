@@ -55,12 +55,13 @@ struct BackendTimer {
 // host-side stage profile (diagnostic: RDVIO_PIPELINE_PROF=1 prints it to stderr when the pipeline is destroyed): inclusive
 // wall time of the orchestration's stages, backend calls included -- subtract the backend counters for the host share
 struct HostProf {
-    static constexpr int N = 17;
+    static constexpr int N = 19;
     static constexpr const char *names[N] = {"tracker.run", "tracker.track_keypoints", "tracker.detect_keypoints", "frontend.run", "swt.mirror_frame",
                                              "swt.localize_newframe", "swt.refine_window", "swt.refine_subwindow", "swt.marginalize_frame0",
                                              "swt.track_landmark+manage", "ba.solve (assembly + backend)", "rd path",
                                              "frontend step (either thread)", "hand-over: wait for the step", "hand-over: publish + tags",
-                                             "tracker.gates (host)", "mirror packet (tracker's side, ahead of the hand-over)"};
+                                             "tracker.gates (host)", "mirror packet (tracker's side, ahead of the hand-over)",
+                                             "swt.refine_window: graph", "swt.refine_window: culling"};
     double seconds[N] = {};
     long calls[N] = {};
     bool on = false;
