@@ -193,55 +193,142 @@ __device__ __forceinline__ float ordered_to_float(uint32_t o) {
     return __uint_as_float(b);
 }
 
+// One workgroup = 64 x 16 output pixels, four per thread.
+//   1. the u8 tile (+2 px all round, +4 on the left so that rows start on a dword) goes to LDS with coalesced dword loads -- one
+//      load per four pixels (the one-pixel-per-thread version issued nine byte loads per gradient);
+//   2. Sobel gradients of the 66 x 18 positions the 3 x 3 box sums need, from LDS, four per thread with dword reads, stored as one
+//      packed (gx, gy) int16 pair per position (|g| <= 1020);
+//   3. per thread the three column sums of products are formed once per column and shared by its four outputs.
+// The box filter's border is REFLECT_101 on the gradient PRODUCTS: the gradient "at" x = -1 is the gradient at x = 1 (not the
+// Sobel of the reflected image there, whose x-derivative has the other sign) -- positions on the outer ring read the reflected
+// position's taps.  Exact integer sums, one double expression per pixel: bit-identical to the one-pixel-per-thread kernel.
+#define HT_W 64
+#define HT_H 16
+#define HT_IMG_STRIDE 76   // bytes per LDS image row: 72 used (4 left, 64, 4 right), 19 dwords
+#define HT_G_STRIDE 67     // words per LDS gradient row: 66 used
+__device__ __forceinline__ int harris_sobel_packed(const uint8_t *simg, int lrow, int lcol) {
+    // taps around LDS image position (lrow, lcol): rows lrow-1..lrow+1, bytes lcol-1..lcol+1
+    const uint8_t *r0 = simg + (lrow - 1) * HT_IMG_STRIDE + lcol, *r1 = r0 + HT_IMG_STRIDE, *r2 = r1 + HT_IMG_STRIDE;
+    const int gx = (r0[1] + 2 * r1[1] + r2[1]) - (r0[-1] + 2 * r1[-1] + r2[-1]);
+    const int gy = (r2[-1] + 2 * r2[0] + r2[1]) - (r0[-1] + 2 * r0[0] + r0[1]);
+    return (gx & 0xffff) | (gy << 16);
+}
 __global__ __launch_bounds__(256) void harris_kernel(rdvio_pyr_layout L, const uint8_t *__restrict__ pyr_img, double k,
                                                     float *__restrict__ resp, uint32_t *__restrict__ max_out) {
-    __shared__ int sdx[(PT_H + 2)][(PT_W + 2) + 1];
-    __shared__ int sdy[(PT_H + 2)][(PT_W + 2) + 1];
+    __shared__ __attribute__((aligned(16))) uint8_t simg[(HT_H + 4) * HT_IMG_STRIDE];
+    __shared__ int sg[(HT_H + 2) * HT_G_STRIDE];
     __shared__ uint32_t smax[4];
     const int B = L.border, w = L.w[0], h = L.h[0], s = L.stride[0];
     const uint8_t *img = pyr_img + L.img_off[0] + (size_t)B * s + B;
     int tbx, tby;
     xcd_tile(tbx, tby);
-    const int bx0 = tbx * PT_W, by0 = tby * PT_H;
-    for (int i = threadIdx.x; i < (PT_H + 2) * (PT_W + 2); i += 256) {
-        int ly = i / (PT_W + 2), lx = i - ly * (PT_W + 2);
-        int x = bx0 + lx - 1, y = by0 + ly - 1;
-        int gx = 0, gy = 0;
-        if (x <= w && y <= h) {
-            // box filter border is REFLECT_101 on the (dx,dy) products -> Sobel at the reflected coordinate;
-            // the Sobel's own border pixels come from the arena's reflect-101 frame.
-            int rx = reflect101(x, w), ry = reflect101(y, h);
-            const uint8_t *r0 = img + (ptrdiff_t)(ry - 1) * s + rx;
-            const uint8_t *r1 = r0 + s, *r2 = r1 + s;
-            gx = (r0[1] + 2 * r1[1] + r2[1]) - (r0[-1] + 2 * r1[-1] + r2[-1]);
-            gy = (r2[-1] + 2 * r2[0] + r2[1]) - (r0[-1] + 2 * r0[0] + r0[1]);
-        }
-        sdx[ly][lx] = gx;
-        sdy[ly][lx] = gy;
+    const int bx0 = tbx * HT_W, by0 = tby * HT_H;
+    const int t = threadIdx.x;
+    // ---- 1. image rows by0-2 .. by0+17, bytes bx0-4 .. bx0+67 (inside the arena's reflect-101 frame or, beyond x = w + 31, in
+    // row padding that only feeds masked outputs)
+    for (int i = t; i < (HT_H + 4) * 18; i += 256) {
+        const int r = i / 18, c = i - 18 * r;
+        int y = by0 - 2 + r;
+        y = y > h + B - 1 ? h + B - 1 : y;   // (rows below the frame feed masked outputs only)
+        *reinterpret_cast<uint32_t *>(simg + r * HT_IMG_STRIDE + 4 * c) = *reinterpret_cast<const uint32_t *>(img + (ptrdiff_t)y * s + bx0 - 4 + 4 * c);
     }
     __syncthreads();
-    const int lx = threadIdx.x % PT_W, ly = threadIdx.x / PT_W;
-    const int x = bx0 + lx, y = by0 + ly;
-    float r = -INFINITY;
-    if (x < w && y < h) {
-        int sxx = 0, sxy = 0, syy = 0;
+    // ---- 2. gradients at x in [bx0-1, bx0+64], y in [by0-1, by0+16]; word (row gy, col gx) of sg is position (by0-1+gy, bx0-1+gx)
+    const int tx = t & 15, ty = t >> 4;
+    for (int grow = ty; grow < HT_H + 2; grow += 16) {
+        const int y = by0 - 1 + grow;
+        const int ry = (y < 0) ? -y : (y >= h ? 2 * (h - 1) - y : y);   // y = -1 -> 1, y = h -> h - 2 (deeper rows feed masked outputs)
+        const int lrow = ry - (by0 - 2);
+        const int x0 = bx0 + 4 * tx;
+        int *dst = sg + grow * HT_G_STRIDE + 1 + 4 * tx;
+        if (lrow >= 1 && lrow <= HT_H + 2) {
+            if (x0 + 3 < w) {
+                // dwords tx, tx+1, tx+2 of three rows: bytes x0-4 .. x0+7, of which x0-1 .. x0+4 are used
+                const uint32_t *q0 = reinterpret_cast<const uint32_t *>(simg + (lrow - 1) * HT_IMG_STRIDE) + tx;
+                const uint32_t *q1 = reinterpret_cast<const uint32_t *>(simg + lrow * HT_IMG_STRIDE) + tx;
+                const uint32_t *q2 = reinterpret_cast<const uint32_t *>(simg + (lrow + 1) * HT_IMG_STRIDE) + tx;
+                int p0[6], p1[6], p2[6];
+                {
+                    const uint32_t a0 = q0[0], b0 = q0[1], c0 = q0[2], a1 = q1[0], b1 = q1[1], c1 = q1[2], a2 = q2[0], b2 = q2[1], c2 = q2[2];
+                    p0[0] = a0 >> 24; p1[0] = a1 >> 24; p2[0] = a2 >> 24;
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+                    for (int j = 0; j < 4; ++j) {
+                        p0[1 + j] = (b0 >> (8 * j)) & 255;
+                        p1[1 + j] = (b1 >> (8 * j)) & 255;
+                        p2[1 + j] = (b2 >> (8 * j)) & 255;
+                    }
+                    p0[5] = c0 & 255; p1[5] = c1 & 255; p2[5] = c2 & 255;
+                }
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                int gx = sdx[ly + j][lx + i], gy = sdy[ly + j][lx + i];
-                sxx += gx * gx;
-                sxy += gx * gy;
-                syy += gy * gy;
+                for (int j = 0; j < 4; ++j) {
+                    const int gx = (p0[j + 2] + 2 * p1[j + 2] + p2[j + 2]) - (p0[j] + 2 * p1[j] + p2[j]);
+                    const int gy = (p2[j] + 2 * p2[j + 1] + p2[j + 2]) - (p0[j] + 2 * p0[j + 1] + p0[j + 2]);
+                    dst[j] = (gx & 0xffff) | (gy << 16);
+                }
+            } else {
+                // the image's right edge runs through this group: x = w reads the taps of w - 2, beyond it nothing is needed
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int x = x0 + j;
+                    const int rx = x >= w ? 2 * (w - 1) - x : x;
+                    dst[j] = (x <= w && rx >= bx0 - 3) ? harris_sobel_packed(simg, lrow, rx - (bx0 - 4)) : 0;
+                }
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[j] = 0;
+        }
+    }
+    if (t < 2 * (HT_H + 2)) {   // the two outer columns: x = bx0 - 1 and x = bx0 + 64
+        const int grow = t >> 1, right = t & 1;
+        const int y = by0 - 1 + grow, x = right ? bx0 + HT_W : bx0 - 1;
+        const int ry = (y < 0) ? -y : (y >= h ? 2 * (h - 1) - y : y);
+        const int rx = (x < 0) ? -x : (x >= w ? 2 * (w - 1) - x : x);
+        const int lrow = ry - (by0 - 2), lcol = rx - (bx0 - 4);
+        const bool ok = x <= w && lrow >= 1 && lrow <= HT_H + 2 && lcol >= 1 && lcol <= 70;
+        sg[grow * HT_G_STRIDE + (right ? HT_W + 1 : 0)] = ok ? harris_sobel_packed(simg, lrow, lcol) : 0;
+    }
+    __syncthreads();
+    // ---- 3. four outputs per thread: pixels (by0 + ty, bx0 + 4 tx + j)
+    const int x0 = bx0 + 4 * tx, y = by0 + ty;
+    int cxx[6], cxy[6], cyy[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        cxx[c] = 0; cxy[c] = 0; cyy[c] = 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int *row = sg + (ty + r) * HT_G_STRIDE + 4 * tx;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int v = row[c];
+            const int gx = (int)(short)(v & 0xffff), gy = v >> 16;
+            cxx[c] += gx * gx;
+            cxy[c] += gx * gy;
+            cyy[c] += gy * gy;
+        }
+    }
+    float rr[4];
+    uint32_t o = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int sxx = cxx[j] + cxx[j + 1] + cxx[j + 2], sxy = cxy[j] + cxy[j + 1] + cxy[j + 2], syy = cyy[j] + cyy[j + 1] + cyy[j + 2];
         const double sc = 1.0 / (4.0 * 3.0 * 255.0);
         const double s2 = sc * sc;
         double a = s2 * (double)sxx, b = s2 * (double)sxy, c = s2 * (double)syy;
-        r = (float)(a * c - b * b - k * (a + c) * (a + c));
-        resp[(size_t)y * w + x] = r;
+        rr[j] = (float)(a * c - b * b - k * (a + c) * (a + c));
+        if (x0 + j < w && y < h) o = max(o, float_to_ordered(rr[j]));
+    }
+    if (y < h) {
+        if (x0 + 3 < w && (w & 3) == 0) {
+            *reinterpret_cast<float4 *>(resp + (size_t)y * w + x0) = float4{rr[0], rr[1], rr[2], rr[3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (x0 + j < w) resp[(size_t)y * w + x0 + j] = rr[j];
+        }
     }
     // block max -> one atomic per block
-    uint32_t o = (x < w && y < h) ? float_to_ordered(r) : 0u;
     for (int off = 32; off > 0; off >>= 1) o = max(o, (uint32_t)__shfl_xor((int)o, off));
     if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = o;
     __syncthreads();
@@ -328,7 +415,7 @@ int rdvio_launch_preprocess(rdvio_hip_ctx *ctx, int slot, const uint8_t *gray_de
 int rdvio_launch_harris(rdvio_hip_ctx *ctx, int slot) {
     ImageSlot &S = ctx->slots[slot];
     RDVIO_HIP_CHECK(ctx, hipMemsetAsync(ctx->harris_scalars, 0, 2 * sizeof(uint32_t), ctx->stream));
-    dim3 grid((S.w + PT_W - 1) / PT_W, (S.h + PT_H - 1) / PT_H);
+    dim3 grid((S.w + HT_W - 1) / HT_W, (S.h + HT_H - 1) / HT_H);
     hipLaunchKernelGGL(harris_kernel, grid, dim3(256), 0, ctx->stream, S.L, S.pyr_img, 0.04, ctx->harris,
                        ctx->harris_scalars);
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
