@@ -1,0 +1,39 @@
+"""How much of the time the HIP lanes of the product pipeline run concurrently, from a rocprofv3 kernel trace (CSV): per stream
+(= lane) the busy time, and the time during which kernels of two or more streams are in flight together.
+usage: lane_overlap.py <kernel_trace.csv>"""
+import csv, re, sys
+from collections import defaultdict
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+if not rows:
+    sys.exit("empty trace")
+key = "Stream_Id" if "Stream_Id" in rows[0] else ("Queue_Id" if "Queue_Id" in rows[0] else None)
+ev = []
+busy = defaultdict(float)
+names = defaultdict(lambda: defaultdict(int))
+for r in rows:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    lane = r.get(key, "?") if key else "?"
+    busy[lane] += (e - s) * 1e-6
+    nm = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0].replace("void ", "")
+    names[lane][nm] += 1
+    ev.append((s, 1, lane))
+    ev.append((e, -1, lane))
+ev.sort()
+t0, t1 = ev[0][0], ev[-1][0]
+active = defaultdict(int)
+last = ev[0][0]
+any_busy = both = 0.0
+for t, d, lane in ev:
+    n = sum(1 for v in active.values() if v > 0)
+    if n >= 1:
+        any_busy += (t - last) * 1e-6
+    if n >= 2:
+        both += (t - last) * 1e-6
+    last = t
+    active[lane] += d
+print(f"trace: {len(rows)} kernel launches over {(t1 - t0) * 1e-6:.1f} ms; lanes identified by {key}")
+for lane in sorted(busy, key=lambda k: -busy[k]):
+    top = sorted(names[lane].items(), key=lambda kv: -kv[1])[:4]
+    print(f"  lane {lane}: busy {busy[lane]:9.2f} ms  ({', '.join(f'{n} x {c}' for n, c in top)})")
+print(f"some lane busy: {any_busy:.2f} ms; two or more lanes busy at once: {both:.2f} ms ({100 * both / max(any_busy, 1e-9):.1f} % of the busy time)")
