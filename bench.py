@@ -784,6 +784,11 @@ def main(argv=None):
                                   "produced them; single-workgroup latency-bound trust-region loop (phase table: DESIGN.md section 4)"),
         }
 
+        # HBM-side bytes per launch of the dominant kernel: the committed PMC passes of this same command (pmc_traffic_bytes)
+        pmc_main, pmc_main_note = pmc_traffic_bytes() if cfg is CONFIGS["euroc_v101"] else ({}, "PMC passes are taken on the default config only")
+        out["roofline"]["traffic"] = pmc_main.get("ba_solve_kernel")
+        out["roofline"]["traffic_unit"] = pmc_main_note
+
         def leg(name, fn):   # the legs beside `value`: a failure in one of them is recorded in its own field and never costs the line
             try:
                 out[name] = fn()
@@ -826,8 +831,6 @@ def main(argv=None):
                 s2 = torch.cuda.Stream(device=dev)
                 torch.cuda.set_stream(s2)
                 rep, pmc, pmc_note = kernel_loop_leg(cfg, torch, dev, local_rank, min(steps, 100), 10, args.serial, s2)
-                out["roofline"]["traffic"] = pmc.get("ba_solve_kernel")
-                out["roofline"]["traffic_unit"] = pmc_note
                 return rep
             leg("kernel_loop", _kl)
         if args.sequences > 1:

@@ -9,23 +9,32 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 FAST="--no-cpu-baseline --no-variants"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py $FAST > $O/stats.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py $FAST > $O/stats.log 2>&1
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 cp $(find $O/stats -name "*kernel_trace.csv" | head -1) $O/kernel_trace_full.csv
 python3 $R/scripts/lane_overlap.py $O/kernel_trace_full.csv > $O/lane_overlap.txt 2>&1 || true
 rm -rf $O/stats $O/kernel_trace_full.csv
 echo "stats done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py $FAST --steps 60 --warmup 5 > $O/pmc_fetch.log 2>&1
-echo "fetch done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py $FAST --steps 60 --warmup 5 > $O/pmc_write.log 2>&1
-echo "write done"
+# (a counter pass that stalls is cut off and tried once more; the summary is written from whatever passes completed)
+for C in FETCH_SIZE WRITE_SIZE; do
+    D=$O/pmc_$(echo $C | cut -d_ -f1 | tr A-Z a-z)
+    for TRY in 1 2; do
+        rm -rf $D
+        if timeout -k 10 240 rocprofv3 --pmc $C --output-format csv -d $D -- python3 $R/bench.py $FAST --no-kernel-loop --steps 60 --warmup 5 > $D.log 2>&1; then
+            echo "$C done (try $TRY)"
+            break
+        fi
+        echo "$C pass failed or stalled (try $TRY)"
+    done
+done
+mkdir -p $O/pmc_fetch $O/pmc_write
 python3 $R/scripts/summarize_pmc.py $O/pmc_fetch $O/pmc_write $O/pmc_all.csv > /dev/null
 grep -v "^__amd\|^at::" $O/pmc_all.csv > $O/pmc_fetch_write.csv
 cp $O/pmc_fetch_write.csv $R/profiles/${TAG}_pmc_fetch_write.csv
 # bench.py reads profiles/<round>_pmc_fetch_write.csv (+ .meta.json): refresh it in place so that the bench lines below carry `traffic`
 ROUND=${TAG%%_*}
 cp $O/pmc_fetch_write.csv $R/profiles/${ROUND}_pmc_fetch_write.csv
-python3 -c "import sys, json; sys.path.insert(0, '$R'); import bench; json.dump({'kernel_source_sha256': bench.kernel_source_hash(), 'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --no-cpu-baseline --no-variants --steps 60 --warmup 5'}, open('$O/pmc_fetch_write.meta.json', 'w'))"
+python3 -c "import sys, json; sys.path.insert(0, '$R'); import bench; json.dump({'kernel_source_sha256': bench.kernel_source_hash(), 'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --no-cpu-baseline --no-variants --no-kernel-loop --steps 60 --warmup 5'}, open('$O/pmc_fetch_write.meta.json', 'w'))"
 cp $O/pmc_fetch_write.meta.json $R/profiles/${TAG}_pmc_fetch_write.meta.json
 cp $O/pmc_fetch_write.meta.json $R/profiles/${ROUND}_pmc_fetch_write.meta.json
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_all.csv
