@@ -38,7 +38,10 @@ CONFIGS = {
     "euroc_mh03_rd": dict(width=752, height=480, features=300, window=10, landmarks=300, iters=30, parsac_stream=True,
                           name="EuRoC MH_03_medium-shaped synthetic stream 752x480, 300 features, window 10, RD path"),
     # configs[4]: roofline run
-    "synthetic_720p": dict(width=1280, height=720, features=1000, window=16, landmarks=1000, iters=30,
+    # (bootstrapped with supplied keyframe states: on this stream the initializer's 8-keyframe SfM + IMU alignment ends in a scale
+    # the tracker does not recover from -- on the CPU path and the GPU path alike, 100 m off after 250 frames --, and a diverging
+    # estimator says nothing about either path; the initializer-bootstrapped rate is reported under pipeline_variants)
+    "synthetic_720p": dict(width=1280, height=720, features=1000, window=16, landmarks=1000, iters=30, bootstrap="groundtruth",
                            name="synthetic 1280x720 stream, 1000 features, window 16"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -442,7 +445,8 @@ def cpu_path_worker(args):
 
     be = Backend()
     shim.rdvio_oracle_backend_fill(ctypes.byref(be))
-    run = PipelineRun(lib, lambda out: lib.rdvio_pipeline_create(out, ctypes.byref(pcfg), ctypes.byref(be)), stream, kp_capacity=2048)
+    run = PipelineRun(lib, lambda out: lib.rdvio_pipeline_create(out, ctypes.byref(pcfg), ctypes.byref(be)), stream,
+                      stream["gt"] if cfg.get("bootstrap") == "groundtruth" else None, kp_capacity=2048)
     run.segment(n_pre)
     c0 = run.counters()
     t = run.segment(steps)
@@ -730,7 +734,8 @@ def main(argv=None):
         return ctx, run, applied
 
     # ---- the timed pipeline
-    ctx, run, applied = hip_run(args.threading, kp_capacity=2048)
+    supplied = cfg.get("bootstrap") == "groundtruth"
+    ctx, run, applied = hip_run(args.threading, init_states=stream["gt"] if supplied else None, kp_capacity=2048)
     n_pre = bootstrap_and_warm_up(run, warmup, n_total - steps)
     c0 = run.counters()
     ctx._check(ctx._lib.rdvio_hip_ctx_set_kernel_timing(ctx._h, 1))
@@ -761,7 +766,8 @@ def main(argv=None):
                        "settings": "configs/baseline_setting.yaml (the reference's configs/setting.yaml values) with only sliding_window.size and "
                                    "feature_tracker.max_keypoint_detection overridden; configs/synthetic_euroc_sensor.yaml",
                        "settings_applied": {k: (v if not isinstance(v, (list, tuple, np.ndarray)) else [float(x) for x in v]) for k, v in applied.items()},
-                       "bootstrap": "full initializer (SfM + IMU alignment), no supplied states",
+                       "bootstrap": "supplied keyframe states (ground truth of the synthetic stream) instead of the SfM / IMU-alignment stages" if supplied
+                                    else "full initializer (SfM + IMU alignment), no supplied states",
                        "schedule": {0: "inline (the reference's THREADING=OFF)", 1: "pipelined tracker / frontend schedule on one thread",
                                     2: "tracker on the caller's thread, frontend's step on a worker thread (frontend lane || solver lane), "
                                        "deterministic hand-over"}[args.threading],
@@ -813,8 +819,10 @@ def main(argv=None):
         if not args.no_variants:
             def _variants():
                 rep = {}
-                for label, thr, init, extra in (("inline_schedule", 0, None, {}), ("groundtruth_bootstrap", args.threading, stream["gt"], {}),
-                                                ("tracker_gates_on_the_device", args.threading, None, {"tracker_gates_on_backend": 1})):
+                own = stream["gt"] if supplied else None
+                other = ("full_initializer_bootstrap", args.threading, None, {}) if supplied else ("groundtruth_bootstrap", args.threading, stream["gt"], {})
+                for label, thr, init, extra in (("inline_schedule", 0, own, {}), other,
+                                                ("tracker_gates_on_the_device", args.threading, own, {"tracker_gates_on_backend": 1})):
                     c2, r2, _ = hip_run(thr, init_states=init, **extra)
                     try:
                         n2 = bootstrap_and_warm_up(r2, warmup, n_total - steps)

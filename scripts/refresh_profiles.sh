@@ -4,17 +4,24 @@
 # bench.py reads for roofline.traffic), then the bench lines of the three configurations and the GPU test log.
 set -e
 TAG=${1:-r03}
+PART=${2:-all}    # all | stats | pmc | bench: a GPU call is limited to 20 minutes, the parts can be run one per call
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 FAST="--no-cpu-baseline --no-variants"
+if [ $PART = all ] || [ $PART = stats ]; then
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py $FAST > $O/stats.log 2>&1
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 cp $(find $O/stats -name "*kernel_trace.csv" | head -1) $O/kernel_trace_full.csv
 python3 $R/scripts/lane_overlap.py $O/kernel_trace_full.csv > $O/lane_overlap.txt 2>&1 || true
 rm -rf $O/stats $O/kernel_trace_full.csv
 echo "stats done"
+fi
+if [ $PART = all ] || [ $PART = pmc ]; then
+# the synthetic stream is rendered by a pool of forked workers; under a counter pass the profiler's library lives in every forked
+# child and its SIGTERM handler stalls when the pool ends -- render in-process there
+export RDVIO_SYNTH_WORKERS=1
 # (a counter pass that stalls is cut off and tried once more; the summary is written from whatever passes completed)
 for C in FETCH_SIZE WRITE_SIZE; do
     D=$O/pmc_$(echo $C | cut -d_ -f1 | tr A-Z a-z)
@@ -38,6 +45,10 @@ python3 -c "import sys, json; sys.path.insert(0, '$R'); import bench; json.dump(
 cp $O/pmc_fetch_write.meta.json $R/profiles/${TAG}_pmc_fetch_write.meta.json
 cp $O/pmc_fetch_write.meta.json $R/profiles/${ROUND}_pmc_fetch_write.meta.json
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_all.csv
+unset RDVIO_SYNTH_WORKERS
+echo "pmc done"
+fi
+if [ $PART = all ] || [ $PART = bench ]; then
 cd $R
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 echo "bench done"
@@ -48,4 +59,5 @@ python3 $R/bench.py --config euroc_mh03_rd --steps 300 --warmup 10 > $O/bench_eu
 echo "mh03 done"
 RDVIO_PIPELINE_PROF=1 python3 $R/scripts/pipeline_fps.py --frames 400 --modes 2 --bootstrap init > $O/pipeline_phases.log 2>&1
 python3 -m pytest $R/tests -m gpu -q > $O/gpu_tests.log 2>&1 || true
+fi
 echo "all done"
