@@ -149,6 +149,11 @@ int rdvio_hip_preintegrate(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off,
 int rdvio_hip_preintegrate_estimator(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off, const double *imu,
                                      const double *t_end, const double *bg, const double *ba, const double *noise,
                                      int compute_jacobian, int compute_covariance, double *preint_out);
+/* The same in two halves (the estimator's per-frame integration sits at the head of its step: _begin enqueues upload, kernel and
+ * download on the solver lane and returns; _end waits and copies the nseg records out).  One integration in flight per context. */
+int rdvio_hip_preintegrate_estimator_begin(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off, const double *imu, const double *t_end,
+                                           const double *bg, const double *ba, const double *noise, int compute_jacobian, int compute_covariance);
+int rdvio_hip_preintegrate_estimator_end(rdvio_hip_ctx *ctx, double *preint_out);
 /* Same with every array resident in HBM: imu_dev (n x 7), par_dev (nseg x 7: t_end, bg, ba), noise_dev (36),
  * seg_off_dev (nseg+1), out_dev (nseg x RDVIO_PREINT_SIZE).  Only enqueues the kernel. */
 int rdvio_hip_preintegrate_dev(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off_dev, const double *imu_dev,

@@ -86,6 +86,11 @@ typedef struct rdvio_backend {
     /* optional (NULL = the orchestration's host solvers generate the hypotheses): rdvio_hip_parsac_generate_score */
     int (*parsac_generate_score)(void *user, const rdvio_parsac_batch *batch, int n_iterations, const int32_t *samples,
                                  int32_t *models_per_iteration, double *models, rdvio_parsac_result *results);
+    /* optional pair (NULL = preintegrate_estimator / preintegrate): the estimator's integration of the new frame in two halves --
+     * begin enqueues, end waits and copies the records out; the sliding-window map's share of mirror_frame runs in between */
+    int (*preintegrate_estimator_begin)(void *user, int nseg, const int32_t *seg_off, const double *imu, const double *t_end, const double *bg,
+                                        const double *ba, const double *noise, int compute_jacobian, int compute_covariance);
+    int (*preintegrate_estimator_end)(void *user, double *preint_out);
 } rdvio_backend;
 
 /* rdvio::Config (types.h:85-151) with the defaults of src/rdvio/src/config.cpp; rdvio_pipeline_config_default fills

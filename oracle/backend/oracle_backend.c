@@ -152,4 +152,6 @@ void rdvio_oracle_backend_fill(rdvio_backend *b) {
     b->ransac_fetch = NULL;
     b->thin_tracks = NULL;
     b->parsac_generate_score = NULL;
+    b->preintegrate_estimator_begin = NULL;
+    b->preintegrate_estimator_end = NULL;
 }

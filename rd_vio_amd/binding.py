@@ -17,7 +17,7 @@ EXPORTS = [
     "rdvio_hip_last_error", "rdvio_hip_sync", "rdvio_hip_ctx_set_lane_stream", "rdvio_hip_ctx_set_wait_mode", "rdvio_hip_lane_wait", "rdvio_hip_lane_sync", "rdvio_hip_image_preprocess", "rdvio_hip_image_upload", "rdvio_hip_image_preprocess_uploaded", "rdvio_hip_image_preprocess_dev",
     "rdvio_hip_image_download", "rdvio_hip_track_keypoints", "rdvio_hip_track_keypoints_dev", "rdvio_hip_lk_flow",
     "rdvio_hip_detect_keypoints", "rdvio_hip_harris_response", "rdvio_hip_image_release", "rdvio_hip_preintegrate",
-    "rdvio_hip_preintegrate_dev", "rdvio_hip_preintegrate_estimator", "rdvio_hip_ctx_attach_thread", "rdvio_hip_ctx_ensure_lane_streams",
+    "rdvio_hip_preintegrate_dev", "rdvio_hip_preintegrate_estimator", "rdvio_hip_preintegrate_estimator_begin", "rdvio_hip_preintegrate_estimator_end", "rdvio_hip_ctx_attach_thread", "rdvio_hip_ctx_ensure_lane_streams",
     "rdvio_hip_reprojection_eval", "rdvio_hip_rotation_prior_eval", "rdvio_hip_ba_solve", "rdvio_hip_ba_upload", "rdvio_hip_ba_solve_resident",
     "rdvio_hip_ba_fetch", "rdvio_hip_ba_linearize", "rdvio_hip_ctx_team_retries", "rdvio_hip_ctx_set_kernel_timing", "rdvio_hip_ctx_get_kernel_timing", "rdvio_hip_marginalize", "rdvio_hip_marginalize_upload", "rdvio_hip_marginalize_resident",
     "rdvio_hip_marginalize_fetch", "rdvio_hip_parsac_score", "rdvio_hip_parsac_generate_score", "rdvio_hip_parsac_fetch", "rdvio_hip_ransac_generate_score", "rdvio_hip_ransac_fetch", "rdvio_hip_thin_tracks",

@@ -497,11 +497,12 @@ struct PreStage {
     double *pinned;
     size_t pinned_bytes;
     double *blob, *out;
+    size_t *pending = nullptr;   // non-null: enqueue only; [0] offset, [1] length (doubles) of the records in the pinned blob
 };
 
 static int preintegrate_host(rdvio_hip_ctx *ctx, const PreStage &S, int nseg, const int32_t *seg_off, const double *imu, const double *t_end,
                              const double *bg, const double *ba, const double *noise, int cj, int cc, double *out) {
-    if (!ctx || nseg < 0 || (nseg > 0 && (!seg_off || !imu || !t_end || !bg || !ba || !noise || !out))) return RDVIO_ERR_INVALID;
+    if (!ctx || nseg < 0 || (nseg > 0 && (!seg_off || !imu || !t_end || !bg || !ba || !noise || (!out && !S.pending)))) return RDVIO_ERR_INVALID;
     if (nseg == 0) return RDVIO_OK;
     if (nseg > ctx->pre_max_seg) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "%d segments exceed capacity %d", nseg, ctx->pre_max_seg);
     if (seg_off[0] != 0) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "seg_off[0] must be 0");
@@ -533,6 +534,11 @@ static int preintegrate_host(rdvio_hip_ctx *ctx, const PreStage &S, int nseg, co
         return rc;
     double *down = blob + in_doubles;
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, S.out, out_doubles * sizeof(double), hipMemcpyDeviceToHost, S.st));
+    if (S.pending) {   // begin / end form: the caller collects the records later
+        S.pending[0] = in_doubles;
+        S.pending[1] = out_doubles;
+        return RDVIO_OK;
+    }
     RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, S.st));
     memcpy(out, down, out_doubles * sizeof(double));
     return RDVIO_OK;
@@ -550,6 +556,27 @@ int rdvio_hip_preintegrate_estimator(rdvio_hip_ctx *ctx, int nseg, const int32_t
     if (!ctx) return RDVIO_ERR_INVALID;
     return preintegrate_host(ctx, PreStage{ctx->lane[RDVIO_LANE_SOLVER], (double *)ctx->pre2_pinned, ctx->pre2_pinned_bytes, ctx->pre2_blob, ctx->pre2_out},
                              nseg, seg_off, imu, t_end, bg, ba, noise, cj, cc, out);
+}
+
+int rdvio_hip_preintegrate_estimator_begin(rdvio_hip_ctx *ctx, int nseg, const int32_t *seg_off, const double *imu, const double *t_end,
+                                           const double *bg, const double *ba, const double *noise, int cj, int cc) {
+    if (!ctx) return RDVIO_ERR_INVALID;
+    if (ctx->pre2_pending[1] != 0) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "an estimator preintegration is already in flight");
+    ctx->pre2_pending[0] = ctx->pre2_pending[1] = 0;
+    PreStage S{ctx->lane[RDVIO_LANE_SOLVER], (double *)ctx->pre2_pinned, ctx->pre2_pinned_bytes, ctx->pre2_blob, ctx->pre2_out};
+    S.pending = ctx->pre2_pending;
+    return preintegrate_host(ctx, S, nseg, seg_off, imu, t_end, bg, ba, noise, cj, cc, nullptr);
+}
+
+int rdvio_hip_preintegrate_estimator_end(rdvio_hip_ctx *ctx, double *out) {
+    if (!ctx) return RDVIO_ERR_INVALID;
+    if (ctx->pre2_pending[1] == 0) return RDVIO_OK;   // nothing in flight (begin with no segments)
+    if (!out) return RDVIO_ERR_INVALID;
+    const size_t off = ctx->pre2_pending[0], n = ctx->pre2_pending[1];
+    ctx->pre2_pending[0] = ctx->pre2_pending[1] = 0;
+    RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->lane[RDVIO_LANE_SOLVER]));
+    memcpy(out, (const double *)ctx->pre2_pinned + off, n * sizeof(double));
+    return RDVIO_OK;
 }
 
 int rdvio_hip_ctx_attach_thread(rdvio_hip_ctx *ctx) {

@@ -84,6 +84,7 @@ struct rdvio_hip_ctx {
     double *pre2_out = nullptr, *pre2_blob = nullptr;
     void *pre2_pinned = nullptr;
     size_t pre2_pinned_bytes = 0;
+    size_t pre2_pending[2] = {0, 0};   // rdvio_hip_preintegrate_estimator_begin / _end: where the records in flight will land
 
     // BA solver: pinned input blob, device arena (inputs + scratch), workspace descriptor
     struct BaSlot {

@@ -152,6 +152,12 @@ int ransac_generate_score(void *user, int kind, int n, int changed, const double
     return rdvio_hip_ransac_generate_score(static_cast<HipBackend *>(user)->ctx, kind, n, changed, pa, pb, thr, n_iter, samples, per_iter, models, counts);
 }
 int ransac_fetch(void *user, int model, uint8_t *mask) { return rdvio_hip_ransac_fetch(static_cast<HipBackend *>(user)->ctx, model, mask); }
+int preintegrate_estimator_begin(void *user, int nseg, const int32_t *seg_off, const double *imu, const double *t_end, const double *bg, const double *ba,
+                                 const double *noise, int cj, int cc) {
+    return rdvio_hip_preintegrate_estimator_begin(static_cast<HipBackend *>(user)->ctx, nseg, seg_off, imu, t_end, bg, ba, noise, cj, cc);
+}
+int preintegrate_estimator_end(void *user, double *out) { return rdvio_hip_preintegrate_estimator_end(static_cast<HipBackend *>(user)->ctx, out); }
+
 int thin_tracks(void *user, int w, int h, double radius, int n, const double *xy, int n_order, const int32_t *order, const uint8_t *trash, uint8_t *keep) {
     return rdvio_hip_thin_tracks(static_cast<HipBackend *>(user)->ctx, w, h, radius, n, xy, n_order, order, trash, keep);
 }
@@ -195,6 +201,8 @@ extern "C" int rdvio_pipeline_create_hip(rdvio_pipeline **out, const rdvio_pipel
     fn.ransac_generate_score = ransac_generate_score;
     fn.ransac_fetch = ransac_fetch;
     fn.thin_tracks = thin_tracks;
+    fn.preintegrate_estimator_begin = preintegrate_estimator_begin;
+    fn.preintegrate_estimator_end = preintegrate_estimator_end;
     fn.marginalize_begin = marginalize_begin;
     fn.marginalize_end = marginalize_end;
     const int rc = rdvio_pipeline_create(out, cfg, &fn);

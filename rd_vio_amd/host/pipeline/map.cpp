@@ -86,6 +86,37 @@ std::vector<char> PreIntegrator::integrate_batch(Backend &be, CallerLane lane, c
     return ok;
 }
 
+void PreIntegrator::integrate_begin(Backend &be, double t, const V3 &bg, const V3 &ba) {
+    pending = Pending{true, false, t, bg, ba};
+    if (!(be.fn.preintegrate_estimator_begin && be.fn.preintegrate_estimator_end) || data.empty()) return;
+    auto same = [](const V3 &a, const V3 &b) { return a.x == b.x && a.y == b.y && a.z == b.z; };
+    if (key.valid && key.n == data.size() && key.t == t && key.t_first == data.front().t && key.t_last == data.back().t && same(key.bg, bg) && same(key.ba, ba) &&
+        key.cj && key.cc)
+        return;   // `delta` already holds exactly this integration
+    std::vector<double> imu;
+    imu.reserve(7 * data.size());
+    for (const ImuData &d : data) imu.insert(imu.end(), {d.t, d.w.x, d.w.y, d.w.z, d.a.x, d.a.y, d.a.z});
+    const int32_t off[2] = {0, (int32_t)data.size()};
+    const double bgv[3] = {bg.x, bg.y, bg.z}, bav[3] = {ba.x, ba.y, ba.z};
+    const auto t0 = std::chrono::steady_clock::now();
+    be.check(be.fn.preintegrate_estimator_begin(be.fn.user, 1, off, imu.data(), &t, bgv, bav, noise, 1, 1), "preintegrate (begin)");
+    be.preintegrate_seconds[LANE_ESTIMATOR] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    pending.in_flight = true;
+}
+
+bool PreIntegrator::integrate_end(Backend &be) {
+    const Pending p = pending;
+    pending = Pending{};
+    if (!p.active) return false;
+    if (!p.in_flight) return integrate(be, LANE_ESTIMATOR, p.t, p.bg, p.ba, true, true);
+    const auto t0 = std::chrono::steady_clock::now();
+    be.check(be.fn.preintegrate_estimator_end(be.fn.user, delta.data()), "preintegrate (end)");
+    be.preintegrate_seconds[LANE_ESTIMATOR] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    be.preintegrate_calls[LANE_ESTIMATOR]++;
+    key = Key{data.size(), p.t, data.front().t, data.back().t, p.bg, p.ba, true, true, true};
+    return true;
+}
+
 void PreIntegrator::predict(const Frame *old_frame, Frame *new_frame) const {
     const V3 gravity{0, 0, -GRAVITY_NOMINAL};
     const double t = dt();

@@ -82,6 +82,10 @@ struct PreIntegrator {
     std::vector<double> delta = std::vector<double>(RDVIO_PREINT_SIZE, 0.0);
     PreIntegrator() { delta[PRE_Q + 3] = 1.0; }
     bool integrate(Backend &be, CallerLane lane, double t, const V3 &bg, const V3 &ba, bool compute_jacobian, bool compute_covariance);
+    // the estimator's integration (Jacobians and covariance) in two halves when the backend offers them: begin enqueues, end
+    // collects (otherwise end is the whole call).  Same result as integrate(be, LANE_ESTIMATOR, t, bg, ba, true, true).
+    void integrate_begin(Backend &be, double t, const V3 &bg, const V3 &ba);
+    bool integrate_end(Backend &be);
     void predict(const Frame *old_frame, Frame *new_frame) const;  // preintegrator.cpp:102-112
     // the same integrate() for several independent integrators in one backend call (all with the same noise model and
     // flags); ok[i] = false where data is empty
@@ -90,6 +94,7 @@ struct PreIntegrator {
     // key of the integration `delta` holds (samples, end time, biases, flags): integrate() with the same key is a no-op --
     // the reference integrates the new frame in mirror_frame and again, from identical inputs, in judge_track_status
     // (sliding_window_tracker.cpp:73-76, 586-590)
+    struct Pending { bool active = false, in_flight = false; double t = 0.0; V3 bg{}, ba{}; } pending;
     struct Key {
         size_t n = 0;
         double t = 0, t_first = 0, t_last = 0;

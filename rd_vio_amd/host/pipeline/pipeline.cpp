@@ -515,6 +515,7 @@ void Frontend::drain() {
 void Frontend::execute(FrontendJob &j) {
     HostTimer host_timer__(sh.prof, 12);
     try {
+        if (j.mirrored) sliding_window_tracker->mirror_frame_begin(j);
         sliding_window_tracker->mirror_frame_apply(j);
         if (j.mirrored) sliding_window_tracker->mirror_frame_finish(j);
         j.ok = sliding_window_tracker->track(j);
@@ -672,6 +673,17 @@ void SlidingWindowTracker::mirror_frame_handover(IdGenerator &ids, const std::ve
     }
 }
 
+// the new frame's preintegration (sliding_window_tracker.cpp:63-64) is issued first: it needs the samples (in the packet) and the
+// newest frame's biases (final since the last step) only, and the map work below runs while the device integrates
+void SlidingWindowTracker::mirror_frame_begin(FrontendJob &job) {
+    HostTimer host_timer__(sh.prof, 4);
+    const Frame *keyframe = map->get_frame(map->frame_num() - 1);
+    const Frame *new_frame_i = keyframe->subframes.empty() ? keyframe : keyframe->subframes.back().get();
+    Frame *new_frame_j = job.packet.curr_frame.get();
+    if (!new_frame_j) return;
+    new_frame_j->preintegration.integrate_begin(sh.backend, new_frame_j->image->t, new_frame_i->motion.bg, new_frame_i->motion.ba);
+}
+
 // ... and the sliding-window map's side (the frontend's step)
 void SlidingWindowTracker::mirror_frame_apply(FrontendJob &job) {
     HostTimer host_timer__(sh.prof, 4);
@@ -704,7 +716,8 @@ void SlidingWindowTracker::newest_frame_summary(size_t &id, std::vector<uint8_t>
 void SlidingWindowTracker::mirror_frame_finish(FrontendJob &job) {
     HostTimer host_timer__(sh.prof, 4);
     Frame *new_frame_i = job.new_frame_i, *new_frame_j = job.new_frame_j;
-    new_frame_j->preintegration.integrate(sh.backend, LANE_ESTIMATOR, new_frame_j->image->t, new_frame_i->motion.bg, new_frame_i->motion.ba, true, true);
+    if (!new_frame_j->preintegration.integrate_end(sh.backend))   // (no begin: an unmirrored path; the whole call here)
+        new_frame_j->preintegration.integrate(sh.backend, LANE_ESTIMATOR, new_frame_j->image->t, new_frame_i->motion.bg, new_frame_i->motion.ba, true, true);
     new_frame_j->preintegration.predict(new_frame_i, new_frame_j);
 }
 

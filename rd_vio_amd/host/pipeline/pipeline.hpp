@@ -182,6 +182,7 @@ class SlidingWindowTracker {
     //   frontend's step: the sliding-window map's side, preintegration, prediction)
     static void gather_mirror_packet(const Map *feature_tracking_map, size_t frame_i_id, size_t frame_j_id, MirrorPacket &out);
     static void mirror_frame_handover(IdGenerator &ids, const std::vector<uint8_t> &newest_flags, const Map *feature_tracking_map, bool parsac, FrontendJob &job);
+    void mirror_frame_begin(FrontendJob &job);     // (issues the new frame's preintegration; _apply runs beside it)
     void mirror_frame_apply(FrontendJob &job);
     void mirror_frame_finish(FrontendJob &job);
     void newest_frame_summary(size_t &id, std::vector<uint8_t> &flags) const;
