@@ -265,6 +265,12 @@ int rdvio_hip_ba_linearize(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, const
 /* Large solves run on a team of workgroups whose members must all be resident.  When a member does not answer within the
  * bounded wait (a device shared with other work), the solve is repeated once on one workgroup inside rdvio_hip_ba_fetch instead of
  * failing; this counts those repeats.  A process with more than one live context on a device keeps every solve on one workgroup. */
+/* diagnostic: how the last rdvio_hip_detect_keypoints selected on the device -- 0 one pass over every Harris maximum, 1 the maxima of
+ * the top response bins sufficed (partial sort), 2 they did not and a second pass took everything; -1 host road / no call yet */
+int rdvio_hip_debug_last_select_path(const rdvio_hip_ctx *ctx);
+/* diagnostic: the selection kernel's own clock (10 ns units since its start) after the key load, the sort, the cell lists and the
+ * greedy pass of the last call, and its number of candidates */
+int rdvio_hip_debug_last_select_stamps(const rdvio_hip_ctx *ctx, int32_t *out5);
 long rdvio_hip_ctx_team_retries(const rdvio_hip_ctx *ctx);
 
 /* Measurement: live timing of the dominant kernel.  With timing on, every ba_solve_kernel launch is bracketed by HIP events on

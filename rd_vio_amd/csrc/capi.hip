@@ -462,6 +462,10 @@ int rdvio_hip_detect_keypoints(rdvio_hip_ctx *ctx, int slot, double *keypoints, 
         int32_t *hdr = (int32_t *)ctx->pinned;
         RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(hdr, ctx->sel_hdr, 64 + (size_t)max_points * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->stream));
+        ctx->last_select_path = hdr[1] == 0 ? hdr[4] : -1;
+        for (int q = 0; q < 4; ++q) ctx->last_select_stamps[q] = hdr[8 + q];
+        ctx->last_select_stamps[4] = hdr[0];
+        if (getenv("RDVIO_DEBUG_SELECT")) fprintf(stderr, "[select] first chunk: neighbours collected at %.1f us, decided at %.1f us, %d polling trips (wave 0)\n", hdr[12] / 100.0, hdr[13] / 100.0, hdr[14]);
         if (hdr[1] == 0) {
             const int n_new = hdr[3];
             if (n_existing + n_new > capacity) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "keypoint capacity %d too small", capacity);
@@ -576,6 +580,13 @@ int rdvio_hip_preintegrate_estimator_end(rdvio_hip_ctx *ctx, double *out) {
     ctx->pre2_pending[0] = ctx->pre2_pending[1] = 0;
     RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->lane[RDVIO_LANE_SOLVER]));
     memcpy(out, (const double *)ctx->pre2_pinned + off, n * sizeof(double));
+    return RDVIO_OK;
+}
+
+int rdvio_hip_debug_last_select_path(const rdvio_hip_ctx *ctx) { return ctx ? ctx->last_select_path : -1; }
+int rdvio_hip_debug_last_select_stamps(const rdvio_hip_ctx *ctx, int32_t *out5) {
+    if (!ctx || !out5) return RDVIO_ERR_INVALID;
+    for (int q = 0; q < 5; ++q) out5[q] = ctx->last_select_stamps[q];
     return RDVIO_OK;
 }
 

@@ -66,6 +66,8 @@ struct rdvio_hip_ctx {
     // uploaded existing keypoints
     int32_t *sel_hdr = nullptr;      // [0] candidates, [1] capacity flags (host road when != 0), [2] corners, [3] new keypoints
     double *sel_new = nullptr;       // = (double *)(sel_hdr + 16)
+    int last_select_path = -1;       // rdvio_hip_debug_last_select_path
+    int32_t last_select_stamps[5] = {0, 0, 0, 0, 0};   // gftt_select_kernel: 10-ns stamps after load / sort / cell lists / greedy pass, candidates
     float *sel_corners = nullptr;
     double *sel_existing = nullptr;
 

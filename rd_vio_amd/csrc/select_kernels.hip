@@ -36,36 +36,150 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
                                                         int w, int h, int max_corners, int cell, float md2, float *__restrict__ corners_out,
                                                         int32_t *__restrict__ hdr) {
     __shared__ unsigned long long keys[RDVIO_SEL_NC_MAX];   // 64 KB: (ordered response << 32) | pixel index, sorted descending
-    __shared__ unsigned short clist[RDVIO_SEL_NC_MAX];      // 16 KB: candidate ranks grouped by grid cell
+    __shared__ unsigned int clist[RDVIO_SEL_NC_MAX];        // 32 KB: candidates grouped by grid cell: rank | x in cell << 13 | y in cell << 19
     __shared__ unsigned char state[RDVIO_SEL_NC_MAX];       //  8 KB: 0 undecided, 1 accepted, 2 rejected
     __shared__ int coff[RDVIO_SEL_GCELLS_MAX + 1];          // 16 KB: first clist entry of a cell
     __shared__ int ccur[RDVIO_SEL_GCELLS_MAX];              // 16 KB: per-cell counters / fill cursors
-    __shared__ unsigned short cx_[RDVIO_SEL_NC_MAX], cy_[RDVIO_SEL_NC_MAX];  // 32 KB: pixel coordinates by rank (decoded once)
     __shared__ int wsum[ST / 64];
     __shared__ int s_total, s_fail;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int nc = (int)min(scalars[1], (uint32_t)cap);
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell, ncell = gw * gh;
+    const unsigned long long clk0 = wall_clock64();   // diagnostic stamps (10 ns units) -> hdr[8..12]
+#define SEL_STAMP(k) do { if (t == 0) hdr[8 + (k)] = (int)(wall_clock64() - clk0); } while (0)
     if (t == 0) {
         hdr[0] = nc;
-        hdr[1] = (nc > RDVIO_SEL_NC_MAX || ncell > RDVIO_SEL_GCELLS_MAX || max_corners > RDVIO_SEL_CORNERS_MAX || w > 65535 || h > 65535) ? 1 : 0;  // host road
+        hdr[1] = (nc > RDVIO_SEL_NC_MAX || ncell > RDVIO_SEL_GCELLS_MAX || max_corners > RDVIO_SEL_CORNERS_MAX || w > 65535 || h > 65535 || cell > 64) ? 1 : 0;  // host road
         hdr[2] = 0;
+        hdr[14] = 0;
     }
-    if (nc > RDVIO_SEL_NC_MAX || ncell > RDVIO_SEL_GCELLS_MAX || max_corners > RDVIO_SEL_CORNERS_MAX || w > 65535 || h > 65535) return;
+    if (nc > RDVIO_SEL_NC_MAX || ncell > RDVIO_SEL_GCELLS_MAX || max_corners > RDVIO_SEL_CORNERS_MAX || w > 65535 || h > 65535 || cell > 64) return;
+    // ---- which candidates take part.  The greedy pass stops at maxCorners accepted corners, as a rule long before the end of the
+    // list: sorting all of it (4096-8192 keys: 78-91 compare-exchange stages) to walk the first few hundred is the kernel's largest
+    // piece.  First attempt: only the candidates of the top response bins -- a histogram over 8 exponent + 4 mantissa bits of the
+    // response, bins taken from the top until they hold `target` candidates; those ARE the head of the sorted list (everything
+    // left out has a smaller key), so the greedy pass over them is the head of the full pass.  If it ends short of maxCorners
+    // the kernel starts over with every candidate.
+    __shared__ int s_bstar, s_n1, s_cnt;
+    const int target = max(1024, 6 * max_corners);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    bool partial = attempt == 0 && nc > 2 * target && (scalars[0] & 0x80000000u) != 0;   // (workgroup-uniform)
+    if (partial) {
+        for (int i = t; i < 4096; i += ST) coff[i] = 0;
+        if (t == 0) {
+            s_bstar = -1;
+            s_n1 = 0;
+            s_cnt = 0;
+        }
+        __syncthreads();
+        for (int i = t; i < nc; i += ST) {
+            const uint32_t o = f2ord(cand[i].v);
+            atomicAdd(&coff[(o & 0x80000000u) ? (int)((o >> 19) & 0xfffu) : 0], 1);
+        }
+        __syncthreads();
+        // counts from the top bin downwards: thread t owns bins 4095 - 4 t - q
+        int v[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[q] = coff[4095 - (4 * t + q)];
+            sum += v[q];
+        }
+        int inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int nn_ = __shfl_up(inc, off);
+            if (lane >= off) inc += nn_;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int run = inc - sum;
+        for (int q = 0; q < wave; ++q) run += wsum[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int after = run + v[q];
+            if (run < target && after >= target) {   // (one bin crosses the target, if the list is long enough)
+                s_bstar = 4095 - (4 * t + q);
+                s_n1 = after;
+            }
+            run = after;
+        }
+        __syncthreads();
+        if (s_bstar < 0 || s_n1 > 2048) partial = false;
+        __syncthreads();
+    }
+    const int n = partial ? s_n1 : nc;   // candidates of this attempt
     // ---- sort (bitonic, descending).  Keys are unique (the pixel index is part of them), padding keys (0) sink to the end.
     int P = 2;
-    while (P < nc) P <<= 1;
-    for (int i = t; i < P; i += ST) {
-        unsigned long long k = 0;
-        if (i < nc) k = ((unsigned long long)f2ord(cand[i].v) << 32) | (uint32_t)cand[i].idx;
-        keys[i] = k;
-        if (i < RDVIO_SEL_NC_MAX) state[i] = 0;
+    while (P < n) P <<= 1;
+    if (partial) {
+        const int bstar = s_bstar;
+        for (int i = t; i < nc; i += ST) {
+            const uint32_t o = f2ord(cand[i].v);
+            const int bin = (o & 0x80000000u) ? (int)((o >> 19) & 0xfffu) : 0;
+            if (bin >= bstar) keys[atomicAdd(&s_cnt, 1)] = ((unsigned long long)o << 32) | (uint32_t)cand[i].idx;
+        }
+        for (int i = n + t; i < P; i += ST) keys[i] = 0;
+        for (int i = t; i < P; i += ST) state[i] = 0;
+    } else {
+        for (int i = t; i < P; i += ST) {
+            unsigned long long k = 0;
+            if (i < nc) k = ((unsigned long long)f2ord(cand[i].v) << 32) | (uint32_t)cand[i].idx;
+            keys[i] = k;
+            if (i < RDVIO_SEL_NC_MAX) state[i] = 0;
+        }
     }
     for (int i = t; i < ncell; i += ST) ccur[i] = 0;
     __syncthreads();
+    SEL_STAMP(0);
     // Thread t owns the elements t, t + ST, ...: a compare-exchange at distance j < 64 stays inside one wavefront (same element
     // row, lanes t and t ^ j), whose LDS operations execute in order -- such a stage needs no workgroup barrier, and 57 of the 78
     // stages of a 4096-key sort are of that kind.  A barrier stands before and behind every stage that crosses wavefronts.
+    // Up to two keys per thread (P <= 2 ST: every frame of the reference's sizes, and the top-bin attempt always) the keys are
+    // sorted IN REGISTERS: wave-local stages exchange through the cross-lane network, the two keys of a thread meet in the
+    // thread, only the stages at distance 64 ... ST/2 go through LDS.
+    if (P <= 2 * ST) {
+        const bool two = P > ST;
+        const int PP = two ? 2 * ST : ST;   // (threads beyond P hold zero keys: they stay at the end of a descending sort)
+        unsigned long long r[2];
+        r[0] = t < P ? keys[t] : 0ull;
+        r[1] = (two && t + ST < P) ? keys[t + ST] : 0ull;
+        __syncthreads();
+        for (int k = 2; k <= PP; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (j >= ST) {   // the thread's own two keys (indices t and t + ST), k = 2 ST: descending
+                    if (r[0] < r[1]) {
+                        const unsigned long long tmp = r[0];
+                        r[0] = r[1];
+                        r[1] = tmp;
+                    }
+                    continue;
+                }
+                unsigned long long o[2];
+                if (j >= 64) {
+                    keys[t] = r[0];
+                    if (two) keys[t + ST] = r[1];
+                    __syncthreads();
+                    o[0] = keys[t ^ j];
+                    o[1] = two ? keys[(t ^ j) + ST] : 0ull;
+                    __syncthreads();
+                } else {
+                    o[0] = __shfl_xor(r[0], j);
+                    o[1] = two ? __shfl_xor(r[1], j) : 0ull;
+                }
+                const bool lower = (t & j) == 0;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (e == 1 && !two) break;
+                    const bool desc = ((t + ST * e) & k) == 0;
+                    const bool take_max = lower == desc;
+                    const unsigned long long mx = r[e] > o[e] ? r[e] : o[e], mn = r[e] > o[e] ? o[e] : r[e];
+                    r[e] = take_max ? mx : mn;
+                }
+            }
+        if (t < P) keys[t] = r[0];
+        if (two && t + ST < P) keys[t + ST] = r[1];
+        __syncthreads();
+    } else {
     bool synced = true;
     for (int k = 2; k <= P; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -92,12 +206,12 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
             }
         }
     if (!synced) __syncthreads();
+    }
+    SEL_STAMP(1);
     // ---- candidates grouped by grid cell (counting sort; the order inside a cell does not matter)
-    for (int i = t; i < nc; i += ST) {
+    for (int i = t; i < n; i += ST) {
         const int idx = (int)(uint32_t)keys[i];
         const int y = idx / w, x = idx - y * w;
-        cx_[i] = (unsigned short)x;
-        cy_[i] = (unsigned short)y;
         atomicAdd(&ccur[(y / cell) * gw + x / cell], 1);
     }
     __syncthreads();
@@ -136,52 +250,66 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
         s_fail = 0;
     }
     __syncthreads();
-    for (int i = t; i < nc; i += ST) {
-        const int x = cx_[i], y = cy_[i], c = (y / cell) * gw + x / cell;
-        clist[coff[c] + atomicAdd(&ccur[c], 1)] = (unsigned short)i;
+    for (int i = t; i < n; i += ST) {
+        const int idx = (int)(uint32_t)keys[i];
+        const int y = idx / w, x = idx - y * w, xc = x / cell, yc = y / cell, c = yc * gw + xc;
+        clist[coff[c] + atomicAdd(&ccur[c], 1)] = (unsigned)i | ((unsigned)(x - xc * cell) << 13) | ((unsigned)(y - yc * cell) << 19);
     }
     __syncthreads();
+    SEL_STAMP(2);
     // ---- greedy minDistance selection, a chunk of 1024 ranks at a time
-    for (int base = 0; base < nc; base += ST) {
+    for (int base = 0; base < n; base += ST) {
         if (s_total >= max_corners) break;  // (uniform: s_total is only written between barriers)
         const int i = base + t;
-        const bool mine = i < nc;
+        const bool mine = i < n;
         int x = 0, y = 0;
         if (mine) {
-            x = cx_[i];
-            y = cy_[i];
+            const int idx = (int)(uint32_t)keys[i];
+            y = idx / w;
+            x = idx - y * w;
         }
         const int xc = x / cell, yc = y / cell;
         const int x1 = max(0, xc - 1), y1 = max(0, yc - 1), x2 = min(gw - 1, xc + 1), y2 = min(gh - 1, yc + 1);
+        // the cells x1..x2 of a grid row are one contiguous run of the cell-ordered list: three runs per candidate, their
+        // boundaries (also the cell boundaries inside a run) read up front; an entry carries its rank and its position inside its
+        // cell, so nothing else is read per entry
+        auto for_each_close_higher = [&](auto &&fn) {
+            for (int yy = y1; yy <= y2; ++yy) {
+                const int c0 = yy * gw + x1;
+                const int b0 = coff[c0], b1 = coff[c0 + 1], b2 = (x1 + 1 <= x2) ? coff[c0 + 2] : b1, b3 = (x1 + 2 <= x2) ? coff[c0 + 3] : b2;
+                for (int e = b0; e < b3; ++e) {
+                    const unsigned v = clist[e];
+                    const int j = (int)(v & 8191u);
+                    if (j >= i) continue;
+                    const int xx = x1 + (e >= b1 ? 1 : 0) + (e >= b2 ? 1 : 0);
+                    const float dx = (float)x - (float)(xx * cell + (int)((v >> 13) & 63u)), dy = (float)y - (float)(yy * cell + (int)((v >> 19) & 63u));
+                    if (!(dx * dx + dy * dy < md2)) continue;
+                    fn(j);
+                }
+            }
+        };
         // higher-priority candidates closer than minDistance, collected once (typically a handful)
         constexpr int NBMAX = 12;
         int nb[NBMAX], nn = 0;
         bool overflow = false;
         if (mine)
-            for (int yy = y1; yy <= y2; ++yy)
-                for (int xx = x1; xx <= x2; ++xx) {
-                    const int cc = yy * gw + xx;
-                    for (int e = coff[cc]; e < coff[cc + 1]; ++e) {
-                        const int j = clist[e];
-                        if (j >= i) continue;
-                        const float dx = (float)x - (float)cx_[j], dy = (float)y - (float)cy_[j];
-                        if (!(dx * dx + dy * dy < md2)) continue;
-                        if (nn < NBMAX) {
+            for_each_close_higher([&](int j) {
+                if (nn < NBMAX) {
 #pragma unroll
-                            for (int q = 0; q < NBMAX; ++q)
-                                if (q == nn) nb[q] = j;   // (static indices: the list stays in registers)
-                            ++nn;
-                        } else {
-                            overflow = true;
-                        }
-                    }
+                    for (int q = 0; q < NBMAX; ++q)
+                        if (q == nn) nb[q] = j;   // (static indices: the list stays in registers)
+                    ++nn;
+                } else {
+                    overflow = true;
                 }
+            });
         // Resolution by polling: a candidate only ever waits for higher-priority ones, so the highest-priority undecided
         // candidate can always decide.  Every thread polls its own neighbours (states only move from undecided to final).
         // The loop is WAVE-UNIFORM (it runs until every lane of the wavefront is done) and the state is stored inside its
         // body: a divergent `store; break` would be moved behind the loop by the compiler's control-flow structurisation,
         // i.e. published only when the whole wavefront has left the loop -- a lane waiting for another lane of its own
         // wavefront would then wait forever.  The trip count is bounded; running out of trips hands the frame to the host road.
+        if (base == 0) SEL_STAMP(4);
         typedef volatile __attribute__((address_space(3))) unsigned char lds_vu8;  // (volatile AND LDS-typed: ds_read / ds_write, re-read every trip)
         lds_vu8 *vstate = (lds_vu8 *)state;
         bool done = !mine;
@@ -196,21 +324,12 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
                         any_acc |= sj == 1;
                         any_und |= sj == 0;
                     }
-                if (overflow && !any_acc) {  // (rare: more than NBMAX close neighbours) the full walk
-                    for (int yy = y1; yy <= y2; ++yy)
-                        for (int xx = x1; xx <= x2; ++xx) {
-                            const int cc = yy * gw + xx;
-                            for (int e = coff[cc]; e < coff[cc + 1]; ++e) {
-                                const int j = clist[e];
-                                if (j >= i) continue;
-                                const float dx = (float)x - (float)cx_[j], dy = (float)y - (float)cy_[j];
-                                if (!(dx * dx + dy * dy < md2)) continue;
-                                const int sj = vstate[j];
-                                any_acc |= sj == 1;
-                                any_und |= sj == 0;
-                            }
-                        }
-                }
+                if (overflow && !any_acc)   // (rare: more than NBMAX close neighbours) the full walk
+                    for_each_close_higher([&](int j) {
+                        const int sj = vstate[j];
+                        any_acc |= sj == 1;
+                        any_und |= sj == 0;
+                    });
                 if (any_acc || !any_und) {
                     vstate[i] = any_acc ? 2 : 1;
                     done = true;
@@ -222,7 +341,9 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
             }
             __builtin_amdgcn_s_sleep(1);
         }
+        if (base == 0 && lane == 0) atomicMax(&hdr[14], trips);
         __syncthreads();
+        if (base == 0) SEL_STAMP(5);
         if (s_fail) {
             if (t == 0) hdr[1] = 4;
             return;
@@ -245,6 +366,11 @@ __global__ __launch_bounds__(ST) void gftt_select_kernel(const HarrisCand *__res
         __syncthreads();
         if (t == 0) s_total += chunk;
         __syncthreads();
+    }
+    __syncthreads();
+    SEL_STAMP(3);
+    if (t == 0) hdr[4] = partial ? 1 : (attempt == 0 ? 0 : 2);   // diagnostic: 1 the top bins sufficed, 2 they did not (second pass over everything), 0 one pass over everything
+    if (!(partial && s_total < max_corners)) break;   // (uniform: s_total is final behind the barrier)
     }
     if (t == 0) hdr[2] = min(s_total, max_corners);
 }

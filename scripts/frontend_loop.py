@@ -33,3 +33,7 @@ timeit("track_keypoints", lambda: ga.track_keypoints(gb, pts, guess))
 timeit("detect_keypoints", lambda: ga.detect_keypoints(pts[: len(pts) // 2], max_points=N, keypoint_distance=20.0))
 nxt, st = ga.track_keypoints(gb, pts, guess)
 print("tracked", int(st.sum()), "of", len(pts))
+import ctypes
+st = (ctypes.c_int32 * 5)()
+ctx._lib.rdvio_hip_debug_last_select_stamps(ctx._h, st)
+print("gftt_select_kernel stamps (us since kernel start): load %.1f sort %.1f cell lists %.1f greedy %.1f; %d candidates, path %d" % (st[0] / 100, st[1] / 100, st[2] / 100, st[3] / 100, st[4], ctx._lib.rdvio_hip_debug_last_select_path(ctx._h)))

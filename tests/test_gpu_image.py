@@ -128,13 +128,18 @@ def test_harris_and_detect_bit_exact(ctx, oracle, size, seed):
             assert len(ref_kp) > len(existing)
 
 
-@pytest.mark.parametrize("kind", ["room_752", "room_1280", "fractional_existing", "radius_above_min_distance", "noise_host_road", "flat"])
+@pytest.mark.parametrize("kind", ["room_752", "room_1280", "fractional_existing", "radius_above_min_distance", "noise_host_road", "flat",
+                                  "top_bins_suffice", "top_bins_fall_short"])
 def test_device_keypoint_selection_is_order_exact(ctx, oracle, kind, monkeypatch):
     """Device-side GFTT ordering + greedy minDistance + Poisson-disk thinning + border test (select_kernels.hip) against the
     oracle AND against the product's own host road (RDVIO_HOST_SELECT=1, host_select.cpp): same keypoints, same order, bit
     for bit.  Cases: ray-cast room frames, existing keypoints at fractional (tracked) positions incl. two in one Poisson cell,
     a Poisson radius above GFTT's minDistance (the inserts then depend on each other), a noise image with > 8192 local maxima
-    (beyond the kernels' LDS capacity: the entry point must take the host road and still be exact), a flat image."""
+    (beyond the kernels' LDS capacity: the entry point must take the host road and still be exact), a flat image; two textures
+    with thousands of maxima for the sort that starts with the top response bins -- one where their maxima yield maxCorners
+    corners (~6800 maxima, 1026 sorted) and one where the strongest maxima crowd into one region, the greedy pass over them ends
+    short and the kernel has to start over with every candidate (both roads asserted through rdvio_hip_debug_last_select_path)."""
+    import scipy.ndimage as ndi
     rng = np.random.default_rng(5)
     w, h, maxp, dist = 752, 480, 150, 10.0
     if kind == "room_1280":
@@ -145,6 +150,18 @@ def test_device_keypoint_selection_is_order_exact(ctx, oracle, kind, monkeypatch
         img = rng.integers(0, 256, (h, w)).astype(np.uint8)
     elif kind == "flat":
         img = np.full((h, w), 77, np.uint8)
+    elif kind == "top_bins_suffice":
+        g7 = np.random.default_rng(7)
+        tex = ndi.gaussian_filter(g7.normal(0, 1, (h, w)), 3.5)
+        img = (128 + 90 * tex / np.abs(tex).max()).astype(np.uint8)
+    elif kind == "top_bins_fall_short":
+        g7 = np.random.default_rng(7)
+        fine = ndi.gaussian_filter(g7.normal(0, 1, (h, w)), 2.0)
+        coarse = ndi.gaussian_filter(g7.normal(0, 1, (h, w)), 3.0)
+        mix = 0.45 * coarse / coarse.std()
+        mix[100:380, 200:480] = (fine / fine.std())[100:380, 200:480]
+        img = np.clip(128 + 30 * mix, 0, 255).astype(np.uint8)
+        maxp = 250
     else:
         img = synth.make_stream(2, w, h, synth.EUROC_K)[0][1]
     Lo, pi, pd = oracle.preprocess(img)
@@ -161,6 +178,13 @@ def test_device_keypoint_selection_is_order_exact(ctx, oracle, kind, monkeypatch
     ref_kp = oracle.detect_keypoints(lvl0, existing, maxp, dist)
     got_kp = g.detect_keypoints(existing, maxp, dist)
     assert ref_kp.shape == got_kp.shape and (ref_kp == got_kp).all()
+    path = ctx._lib.rdvio_hip_debug_last_select_path(ctx._h)
+    if kind == "top_bins_suffice":
+        assert path == 1
+    elif kind == "top_bins_fall_short":
+        assert path == 2
+    elif kind == "noise_host_road":
+        assert path == -1
     if kind == "flat":
         assert len(got_kp) == len(existing)
     else:
