@@ -358,6 +358,42 @@ def test_one_wavefront_solve_of_one_frame_problems(ctx, oracle, monkeypatch):
         assert got_sm.iterations >= 2 and np.array_equal(got_d, ref_d)   # (no free landmark: depths untouched)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("k_free", [2, 3, 4, 5])
+def test_subwindow_shaped_problems(ctx, oracle, monkeypatch, k_free):
+    """refine_subwindow's shape: a fixed keyframe, K free frames behind it, every landmark fixed, a chain of preintegration
+    factors (no Schur complement to form, a block-tridiagonal reduced system).  Same accept / reject path as the oracle; the
+    switch that sends one-frame problems down the general road must not matter for K >= 2.  (A one-wavefront factorisation for
+    K <= 4 was built and measured in round 3 -- rows in lanes, unblocked, fully unrolled: it spilled ~1000 scratch accesses and
+    ran 1.5-2.3 x SLOWER than the blocked eight-wavefront road; not kept)"""
+    for seed in (662, 663):
+        sub = synth.make_window_problem(9, 150, seed, preintegrate=_oracle_pre(oracle))
+        sub["frame_fixed"] = np.ones(9, dtype=np.uint8)
+        sub["frame_fixed"][9 - k_free:] = 0
+        sub["lm_fixed"] = np.ones(len(sub["inv_depth"]), dtype=np.uint8)
+        keep = sub["tgt"] >= 9 - k_free
+        for k in ("tgt", "ref", "lm", "tangent"):
+            sub[k] = sub[k][keep]
+        sub["pre_i"], sub["pre_j"], sub["preint"] = sub["pre_i"][-k_free:], sub["pre_j"][-k_free:], sub["preint"][-k_free:]
+        for k in ("prior_frames", "lin", "S", "f"):
+            sub.pop(k, None)
+        rng = np.random.default_rng(seed)
+        sub["states"] = sub["states"].copy()
+        sub["states"][9 - k_free:, 4:7] += rng.normal(0, 0.02, (k_free, 3))
+        sub["states"][9 - k_free:, 7:10] += rng.normal(0, 0.05, (k_free, 3))
+        ref_s, ref_d, ref_sm = oracle.ba_solve(sub, 30)
+        got_s, got_d, got_sm = ctx.ba_solve(sub, 30)
+        monkeypatch.setenv("RDVIO_NO_SMALL_SOLVE", "1")
+        gen_s, gen_d, gen_sm = ctx.ba_solve(sub, 30)
+        monkeypatch.setenv("RDVIO_NO_SMALL_SOLVE", "0")
+        for sm in (got_sm, gen_sm):
+            assert (sm.iterations, sm.successful_steps, sm.termination) == (ref_sm.iterations, ref_sm.successful_steps, ref_sm.termination)
+            assert abs(sm.final_cost - ref_sm.final_cost) <= 1e-6 * abs(ref_sm.final_cost)
+        assert np.abs(got_s - ref_s).max() < 1e-6 and np.abs(gen_s - ref_s).max() < 1e-6
+        assert np.abs(got_s - gen_s).max() < 1e-8
+        assert got_sm.iterations >= 2 and np.array_equal(got_d, ref_d)
+
+
 # ---------------------------------------------------------------------------------------------- row A10
 def test_rotation_prior_eval_parity(ctx, oracle):
     """CeresRotationPriorFactor::Evaluate (ceres/rotation_factor.h:22-58) on the device against the oracle, 1e-11 relative
