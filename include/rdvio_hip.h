@@ -235,6 +235,12 @@ int rdvio_hip_ba_solve(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, int max_i
  * without any host->device traffic; fetch copies the result back. */
 #define RDVIO_BA_SLOTS 2 /* e.g. slot 0 = window BA (refine_window), slot 1 = localize_newframe */
 int rdvio_hip_ba_upload(rdvio_hip_ctx *ctx, int slot, const rdvio_ba_problem *pb);
+/* rdvio_hip_ba_upload for a solve that CONTINUES another one: the initial state of frame `to_frame` of this problem is the result
+ * of frame `from_frame` of the solve in `from_slot`, copied on the device in stream order -- the host packs and uploads this
+ * problem while the other solve is still running and fetches both afterwards (localize_newframe -> refine_subwindow,
+ * sliding_window_tracker.cpp:80-99: the second graph does not depend on the first result, only its starting point does).
+ * pb->states' row to_frame is ignored.  Waits for this slot's previous upload only, not for the lane. */
+int rdvio_hip_ba_upload_chained(rdvio_hip_ctx *ctx, int slot, const rdvio_ba_problem *pb, int from_slot, int from_frame, int to_frame);
 int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int slot, int max_iterations);
 int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double *inv_depth_out,
                        rdvio_ba_summary *summary);

@@ -91,6 +91,13 @@ typedef struct rdvio_backend {
     int (*preintegrate_estimator_begin)(void *user, int nseg, const int32_t *seg_off, const double *imu, const double *t_end, const double *bg,
                                         const double *ba, const double *noise, int compute_jacobian, int compute_covariance);
     int (*preintegrate_estimator_end)(void *user, double *preint_out);
+    /* optional pair (NULL = ba_solve): Solver::solve in two halves on one of two slots (0 / 1).  begin packs, uploads and enqueues;
+     * with chain_from_slot >= 0 the initial state of frame chain_to_frame is the RESULT of frame chain_from_frame of the solve begun
+     * in that slot (copied behind the backend: the orchestration builds the second graph while the first solve runs --
+     * localize_newframe -> refine_subwindow); end waits and copies out.  Ends may come in any order after the begins. */
+    int (*ba_solve_begin)(void *user, int slot, const rdvio_ba_problem *pb, int max_iterations, int chain_from_slot, int chain_from_frame,
+                          int chain_to_frame);
+    int (*ba_solve_end)(void *user, int slot, double *states_out, double *inv_depth_out, rdvio_ba_summary *summary);
 } rdvio_backend;
 
 /* rdvio::Config (types.h:85-151) with the defaults of src/rdvio/src/config.cpp; rdvio_pipeline_config_default fills

@@ -154,4 +154,6 @@ void rdvio_oracle_backend_fill(rdvio_backend *b) {
     b->parsac_generate_score = NULL;
     b->preintegrate_estimator_begin = NULL;
     b->preintegrate_estimator_end = NULL;
+    b->ba_solve_begin = NULL; /* the CPU path solves one problem after the other */
+    b->ba_solve_end = NULL;
 }

@@ -247,6 +247,9 @@ void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
     for (int s = 0; s < RDVIO_BA_SLOTS; ++s) {
         if (ctx->ba[s].ev0) (void)hipEventDestroy(ctx->ba[s].ev0);
         if (ctx->ba[s].ev1) (void)hipEventDestroy(ctx->ba[s].ev1);
+        if (ctx->ba[s].up_ev) (void)hipEventDestroy(ctx->ba[s].up_ev);
+        if (s == 0 && ctx->chain_ev) (void)hipEventDestroy(ctx->chain_ev);
+        if (s == 0 && ctx->chain_stream) (void)hipStreamDestroy(ctx->chain_stream);
         if (ctx->ba[s].host) (void)hipHostFree(ctx->ba[s].host);
         (void)hipFree(ctx->ba[s].arena);
     }

@@ -97,6 +97,7 @@ struct rdvio_hip_ctx {
         // fused preintegration jobs of the uploaded problem (rdvio_ba_problem::n_pre_jobs): device views of the raw samples and
         // where the records go back to
         bool retried = false;   // a team solve whose helpers stayed silent was repeated on the leader alone
+        hipEvent_t up_ev = nullptr;   // behind this slot's last upload (rdvio_hip_ba_upload_chained waits for it, not for the lane)
         size_t user0_off = 0;
         int n_jobs = 0;
         const int32_t *job_off = nullptr;
@@ -109,6 +110,10 @@ struct rdvio_hip_ctx {
         bool timed_launch = false;
     } ba[RDVIO_BA_SLOTS];
     size_t ba_host_bytes = 0, ba_arena_bytes = 0;
+    // rdvio_hip_ba_upload_chained: the continuing solve's inputs (and its preintegration jobs) travel on a stream of their own,
+    // beside the solve they continue; the solver lane waits for chain_ev before the continuing kernel
+    hipStream_t chain_stream = nullptr;
+    hipEvent_t chain_ev = nullptr;
     // marginalisation: a solver slot of its own (the linearisation is shared with the solver) + tail scratch
     BaSlot marg;
     size_t marg_bytes = 0;

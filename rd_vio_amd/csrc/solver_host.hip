@@ -335,12 +335,46 @@ int rdvio_hip_ba_upload(rdvio_hip_ctx *ctx, int slot, const rdvio_ba_problem *pb
     // the pinned blob may still be in flight from a previous upload on this stream
     RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->lane[RDVIO_LANE_SOLVER]));
     if (int rc = rdvio_ba_prepare(ctx, S, pb, ctx->ba_arena_bytes, false)) return rc;
+    S.ws.chain_src = nullptr;
+    S.ws.chain_frame = 0;
     RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(S.arena, S.host, S.in_bytes, hipMemcpyHostToDevice, ctx->lane[RDVIO_LANE_SOLVER]));
     // fused PreIntegrator::integrate: the records of this solve's preintegration factors, straight into their slots of the arena
     if (S.n_jobs > 0)
         if (int rc = rdvio_launch_preintegrate(ctx, ctx->lane[RDVIO_LANE_SOLVER], S.n_jobs, S.job_off, S.job_imu, S.job_par, S.job_noise, 1, 1,
                                                const_cast<double *>(S.ws.preint)))
             return rc;
+    return RDVIO_OK;
+}
+
+int rdvio_hip_ba_upload_chained(rdvio_hip_ctx *ctx, int slot, const rdvio_ba_problem *pb, int from_slot, int from_frame, int to_frame) {
+    if (!ctx || bad_slot(slot) || bad_slot(from_slot) || from_slot == slot) return RDVIO_ERR_INVALID;
+    rdvio_hip_ctx::BaSlot &S = ctx->ba[slot], &F = ctx->ba[from_slot];
+    if (!F.ready) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "no BA problem uploaded in slot %d to chain from", from_slot);
+    if (!pb || from_frame < 0 || from_frame >= F.ws.nfr || to_frame < 0 || to_frame >= pb->n_frames)
+        return rdvio_fail(ctx, RDVIO_ERR_INVALID, "chained frame index out of range");
+    S.ready = false;
+    if (!ctx->chain_stream) {
+        RDVIO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->chain_stream, hipStreamNonBlocking));
+        RDVIO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->chain_ev, hipEventDisableTiming));
+    }
+    // only THIS slot's pinned blob must have left for the device (the solve of the other slot may still be running: that is the point)
+    if (S.up_ev) RDVIO_HIP_CHECK(ctx, hipEventSynchronize(S.up_ev));
+    else RDVIO_HIP_CHECK(ctx, hipEventCreateWithFlags(&S.up_ev, hipEventDisableTiming));
+    if (int rc = rdvio_ba_prepare(ctx, S, pb, ctx->ba_arena_bytes, false)) return rc;
+    // Inputs and preintegration jobs on the side stream, BESIDE the solve this one continues (copies and kernels that alternate on
+    // one stream cost an engine hand-over each, and the jobs would sit between the two solves); the solver lane only waits for them.
+    hipStream_t side = ctx->chain_stream;
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(S.arena, S.host, S.in_bytes, hipMemcpyHostToDevice, side));
+    RDVIO_HIP_CHECK(ctx, hipEventRecord(S.up_ev, side));
+    if (S.n_jobs > 0)
+        if (int rc = rdvio_launch_preintegrate(ctx, side, S.n_jobs, S.job_off, S.job_imu, S.job_par, S.job_noise, 1, 1, const_cast<double *>(S.ws.preint)))
+            return rc;
+    RDVIO_HIP_CHECK(ctx, hipEventRecord(ctx->chain_ev, side));
+    RDVIO_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->lane[RDVIO_LANE_SOLVER], ctx->chain_ev, 0));
+    // the initial value of frame to_frame = the other solve's result for its frame from_frame: read by this solve's own setup (it
+    // runs behind that solve on the solver lane)
+    S.ws.chain_src = F.ws.x + 16 * (size_t)from_frame;
+    S.ws.chain_frame = to_frame;
     return RDVIO_OK;
 }
 

@@ -1171,7 +1171,8 @@ __device__ __attribute__((noinline)) void solver_setup(LdsWs &w, Shared &sh, lds
     const int nl = w.nl, nfree = w.nfree, NAs = 6 * nfree + 2;
     if (t == 0) { sh.seq = 0; sh.lost = 0; }
     for (int i = t; i < w.nfr * 16; i += T) {
-        const double v = w.x0[i];
+        double v = w.x0[i];
+        if (w.chain_src && i / 16 == w.chain_frame) v = w.chain_src[i % 16];   // (stream order: that solve has finished)
         w.x[i] = v;
         w.user[i] = w.user0 ? w.user0[i] : v;
     }

@@ -70,6 +70,10 @@ struct SolverWs {
     int mute_helpers;                    // test switch (RDVIO_TEST_MUTE_HELPERS): helper workgroups exit at once
     int poison_lds;                      // test switch (RDVIO_TEST_POISON_LDS): every workgroup fills its LDS with 0xFF bytes first
     int no_lds_vectors;                  // diagnostic switch (RDVIO_NO_LDS_VECTORS): no LDS-resident small vectors
+    // a solve that continues another one (rdvio_hip_ba_upload_chained): frame chain_frame starts from the 16 doubles at chain_src
+    // (the other solve's result, in its arena) instead of its row of x0
+    const double *chain_src;
+    int chain_frame;
     int small_system;                    // one free frame, no free landmark (N = 15): the one-wavefront solve (set at launch)
     int wg_stride;                       // multi-workgroup launches: every wg_stride-th block of the grid is a team member (8: one XCD)
     double *m_Tm, *m_Lr, *m_er, *m_Wk, *m_V, *m_cs, *m_yv;

@@ -125,6 +125,15 @@ int ba_solve(void *user, const rdvio_ba_problem *pb, int max_iter, double *state
     return rdvio_hip_ba_solve(static_cast<HipBackend *>(user)->ctx, pb, max_iter, states, invd, sm);
 }
 
+int ba_solve_begin(void *user, int slot, const rdvio_ba_problem *pb, int max_iter, int from_slot, int from_frame, int to_frame) {
+    rdvio_hip_ctx *ctx = static_cast<HipBackend *>(user)->ctx;
+    if (int rc = from_slot >= 0 ? rdvio_hip_ba_upload_chained(ctx, slot, pb, from_slot, from_frame, to_frame) : rdvio_hip_ba_upload(ctx, slot, pb)) return rc;
+    return rdvio_hip_ba_solve_resident(ctx, slot, max_iter);
+}
+int ba_solve_end(void *user, int slot, double *states, double *invd, rdvio_ba_summary *sm) {
+    return rdvio_hip_ba_fetch(static_cast<HipBackend *>(user)->ctx, slot, states, invd, sm);
+}
+
 int marginalize(void *user, const rdvio_marg_problem *pb, double *S, double *f, double *lin) {
     return rdvio_hip_marginalize(static_cast<HipBackend *>(user)->ctx, pb, 0, S, f, lin, nullptr, nullptr, nullptr);
 }
@@ -201,6 +210,8 @@ extern "C" int rdvio_pipeline_create_hip(rdvio_pipeline **out, const rdvio_pipel
     fn.ransac_generate_score = ransac_generate_score;
     fn.ransac_fetch = ransac_fetch;
     fn.thin_tracks = thin_tracks;
+    fn.ba_solve_begin = ba_solve_begin;
+    fn.ba_solve_end = ba_solve_end;
     fn.preintegrate_estimator_begin = preintegrate_estimator_begin;
     fn.preintegrate_estimator_end = preintegrate_estimator_end;
     fn.marginalize_begin = marginalize_begin;

@@ -106,31 +106,50 @@ bool BaBuilder::add_integrated_preintegration(Frame *frame_i, Frame *frame_j, Pr
     return true;
 }
 
-bool BaBuilder::solve(rdvio_ba_summary *summary_out) {
-    HostTimer host_timer__(sh.prof, 10);
-    const int nfr = (int)frames.size(), nl = (int)lms.size();
-    std::vector<double> states((size_t)nfr * 16), invd((size_t)std::max(nl, 1)), zref((size_t)std::max(nl, 1) * 3);
-    for (int i = 0; i < nfr; ++i) frames[i]->get_state(&states[16 * (size_t)i]);
+// everything Solver::solve hands to the backend, packed once (the vectors live until the result has been applied)
+struct BaBuilder::Packed {
+    int nfr = 0, nl = 0, nf = 0, nrot = 0, npre = 0, njobs = 0;
+    std::vector<double> states, invd, zref, tangent, rot_zref, rot_tangent, preint, job_imu, job_par, states_out, invd_out;
+    std::vector<int32_t> tgt, ref, lm, rot_tgt, rot_ref, pre_i, pre_j, job_off, prior_frames;
+    double extr[14];
+    rdvio_ba_problem pb;
+    rdvio_ba_summary sm;
+    int slot = -1;   // >= 0: begun behind the backend, waiting for solve_end
+    std::chrono::steady_clock::time_point t0;
+    double seconds = 0.0;
+};
+
+BaBuilder::BaBuilder(Shared &sh) : sh(sh) {}
+BaBuilder::~BaBuilder() = default;
+
+void BaBuilder::pack() {
+    packed = std::make_unique<Packed>();
+    Packed &P = *packed;
+    const int nfr = P.nfr = (int)frames.size(), nl = P.nl = (int)lms.size();
+    P.states.resize((size_t)nfr * 16);
+    P.invd.resize((size_t)std::max(nl, 1));
+    P.zref.resize((size_t)std::max(nl, 1) * 3);
+    for (int i = 0; i < nfr; ++i) frames[i]->get_state(&P.states[16 * (size_t)i]);
     for (int l = 0; l < nl; ++l) {
-        invd[l] = lms[l]->inv_depth;
+        P.invd[l] = lms[l]->inv_depth;
         const auto [ref, kp] = lms[l]->first_keypoint();
         const V3 &z = ref->get_keypoint(kp);
-        zref[3 * l] = z.x; zref[3 * l + 1] = z.y; zref[3 * l + 2] = z.z;
+        P.zref[3 * l] = z.x; P.zref[3 * l + 1] = z.y; P.zref[3 * l + 2] = z.z;
     }
     std::stable_sort(facs.begin(), facs.end(), [](const Fac &a, const Fac &b) { return a.lm < b.lm; });
-    const int nf = (int)facs.size(), nrot = (int)rots.size(), npre = (int)pres.size();
-    std::vector<int32_t> tgt(std::max(nf, 1)), ref(std::max(nf, 1)), lm(std::max(nf, 1));
-    std::vector<double> tangent((size_t)std::max(nf, 1) * 9);
+    const int nf = P.nf = (int)facs.size(), nrot = P.nrot = (int)rots.size(), npre = P.npre = (int)pres.size();
+    P.tgt.resize(std::max(nf, 1)); P.ref.resize(std::max(nf, 1)); P.lm.resize(std::max(nf, 1));
+    P.tangent.resize((size_t)std::max(nf, 1) * 9);
     for (int k = 0; k < nf; ++k) {
-        tgt[k] = facs[k].tgt; ref[k] = facs[k].ref; lm[k] = facs[k].lm;
-        std::copy(facs[k].tangent, facs[k].tangent + 9, &tangent[9 * (size_t)k]);
+        P.tgt[k] = facs[k].tgt; P.ref[k] = facs[k].ref; P.lm[k] = facs[k].lm;
+        std::copy(facs[k].tangent, facs[k].tangent + 9, &P.tangent[9 * (size_t)k]);
     }
-    std::vector<int32_t> rot_tgt(std::max(nrot, 1)), rot_ref(std::max(nrot, 1));
-    std::vector<double> rot_zref((size_t)std::max(nrot, 1) * 3), rot_tangent((size_t)std::max(nrot, 1) * 9);
+    P.rot_tgt.resize(std::max(nrot, 1)); P.rot_ref.resize(std::max(nrot, 1));
+    P.rot_zref.resize((size_t)std::max(nrot, 1) * 3); P.rot_tangent.resize((size_t)std::max(nrot, 1) * 9);
     for (int k = 0; k < nrot; ++k) {
-        rot_tgt[k] = rots[k].tgt; rot_ref[k] = rots[k].ref;
-        rot_zref[3 * k] = rots[k].zref.x; rot_zref[3 * k + 1] = rots[k].zref.y; rot_zref[3 * k + 2] = rots[k].zref.z;
-        std::copy(rots[k].tangent, rots[k].tangent + 9, &rot_tangent[9 * (size_t)k]);
+        P.rot_tgt[k] = rots[k].tgt; P.rot_ref[k] = rots[k].ref;
+        P.rot_zref[3 * k] = rots[k].zref.x; P.rot_zref[3 * k + 1] = rots[k].zref.y; P.rot_zref[3 * k + 2] = rots[k].zref.z;
+        std::copy(rots[k].tangent, rots[k].tangent + 9, &P.rot_tangent[9 * (size_t)k]);
     }
     // integrations that ride inside the solve call: only when EVERY preintegration factor asks for it (the records then fill
     // the solve's slots in order); a mixed solve integrates through the separate entry first
@@ -143,65 +162,64 @@ bool BaBuilder::solve(rdvio_ba_summary *summary_out) {
         (void)PreIntegrator::integrate_batch(sh.backend, LANE_ESTIMATOR, jobs, true, true);
         njobs = 0;
     }
-    std::vector<int32_t> pre_i(std::max(npre, 1)), pre_j(std::max(npre, 1));
-    std::vector<double> preint((size_t)std::max(npre, 1) * RDVIO_PREINT_SIZE);
-    std::vector<int32_t> job_off(1, 0);
-    std::vector<double> job_imu, job_par;
+    P.njobs = njobs;
+    P.pre_i.resize(std::max(npre, 1)); P.pre_j.resize(std::max(npre, 1));
+    P.preint.resize((size_t)std::max(npre, 1) * RDVIO_PREINT_SIZE);
+    P.job_off.assign(1, 0);
     for (int k = 0; k < npre; ++k) {
-        pre_i[k] = pres[k].i; pre_j[k] = pres[k].j;
+        P.pre_i[k] = pres[k].i; P.pre_j[k] = pres[k].j;
         if (njobs > 0) {
-            for (const ImuData &d : pres[k].job->data) job_imu.insert(job_imu.end(), {d.t, d.w.x, d.w.y, d.w.z, d.a.x, d.a.y, d.a.z});
-            job_off.push_back((int32_t)(job_imu.size() / 7));
-            job_par.insert(job_par.end(), {pres[k].t, pres[k].bg.x, pres[k].bg.y, pres[k].bg.z, pres[k].ba.x, pres[k].ba.y, pres[k].ba.z});
+            for (const ImuData &d : pres[k].job->data) P.job_imu.insert(P.job_imu.end(), {d.t, d.w.x, d.w.y, d.w.z, d.a.x, d.a.y, d.a.z});
+            P.job_off.push_back((int32_t)(P.job_imu.size() / 7));
+            P.job_par.insert(P.job_par.end(), {pres[k].t, pres[k].bg.x, pres[k].bg.y, pres[k].bg.z, pres[k].ba.x, pres[k].ba.y, pres[k].ba.z});
         } else {
-            std::copy(pres[k].delta, pres[k].delta + RDVIO_PREINT_SIZE, &preint[(size_t)k * RDVIO_PREINT_SIZE]);
+            std::copy(pres[k].delta, pres[k].delta + RDVIO_PREINT_SIZE, &P.preint[(size_t)k * RDVIO_PREINT_SIZE]);
         }
     }
-    std::vector<int32_t> prior_frames;
     if (prior) const_cast<MarginalizationPrior *>(prior)->ready(sh.backend);   // a marginalisation begun frames ago lands here
     if (prior)
         for (Frame *f : prior->frames) {
             const int i = frame_index(f);
             if (i < 0) throw std::runtime_error("marginalisation prior covers a frame that is not a state of the solve");
-            prior_frames.push_back(i);
+            P.prior_frames.push_back(i);
         }
-    double extr[14];
+    double *extr = P.extr;
     const Frame *f0 = frames[0];
     extr[0] = f0->camera.q_cs.x; extr[1] = f0->camera.q_cs.y; extr[2] = f0->camera.q_cs.z; extr[3] = f0->camera.q_cs.w;
     extr[4] = f0->camera.p_cs.x; extr[5] = f0->camera.p_cs.y; extr[6] = f0->camera.p_cs.z;
     extr[7] = f0->imu.q_cs.x; extr[8] = f0->imu.q_cs.y; extr[9] = f0->imu.q_cs.z; extr[10] = f0->imu.q_cs.w;
     extr[11] = f0->imu.p_cs.x; extr[12] = f0->imu.p_cs.y; extr[13] = f0->imu.p_cs.z;
 
-    rdvio_ba_problem pb;
+    rdvio_ba_problem &pb = P.pb;
     std::memset(&pb, 0, sizeof pb);
     pb.n_frames = nfr;
-    pb.states = states.data();
+    pb.states = P.states.data();
     pb.frame_fixed = frame_fixed.data();
     pb.extr = extr;
     pb.sqrt_inv_cov = f0->sqrt_inv_cov;
     pb.n_landmarks = nl;
-    pb.z_ref = zref.data();
-    pb.inv_depth = invd.data();
+    pb.z_ref = P.zref.data();
+    pb.inv_depth = P.invd.data();
     pb.lm_fixed = lm_fixed.empty() ? reinterpret_cast<const uint8_t *>("") : lm_fixed.data();
     pb.n_factors = nf;
-    pb.tgt = tgt.data(); pb.ref = ref.data(); pb.lm = lm.data();
-    pb.tangent = tangent.data();
+    pb.tgt = P.tgt.data(); pb.ref = P.ref.data(); pb.lm = P.lm.data();
+    pb.tangent = P.tangent.data();
     pb.n_rot = nrot;
-    pb.rot_tgt = rot_tgt.data(); pb.rot_ref = rot_ref.data();
-    pb.rot_zref = rot_zref.data(); pb.rot_tangent = rot_tangent.data();
+    pb.rot_tgt = P.rot_tgt.data(); pb.rot_ref = P.rot_ref.data();
+    pb.rot_zref = P.rot_zref.data(); pb.rot_tangent = P.rot_tangent.data();
     pb.n_preint = npre;
-    pb.pre_i = pre_i.data(); pb.pre_j = pre_j.data(); pb.preint = preint.data();
+    pb.pre_i = P.pre_i.data(); pb.pre_j = P.pre_j.data(); pb.preint = P.preint.data();
     if (njobs > 0) {
         pb.n_pre_jobs = njobs;
-        pb.job_seg_off = job_off.data();
-        pb.job_imu = job_imu.data();
-        pb.job_par = job_par.data();
+        pb.job_seg_off = P.job_off.data();
+        pb.job_imu = P.job_imu.data();
+        pb.job_par = P.job_par.data();
         pb.job_noise = pres[0].job->noise;
-        pb.job_preint_out = preint.data();
+        pb.job_preint_out = P.preint.data();
     }
-    pb.n_prior = (int)prior_frames.size();
+    pb.n_prior = (int)P.prior_frames.size();
     if (prior) {
-        pb.prior_frames = prior_frames.data();
+        pb.prior_frames = P.prior_frames.data();
         pb.prior_lin = prior->lin.data();
         pb.prior_S = prior->S.data();
         pb.prior_f = prior->f.data();
@@ -209,34 +227,84 @@ bool BaBuilder::solve(rdvio_ba_summary *summary_out) {
     sh.counters.max_problem_frames = std::max<int64_t>(sh.counters.max_problem_frames, nfr);
     sh.counters.max_problem_factors = std::max<int64_t>(sh.counters.max_problem_factors, nf);
     sh.counters.rotation_prior_factors += nrot;
-    std::vector<double> states_out(states.size()), invd_out(invd.size());
-    rdvio_ba_summary sm;
-    std::memset(&sm, 0, sizeof sm);
-    {
-        BackendTimer timer(sh.counters, 4);
-        const auto t0 = std::chrono::steady_clock::now();
-        sh.backend.check(sh.backend.fn.ba_solve(sh.backend.fn.user, &pb, sh.cfg.solver_iteration_limit, states_out.data(), invd_out.data(), &sm),
-                         "ba_solve");
-        if (sh.prof.on) {
-            SolveProf &sp = sh.solve_prof;
-            sp.calls[kind]++; sp.iterations[kind] += sm.iterations; sp.factors[kind] += nf; sp.frames[kind] += nfr;
-            sp.seconds[kind] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        }
+    P.states_out.resize(P.states.size());
+    P.invd_out.resize(P.invd.size());
+    std::memset(&P.sm, 0, sizeof P.sm);
+}
+
+// the result back into the Frame / Track members, the integrators' records, the counters
+bool BaBuilder::apply(rdvio_ba_summary *summary_out) {
+    Packed &P = *packed;
+    const rdvio_ba_summary sm = P.sm;
+    if (sh.prof.on) {
+        SolveProf &sp = sh.solve_prof;
+        sp.calls[kind]++; sp.iterations[kind] += sm.iterations; sp.factors[kind] += P.nf; sp.frames[kind] += P.nfr;
+        sp.seconds[kind] += P.seconds;
     }
     sh.counters.solver_iterations += sm.iterations;
-    if (njobs > 0)   // the integrators keep their records, like after PreIntegrator::integrate
-        for (int k = 0; k < npre; ++k) {
+    if (P.njobs > 0)   // the integrators keep their records, like after PreIntegrator::integrate
+        for (int k = 0; k < P.npre; ++k) {
             PreIntegrator &pre = *pres[k].job;
-            std::copy(&preint[(size_t)k * RDVIO_PREINT_SIZE], &preint[(size_t)(k + 1) * RDVIO_PREINT_SIZE], pre.delta.begin());
+            std::copy(&P.preint[(size_t)k * RDVIO_PREINT_SIZE], &P.preint[(size_t)(k + 1) * RDVIO_PREINT_SIZE], pre.delta.begin());
             pre.key = PreIntegrator::Key{pre.data.size(), pres[k].t, pre.data.front().t, pre.data.back().t, pres[k].bg, pres[k].ba, true, true, true};
         }
     // the reference's parameter blocks ARE the Frame / Track members (solver.cpp:88-114): copy the result back
-    for (int i = 0; i < nfr; ++i)
-        if (frame_fixed[i] != 1) frames[i]->set_state(&states_out[16 * (size_t)i]);
-    for (int l = 0; l < nl; ++l)
-        if (!lm_fixed[l]) lms[l]->inv_depth = invd_out[l];
+    for (int i = 0; i < P.nfr; ++i)
+        if (frame_fixed[i] != 1) frames[i]->set_state(&P.states_out[16 * (size_t)i]);
+    for (int l = 0; l < P.nl; ++l)
+        if (!lm_fixed[l]) lms[l]->inv_depth = P.invd_out[l];
     if (summary_out) *summary_out = sm;
+    packed.reset();
     return sm.termination != 2;
+}
+
+bool BaBuilder::solve(rdvio_ba_summary *summary_out) {
+    HostTimer host_timer__(sh.prof, 10);
+    pack();
+    Packed &P = *packed;
+    {
+        BackendTimer timer(sh.counters, 4);
+        const auto t0 = std::chrono::steady_clock::now();
+        sh.backend.check(sh.backend.fn.ba_solve(sh.backend.fn.user, &P.pb, sh.cfg.solver_iteration_limit, P.states_out.data(), P.invd_out.data(), &P.sm),
+                         "ba_solve");
+        P.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return apply(summary_out);
+}
+
+bool BaBuilder::can_begin() const { return sh.backend.fn.ba_solve_begin && sh.backend.fn.ba_solve_end; }
+
+// Solver::solve in two halves (rdvio_backend::ba_solve_begin / _end).  chain: the builder of a solve that has been begun and whose
+// result for `chain_frame` is this solve's initial value for the same frame.
+void BaBuilder::solve_begin(int slot, const BaBuilder *chain, Frame *chain_frame) {
+    HostTimer host_timer__(sh.prof, 10);
+    pack();
+    Packed &P = *packed;
+    int from_slot = -1, from_frame = 0, to_frame = 0;
+    if (chain) {
+        if (!chain->packed || chain->packed->slot < 0) throw std::logic_error("BaBuilder::solve_begin: the solve to continue has not been begun");
+        from_slot = chain->packed->slot;
+        from_frame = chain->frame_index(chain_frame);
+        to_frame = frame_index(chain_frame);
+        if (from_frame < 0 || to_frame < 0) throw std::logic_error("BaBuilder::solve_begin: the chained frame is not a state of both solves");
+    }
+    BackendTimer timer(sh.counters, 4);
+    const auto t0 = std::chrono::steady_clock::now();
+    sh.backend.check(sh.backend.fn.ba_solve_begin(sh.backend.fn.user, slot, &P.pb, sh.cfg.solver_iteration_limit, from_slot, from_frame, to_frame), "ba_solve (begin)");
+    P.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    P.slot = slot;
+}
+
+bool BaBuilder::solve_end(rdvio_ba_summary *summary_out) {
+    HostTimer host_timer__(sh.prof, 10);
+    Packed &P = *packed;
+    {
+        BackendTimer timer(sh.counters, 4);
+        const auto t0 = std::chrono::steady_clock::now();
+        sh.backend.check(sh.backend.fn.ba_solve_end(sh.backend.fn.user, P.slot, P.states_out.data(), P.invd_out.data(), &P.sm), "ba_solve (end)");
+        P.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return apply(summary_out);
 }
 
 // =====================================================================================================================
@@ -725,20 +793,48 @@ bool SlidingWindowTracker::track(FrontendJob &job) {
     if (sh.cfg.parsac_flag) {
         if (judge_track_status()) update_track_status(job);
     }
-    localize_newframe();
+    BaBuilder localize(sh);
+    Frame *frame_j = localize_newframe(localize);
+    if (!localize.can_begin()) {
+        // one solve after the other (sliding_window_tracker.cpp:80-99 as written)
+        {
+            HostTimer host_timer__(sh.prof, 5);
+            localize.solve();
+        }
+        if (manage_keyframe()) {
+            track_landmark();
+            refine_window();
+            slide_window();
+        } else {
+            refine_subwindow();
+        }
+        return true;
+    }
+    // The backend takes solves in two halves.  manage_keyframe decides from tags and counts, not from the localised pose, and the
+    // subwindow's graph does not depend on it either -- only the new frame's starting point does: the localisation is begun, the
+    // decision taken, and on the subframe road (four frames of five) the subwindow solve is built, uploaded and begun behind it,
+    // starting the new frame from the localisation's result as the DEVICE holds it.  Same numbers as one after the other.
+    {
+        HostTimer host_timer__(sh.prof, 5);
+        localize.solve_begin(1);
+    }
     if (manage_keyframe()) {
+        {
+            HostTimer host_timer__(sh.prof, 5);
+            localize.solve_end();
+        }
         track_landmark();
         refine_window();
         slide_window();
     } else {
-        refine_subwindow();
+        refine_subwindow(&localize, frame_j);
     }
     return true;
 }
 
-void SlidingWindowTracker::localize_newframe() {
+// the graph of localize_newframe (sliding_window_tracker.cpp:101-125); returns the new frame
+Frame *SlidingWindowTracker::localize_newframe(BaBuilder &solver) {
     HostTimer host_timer__(sh.prof, 5);
-    BaBuilder solver(sh);
     Frame *frame_i = map->get_frame(map->frame_num() - 2);
     if (!frame_i->subframes.empty()) frame_i = frame_i->subframes.back().get();
     Frame *frame_j = map->get_frame(map->frame_num() - 1);
@@ -748,8 +844,8 @@ void SlidingWindowTracker::localize_newframe() {
         if (Track *track = frame_j->get_track(k))
             if (track->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) solver.add_reprojection_prior(frame_j, track);
     solver.kind = 0;
-    solver.solve();
     sh.counters.localizations++;
+    return frame_j;
 }
 
 bool SlidingWindowTracker::manage_keyframe() {
@@ -1005,10 +1101,24 @@ void SlidingWindowTracker::marginalize_frame0() {
     sh.counters.marginalizations++;
 }
 
-void SlidingWindowTracker::refine_subwindow() {
+// `after` / `after_frame`: a solve that has been begun (the localisation) whose result for after_frame is this solve's starting
+// point for that frame; both are ended here
+void SlidingWindowTracker::refine_subwindow(BaBuilder *after, Frame *after_frame) {
     HostTimer host_timer__(sh.prof, 7);
+    auto run = [&](BaBuilder &solver) {
+        if (!after) {
+            solver.solve();
+            return;
+        }
+        solver.solve_begin(0, after, after_frame);
+        after->solve_end();
+        solver.solve_end();
+    };
     Frame *frame = map->get_frame(map->frame_num() - 1);
-    if (frame->subframes.empty()) return;
+    if (frame->subframes.empty()) {
+        if (after) after->solve_end();
+        return;
+    }
     if (frame->subframes[0]->tag(FT_NO_TRANSLATION)) {
         if (frame->subframes.size() >= 9) {
             // compress a long rotation-only run: keep every third subframe, merging the IMU data (:353-371)
@@ -1047,7 +1157,7 @@ void SlidingWindowTracker::refine_subwindow() {
                     }
                 }
         solver.kind = 2;
-        solver.solve();
+        run(solver);
         frame->set_tag(FT_FIX_POSE, false);
         frame->set_tag(FT_FIX_MOTION, false);
     } else {
@@ -1072,7 +1182,7 @@ void SlidingWindowTracker::refine_subwindow() {
                     }
         }
         solver.kind = 2;
-        solver.solve();
+        run(solver);
         frame->set_tag(FT_FIX_POSE, false);
         frame->set_tag(FT_FIX_MOTION, false);
     }

@@ -102,7 +102,8 @@ struct Shared {  // what every stage needs
 // SoA export of one Solver problem (row A16): frames / landmarks / factors by index, ordered by landmark
 class BaBuilder {
   public:
-    explicit BaBuilder(Shared &sh) : sh(sh) {}
+    explicit BaBuilder(Shared &sh);
+    ~BaBuilder();
     // Solver::add_frame_states: constancy from the frame's FT_FIX_POSE / FT_FIX_MOTION tags (solver.cpp:88-114)
     int add_frame_states(Frame *frame, bool with_motion = true);
     // a frame whose values are read by a factor but which is not a parameter of this solve
@@ -118,13 +119,23 @@ class BaBuilder {
     bool add_integrated_preintegration(Frame *frame_i, Frame *frame_j, PreIntegrator &pre, double t, const V3 &bg, const V3 &ba);
     void add_marginalization(const MarginalizationPrior *prior) { this->prior = prior; }
     bool solve(rdvio_ba_summary *summary = nullptr);                    // Solver::solve + in-place state update
+    // the same in two halves when the backend offers them (can_begin): begin packs and enqueues, end waits and updates the
+    // states.  `chain`: a builder whose solve has been begun; this solve starts frame `chain_frame` from THAT solve's result
+    // (handed over behind the backend), so it can be built and begun while the first one is still running.
+    bool can_begin() const;
+    void solve_begin(int slot, const BaBuilder *chain = nullptr, Frame *chain_frame = nullptr);
+    bool solve_end(rdvio_ba_summary *summary = nullptr);
     int kind = 3;                                                       // call site, for the diagnostic profile
 
   private:
     struct Fac { int tgt, ref, lm; const double *tangent; };
     struct Rot { int tgt, ref; V3 zref; const double *tangent; };
     struct Pre { int i, j; const double *delta; PreIntegrator *job; double t; V3 bg, ba; };
+    struct Packed;
+    void pack();
+    bool apply(rdvio_ba_summary *summary);
     int frame_index(Frame *frame) const;
+    std::unique_ptr<Packed> packed;
     Shared &sh;
     std::vector<Frame *> frames;
     std::vector<uint8_t> frame_fixed;
@@ -191,12 +202,12 @@ class SlidingWindowTracker {
     std::unique_ptr<Map> map;
 
   private:
-    void localize_newframe();
+    Frame *localize_newframe(BaBuilder &solver);
     bool manage_keyframe();
     void track_landmark();
     void refine_window();
     void slide_window();
-    void refine_subwindow();
+    void refine_subwindow(BaBuilder *after = nullptr, Frame *after_frame = nullptr);
     void marginalize_frame0();
     // RD dynamic-outlier path (parsac_flag; sliding_window_tracker.cpp:487-769)
     bool judge_track_status();

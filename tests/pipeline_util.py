@@ -17,7 +17,7 @@ BUILD = os.path.join(ROOT, "tests", "_build")
 class Backend(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("user", "image_create", "image_preprocess", "image_detect", "image_track", "image_release",
                                                "image_destroy", "preintegrate", "ba_solve", "marginalize", "last_error", "destroy", "parsac_score",
-                                               "parsac_fetch", "preintegrate_estimator", "thread_attach", "marginalize_begin", "marginalize_end", "ransac_generate_score", "ransac_fetch", "thin_tracks", "parsac_generate_score", "preintegrate_estimator_begin", "preintegrate_estimator_end")]
+                                               "parsac_fetch", "preintegrate_estimator", "thread_attach", "marginalize_begin", "marginalize_end", "ransac_generate_score", "ransac_fetch", "thin_tracks", "parsac_generate_score", "preintegrate_estimator_begin", "preintegrate_estimator_end", "ba_solve_begin", "ba_solve_end")]
 
 
 PIPELINE_EXPORTS = [
