@@ -178,6 +178,7 @@ int rdvio_hip_ctx_create(rdvio_hip_ctx **out, int device, int max_w, int max_h, 
         // behind the inputs: the results of a batch -- per-model records, generated models, and (when small enough to ride along)
         // every model's inlier mask and bin counts
         P.down_bytes = (size_t)RDVIO_PARSAC_MAX_MODELS * (sizeof(rdvio_parsac_result) + 12 * 8 + 4) + n + (size_t)RDVIO_PARSAC_MASKS_INLINE + 65536;
+        CTX_ALLOC(P.down_dev, P.down_bytes);
         if (hipHostMalloc(&P.host, P.in_bytes + P.down_bytes, hipHostMallocDefault) != hipSuccess) {
             rdvio_fail(ctx, RDVIO_ERR_HIP, "hipHostMalloc(parsac blob) failed");
             *out = ctx;
@@ -230,7 +231,7 @@ void rdvio_hip_ctx_destroy(rdvio_hip_ctx *ctx) {
         if (ctx->gray_pinned[s]) (void)hipHostFree(ctx->gray_pinned[s]);
         if (ctx->gray_ev[s]) (void)hipEventDestroy(ctx->gray_ev[s]);
     }
-    void *bufs[] = {ctx->gray, ctx->clahe_lut, ctx->harris, ctx->harris_scalars, ctx->harris_cand, ctx->sel_hdr, ctx->sel_corners, ctx->sel_existing, ctx->ps[0].dev, ctx->ps[0].masks, ctx->ps[0].bins, ctx->ps[0].results, ctx->ps[1].dev, ctx->ps[1].masks, ctx->ps[1].bins,
+    void *bufs[] = {ctx->gray, ctx->clahe_lut, ctx->harris, ctx->harris_scalars, ctx->harris_cand, ctx->sel_hdr, ctx->sel_corners, ctx->sel_existing, ctx->ps[0].dev, ctx->ps[0].down_dev, ctx->ps[1].down_dev, ctx->ps[0].masks, ctx->ps[0].bins, ctx->ps[0].results, ctx->ps[1].dev, ctx->ps[1].masks, ctx->ps[1].bins,
                     ctx->ps[1].results, ctx->thin_dev,
                     ctx->lk_curr,
                     ctx->lk_next, ctx->lk_prevf, ctx->lk_nextf, ctx->lk_status, ctx->ba_states, ctx->ba_extr,

@@ -124,6 +124,7 @@ struct rdvio_hip_ctx {
     struct PsState {
         int lane = RDVIO_LANE_SOLVER;
         void *host = nullptr, *dev = nullptr;
+        void *down_dev = nullptr;   // device image of the blob's result part: everything a batch brings back is contiguous -- ONE copy
         size_t in_bytes = 0, down_bytes = 0;
         int max_points = 0;
         uint8_t *masks = nullptr;           // RDVIO_PARSAC_MAX_MODELS x max_points

@@ -236,12 +236,10 @@ static int parsac_run(rdvio_hip_ctx *ctx, int which, const rdvio_parsac_batch *b
     const size_t o_pm = put(hb, off, b->points_changed ? b->prior_mask : (const uint8_t *)nullptr, has_prior ? (size_t)n : 0);
     const size_t o_dyn = (off + 15) & ~(size_t)15;
     off = o_dyn;
-    size_t o_models, o_samples = 0, o_counts = 0, up_end;
+    size_t o_models = 0, o_samples = 0, up_end;
     if (gen) {
         o_samples = put(hb, off, samples, (size_t)n_iter * dof);
-        up_end = off;                                                         // only the samples travel up
-        o_counts = put(hb, off, (const int32_t *)nullptr, (size_t)n_iter);   // device-written: counts, then the model slots
-        o_models = put(hb, off, (const double *)nullptr, (size_t)nm * mdim);
+        up_end = off;   // only the samples travel up (counts and models are written into the result region on the device)
     } else {
         o_models = put(hb, off, b->models, (size_t)nm * mdim);
         up_end = off;
@@ -257,44 +255,50 @@ static int parsac_run(rdvio_hip_ctx *ctx, int which, const rdvio_parsac_batch *b
     } else {
         RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(db + o_dyn, hb + o_dyn, up_end - o_dyn, hipMemcpyHostToDevice, st));
     }
+    // Everything the batch brings back -- per-model records, (generated) counts and models, and, when small enough to ride along,
+    // every model's inlier mask and bin counts (the winner's are what the caller asks for next: rdvio_hip_parsac_fetch) -- is
+    // written into ONE device region that mirrors the result part of the pinned blob: one copy down instead of four.
+    const size_t mask_bytes = (size_t)nm * n, bins_bytes = (size_t)nm * nv * sizeof(int32_t);
+    const bool inline_masks = mask_bytes + bins_bytes <= RDVIO_PARSAC_MASKS_INLINE;
+    const size_t r_gen = ((size_t)nm * sizeof(rdvio_parsac_result) + 15) & ~(size_t)15;
+    const size_t r_models = r_gen + (gen ? (((size_t)n_iter * sizeof(int32_t) + 15) & ~(size_t)15) : 0);
+    const size_t gen_end = r_models + (gen ? (size_t)nm * mdim * sizeof(double) : 0);
+    const size_t r_masks = (gen_end + 15) & ~(size_t)15, r_bins = r_masks + ((mask_bytes + 15) & ~(size_t)15);
+    const size_t down_total = inline_masks ? r_bins + bins_bytes : gen_end;
+    if (down_total > P.down_bytes) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "PARSAC result region too small");
+    uint8_t *dd = (uint8_t *)P.down_dev;
     if (gen) {
         GenArgs g;
         g.kind = b->kind; g.n_iter = n_iter;
         g.pa = (const double *)(db + o_pa); g.pb = (const double *)(db + o_pb);
         g.samples = (const int32_t *)(db + o_samples);
-        g.models = (double *)(db + o_models);
-        g.counts = (int32_t *)(db + o_counts);
+        g.models = (double *)(dd + r_models);
+        g.counts = (int32_t *)(dd + r_gen);
         hipLaunchKernelGGL(parsac_generate_kernel, dim3(n_iter), dim3(64), 0, st, g);
         RDVIO_HIP_CHECK(ctx, hipGetLastError());
     }
     PsArgs a;
     a.kind = b->kind; a.n = n; a.n_valid = nv; a.n_models = nm; a.has_prior = P.has_prior; a.has_lens = P.has_lens;
     a.per_iter = per_iter;
-    a.counts = gen ? (const int32_t *)(db + o_counts) : nullptr;
+    a.counts = gen ? (const int32_t *)(dd + r_gen) : nullptr;
     a.threshold = b->threshold;
     a.pa = (const double *)(db + o_pa); a.pb = (const double *)(db + o_pb); a.bin_xy = (const double *)(db + o_xy);
-    a.models = (const double *)(db + o_models);
+    a.models = gen ? (const double *)(dd + r_models) : (const double *)(db + o_models);
     a.d2v = (const int32_t *)(db + o_d2v); a.valid_sizes = (const int32_t *)(db + o_vs);
     a.lens_w = (const float *)(db + o_lw); a.prior = db + o_pm;
-    a.masks = P.masks; a.bin_inliers = P.bins; a.results = P.results;
+    a.masks = inline_masks ? dd + r_masks : P.masks;
+    a.bin_inliers = inline_masks ? (int32_t *)(dd + r_bins) : P.bins;
+    a.results = (rdvio_parsac_result *)dd;
     hipLaunchKernelGGL(parsac_score_kernel, dim3(nm), dim3(64), 0, st, a);
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
     uint8_t *down0 = (uint8_t *)P.host + P.in_bytes;
     rdvio_parsac_result *down = (rdvio_parsac_result *)down0;
-    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down, P.results, (size_t)nm * sizeof(rdvio_parsac_result), hipMemcpyDeviceToHost, st));
-    const size_t gen_bytes = gen ? (o_models + (size_t)nm * mdim * sizeof(double)) - o_counts : 0;
-    uint8_t *down_gen = down0 + (((size_t)nm * sizeof(rdvio_parsac_result) + 15) & ~(size_t)15);
-    if (gen) RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down_gen, db + o_counts, gen_bytes, hipMemcpyDeviceToHost, st));   // counts | models, one copy
-    // the winner's inlier mask and bin counts are what the caller asks for next (rdvio_hip_parsac_fetch): a small batch brings
-    // everybody's along now instead of paying a second round trip then
-    const size_t mask_bytes = (size_t)nm * n, bins_bytes = (size_t)nm * nv * sizeof(int32_t);
+    uint8_t *down_gen = down0 + r_gen;
+    RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down0, dd, down_total, hipMemcpyDeviceToHost, st));
     P.masks_host = P.bins_host = 0;
-    if (mask_bytes + bins_bytes <= RDVIO_PARSAC_MASKS_INLINE) {
-        uint8_t *dm = down_gen + ((gen_bytes + 15) & ~(size_t)15), *dbins = dm + ((mask_bytes + 15) & ~(size_t)15);
-        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(dm, P.masks, mask_bytes, hipMemcpyDeviceToHost, st));
-        RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(dbins, P.bins, bins_bytes, hipMemcpyDeviceToHost, st));
-        P.masks_host = (size_t)(dm - (uint8_t *)P.host);
-        P.bins_host = (size_t)(dbins - (uint8_t *)P.host);
+    if (inline_masks) {
+        P.masks_host = P.in_bytes + r_masks;
+        P.bins_host = P.in_bytes + r_bins;
     }
     RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, st));
     if (!gen) {
@@ -305,7 +309,7 @@ static int parsac_run(rdvio_hip_ctx *ctx, int which, const rdvio_parsac_batch *b
     }
     // pack the occupied slots in iteration order (the order Parsac<>::solve meets the models in)
     const int32_t *cnt = (const int32_t *)down_gen;
-    const double *mod = (const double *)(down_gen + (o_models - o_counts));
+    const double *mod = (const double *)(down0 + r_models);
     int packed = 0;
     for (int it = 0; it < n_iter; ++it) {
         const int c = cnt[it] < 0 ? 0 : (cnt[it] > per_iter ? per_iter : cnt[it]);
