@@ -54,6 +54,7 @@ def main():
             rep_ = pr.counters_report(r["counters"])
             rep_.update(threading=mode, fps_all=round(len(d) / r["elapsed_s"], 1), first_tracking_frame=i0,
                         fps_tracking=round((len(d) - 1 - i0) / (d[-1] - d[i0]), 1), ms_per_frame_tracking=round(1e3 * (d[-1] - d[i0]) / (len(d) - 1 - i0), 4))
+            rep_["fps_per_100_frames"] = [round(100.0 / (d[k + 100] - d[k]), 1) for k in range(i0, len(d) - 101, 100)]
             res[mode] = (r, rep_)
             runs.append((mode, r))
             print(json.dumps(rep_))
