@@ -824,7 +824,9 @@ def main(argv=None):
                 rep = {}
                 own = stream["gt"] if supplied else None
                 other = ("full_initializer_bootstrap", args.threading, None, {}) if supplied else ("groundtruth_bootstrap", args.threading, stream["gt"], {})
-                for label, thr, init, extra in (("inline_schedule", 0, own, {}), other,
+                # (`value` is measured with the live kernel timing on -- two HIP events around every solver launch, read at the fetch --
+                # which the roofline needs and a deployment does not: the first variant is the same run without it)
+                for label, thr, init, extra in (("without_live_kernel_timing", args.threading, own, {}), ("inline_schedule", 0, own, {}), other,
                                                 ("tracker_gates_on_the_device", args.threading, own, {"tracker_gates_on_backend": 1})):
                     c2, r2, _ = hip_run(thr, init_states=init, **extra)
                     try:
