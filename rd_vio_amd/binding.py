@@ -160,6 +160,12 @@ def load_library():
     lib.rdvio_hip_ba_solve.argtypes = [ctypes.c_void_p, ctypes.POINTER(BaProblem), ctypes.c_int, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.POINTER(BaSummary)]
     lib.rdvio_hip_ba_upload.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(BaProblem)]
+    lib.rdvio_hip_ba_upload_chained.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(BaProblem), ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.rdvio_hip_preintegrate_estimator.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.rdvio_hip_preintegrate_estimator_begin.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_int]
+    lib.rdvio_hip_preintegrate_estimator_end.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.rdvio_hip_debug_last_select_path.argtypes = [ctypes.c_void_p]
+    lib.rdvio_hip_debug_last_select_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.rdvio_hip_ba_solve_resident.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.rdvio_hip_ba_fetch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.POINTER(BaSummary)]
@@ -326,6 +332,33 @@ class Context:
         if not hasattr(self, "_ba_shape"):
             self._ba_shape = {}
         self._ba_shape[int(slot)] = (c.n_frames, c.n_landmarks)
+
+    def ba_upload_chained(self, pb, slot, from_slot, from_frame, to_frame):
+        """rdvio_hip_ba_upload_chained: frame `to_frame` of this problem starts from the result of frame `from_frame` of the solve in
+        `from_slot` (taken on the device, in stream order)."""
+        c, keep = self._ba_problem(pb)
+        self._check(self._lib.rdvio_hip_ba_upload_chained(self._h, int(slot), ctypes.byref(c), int(from_slot), int(from_frame), int(to_frame)))
+        if not hasattr(self, "_ba_shape"):
+            self._ba_shape = {}
+        self._ba_shape[int(slot)] = (c.n_frames, c.n_landmarks)
+        self._ba_keep = keep   # (the pinned blob was packed during the call; kept anyway until the next upload)
+
+    def preintegrate_estimator(self, segments, t_end, bg, ba, noise, two_halves=False):
+        """rdvio_hip_preintegrate_estimator (solver lane, staging of its own), in one call or as _begin / _end. -> (nseg, 506)"""
+        nseg = len(segments)
+        off = np.zeros(nseg + 1, dtype=np.int32)
+        for i, s in enumerate(segments):
+            off[i + 1] = off[i] + len(s)
+        imu = _f64(np.concatenate([np.asarray(s, dtype=np.float64).reshape(-1, 7) for s in segments], axis=0))
+        t_end, bg, ba, noise = _f64(t_end).reshape(nseg), _f64(bg).reshape(nseg, 3), _f64(ba).reshape(nseg, 3), _f64(noise)
+        out = np.zeros((nseg, PREINT_SIZE))
+        args = (self._h, nseg, off.ctypes.data, imu.ctypes.data, t_end.ctypes.data, bg.ctypes.data, ba.ctypes.data, noise.ctypes.data, 1, 1)
+        if two_halves:
+            self._check(self._lib.rdvio_hip_preintegrate_estimator_begin(*args))
+            self._check(self._lib.rdvio_hip_preintegrate_estimator_end(self._h, out.ctypes.data))
+        else:
+            self._check(self._lib.rdvio_hip_preintegrate_estimator(*args, out.ctypes.data))
+        return out
 
     def ba_solve_resident(self, max_iterations=30, slot=0):
         self._check(self._lib.rdvio_hip_ba_solve_resident(self._h, int(slot), int(max_iterations)))

@@ -394,6 +394,69 @@ def test_subwindow_shaped_problems(ctx, oracle, monkeypatch, k_free):
         assert got_sm.iterations >= 2 and np.array_equal(got_d, ref_d)
 
 
+@pytest.mark.gpu
+def test_chained_solves_equal_one_after_the_other(ctx, oracle):
+    """rdvio_hip_ba_upload_chained (localize_newframe -> refine_subwindow, sliding_window_tracker.cpp:80-99): the second solve is
+    uploaded and begun while the first one is in flight and starts its last frame from the first result as the device holds it.
+    Bit-identical to fetching the first result, writing it into the second problem's states on the host and solving that."""
+    for seed in (671, 672):
+        pb = synth.make_window_problem(9, 150, seed, preintegrate=_oracle_pre(oracle))
+        rng = np.random.default_rng(seed)
+        pb["states"] = pb["states"].copy()
+        pb["states"][8, 4:7] += rng.normal(0, 0.02, 3)
+
+        def shaped(k_free):
+            q = dict(pb)
+            q["frame_fixed"] = np.ones(9, dtype=np.uint8)
+            q["frame_fixed"][9 - k_free:] = 0
+            q["lm_fixed"] = np.ones(len(pb["inv_depth"]), dtype=np.uint8)
+            keep = pb["tgt"] >= 9 - k_free
+            for k in ("tgt", "ref", "lm", "tangent"):
+                q[k] = pb[k][keep]
+            q["pre_i"], q["pre_j"], q["preint"] = pb["pre_i"][-k_free:], pb["pre_j"][-k_free:], pb["preint"][-k_free:]
+            for k in ("prior_frames", "lin", "S", "f"):
+                q.pop(k, None)
+            return q
+
+        loc, sub = shaped(1), shaped(3)
+        # one after the other
+        s1, _, sm1 = ctx.ba_solve(loc, 30)
+        sub_seq = dict(sub, states=sub["states"].copy())
+        sub_seq["states"][8] = s1[8]
+        s2, d2, sm2 = ctx.ba_solve(sub_seq, 30)
+        # chained: the subwindow problem carries the UNlocalised state of frame 8 (ignored)
+        ctx.ba_upload(loc, 1)
+        ctx.ba_solve_resident(30, 1)
+        ctx.ba_upload_chained(sub, 0, from_slot=1, from_frame=8, to_frame=8)
+        ctx.ba_solve_resident(30, 0)
+        c1, _, cm1 = ctx.ba_fetch(1)
+        c2, e2, cm2 = ctx.ba_fetch(0)
+        assert np.array_equal(c1, s1) and (cm1.iterations, cm1.final_cost) == (sm1.iterations, sm1.final_cost)
+        assert np.array_equal(c2, s2) and np.array_equal(e2, d2)
+        assert (cm2.iterations, cm2.successful_steps, cm2.termination, cm2.initial_cost, cm2.final_cost) == (sm2.iterations, sm2.successful_steps, sm2.termination,
+                                                                                                            sm2.initial_cost, sm2.final_cost)
+        assert sm1.iterations >= 2 and sm2.iterations >= 2
+    with pytest.raises(rd_vio_amd.RdvioError):
+        ctx.ba_upload_chained(sub, 0, from_slot=0, from_frame=8, to_frame=8)    # a solve cannot continue itself
+    with pytest.raises(rd_vio_amd.RdvioError):
+        ctx.ba_upload_chained(sub, 0, from_slot=1, from_frame=99, to_frame=8)
+
+
+@pytest.mark.gpu
+def test_estimator_preintegration_in_two_halves(ctx, oracle):
+    """rdvio_hip_preintegrate_estimator_begin / _end == rdvio_hip_preintegrate_estimator == rdvio_hip_preintegrate, bit for bit."""
+    rng = np.random.default_rng(5)
+    segs = [synth.make_imu_segment(1.0, 1.0 + 0.05 * (k + 1), rate=200.0, rng=rng) for k in range(3)]
+    t_end = [s[-1, 0] + 0.005 for s in segs]
+    bg, ba = rng.normal(0, 0.01, (3, 3)), rng.normal(0, 0.05, (3, 3))
+    one = ctx.preintegrate(segs, t_end, bg, ba, synth.EUROC_NOISE)
+    est = ctx.preintegrate_estimator(segs, t_end, bg, ba, synth.EUROC_NOISE)
+    two = ctx.preintegrate_estimator(segs, t_end, bg, ba, synth.EUROC_NOISE, two_halves=True)
+    assert np.array_equal(one, est) and np.array_equal(one, two)
+    # an end without a begin is a no-op
+    assert ctx._lib.rdvio_hip_preintegrate_estimator_end(ctx._h, two.ctypes.data) == 0
+
+
 # ---------------------------------------------------------------------------------------------- row A10
 def test_rotation_prior_eval_parity(ctx, oracle):
     """CeresRotationPriorFactor::Evaluate (ceres/rotation_factor.h:22-58) on the device against the oracle, 1e-11 relative
