@@ -702,6 +702,11 @@ def main(argv=None):
 
     import ctypes
 
+    # the synthetic stream is rendered by a pool of forked workers: before anything in this process touches the GPU
+    steps, warmup = args.steps, args.warmup
+    n_total = BOOT_FRAMES + 24 + warmup + steps
+    stream = make_stream(cfg, n_total)
+
     import torch
 
     from rd_vio_amd import replica
@@ -722,10 +727,6 @@ def main(argv=None):
 
     rbuild.build()
     lib = pr.load_pipeline_lib()
-    steps, warmup = args.steps, args.warmup
-    n_total = BOOT_FRAMES + 24 + warmup + steps
-    stream = make_stream(cfg, n_total)
-
     def hip_context():
         return rd_vio_amd.Context(max_width=cfg["width"], max_height=cfg["height"], max_features=max(1024, 4 * cfg["features"]),
                                   max_window=cfg["window"] + 8, max_factors=40000, device=local_rank)
