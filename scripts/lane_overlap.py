@@ -1,6 +1,6 @@
 """How much of the time the HIP lanes of the product pipeline run concurrently, from a rocprofv3 kernel trace (CSV): per stream
 (= lane) the busy time, and the time during which kernels of two or more streams are in flight together.
-usage: lane_overlap.py <kernel_trace.csv>"""
+usage: lane_overlap.py <kernel_trace.csv> [excerpt.csv]   (excerpt: every launch of a 6 ms window late in the run, for the timeline)"""
 import csv, re, sys
 from collections import defaultdict
 
@@ -37,3 +37,16 @@ for lane in sorted(busy, key=lambda k: -busy[k]):
     top = sorted(names[lane].items(), key=lambda kv: -kv[1])[:4]
     print(f"  lane {lane}: busy {busy[lane]:9.2f} ms  ({', '.join(f'{n} x {c}' for n, c in top)})")
 print(f"some lane busy: {any_busy:.2f} ms; two or more lanes busy at once: {both:.2f} ms ({100 * both / max(any_busy, 1e-9):.1f} % of the busy time)")
+
+if len(sys.argv) > 2:
+    # a 6 ms window four fifths into the run: stream, kernel, start and end in microseconds relative to the window
+    w0 = t0 + int(0.8 * (t1 - t0))
+    w1 = w0 + 6_000_000
+    with open(sys.argv[2], "w") as out:
+        out.write("stream,kernel,start_us,end_us\n")
+        for r in sorted(rows, key=lambda r: int(r["Start_Timestamp"])):
+            a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            if b < w0 or a > w1:
+                continue
+            nm = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0].replace("void ", "")
+            out.write(f"{r.get(key, '?')},{nm},{(a - w0) / 1e3:.2f},{(b - w0) / 1e3:.2f}\n")

@@ -14,7 +14,7 @@ if [ $PART = all ] || [ $PART = stats ]; then
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py $FAST > $O/stats.log 2>&1
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 cp $(find $O/stats -name "*kernel_trace.csv" | head -1) $O/kernel_trace_full.csv
-python3 $R/scripts/lane_overlap.py $O/kernel_trace_full.csv > $O/lane_overlap.txt 2>&1 || true
+python3 $R/scripts/lane_overlap.py $O/kernel_trace_full.csv $O/trace_excerpt.csv > $O/lane_overlap.txt 2>&1 || true
 rm -rf $O/stats $O/kernel_trace_full.csv
 echo "stats done"
 fi
