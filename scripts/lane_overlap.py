@@ -1,6 +1,6 @@
 """How much of the time the HIP lanes of the product pipeline run concurrently, from a rocprofv3 kernel trace (CSV): per stream
 (= lane) the busy time, and the time during which kernels of two or more streams are in flight together.
-usage: lane_overlap.py <kernel_trace.csv> [excerpt.csv]   (excerpt: every launch of a 6 ms window late in the run, for the timeline)"""
+usage: lane_overlap.py <kernel_trace.csv> [excerpt.csv]   (excerpt: every launch of a 6 ms window inside the product pipeline's timed region, for the timeline)"""
 import csv, re, sys
 from collections import defaultdict
 
@@ -39,8 +39,9 @@ for lane in sorted(busy, key=lambda k: -busy[k]):
 print(f"some lane busy: {any_busy:.2f} ms; two or more lanes busy at once: {both:.2f} ms ({100 * both / max(any_busy, 1e-9):.1f} % of the busy time)")
 
 if len(sys.argv) > 2:
-    # a 6 ms window four fifths into the run: stream, kernel, start and end in microseconds relative to the window
-    w0 = t0 + int(0.8 * (t1 - t0))
+    # a 6 ms window: stream, kernel, start and end in microseconds relative to the window
+    solves = sorted(int(r["Start_Timestamp"]) for r in rows if "ba_solve_kernel" in r["Kernel_Name"])
+    w0 = solves[len(solves) // 3] if solves else t0   # (a third into the solver launches: the timed region of the product pipeline)
     w1 = w0 + 6_000_000
     with open(sys.argv[2], "w") as out:
         out.write("stream,kernel,start_us,end_us\n")
