@@ -235,6 +235,9 @@ int rdvio_hip_ba_solve(rdvio_hip_ctx *ctx, const rdvio_ba_problem *pb, int max_i
  * without any host->device traffic; fetch copies the result back. */
 #define RDVIO_BA_SLOTS 2 /* e.g. slot 0 = window BA (refine_window), slot 1 = localize_newframe */
 int rdvio_hip_ba_upload(rdvio_hip_ctx *ctx, int slot, const rdvio_ba_problem *pb);
+/* the result copies of rdvio_hip_ba_fetch without its wait: with several solves in flight, enqueue them all, then fetch -- the first
+ * fetch waits once for everything */
+int rdvio_hip_ba_fetch_enqueue(rdvio_hip_ctx *ctx, int slot);
 /* rdvio_hip_ba_upload for a solve that CONTINUES another one: the initial state of frame `to_frame` of this problem is the result
  * of frame `from_frame` of the solve in `from_slot`, copied on the device in stream order -- the host packs and uploads this
  * problem while the other solve is still running and fetches both afterwards (localize_newframe -> refine_subwindow,

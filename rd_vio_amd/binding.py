@@ -19,7 +19,7 @@ EXPORTS = [
     "rdvio_hip_detect_keypoints", "rdvio_hip_harris_response", "rdvio_hip_image_release", "rdvio_hip_preintegrate",
     "rdvio_hip_preintegrate_dev", "rdvio_hip_preintegrate_estimator", "rdvio_hip_preintegrate_estimator_begin", "rdvio_hip_preintegrate_estimator_end", "rdvio_hip_ctx_attach_thread", "rdvio_hip_ctx_ensure_lane_streams",
     "rdvio_hip_reprojection_eval", "rdvio_hip_rotation_prior_eval", "rdvio_hip_ba_solve", "rdvio_hip_ba_upload", "rdvio_hip_ba_solve_resident",
-    "rdvio_hip_ba_fetch", "rdvio_hip_ba_upload_chained", "rdvio_hip_ba_linearize", "rdvio_hip_ctx_team_retries", "rdvio_hip_debug_last_select_path", "rdvio_hip_debug_last_select_stamps", "rdvio_hip_ctx_set_kernel_timing", "rdvio_hip_ctx_get_kernel_timing", "rdvio_hip_marginalize", "rdvio_hip_marginalize_upload", "rdvio_hip_marginalize_resident",
+    "rdvio_hip_ba_fetch", "rdvio_hip_ba_fetch_enqueue", "rdvio_hip_ba_upload_chained", "rdvio_hip_ba_linearize", "rdvio_hip_ctx_team_retries", "rdvio_hip_debug_last_select_path", "rdvio_hip_debug_last_select_stamps", "rdvio_hip_ctx_set_kernel_timing", "rdvio_hip_ctx_get_kernel_timing", "rdvio_hip_marginalize", "rdvio_hip_marginalize_upload", "rdvio_hip_marginalize_resident",
     "rdvio_hip_marginalize_fetch", "rdvio_hip_parsac_score", "rdvio_hip_parsac_generate_score", "rdvio_hip_parsac_fetch", "rdvio_hip_ransac_generate_score", "rdvio_hip_ransac_fetch", "rdvio_hip_thin_tracks",
     "rdvio_hip_frame_step", "rdvio_hip_run_sequences",
 ]

@@ -97,6 +97,7 @@ struct rdvio_hip_ctx {
         // fused preintegration jobs of the uploaded problem (rdvio_ba_problem::n_pre_jobs): device views of the raw samples and
         // where the records go back to
         bool retried = false;   // a team solve whose helpers stayed silent was repeated on the leader alone
+        bool down_enqueued = false;   // rdvio_hip_ba_fetch_enqueue has put this launch's result copies on the lane
         hipEvent_t up_ev = nullptr;   // behind this slot's last upload (rdvio_hip_ba_upload_chained waits for it, not for the lane)
         size_t user0_off = 0;
         int n_jobs = 0;

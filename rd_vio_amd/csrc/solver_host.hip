@@ -386,6 +386,7 @@ int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int slot, int max_iterations
     SolverWs &w = S.ws;
     w.max_iter = max_iterations;
     S.retried = false;
+    S.down_enqueued = false;
     // several contexts live on this device (sequences sharing a GPU): a team's helper workgroups are not guaranteed a compute unit
     // each, so large solves stay on one workgroup there (slower per solve, never a time-out)
     if (w.n_wg > 1 && rdvio_live_contexts(ctx->device) > 1) {
@@ -408,10 +409,13 @@ int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int slot, int max_iterations
     return RDVIO_OK;
 }
 
-int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double *inv_depth_out, rdvio_ba_summary *summary) {
+// the device-to-host copies of a slot's result, without the wait: a caller with several solves in flight (chained solves) enqueues
+// all of them and waits once
+int rdvio_hip_ba_fetch_enqueue(rdvio_hip_ctx *ctx, int slot) {
     if (!ctx || bad_slot(slot)) return RDVIO_ERR_INVALID;
     rdvio_hip_ctx::BaSlot &S = ctx->ba[slot];
     if (!S.ready) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "no BA problem uploaded in slot %d", slot);
+    if (S.down_enqueued) return RDVIO_OK;
     SolverWs &w = S.ws;
     // x | xd | summary[0..7] in one device-to-host copy into the slot's pinned blob (behind the uploaded inputs)
     const size_t n_out = (size_t)(w.summary + 8 - w.x);
@@ -425,6 +429,22 @@ int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double 
         if ((size_t)((uint8_t *)(down_pre + pre_doubles) - (uint8_t *)S.host) > S.host_bytes) return rdvio_fail(ctx, RDVIO_ERR_CAPACITY, "records do not fit the pinned blob");
         RDVIO_HIP_CHECK(ctx, hipMemcpyAsync(down_pre, w.preint, pre_doubles * sizeof(double), hipMemcpyDeviceToHost, ctx->lane[RDVIO_LANE_SOLVER]));
     }
+    S.down_enqueued = true;
+    return RDVIO_OK;
+}
+
+int rdvio_hip_ba_fetch(rdvio_hip_ctx *ctx, int slot, double *states_out, double *inv_depth_out, rdvio_ba_summary *summary) {
+    if (!ctx || bad_slot(slot)) return RDVIO_ERR_INVALID;
+    rdvio_hip_ctx::BaSlot &S = ctx->ba[slot];
+    if (!S.ready) return rdvio_fail(ctx, RDVIO_ERR_INVALID, "no BA problem uploaded in slot %d", slot);
+    SolverWs &w = S.ws;
+    if (int rc = rdvio_hip_ba_fetch_enqueue(ctx, slot)) return rc;
+    S.down_enqueued = false;
+    const size_t n_out = (size_t)(w.summary + 8 - w.x);
+    const size_t host_off = (S.in_bytes + 63) & ~(size_t)63;
+    double *down = (double *)((uint8_t *)S.host + host_off);
+    double *down_pre = down + ((n_out + 7) & ~(size_t)7);
+    const size_t pre_doubles = (size_t)S.n_jobs * RDVIO_PREINT_SIZE;
     RDVIO_HIP_CHECK(ctx, rdvio_wait(ctx, ctx->lane[RDVIO_LANE_SOLVER]));
     if (S.n_jobs > 0 && S.job_out_host) memcpy(S.job_out_host, down_pre, pre_doubles * sizeof(double));
     if (states_out) memcpy(states_out, down, (size_t)w.nfr * 16 * sizeof(double));

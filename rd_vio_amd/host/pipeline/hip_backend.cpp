@@ -128,7 +128,11 @@ int ba_solve(void *user, const rdvio_ba_problem *pb, int max_iter, double *state
 int ba_solve_begin(void *user, int slot, const rdvio_ba_problem *pb, int max_iter, int from_slot, int from_frame, int to_frame) {
     rdvio_hip_ctx *ctx = static_cast<HipBackend *>(user)->ctx;
     if (int rc = from_slot >= 0 ? rdvio_hip_ba_upload_chained(ctx, slot, pb, from_slot, from_frame, to_frame) : rdvio_hip_ba_upload(ctx, slot, pb)) return rc;
-    return rdvio_hip_ba_solve_resident(ctx, slot, max_iter);
+    if (int rc = rdvio_hip_ba_solve_resident(ctx, slot, max_iter)) return rc;
+    if (from_slot < 0) return RDVIO_OK;
+    // the last solve of a chain: both results' copies go onto the lane now, behind it -- the two ends then share one wait
+    if (int rc = rdvio_hip_ba_fetch_enqueue(ctx, from_slot)) return rc;
+    return rdvio_hip_ba_fetch_enqueue(ctx, slot);
 }
 int ba_solve_end(void *user, int slot, double *states, double *invd, rdvio_ba_summary *sm) {
     return rdvio_hip_ba_fetch(static_cast<HipBackend *>(user)->ctx, slot, states, invd, sm);
