@@ -184,6 +184,9 @@ class Track {
     size_t map_index = 0;
     double inv_depth = 0.0;
     size_t m_life = 0;
+    // scratch of the solver's graph assembly (BaBuilder): this track's state index in the builder whose stamp is ba_stamp
+    mutable int ba_index = -1;
+    mutable uint64_t ba_stamp = 0;
 
   private:
     size_t id_;

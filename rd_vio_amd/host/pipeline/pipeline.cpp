@@ -53,9 +53,9 @@ int BaBuilder::add_constant_frame(Frame *frame) {
 }
 
 int BaBuilder::add_track_states(Track *track, bool constant) {
-    auto it = lidx.find(track);
-    if (it != lidx.end()) return it->second;
-    lidx[track] = (int)lms.size();
+    if (track->ba_stamp == stamp) return track->ba_index;
+    track->ba_stamp = stamp;
+    track->ba_index = (int)lms.size();
     lms.push_back(track);
     lm_fixed.push_back(constant ? 1 : 0);
     return (int)lms.size() - 1;
@@ -71,13 +71,15 @@ void BaBuilder::add_reprojection_error(Frame *frame, size_t keypoint_index) {
     facs.push_back({t, r, l, frame->tangents[keypoint_index].data()});
 }
 
-void BaBuilder::add_reprojection_prior(Frame *frame, Track *track) {
+void BaBuilder::add_reprojection_prior(Frame *frame, Track *track) { add_reprojection_prior(frame, track, track->get_keypoint_index(frame)); }
+
+void BaBuilder::add_reprojection_prior(Frame *frame, Track *track, size_t keypoint_index) {
     // CeresReprojectionPriorFactor (reprojection_factor.h:99-121): anchor pose and inverse depth held constant
     int t = frame_index(frame);
     if (t < 0) t = add_constant_frame(frame);
     const int r = add_constant_frame(track->first_frame());
     const int l = add_track_states(track, true);
-    facs.push_back({t, r, l, frame->tangents[track->get_keypoint_index(frame)].data()});
+    facs.push_back({t, r, l, frame->tangents[keypoint_index].data()});
 }
 
 void BaBuilder::add_rotation_prior(Frame *frame, Track *track) {
@@ -119,7 +121,7 @@ struct BaBuilder::Packed {
     double seconds = 0.0;
 };
 
-BaBuilder::BaBuilder(Shared &sh) : sh(sh) {}
+BaBuilder::BaBuilder(Shared &sh) : sh(sh), stamp(sh.ba_stamps.fetch_add(1, std::memory_order_relaxed) + 1) {}
 BaBuilder::~BaBuilder() = default;
 
 void BaBuilder::pack() {
@@ -842,7 +844,7 @@ Frame *SlidingWindowTracker::localize_newframe(BaBuilder &solver) {
     solver.add_preintegration(frame_i, frame_j, frame_j->preintegration, true);
     for (size_t k = 0; k < frame_j->keypoint_num(); ++k)
         if (Track *track = frame_j->get_track(k))
-            if (track->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) solver.add_reprojection_prior(frame_j, track);
+            if (track->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) solver.add_reprojection_prior(frame_j, track, k);
     solver.kind = 0;
     sh.counters.localizations++;
     return frame_j;
@@ -1151,7 +1153,7 @@ void SlidingWindowTracker::refine_subwindow(BaBuilder *after, Frame *after_frame
             if (Track *track = last_subframe->get_track(k))
                 if (track->tag(TT_VALID)) {
                     if (track->tag(TT_TRIANGULATED)) {
-                        if (track->tag(TT_STATIC)) solver.add_reprojection_prior(last_subframe, track);
+                        if (track->tag(TT_STATIC)) solver.add_reprojection_prior(last_subframe, track, k);
                     } else {
                         solver.add_rotation_prior(last_subframe, track);
                     }
@@ -1175,7 +1177,7 @@ void SlidingWindowTracker::refine_subwindow(BaBuilder *after, Frame *after_frame
             for (size_t k = 0; k < subframe->keypoint_num(); ++k)
                 if (Track *track = subframe->get_track(k))
                     if (track->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) {
-                        if (track->first_frame()->tag(FT_KEYFRAME)) solver.add_reprojection_prior(subframe, track);
+                        if (track->first_frame()->tag(FT_KEYFRAME)) solver.add_reprojection_prior(subframe, track, k);
                         // else: tracks anchored in a later subframe -- the reference indexes the KEYFRAME's factor list
                         // with the SUBFRAME's keypoint index here (:431-434), which reads an unrelated or out-of-range
                         // entry; that access is not reproduced ("deliberate deviations")

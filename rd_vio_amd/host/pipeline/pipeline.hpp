@@ -93,6 +93,7 @@ struct Shared {  // what every stage needs
     rdvio_pipeline_config cfg;
     Backend backend;
     IdGenerator ids;
+    std::atomic<uint64_t> ba_stamps{0};   // one stamp per BaBuilder (Track::ba_stamp)
     Counters counters;
     std::vector<std::array<double, 17>> init_states;
     // bin confidences of the two PARSAC call sites (function-local statics in the reference: pnp.h:195, stereo.cpp:147)
@@ -111,6 +112,7 @@ class BaBuilder {
     int add_track_states(Track *track, bool constant);
     void add_reprojection_error(Frame *frame, size_t keypoint_index);   // Solver::add_factor(ReprojectionErrorFactor *)
     void add_reprojection_prior(Frame *frame, Track *track);            // create_reprojection_prior_factor
+    void add_reprojection_prior(Frame *frame, Track *track, size_t keypoint_index);   // (the caller knows the track's keypoint in `frame`)
     void add_rotation_prior(Frame *frame, Track *track);                // create_rotation_prior_factor
     void add_preintegration(Frame *frame_i, Frame *frame_j, const PreIntegrator &pre, bool prior);
     // PreIntegrator::integrate(t, bg, ba, true, true) + add_preintegration in one: the integration runs inside the solve call
@@ -142,7 +144,7 @@ class BaBuilder {
     std::unordered_map<const Frame *, int> fidx;
     std::vector<Track *> lms;
     std::vector<uint8_t> lm_fixed;
-    std::unordered_map<const Track *, int> lidx;
+    uint64_t stamp;   // a track knows its index in THIS builder while Track::ba_stamp == stamp (no hash map on the assembly path)
     std::vector<Fac> facs;
     std::vector<Rot> rots;
     std::vector<Pre> pres;
