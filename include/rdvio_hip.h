@@ -282,8 +282,9 @@ int rdvio_hip_debug_last_select_path(const rdvio_hip_ctx *ctx);
 int rdvio_hip_debug_last_select_stamps(const rdvio_hip_ctx *ctx, int32_t *out5);
 long rdvio_hip_ctx_team_retries(const rdvio_hip_ctx *ctx);
 
-/* Measurement: live timing of the dominant kernel.  With timing on, every ba_solve_kernel launch is bracketed by HIP events on
- * the solver lane and read at the fetch that follows; get returns the sums since timing was switched on:
+/* Measurement: live timing of the dominant kernel.  on = k > 0: every k-th ba_solve_kernel launch (1: every launch, what bench.py
+ * uses) is bracketed by HIP events on the solver lane and read at the fetch that follows; 0 switches it off.  get returns the sums
+ * over the TIMED launches since timing was switched on:
  * out4 = { launches, kernel milliseconds, algorithmic FP64 flops (SURVEY.md 8d per-unit figures x the units of each launch:
  * (successful steps + 1) linearisations + iterations cost evaluations), solver iterations }. */
 int rdvio_hip_ctx_set_kernel_timing(rdvio_hip_ctx *ctx, int on);

@@ -149,7 +149,8 @@ struct rdvio_hip_ctx {
     // read at the fetch that follows; sums since the last reset
     bool counted = false;    // this context is in the device's live-context count
     long team_retries = 0;   // solves repeated on one workgroup after a helper time-out (rdvio_hip_ctx_team_retries)
-    bool kernel_timing = false;
+    int kernel_timing = 0;       // 0 off; k > 0: every k-th launch is bracketed by events (rdvio_hip_ctx_set_kernel_timing)
+    long kt_seen = 0;            // launches since timing was switched on
     double kt_launches = 0.0, kt_ms = 0.0, kt_flops = 0.0, kt_iterations = 0.0;
 
     char err[512] = {0};

@@ -395,7 +395,7 @@ int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int slot, int max_iterations
     }
     // the kernel (re)starts from the uploaded initial values (SolverWs::x0 / xd0): no host traffic, no extra copies
     if (w.n_wg > 1) RDVIO_HIP_CHECK(ctx, hipMemsetAsync(w.sync, 0, 8 * sizeof(double), ctx->lane[RDVIO_LANE_SOLVER]));
-    S.timed_launch = ctx->kernel_timing;
+    S.timed_launch = ctx->kernel_timing > 0 && (ctx->kt_seen++ % ctx->kernel_timing) == 0;
     if (S.timed_launch) {
         if (!S.ev0) {
             RDVIO_HIP_CHECK(ctx, hipEventCreate(&S.ev0));
@@ -551,7 +551,8 @@ long rdvio_hip_ctx_team_retries(const rdvio_hip_ctx *ctx) { return ctx ? ctx->te
 
 int rdvio_hip_ctx_set_kernel_timing(rdvio_hip_ctx *ctx, int on) {
     if (!ctx) return RDVIO_ERR_INVALID;
-    ctx->kernel_timing = on != 0;
+    ctx->kernel_timing = on < 0 ? 0 : on;
+    ctx->kt_seen = 0;
     ctx->kt_launches = ctx->kt_ms = ctx->kt_flops = ctx->kt_iterations = 0.0;
     return RDVIO_OK;
 }
