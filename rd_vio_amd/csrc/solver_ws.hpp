@@ -70,6 +70,7 @@ struct SolverWs {
     int mute_helpers;                    // test switch (RDVIO_TEST_MUTE_HELPERS): helper workgroups exit at once
     int poison_lds;                      // test switch (RDVIO_TEST_POISON_LDS): every workgroup fills its LDS with 0xFF bytes first
     int no_lds_vectors;                  // diagnostic switch (RDVIO_NO_LDS_VECTORS): no LDS-resident small vectors
+    int fuse_accept;                     // trial steps that follow an accepted step are evaluated WITH their linearisation (set at launch)
     // a solve that continues another one (rdvio_hip_ba_upload_chained): frame chain_frame starts from the 16 doubles at chain_src
     // (the other solve's result, in its arena) instead of its row of x0
     const double *chain_src;
