@@ -401,11 +401,11 @@ int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int slot, int max_iterations
             RDVIO_HIP_CHECK(ctx, hipEventCreate(&S.ev0));
             RDVIO_HIP_CHECK(ctx, hipEventCreate(&S.ev1));
         }
-        RDVIO_HIP_CHECK(ctx, hipEventRecord(S.ev0, ctx->lane[RDVIO_LANE_SOLVER]));
     }
-    rdvio_launch_ba_solve(ctx->lane[RDVIO_LANE_SOLVER], w);
+    // (timed: the two events ride on the launch itself -- the dispatch's own start / stop timestamps; two hipEventRecord calls around
+    // it put marker packets on the lane and cost the pipeline up to a tenth of its rate)
+    rdvio_launch_ba_solve(ctx->lane[RDVIO_LANE_SOLVER], w, S.timed_launch ? S.ev0 : nullptr, S.timed_launch ? S.ev1 : nullptr);
     RDVIO_HIP_CHECK(ctx, hipGetLastError());
-    if (S.timed_launch) RDVIO_HIP_CHECK(ctx, hipEventRecord(S.ev1, ctx->lane[RDVIO_LANE_SOLVER]));
     return RDVIO_OK;
 }
 

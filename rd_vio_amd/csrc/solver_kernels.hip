@@ -25,6 +25,7 @@
 // re-walking the factors:  |J x|^2 = xp^T H xp + 2 sum_l xl (A_l . xp) + sum_l m_l xl^2.
 #include "ctx.hpp"
 #include "factors.hpp"
+#include <hip/hip_ext.h>
 #include "solver_ws.hpp"
 #include "block_linalg.hpp"
 #include "marg_tail.hpp"
@@ -2360,7 +2361,7 @@ void rdvio_launch_marginalize(hipStream_t stream, const SolverWs &w0) {
     hipLaunchKernelGGL(marginalize_kernel, dim3(1), dim3(T), 0, stream, w);
 }
 
-void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w0) {
+void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w0, hipEvent_t ev0, hipEvent_t ev1) {
     SolverWs w = w0;
     const char *ns = getenv("RDVIO_NO_SPECULATION");
     w.no_speculation = (ns && ns[0] == '1') ? 1 : 0;
@@ -2376,5 +2377,6 @@ void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w0) {
     w.no_lds_vectors = (nv && nv[0] == '1') ? 1 : 0;
     const char *sp = getenv("RDVIO_SOLVER_SPREAD");   // diagnostic: one team member per XCD (the round-robin placement of a plain grid)
     w.wg_stride = (w.n_wg > 1 && !(sp && sp[0] == '1')) ? 8 : 1;
-    hipLaunchKernelGGL(ba_solve_kernel, dim3((w.n_wg > 1 ? w.n_wg : 1) * w.wg_stride), dim3(T), 0, stream, w);
+    if (ev0 && ev1) hipExtLaunchKernelGGL(ba_solve_kernel, dim3((w.n_wg > 1 ? w.n_wg : 1) * w.wg_stride), dim3(T), 0, stream, ev0, ev1, 0, w);
+    else hipLaunchKernelGGL(ba_solve_kernel, dim3((w.n_wg > 1 ? w.n_wg : 1) * w.wg_stride), dim3(T), 0, stream, w);
 }

@@ -89,7 +89,9 @@ struct SolverWs {
 typedef const __attribute__((address_space(3))) SolverWs LdsWs;
 #endif
 
-void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w);
+// ev0 / ev1 (both or neither): HIP events attached to the launch itself (hipExtLaunchKernelGGL: the dispatch's own start / stop
+// timestamps, no marker packets on the stream)
+void rdvio_launch_ba_solve(hipStream_t stream, const SolverWs &w, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void rdvio_launch_marginalize(hipStream_t stream, const SolverWs &w);
 void rdvio_launch_ba_linearize(hipStream_t stream, const SolverWs &w);
 unsigned rdvio_ug_violations();   // RDVIO_CHECK_UG builds: global-typed accesses that were handed an LDS address (else 0)
