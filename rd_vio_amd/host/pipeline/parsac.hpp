@@ -369,9 +369,18 @@ ParsacResult<DoF, Model, SolveFn, ErrorFn> parsac_solve(size_t size, const std::
     bool first_batch = true;
     const bool generated = on_device && dev->generate;
     const size_t batch = !generated ? PARSAC_BATCH : (MD == 12 ? PARSAC_BATCH_GENERATED_PNP : PARSAC_BATCH_GENERATED_ESSENTIAL);
-    for (size_t iter0 = 0; iter0 < iter_max; iter0 += batch) {
+    // A batch behind the first one takes everything the adaptive iteration count still asks for (it has been cut down by the
+    // first batch's best model), up to the backend's model capacity and -- so that the masks still ride back with the results --
+    // 256 KB of masks + bin counts: a solve that needs a hundred iterations (1000 points, a low inlier ratio) is two round trips
+    // instead of four.  The replay stops where the sequential loop stops; a batch's size never shows in the result.
+    const size_t per_iteration = MD == 12 ? 1 : 10;
+    const size_t batch_cap = !generated ? batch
+                                        : std::max(batch, std::min<size_t>(RDVIO_PARSAC_MAX_MODELS / per_iteration,
+                                                                           (size_t)(256 * 1024) / (size + 4 * grid.nValidBins + 1) / per_iteration));
+    size_t B = 0;
+    for (size_t iter0 = 0; iter0 < iter_max; iter0 += B) {
         // ---- hypotheses of iterations iter0 .. iter0 + B - 1
-        const size_t B = std::min(batch, iter_max - iter0);
+        B = std::min(iter0 == 0 ? batch : batch_cap, iter_max - iter0);
         std::vector<Model> models;
         std::vector<size_t> first_of(B + 1, 0);
         std::vector<int32_t> samples(generated ? B * DoF : 0);

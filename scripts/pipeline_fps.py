@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--mover", action="store_true")
     ap.add_argument("--cpu", action="store_true", help="also run the CPU path (oracle backend, threading 1) and compare")
     ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("--hd", action="store_true", help="the 1280 x 720 camera of BASELINE config 5 (focal 900) instead of the EuRoC one")
     ap.add_argument("--gates", type=int, default=0, choices=(0, 1), help="1: the tracker's two-view gates + thinning behind the backend hooks")
     args = ap.parse_args()
 
@@ -32,6 +33,11 @@ def main():
     from rd_vio_amd import synth
 
     W, H, K = 752, 480, synth.EUROC_K
+    kw = {}
+    if args.hd:
+        W, H = 1280, 720
+        K = np.array([[900.0, 0, 640.0], [0, 900.0, 360.0], [0, 0, 1.0]])
+        kw = dict(width=W, height=H, K=K)
     t0 = time.time()
     frames, ts, imu, gt = synth.make_stream(args.frames, W, H, K, mover=args.mover)
     print(f"# rendered {args.frames} frames in {time.time() - t0:.1f} s", file=sys.stderr)
@@ -41,7 +47,7 @@ def main():
     runs = []
     for mode in [int(m) for m in args.modes.split(",")]:
         for rep in range(args.repeat):
-            cfg, over = pr.baseline_config(lib, args.window, args.features, threading=mode, tracker_gates_on_backend=args.gates)
+            cfg, over = pr.baseline_config(lib, args.window, args.features, threading=mode, tracker_gates_on_backend=args.gates, **kw)
             ctx = rd_vio_amd.Context(max_width=W, max_height=H, max_features=max(1024, 4 * args.features), max_window=args.window + 8, max_factors=40000)
             try:
                 r = pr.run_pipeline(lib, lambda out: lib.rdvio_pipeline_create_hip(out, __import__("ctypes").byref(cfg), ctx._h), frames, ts, imu, init, kp_capacity=2048)
@@ -65,7 +71,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import pipeline_util as pu
 
-        cfg, over = pr.baseline_config(lib, args.window, args.features, threading=1)
+        cfg, over = pr.baseline_config(lib, args.window, args.features, threading=1, **kw)
         c = pr.run_pipeline(lib, pu.oracle_pipeline_factory(lib, shim, cfg), frames, ts, imu, init, kp_capacity=2048)
         for mode, r in runs:
             if mode == 0:
