@@ -239,6 +239,10 @@ struct ParsacDeviceScorer {
     // in the same call; NULL = models come from the host solvers
     int (*generate)(void *user, const rdvio_parsac_batch *batch, int n_iterations, const int32_t *samples, int32_t *models_per_iteration,
                     double *models, rdvio_parsac_result *results) = nullptr;
+    // optional: where the caller keeps how many iterations its last solve of this kind replayed -- the first batch of the next one
+    // is sized to that (a solve over 1000 points needs ~100 iterations every frame: one round trip instead of two).  A batch's size
+    // never shows in the result, so neither does the hint.
+    size_t *iterations_hint = nullptr;
 };
 inline void parsac_flatten(const M3 &E, double *out) {
     for (int q = 0; q < 9; ++q) out[q] = E.m[q];
@@ -377,10 +381,11 @@ ParsacResult<DoF, Model, SolveFn, ErrorFn> parsac_solve(size_t size, const std::
     const size_t batch_cap = !generated ? batch
                                         : std::max(batch, std::min<size_t>(RDVIO_PARSAC_MAX_MODELS / per_iteration,
                                                                            (size_t)(256 * 1024) / (size + 4 * grid.nValidBins + 1) / per_iteration));
-    size_t B = 0;
+    size_t B = 0, replayed = 0;
     for (size_t iter0 = 0; iter0 < iter_max; iter0 += B) {
         // ---- hypotheses of iterations iter0 .. iter0 + B - 1
-        B = std::min(iter0 == 0 ? batch : batch_cap, iter_max - iter0);
+        const size_t first = (generated && dev->iterations_hint) ? std::min(batch_cap, std::max(batch, (*dev->iterations_hint + 7) / 8 * 8)) : batch;
+        B = std::min(iter0 == 0 ? first : batch_cap, iter_max - iter0);
         std::vector<Model> models;
         std::vector<size_t> first_of(B + 1, 0);
         std::vector<int32_t> samples(generated ? B * DoF : 0);
@@ -496,7 +501,7 @@ ParsacResult<DoF, Model, SolveFn, ErrorFn> parsac_solve(size_t size, const std::
         delete tick_score;
         // ---- replay of the reference's loop body on the results, in iteration order
         long best_in_batch = -1;
-        for (size_t b = 0; b < B && iter0 + b < iter_max; ++b, prof.iterations++)
+        for (size_t b = 0; b < B && iter0 + b < iter_max; ++b, prof.iterations++, ++replayed)
             for (size_t k = first_of[b]; k < first_of[b + 1]; ++k) {
                 const size_t effective = effs[k];
                 if (imu_prior && effective < DoF) continue;
@@ -526,6 +531,7 @@ ParsacResult<DoF, Model, SolveFn, ErrorFn> parsac_solve(size_t size, const std::
             }
         }
     }
+    if (generated && dev->iterations_hint) *dev->iterations_hint = replayed;
     if (imu_prior && inlier_count < DoF) {
         out.inlier_mask.assign(size, 1);
         out.model = identity;

@@ -1269,6 +1269,7 @@ bool SlidingWindowTracker::judge_track_status() {
     const V3 tcw = -(Rcw * pose.p);
     ParsacDeviceScorer dev{sh.backend.fn.parsac_score, sh.backend.fn.parsac_fetch, sh.backend.fn.user};
     dev.generate = sh.backend.fn.parsac_generate_score;
+    dev.iterations_hint = &sh.pnp_iterations_hint;
     (void)find_pnp_matrix_parsac_imu(P3D, P2D, lens, Rcw, tcw, 0.20, 1.0, mask, sh.pnp_bin_confidences, 1.0 / curr_frame->K[0], 0.999, 1000, 0,
                                      sh.backend.fn.parsac_score ? &dev : nullptr);
     mask.resize(P2D.size(), 0);

@@ -98,6 +98,7 @@ struct Shared {  // what every stage needs
     std::vector<std::array<double, 17>> init_states;
     // bin confidences of the two PARSAC call sites (function-local statics in the reference: pnp.h:195, stereo.cpp:147)
     std::vector<float> pnp_bin_confidences = std::vector<float>(400, 0.5f), essential_bin_confidences = std::vector<float>(400, 0.5f);
+    size_t pnp_iterations_hint = 0;   // iterations the last IMU-PARSAC solve replayed (sizes the next solve's first device batch)
 };
 
 // SoA export of one Solver problem (row A16): frames / landmarks / factors by index, ordered by landmark
