@@ -753,9 +753,10 @@ def main(argv=None):
     ctx, run, applied = hip_run(args.threading, init_states=stream["gt"] if supplied else None, kp_capacity=2048)
     n_pre = bootstrap_and_warm_up(run, warmup, n_total - steps)
     c0 = run.counters()
-    # every solver launch of the timed region is bracketed by HIP events on the solver lane (measured cost: within the run-to-run
-    # spread -- 1200 frames/s with every launch timed, 1185-1202 with every 2nd / 3rd / 5th; RDVIO_BENCH_KT_STRIDE=k times every
-    # k-th launch, for that experiment only: a stride samples the alternating localisation / window launches unevenly)
+    # Every solver launch of the timed region carries HIP start / stop events (attached to the launch itself).  A timed launch costs
+    # the lane a few microseconds (its stop event keeps the chained next solve from following it directly): measured on `value`,
+    # between nothing and 6 % depending on the box, inside the box-to-box spread.  RDVIO_BENCH_KT_STRIDE=k times the launches of one
+    # frame in k (picked by a hash of the frame index: a fixed stride aliases with the keyframe cadence), 0 none -- for that A/B.
     KT_STRIDE = int(os.environ.get("RDVIO_BENCH_KT_STRIDE", "1"))
     ctx._check(ctx._lib.rdvio_hip_ctx_set_kernel_timing(ctx._h, KT_STRIDE))
     timed = {}
@@ -806,9 +807,9 @@ def main(argv=None):
                              avg_launch_us=round(1e3 * k_ms / max(launches, 1), 2),
                              algorithmic_flops_per_launch=int(k_flops / max(launches, 1)), solver_iterations_timed=int(kt[3]),
                              kernel_ms_per_frame=round((k_ms / max(launches, 1)) * float(dc[1] + dc[4] + dc[5]) / steps, 4),
-                             note="measured live over the timed region with HIP events on the solver lane around every launch (localize_newframe, "
-                                  "refine_window and refine_subwindow launches as the stream produced them); single-workgroup latency-bound "
-                                  "trust-region loop (phase table: DESIGN.md section 4)"),
+                             note="measured live over the timed region with HIP start / stop events attached to every launch on the solver lane "
+                                  "(localize_newframe + refine_window or refine_subwindow, as the stream produced them); single-workgroup "
+                                  "latency-bound trust-region loop (phase table: DESIGN.md section 4)"),
         }
 
         # HBM-side bytes per launch of the dominant kernel: the committed PMC passes of this same command (pmc_traffic_bytes)

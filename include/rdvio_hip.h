@@ -282,9 +282,11 @@ int rdvio_hip_debug_last_select_path(const rdvio_hip_ctx *ctx);
 int rdvio_hip_debug_last_select_stamps(const rdvio_hip_ctx *ctx, int32_t *out5);
 long rdvio_hip_ctx_team_retries(const rdvio_hip_ctx *ctx);
 
-/* Measurement: live timing of the dominant kernel.  on = k > 0: every k-th ba_solve_kernel launch (1: every launch, what bench.py
- * uses) is bracketed by HIP events on the solver lane and read at the fetch that follows; 0 switches it off.  get returns the sums
- * over the TIMED launches since timing was switched on:
+/* Measurement: live timing of the dominant kernel.  on = k > 0: the launches of one in k PAIRS of consecutive ba_solve_kernel
+ * launches (a frame's two solves, picked by a hash of the pair's index; 1: every launch) carry HIP start / stop events on the solver lane, read at the fetch that follows;
+ * 0 switches it off.  A timed launch costs the lane a few microseconds (its stop event keeps the next command from following it
+ * directly); bench.py times every launch.  get returns the sums over the TIMED launches since
+ * timing was switched on:
  * out4 = { launches, kernel milliseconds, algorithmic FP64 flops (SURVEY.md 8d per-unit figures x the units of each launch:
  * (successful steps + 1) linearisations + iterations cost evaluations), solver iterations }. */
 int rdvio_hip_ctx_set_kernel_timing(rdvio_hip_ctx *ctx, int on);

@@ -395,7 +395,15 @@ int rdvio_hip_ba_solve_resident(rdvio_hip_ctx *ctx, int slot, int max_iterations
     }
     // the kernel (re)starts from the uploaded initial values (SolverWs::x0 / xd0): no host traffic, no extra copies
     if (w.n_wg > 1) RDVIO_HIP_CHECK(ctx, hipMemsetAsync(w.sync, 0, 8 * sizeof(double), ctx->lane[RDVIO_LANE_SOLVER]));
-    S.timed_launch = ctx->kernel_timing > 0 && (ctx->kt_seen++ % ctx->kernel_timing) == 0;
+    // (k > 1 times PAIRS of consecutive launches -- the two solves of a frame -- of every k-th pair: a stride over single launches
+    // would sample the alternating localisation / window launches unevenly)
+    // and the pairs are picked by a hash of their index, not by a stride: keyframes come every sixth frame or so, and any fixed
+    // stride would sample the window solves unevenly (every fourth frame never met one)
+    {
+        const unsigned long pair = (unsigned long)(ctx->kt_seen++ / 2);
+        const unsigned h = (unsigned)((pair * 2654435761ul) >> 13);
+        S.timed_launch = ctx->kernel_timing == 1 || (ctx->kernel_timing > 1 && h % (unsigned)ctx->kernel_timing == 0);
+    }
     if (S.timed_launch) {
         if (!S.ev0) {
             RDVIO_HIP_CHECK(ctx, hipEventCreate(&S.ev0));
